@@ -1,0 +1,269 @@
+"""Oracle (test infrastructure only): the DCA autoencoder training path in numpy.
+
+Restates, in fp64 (truth) or fp32, everything the reference executes between
+``train()`` and ``predict()`` for ae_types zinb-conddisp / zinb / nb-conddisp / nb:
+
+* stack Dense -> BatchNormalization(center=True, scale=False) -> relu per hidden
+  layer, centre index floor(L/2)                       dca/network.py:92-141
+* output heads + size-factor scaling                   dca/network.py:249-339, 366-393, 496-516
+* loss                                                 dca/loss.py (via zinb_np.py)
+* clipvalue + RMSprop, Keras ``fit`` loop with validation_split / shuffle,
+  ReduceLROnPlateau, EarlyStopping                     dca/train.py:54-98
+* predict outputs                                      dca/network.py:188-211, 395-405
+
+Keras / TensorFlow semantics (un-vendored; documented behaviour, parity unpinned --
+see oracle/__init__.py):
+  Dense:       y = x W + b
+  BatchNorm:   momentum .99, eps 1e-3, train = biased batch moments, moving stats updated
+               with the biased variance; inference = moving stats
+  RMSprop:     ms = .9 ms + .1 g^2 ; w -= lr g / sqrt(ms + 1e-7)  (eps inside the sqrt)
+  clipvalue:   g = clip(g, -c, c) element-wise before the update
+  fit:         validation = last n - int(n*(1-split)) rows; per epoch a fresh arange is
+               shuffled with the numpy global RNG; last partial batch kept; epoch loss =
+               sample-weighted mean of batch losses; val loss in inference mode.
+"""
+import numpy as np
+from . import zinb_np as Z
+
+BN_MOMENTUM = 0.99
+BN_EPS = 1e-3
+AE_TYPES = ('zinb-conddisp', 'zinb', 'nb-conddisp', 'nb')
+
+
+def glorot_uniform(rng, fan_in, fan_out, dtype):
+    lim = np.sqrt(6.0 / (fan_in + fan_out))
+    return rng.uniform(-lim, lim, size=(fan_in, fan_out)).astype(dtype)
+
+
+def init_params(ae_type, input_size, hidden_size, output_size=None, batchnorm=True,
+                seed=0, dtype=np.float64):
+    """Glorot-uniform kernels, zero biases / beta, moving_mean 0, moving_var 1, theta_w 0."""
+    assert ae_type in AE_TYPES
+    output_size = input_size if output_size is None else output_size
+    rng = np.random.RandomState(seed)
+    p = {}
+    fan_in = input_size
+    for i, h in enumerate(hidden_size):
+        p['W%d' % i] = glorot_uniform(rng, fan_in, h, dtype)
+        p['b%d' % i] = np.zeros(h, dtype)
+        if batchnorm:
+            p['beta%d' % i] = np.zeros(h, dtype)
+            p['mm%d' % i] = np.zeros(h, dtype)
+            p['mv%d' % i] = np.ones(h, dtype)
+        fan_in = h
+    heads = ['mean']
+    if ae_type in ('zinb-conddisp', 'nb-conddisp'):
+        heads.append('disp')
+    if ae_type.startswith('zinb'):
+        heads.append('pi')
+    for hd in heads:
+        p['W_' + hd] = glorot_uniform(rng, fan_in, output_size, dtype)
+        p['b_' + hd] = np.zeros(output_size, dtype)
+    if ae_type in ('zinb', 'nb'):
+        p['theta_w'] = np.zeros(output_size, dtype)
+    return p
+
+
+STATE_KEYS = ('mm', 'mv')
+
+
+def is_trainable(name):
+    return not name.startswith(STATE_KEYS)
+
+
+class OracleAE:
+    def __init__(self, ae_type, params, hidden_size, batchnorm=True, ridge=0.0):
+        assert ae_type in AE_TYPES
+        self.ae_type = ae_type
+        self.p = params
+        self.hidden_size = tuple(hidden_size)
+        self.batchnorm = batchnorm
+        self.ridge = ridge
+        self.center = int(np.floor(len(self.hidden_size) / 2.0))   # network.py:102
+        self.dtype = params['W0'].dtype
+
+    # ---------------------------------------------------------------- forward
+    def forward(self, X, sf, training):
+        p, dt = self.p, self.dtype
+        H = X.astype(dt)
+        cache = {'H': [H], 'xh': [], 'inv': [], 'Yb': [], 'Z': []}
+        for i in range(len(self.hidden_size)):
+            Zi = H @ p['W%d' % i] + p['b%d' % i]
+            cache['Z'].append(Zi)
+            if self.batchnorm:
+                if training:
+                    mu = Zi.mean(axis=0)
+                    var = np.square(Zi - mu).mean(axis=0)
+                    # moving = moving*momentum + batch*(1-momentum), biased variance
+                    p['mm%d' % i] = p['mm%d' % i] - (p['mm%d' % i] - mu) * dt.type(1 - BN_MOMENTUM)
+                    p['mv%d' % i] = p['mv%d' % i] - (p['mv%d' % i] - var) * dt.type(1 - BN_MOMENTUM)
+                else:
+                    mu, var = p['mm%d' % i], p['mv%d' % i]
+                inv = 1 / np.sqrt(var + dt.type(BN_EPS))
+                xh = (Zi - mu) * inv
+                Yb = xh + p['beta%d' % i]
+                cache['xh'].append(xh)
+                cache['inv'].append(inv)
+            else:
+                Yb = Zi
+            cache['Yb'].append(Yb)
+            H = np.maximum(Yb, 0)
+            cache['H'].append(H)
+        cache['a_mean'] = H @ p['W_mean'] + p['b_mean']
+        cache['a_disp'] = H @ p['W_disp'] + p['b_disp'] if 'W_disp' in p else None
+        cache['a_pi'] = H @ p['W_pi'] + p['b_pi'] if 'W_pi' in p else None
+        cache['sf'] = sf.astype(dt)
+        return cache
+
+    def _loss_grads(self, c, Y, n_total):
+        tw = self.p.get('theta_w')
+        if self.ae_type.startswith('zinb'):
+            ls, lm, dm, dd, dpi = Z.zinb_loss_and_grads(c['a_mean'], c['a_disp'], c['a_pi'], Y,
+                                                        c['sf'], self.ridge, n_total, tw)
+        else:
+            ls, lm, dm, dd = Z.nb_loss_and_grads(c['a_mean'], c['a_disp'], Y, c['sf'], n_total, tw)
+            dpi = None
+        return ls, lm, dm, dd, dpi
+
+    def loss_and_grads(self, X, Y, sf, n_total=None):
+        """One training-mode forward + backward. Returns (mean loss, grads dict)."""
+        p = self.p
+        c = self.forward(X, sf, training=True)
+        _, loss, d_mean, d_disp, d_pi = self._loss_grads(c, Y, n_total)
+        g = {}
+        HL = c['H'][-1]
+        g['W_mean'] = HL.T @ d_mean
+        g['b_mean'] = d_mean.sum(axis=0)
+        dH = d_mean @ p['W_mean'].T
+        if 'W_disp' in p:
+            g['W_disp'] = HL.T @ d_disp
+            g['b_disp'] = d_disp.sum(axis=0)
+            dH = dH + d_disp @ p['W_disp'].T
+        else:
+            g['theta_w'] = d_disp
+        if 'W_pi' in p:
+            g['W_pi'] = HL.T @ d_pi
+            g['b_pi'] = d_pi.sum(axis=0)
+            dH = dH + d_pi @ p['W_pi'].T
+        for i in reversed(range(len(self.hidden_size))):
+            dYb = dH * (c['Yb'][i] > 0)
+            if self.batchnorm:
+                xh, inv = c['xh'][i], c['inv'][i]
+                g['beta%d' % i] = dYb.sum(axis=0)
+                dZ = inv * (dYb - dYb.mean(axis=0) - xh * (dYb * xh).mean(axis=0))
+            else:
+                dZ = dYb
+            g['W%d' % i] = c['H'][i].T @ dZ
+            g['b%d' % i] = dZ.sum(axis=0)
+            if i > 0:
+                dH = dZ @ p['W%d' % i].T
+        return loss, g
+
+    def eval_loss_sum(self, X, Y, sf):
+        """Inference-mode sum of element-wise NLL over the given rows."""
+        c = self.forward(X, sf, training=False)
+        ls, _, _, _, _ = self._loss_grads(c, Y, None)
+        return ls
+
+    def predict(self, X, sf):
+        """network.py:188-211, 395-405: mean*sf, theta, pi, latent (centre Dense output)."""
+        c = self.forward(X, sf, training=False)
+        mu, theta, pi = Z.heads_forward(c['a_mean'], c['a_disp'], c['a_pi'], c['sf'])
+        if 'theta_w' in self.p:
+            theta = Z.const_disp(self.p['theta_w'])          # layers.py:21, per gene
+        return {'mean': mu, 'dispersion': theta, 'dropout': pi, 'latent': c['Z'][self.center]}
+
+
+# ------------------------------------------------------------------ optimizer
+def rmsprop_step(params, grads, ms, lr, rho=0.9, eps=1e-7, clip=5.0):
+    """Keras clipvalue then tf.keras RMSprop (momentum 0, not centered), train.py:54-57."""
+    for k, g in grads.items():
+        dt = params[k].dtype
+        if clip is not None and clip > 0:
+            g = np.clip(g, dt.type(-clip), dt.type(clip))
+        if k not in ms:
+            ms[k] = np.zeros_like(params[k])
+        ms[k] = dt.type(rho) * ms[k] + dt.type(1 - rho) * np.square(g)
+        params[k] = params[k] - dt.type(lr) * g / np.sqrt(ms[k] + dt.type(eps))
+
+
+# ------------------------------------------------------------------ callbacks
+class ReduceLROnPlateau:
+    """keras.callbacks.ReduceLROnPlateau(monitor='val_loss', patience=p): factor .1,
+    mode min, min_delta 1e-4, cooldown 0, min_lr 0 (train.py:70-72)."""
+
+    def __init__(self, patience, factor=0.1, min_delta=1e-4, min_lr=0.0):
+        self.patience, self.factor, self.min_delta, self.min_lr = patience, factor, min_delta, min_lr
+        self.best, self.wait = np.inf, 0
+
+    def on_epoch_end(self, val_loss, lr):
+        if val_loss < self.best - self.min_delta:
+            self.best, self.wait = val_loss, 0
+        else:
+            self.wait += 1
+            if self.wait >= self.patience:
+                if lr > self.min_lr:
+                    lr = float(np.float32(max(lr * self.factor, self.min_lr)))
+                self.wait = 0
+        return lr
+
+
+class EarlyStopping:
+    """keras.callbacks.EarlyStopping(monitor='val_loss', patience=p): min_delta 0,
+    restore_best_weights False (train.py:73-75)."""
+
+    def __init__(self, patience):
+        self.patience, self.best, self.wait = patience, np.inf, 0
+
+    def on_epoch_end(self, val_loss):
+        if val_loss < self.best:
+            self.best, self.wait = val_loss, 0
+            return False
+        self.wait += 1
+        return self.wait >= self.patience
+
+
+def fit(net, X, Y, sf, epochs=300, batch_size=32, validation_split=0.1, learning_rate=None,
+        clip_grad=5.0, reduce_lr=10, early_stop=15, shuffle_rng=np.random, val_batch_size=None,
+        on_batch=None):
+    """Keras Model.fit as train.py:91-98 drives it. Returns history dict (loss, val_loss, lr).
+
+    shuffle_rng: object with .shuffle (the numpy global RNG in the reference).
+    """
+    n = X.shape[0]
+    split_at = int(n * (1.0 - validation_split)) if validation_split else n
+    Xt, Yt, sft = X[:split_at], Y[:split_at], sf[:split_at]
+    Xv, Yv, sfv = X[split_at:], Y[split_at:], sf[split_at:]
+    lr = float(np.float32(0.001 if learning_rate is None else learning_rate))
+    ms = {}
+    rl = ReduceLROnPlateau(reduce_lr) if reduce_lr else None
+    es = EarlyStopping(early_stop) if early_stop else None
+    hist = {'loss': [], 'val_loss': [], 'lr': []}
+    G = Y.shape[1]
+    vb = batch_size if val_batch_size is None else val_batch_size
+    for epoch in range(epochs):
+        idx = np.arange(split_at)
+        shuffle_rng.shuffle(idx)
+        tot = 0.0
+        for s in range(0, split_at, batch_size):
+            b = idx[s:s + batch_size]
+            loss, g = net.loss_and_grads(Xt[b], Yt[b], sft[b])
+            rmsprop_step(net.p, g, ms, lr, clip=clip_grad)
+            tot += float(loss) * len(b)
+            if on_batch is not None:
+                on_batch(epoch, s // batch_size, float(loss))
+        hist['loss'].append(tot / split_at)
+        hist['lr'].append(lr)
+        if len(Xv):
+            vt = 0.0
+            for s in range(0, len(Xv), vb):
+                e = min(s + vb, len(Xv))
+                # Keras averages per-batch means weighted by batch size == sum / (nv*G)
+                vt += float(net.eval_loss_sum(Xv[s:e], Yv[s:e], sfv[s:e])) / G
+            val = vt / len(Xv)
+            hist['val_loss'].append(val)
+            if rl is not None:
+                lr = rl.on_epoch_end(val, lr)
+            if es is not None and es.on_epoch_end(val):
+                break
+    return hist

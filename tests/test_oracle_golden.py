@@ -1,0 +1,160 @@
+"""Pins the oracle (oracle/zinb_np.py, net_np.py) before anything is compared against it.
+
+KAT-1/KAT-2 come from the reference's own R-generated fixtures (data/biochemists*.tsv,
+data/biochemists.R:16-42): pscl::zeroinfl / MASS::glm.nb maximum-likelihood fits.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import zinb_np as Z
+from oracle import net_np as N
+from oracle import torch_ref as T
+from conftest import synth_counts
+
+
+def _design(b):
+    tab = b['table']
+    return tab[:, 0], np.c_[np.ones(len(tab)), tab[:, 1:]]
+
+
+def test_fixture_predictions_reproduce(biochemists):
+    b = biochemists
+    y, Xd = _design(b)
+    assert y.shape == (915,) and (y == 0).sum() == 275 and y.max() == 19
+    np.testing.assert_allclose(np.exp(Xd @ b['zinb_count_coef']), b['zinb_pred_count'], rtol=1e-12)
+    np.testing.assert_allclose(Z.sigmoid(Xd @ b['zinb_zero_coef']), b['zinb_pred_zero'], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(np.exp(Xd @ b['nb_coef']), b['nb_pred_count'], rtol=1e-12)
+
+
+def test_kat1_loglik_at_R_mle(biochemists):
+    """Sum of loss.py's NLL at R's MLE == -logLik published by pscl (-1550 on 13 df) and
+    MASS (-1561 on 7 df)."""
+    b = biochemists
+    y, Xd = _design(b)
+    mu, pi = b['zinb_pred_count'], b['zinb_pred_zero']
+    th = np.full_like(mu, b['zinb_theta'])
+    assert abs(Z.zinb_nll(y, mu, th, pi).sum() - 1549.9909) < 1e-3
+    assert abs(Z.nb_nll(y, b['nb_pred_count'], np.full_like(mu, b['nb_theta'])).sum() - 1560.9583) < 1e-3
+    # fp32 evaluation of the same formula
+    l32 = Z.zinb_nll(y.astype(np.float32), mu.astype(np.float32), th.astype(np.float32),
+                     pi.astype(np.float32)).sum(dtype=np.float64)
+    assert abs(l32 - 1549.9909) / 1549.9909 < 2e-6
+
+
+def test_kat2_gradient_vanishes_at_R_mle(biochemists):
+    b = biochemists
+    y, Xd = _design(b)
+    mu, pi = b['zinb_pred_count'], b['zinb_pred_zero']
+    th = np.full_like(mu, b['zinb_theta'])
+    dmu, dth, dpi = Z.zinb_grads(y, mu, th, pi)
+    g = np.r_[(dmu * mu) @ Xd, (dpi * pi * (1 - pi)) @ Xd, dth.sum()]
+    assert np.abs(g).max() < 1e-3
+    dmu, dth = Z.nb_grads(y, b['nb_pred_count'], np.full_like(mu, b['nb_theta']))
+    g = np.r_[(dmu * b['nb_pred_count']) @ Xd, dth.sum()]
+    assert np.abs(g).max() < 1e-3
+    # and it does NOT vanish away from the MLE (the test has teeth)
+    dmu, dth, dpi = Z.zinb_grads(y, mu * 1.3, th, pi)
+    assert np.abs((dmu * mu) @ Xd).max() > 1.0
+
+
+def _rand_heads(B, G, seed, edge=False):
+    rng = np.random.RandomState(seed)
+    am = rng.normal(0, 1.5, (B, G)); ad = rng.normal(0, 2, (B, G)); ap = rng.normal(0, 2, (B, G))
+    y = synth_counts(B, G, seed)
+    sf = rng.lognormal(0, 0.3, B)
+    if edge:
+        am[0, :4] = [-14., 15., 0., 30.]      # mean clip low / high
+        ad[1, :4] = [-12., 9500., 20., -3.]   # theta clip low / softplus ~ x / high clip
+        ap[2, :4] = [-30., 30., 0., 12.]
+        y[3, :4] = [0, 1, 200, 5000]
+        am[3, :4] = [1., 1., 5., 8.]
+    return am, ad, ap, y, sf
+
+
+@pytest.mark.parametrize('edge', [False, True])
+def test_analytic_grads_match_autograd(edge):
+    am, ad, ap, y, sf = _rand_heads(16, 40, 3, edge)
+    ridge = 0.07
+    _, loss, dm, dd, dp = Z.zinb_loss_and_grads(am, ad, ap, y, sf, ridge)
+    t = [torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in (am, ad, ap)]
+    mu = T.mean_act(t[0]) * torch.tensor(sf).reshape(-1, 1)
+    lt = T.zinb_nll(torch.tensor(y), mu, T.disp_act(t[1]), torch.sigmoid(t[2]), ridge).mean()
+    lt.backward()
+    assert abs(loss - lt.item()) <= 1e-10 * abs(loss)
+    for a, b in zip((dm, dd, dp), t):
+        np.testing.assert_allclose(a, b.grad.numpy(), rtol=1e-9, atol=1e-16)
+    # NB twin
+    _, loss, dm, dd = Z.nb_loss_and_grads(am, ad, y, sf)
+    t = [torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in (am, ad)]
+    mu = T.mean_act(t[0]) * torch.tensor(sf).reshape(-1, 1)
+    lt = T.nb_nll(torch.tensor(y), mu, T.disp_act(t[1])).mean()
+    lt.backward()
+    assert abs(loss - lt.item()) <= 1e-10 * abs(loss)
+    np.testing.assert_allclose(dm, t[0].grad.numpy(), rtol=1e-9, atol=1e-16)
+    np.testing.assert_allclose(dd, t[1].grad.numpy(), rtol=1e-9, atol=1e-16)
+
+
+@pytest.mark.parametrize('ae_type', N.AE_TYPES)
+@pytest.mark.parametrize('batchnorm', [True, False])
+def test_network_backward_matches_autograd(ae_type, batchnorm):
+    n, G, hs = 24, 30, (8, 4, 8)
+    y = synth_counts(n, G, 5)
+    rng = np.random.RandomState(1)
+    X = rng.normal(size=(n, G)); sf = rng.lognormal(0, .3, n)
+    p = N.init_params(ae_type, G, hs, batchnorm=batchnorm, seed=2)
+    for k in p:                       # move biases / beta / theta_w off their zero init
+        if k[0] in 'bt':
+            p[k] = rng.normal(0, .1, p[k].shape)
+    net = N.OracleAE(ae_type, {k: v.copy() for k, v in p.items()}, hs, batchnorm, ridge=0.01)
+    tnet = T.TorchAE(ae_type, p, hs, batchnorm, ridge=0.01, dtype=torch.float64)
+    loss, g = net.loss_and_grads(X, y, sf)
+    tl, tg = tnet.grads(torch.tensor(X), torch.tensor(y), torch.tensor(sf))
+    assert abs(loss - tl.item()) < 1e-12 * abs(loss)
+    assert set(g) == set(tg)
+    for k in g:
+        np.testing.assert_allclose(g[k], tg[k].numpy(), rtol=1e-7, atol=1e-13, err_msg=k)
+    if batchnorm:   # moving statistics updated identically
+        np.testing.assert_allclose(net.p['mv1'], tnet.p['mv1'].numpy(), rtol=1e-12)
+
+
+def test_rmsprop_and_fit_loop_semantics():
+    """Keras split / partial batch / callbacks bookkeeping on a tiny problem; fp64 vs torch."""
+    n, G, hs = 50, 12, (4, 2, 4)
+    y = synth_counts(n, G, 7)
+    rng = np.random.RandomState(0)
+    X = rng.normal(size=(n, G)); sf = rng.lognormal(0, .3, n)
+    p = N.init_params('zinb-conddisp', G, hs, seed=3)
+    net = N.OracleAE('zinb-conddisp', {k: v.copy() for k, v in p.items()}, hs)
+    batches = []
+    h = N.fit(net, X, y, sf, epochs=3, batch_size=8, shuffle_rng=np.random.RandomState(11),
+              on_batch=lambda e, b, l: batches.append((e, b)))
+    # 45 train / 5 val ; 6 batches per epoch (5 x 8 + 5)
+    assert len(batches) == 18 and len(h['loss']) == 3 and len(h['val_loss']) == 3
+    assert h['lr'] == [float(np.float32(1e-3))] * 3
+    # the same three epochs with torch autograd + the torch RMSprop restatement
+    tnet = T.TorchAE('zinb-conddisp', p, hs, dtype=torch.float64)
+    r = np.random.RandomState(11)
+    Xt, Yt, St = torch.tensor(X), torch.tensor(y), torch.tensor(sf)
+    for e in range(3):
+        idx = np.arange(45); r.shuffle(idx)
+        tot = 0.
+        for s in range(0, 45, 8):
+            b = idx[s:s + 8]
+            tot += tnet.train_step(Xt[b], Yt[b], St[b]).item() * len(b)
+        assert abs(tot / 45 - h['loss'][e]) < 1e-9 * abs(h['loss'][e])
+        v = tnet.loss(Xt[45:], Yt[45:], St[45:], training=False).item()
+        assert abs(v - h['val_loss'][e]) < 1e-9 * abs(v)
+
+
+def test_callbacks():
+    rl = N.ReduceLROnPlateau(patience=2)
+    lr = 1e-3
+    seq = [1.0, 0.9, 0.95, 0.9 - 5e-5, 0.8, 0.81, 0.82]
+    out = []
+    for v in seq:
+        lr = rl.on_epoch_end(v, lr); out.append(lr)
+    # epochs 2,3 do not improve by > 1e-4 -> reduce after the 2nd; epochs 5,6 again
+    assert np.allclose(out, [1e-3, 1e-3, 1e-3, 1e-4, 1e-4, 1e-4, 1e-5])
+    es = N.EarlyStopping(patience=2)
+    assert [es.on_epoch_end(v) for v in [1.0, 0.9, 0.9, 0.95]] == [False, False, False, True]
