@@ -1,0 +1,50 @@
+"""Builds dca_amd/csrc/libdcahip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python -m dca_amd.build            # rebuild if any source is newer than the library
+    python -m dca_amd.build --force
+
+The library is a plain C-ABI shared object (include/dcahip.h); no torch headers, no JIT cache:
+it lives in-tree so it travels with the repository snapshot to the GPU box.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, 'csrc')
+LIB = os.path.join(CSRC, 'libdcahip.so')
+SOURCES = ['dcahip_zinb.hip', 'dcahip_gemm.hip', 'dcahip_layers.hip', 'dcahip_prep.hip']
+ARCH = 'gfx950'
+
+
+def _hipcc():
+    for c in (shutil.which('hipcc'), '/opt/rocm/bin/hipcc'):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError('hipcc not found: cannot build libdcahip.so')
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(ROOT, 'include', 'dcahip.h')]
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build_hip(force=False, verbose=True):
+    if not force and not needs_build():
+        return LIB
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    cmd = [_hipcc(), '--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-shared',
+           '-I' + os.path.join(ROOT, 'include'), '-o', LIB] + srcs
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build_hip(force='--force' in sys.argv))

@@ -1,0 +1,355 @@
+// K-GEMM: fp32 GEMM on the gfx950 matrix pipe (v_mfma_f32_32x32x2_f32: exact fp32, bitwise a
+// k-ordered fmaf chain), LDS-tiled, 4 waves per workgroup, register-staged prefetch of the
+// next K-chunk, deterministic split-K through a workspace + ordered reduce.
+//
+// One template covers the three operand layouts the Dense layers of the autoencoder need
+// (dca/network.py:124-126, 369-380 and their autodiff):
+//   NN  C = A  B      forward             A [M,K] k-contiguous, B [K,N] n-contiguous
+//   TN  C = A^T B     weight gradient     A [K,M] m-contiguous, B [K,N] n-contiguous
+//   NT  C = A  B^T    input gradient      A [M,K] k-contiguous, B [N,K] k-contiguous
+// The minibatch gather (storage row = perm[*cursor + r]) is folded into the A loads, so the
+// shuffled batch of the resident [n_cells, n_genes] matrix is never copied.
+//
+// LDS image: As[k][m], Bs[k][n] (k-major).  A wave's MFMA fragment read is then 32
+// consecutive floats per half-wave: conflict-free ds_read_b32.  k-contiguous sources are
+// transposed on the way in (4 x ds_write_b32, odd row stride -> conflict-free), m/n-
+// contiguous sources are stored with one aligned ds_write_b128 per lane.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "dcahip.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+struct GemmArgs {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias;
+    const int* perm;
+    const long long* cursor;
+    float* ws;
+    long lda, ldb, ldc;
+    int M, N, K;
+    int split, kslab;
+    int colsum;
+    int mtiles, ntiles;
+};
+
+struct RowMap {
+    const int* perm;
+    long long cur;
+    __device__ __forceinline__ long operator()(int r) const {
+        return perm ? (long)perm[cur + r] : (long)(cur + r);
+    }
+};
+struct Identity {
+    __device__ __forceinline__ long operator()(int r) const { return r; }
+};
+
+// ---- tile loaders: global -> registers, registers -> LDS --------------------------------
+// KContig: source row index = m/n (ROWS per tile), contiguous along k.
+template <int ROWS, int BK, int V>
+struct KContig {
+    static constexpr int TK = BK / V;            // threads along k
+    static constexpr int RPP = 256 / TK;         // rows per pass
+    static constexpr int PASSES = ROWS / RPP;
+    float r[PASSES][V];
+    template <class Map>
+    __device__ __forceinline__ void load(const float* base, long ld, int row0, int nrows, int k0,
+                                         int kend, const Map& map) {
+        const int t = threadIdx.x;
+        const int k = k0 + (t % TK) * V;
+        const int mr = t / TK;
+#pragma unroll
+        for (int i = 0; i < PASSES; ++i) {
+            const int m = row0 + mr + i * RPP;
+#pragma unroll
+            for (int j = 0; j < V; ++j) r[i][j] = 0.f;
+            if (m < nrows && k < kend) {
+                const float* p = base + map(m) * ld + k;
+                if (V == 4 && k + 4 <= kend) {
+                    const float4 v = *reinterpret_cast<const float4*>(p);
+                    r[i][0] = v.x; r[i][1 % V] = v.y; r[i][2 % V] = v.z; r[i][3 % V] = v.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < V; ++j) if (k + j < kend) r[i][j] = p[j];
+                }
+            }
+        }
+    }
+    // LDS image S[k][row], row stride LDS_ (odd)
+    template <int LDS_>
+    __device__ __forceinline__ void store(float* S) const {
+        const int t = threadIdx.x;
+        const int k = (t % TK) * V;
+        const int mr = t / TK;
+#pragma unroll
+        for (int i = 0; i < PASSES; ++i)
+#pragma unroll
+            for (int j = 0; j < V; ++j) S[(k + j) * LDS_ + mr + i * RPP] = r[i][j];
+    }
+};
+
+// MNContig: source row index = k, contiguous along m/n (COLS per tile).
+template <int COLS, int BK, int V>
+struct MNContig {
+    static constexpr int TC = COLS / V;          // threads along m/n
+    static constexpr int KPP = 256 / TC;         // k rows per pass
+    static constexpr int PASSES = (BK + KPP - 1) / KPP;
+    float r[PASSES][V];
+    template <class Map>
+    __device__ __forceinline__ void load(const float* base, long ld, int col0, int ncols, int k0,
+                                         int kend, const Map& map) {
+        const int t = threadIdx.x;
+        const int c = col0 + (t % TC) * V;
+        const int kr = t / TC;
+#pragma unroll
+        for (int i = 0; i < PASSES; ++i) {
+            const int k = k0 + kr + i * KPP;
+#pragma unroll
+            for (int j = 0; j < V; ++j) r[i][j] = 0.f;
+            if (kr + i * KPP < BK && k < kend && c < ncols) {
+                const float* p = base + map(k) * ld + c;
+                if (V == 4 && c + 4 <= ncols) {
+                    const float4 v = *reinterpret_cast<const float4*>(p);
+                    r[i][0] = v.x; r[i][1 % V] = v.y; r[i][2 % V] = v.z; r[i][3 % V] = v.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < V; ++j) if (c + j < ncols) r[i][j] = p[j];
+                }
+            }
+        }
+    }
+    // LDS image S[k][col], row stride LDS_ (multiple of 4)
+    template <int LDS_>
+    __device__ __forceinline__ void store(float* S) const {
+        const int t = threadIdx.x;
+        const int c = (t % TC) * V;
+        const int kr = t / TC;
+#pragma unroll
+        for (int i = 0; i < PASSES; ++i) {
+            const int k = kr + i * KPP;
+            if (k < BK) {
+                if (V == 4) *reinterpret_cast<float4*>(&S[k * LDS_ + c]) = make_float4(r[i][0], r[i][1 % V], r[i][2 % V], r[i][3 % V]);
+                else S[k * LDS_ + c] = r[i][0];
+            }
+        }
+    }
+};
+
+template <bool KC, int DIM, int BK, int V> struct LoaderSel;
+template <int DIM, int BK, int V> struct LoaderSel<true, DIM, BK, V> { using T = KContig<DIM, BK, V>; };
+template <int DIM, int BK, int V> struct LoaderSel<false, DIM, BK, V> { using T = MNContig<DIM, BK, V>; };
+
+template <int BM, int BN, int BK, int WGM, int WGN, bool TA, bool TB, int V>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
+    static_assert(WGM * WGN == 4, "4 waves per workgroup");
+    constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
+    constexpr bool A_KC = !TA;                  // A k-contiguous unless transposed
+    constexpr bool B_KC = TB;                   // B k-contiguous only when stored [N,K]
+    constexpr int LDA_S = BM + (A_KC ? 1 : 0);
+    constexpr int LDB_S = BN + (B_KC ? 1 : 0);
+    __shared__ __attribute__((aligned(16))) float As[BK * LDA_S];
+    __shared__ __attribute__((aligned(16))) float Bs[BK * LDB_S];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    int id = blockIdx.x;
+    const int s = id % p.split; id /= p.split;
+    const int nt = id % p.ntiles;
+    const int mt = id / p.ntiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int kbeg = s * p.kslab;
+    const int kend = min(p.K, kbeg + p.kslab);
+    const RowMap amap{p.perm, p.cursor ? *p.cursor : 0};
+    const Identity ident;
+
+    typename LoaderSel<A_KC, BM, BK, V>::T la;
+    typename LoaderSel<B_KC, BN, BK, V>::T lb;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const bool do_colsum = TA && p.colsum && mt == 0;
+    constexpr int NPH = 256 / BN > 0 ? 256 / BN : 1;   // column-sum phases (BN <= 256)
+    const int cn = t % BN, cph = t / BN;
+    float csum = 0.f;
+
+    const int wm0 = (wave / WGN) * WM, wn0 = (wave % WGN) * WN;
+    const int nchunks = (kend - kbeg + BK - 1) / BK;
+
+    la.load(p.A, p.lda, A_KC ? m0 : m0, A_KC ? p.M : p.M, kbeg, kend, amap);
+    lb.load(p.B, p.ldb, n0, p.N, kbeg, kend, ident);
+    for (int c = 0; c < nchunks; ++c) {
+        la.template store<LDA_S>(As);
+        lb.template store<LDB_S>(Bs);
+        __syncthreads();
+        if (c + 1 < nchunks) {
+            const int k0 = kbeg + (c + 1) * BK;
+            la.load(p.A, p.lda, m0, p.M, k0, kend, amap);
+            lb.load(p.B, p.ldb, n0, p.N, k0, kend, ident);
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            const int k = 2 * kk + (lane >> 5);
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = As[k * LDA_S + wm0 + i * 32 + (lane & 31)];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Bs[k * LDB_S + wn0 + j * 32 + (lane & 31)];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (do_colsum && cph < NPH) {
+#pragma unroll 4
+            for (int k = cph; k < BK; k += NPH) csum += Bs[k * LDB_S + cn];
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue ------------------------------------------------------------------------
+    const int Mo = p.M + (p.colsum ? 1 : 0);
+    float* out = p.split > 1 ? p.ws + (long)s * Mo * p.N : p.C;
+    const long ldo = p.split > 1 ? (long)p.N : p.ldc;
+    const bool add_bias = p.split == 1 && p.bias != nullptr;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn0 + j * 32 + (lane & 31);
+        const float bv = (add_bias && n < p.N) ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < p.M && n < p.N) out[(long)m * ldo + n] = acc[i][j][r] + bv;
+            }
+        }
+    }
+    if (do_colsum) {
+        float* red = As;                          // safe: last loop iteration ended with a barrier
+        if (cph < NPH) red[cph * BN + cn] = csum;
+        __syncthreads();
+        if (cph == 0) {
+            float v = 0.f;
+#pragma unroll
+            for (int q = 0; q < NPH; ++q) v += red[q * BN + cn];
+            const int n = n0 + cn;
+            if (n < p.N) out[(long)p.M * ldo + n] = v;
+        }
+    }
+}
+
+// C[m,n] = bias[n] + sum_s ws[s][m][n]  (ordered: deterministic)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, int S, int Mo, int N,
+                                                            const float* bias, int Mbias,
+                                                            float* C, long ldc) {
+    const long total = (long)Mo * N;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int m = (int)(i / N), n = (int)(i - (long)m * N);
+        float v = 0.f;
+        for (int s = 0; s < S; ++s) v += ws[(long)s * total + i];
+        if (bias && m < Mbias) v += bias[n];
+        C[(long)m * ldc + n] = v;
+    }
+}
+
+struct Plan {
+    int cfg;       // 0: 128x64, 1: 64x128, 2: 128x128
+    int BM, BN;
+    int mtiles, ntiles, split, kslab;
+};
+
+constexpr int kBK = 32;
+
+Plan make_plan(int M, int N, int K, int split_k) {
+    Plan p;
+    if (N <= 64) { p.cfg = 0; p.BM = 128; p.BN = 64; }
+    else if (M <= 64) { p.cfg = 1; p.BM = 64; p.BN = 128; }
+    else { p.cfg = 2; p.BM = 128; p.BN = 128; }
+    p.mtiles = (M + p.BM - 1) / p.BM;
+    p.ntiles = (N + p.BN - 1) / p.BN;
+    const int nchunks = (K + kBK - 1) / kBK;
+    int S = split_k;
+    if (S <= 0) {
+        const long tiles = (long)p.mtiles * p.ntiles;
+        S = 1;
+        if (tiles < 256) {
+            S = (int)((384 + tiles - 1) / tiles);
+            if (S > nchunks / 2) S = nchunks / 2;
+            if (S > 128) S = 128;
+            if (S < 1) S = 1;
+        }
+    }
+    if (S > nchunks) S = nchunks;
+    if (S < 1) S = 1;
+    const int cps = (nchunks + S - 1) / S;          // chunks per split
+    p.kslab = cps * kBK;
+    p.split = (nchunks + cps - 1) / cps;            // drop empty trailing splits
+    return p;
+}
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <int BM, int BN, int WGM, int WGN>
+int launch_cfg(const GemmArgs& a, int ta, int tb, bool vec, int grid, hipStream_t s) {
+#define DCA_L(TA, TB, V) hipLaunchKernelGGL((gemm_kernel<BM, BN, kBK, WGM, WGN, TA, TB, V>), dim3(grid), dim3(256), 0, s, a)
+    if (!ta && !tb) { if (vec) DCA_L(false, false, 4); else DCA_L(false, false, 1); }
+    else if (ta && !tb) { if (vec) DCA_L(true, false, 4); else DCA_L(true, false, 1); }
+    else if (!ta && tb) { if (vec) DCA_L(false, true, 4); else DCA_L(false, true, 1); }
+    else return DCAHIP_EINVAL;
+#undef DCA_L
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" long dcahip_sgemm_workspace_bytes(int ta, int tb, int M, int N, int K, int colsum_row,
+                                             int split_k) {
+    (void)ta; (void)tb;
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const Plan p = make_plan(M, N, K, split_k);
+    if (p.split <= 1) return 0;
+    return (long)p.split * (M + (colsum_row ? 1 : 0)) * N * (long)sizeof(float);
+}
+
+extern "C" int dcahip_sgemm(int ta, int tb, int M, int N, int K, const float* A, long lda,
+                            const float* B, long ldb, float* C, long ldc, const float* bias,
+                            const int* perm, const long long* cursor, int colsum_row, int split_k,
+                            void* workspace, long workspace_bytes, void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C) return DCAHIP_EINVAL;
+    if (ta && tb) return DCAHIP_EINVAL;
+    if (colsum_row && !ta) return DCAHIP_EINVAL;
+    const Plan p = make_plan(M, N, K, split_k);
+    const long need = dcahip_sgemm_workspace_bytes(ta, tb, M, N, K, colsum_row, split_k);
+    if (need > 0 && (!workspace || workspace_bytes < need)) return DCAHIP_EINVAL;
+    // 16-byte vector loads need aligned bases and leading dimensions
+    const bool vec = al16(A) && al16(B) && (lda % 4 == 0) && (ldb % 4 == 0);
+    GemmArgs a{A, B, C, bias, perm, cursor, static_cast<float*>(workspace), lda, ldb, ldc,
+               M, N, K, p.split, p.kslab, colsum_row, p.mtiles, p.ntiles};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int grid = p.mtiles * p.ntiles * p.split;
+    int rc;
+    if (p.cfg == 0) rc = launch_cfg<128, 64, 4, 1>(a, ta, tb, vec, grid, s);
+    else if (p.cfg == 1) rc = launch_cfg<64, 128, 1, 4>(a, ta, tb, vec, grid, s);
+    else rc = launch_cfg<128, 128, 2, 2>(a, ta, tb, vec, grid, s);
+    if (rc != 0) return rc;
+    if (p.split > 1) {
+        const int Mo = M + (colsum_row ? 1 : 0);
+        const long total = (long)Mo * N;
+        long g = (total + 255) / 256;
+        if (g > 4096) g = 4096;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)g), dim3(256), 0, s, a.ws, p.split, Mo, N,
+                           bias, M, C, ldc);
+        rc = (int)hipGetLastError();
+    }
+    return rc;
+}

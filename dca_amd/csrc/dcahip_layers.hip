@@ -1,0 +1,345 @@
+// Small-tensor kernels of the training step: batch-norm statistics / apply / backward (+ReLU),
+// column sums, clipvalue + RMSprop.  gfx950, wave64.
+//
+// Activations here are [B, H] with H = hidden width (64/32/64 by default): every kernel maps
+// 64 consecutive columns to the 64 lanes of a wave (coalesced 256-byte row segments) and the 4
+// waves of a workgroup to 4 interleaved row lanes, reduced through LDS.  All reductions have a
+// fixed order (deterministic), statistics are merged with Chan's parallel formula so that
+// data-parallel ranks can exchange (count, mean, M2) triples instead of raw sums.
+//
+// Reference semantics restated: keras BatchNormalization(center=True, scale=False), momentum
+// .99, eps 1e-3, biased batch variance (dca/network.py:127-128); Activation('relu')
+// (network.py:132-135); opt.RMSprop(clipvalue) (dca/train.py:54-57);
+// ConstantDispersionLayer gradient (dca/layers.py:17-21).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "dcahip.h"
+
+namespace {
+
+constexpr int kMaxChunks = 256;
+constexpr int kApplyRows = 64;   // rows per workgroup in the apply kernels
+
+__host__ __device__ inline int n_chunks(int B) {
+    int r = (B + 63) / 64;
+    return r < 1 ? 1 : (r > kMaxChunks ? kMaxChunks : r);
+}
+__host__ __device__ inline int chunk_rows(int B, int R) { return (B + R - 1) / R; }
+
+// sum over the 4 row lanes (waves) of a workgroup; result valid in every thread
+__device__ __forceinline__ float wg_rowlane_sum(float v, float* sm /*[4][64]*/) {
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    __syncthreads();
+    sm[ty * 64 + tx] = v;
+    __syncthreads();
+    return (sm[tx] + sm[64 + tx]) + (sm[128 + tx] + sm[192 + tx]);
+}
+
+// part[r][0][c] = mean of column c over the chunk's rows, part[r][1][c] = sum (x - mean)^2
+__global__ __launch_bounds__(256) void col_moments_kernel(const float* Z, long ldz, int B, int H,
+                                                          float* part) {
+    __shared__ float sm[256];
+    const int R = gridDim.x, r = blockIdx.x;
+    const int cr = chunk_rows(B, R);
+    const int r0 = r * cr, r1 = min(B, r0 + cr);
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const float cnt = (float)max(r1 - r0, 0);
+    for (int c0 = 0; c0 < H; c0 += 64) {
+        const int c = c0 + tx;
+        float s = 0.f;
+        if (c < H) for (int i = r0 + ty; i < r1; i += 4) s += Z[(long)i * ldz + c];
+        const float mean = cnt > 0.f ? wg_rowlane_sum(s, sm) / cnt : 0.f;
+        float q = 0.f;
+        if (c < H) for (int i = r0 + ty; i < r1; i += 4) { const float d = Z[(long)i * ldz + c] - mean; q += d * d; }
+        const float m2 = wg_rowlane_sum(q, sm);
+        if (c < H && ty == 0) {
+            part[((long)r * 2 + 0) * H + c] = mean;
+            part[((long)r * 2 + 1) * H + c] = m2;
+        }
+    }
+}
+
+// Chan et al. merge of E (count, mean, M2) entries for column c
+__device__ __forceinline__ void merge_entries(const float* entries, const float* counts, int E,
+                                              int H, int c, int Bfallback, double& n_out,
+                                              double& mean_out, double& m2_out) {
+    double n = 0.0, mean = 0.0, m2 = 0.0;
+    const int cr = chunk_rows(Bfallback, E);
+    for (int e = 0; e < E; ++e) {
+        double ne;
+        if (counts) ne = (double)counts[e];
+        else { const int r0 = e * cr; int r1 = r0 + cr; if (r1 > Bfallback) r1 = Bfallback; ne = r1 > r0 ? (double)(r1 - r0) : 0.0; }
+        if (ne <= 0.0) continue;
+        const double me = (double)entries[((long)e * 2 + 0) * H + c];
+        const double qe = (double)entries[((long)e * 2 + 1) * H + c];
+        const double tot = n + ne;
+        const double delta = me - mean;
+        mean += delta * ne / tot;
+        m2 += qe + delta * delta * n * ne / tot;
+        n = tot;
+    }
+    n_out = n; mean_out = mean; m2_out = m2;
+}
+
+__global__ __launch_bounds__(256) void moments_combine_kernel(const float* entries,
+                                                              const float* counts, int E, int H,
+                                                              float* out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= H) return;
+    double n, mean, m2;
+    merge_entries(entries, counts, E, H, c, 0, n, mean, m2);
+    out[c] = (float)mean;
+    out[H + c] = (float)m2;
+}
+
+struct BnApplyArgs {
+    const float* Z; long ldz; int B, H;
+    const float* entries; const float* counts; int E;
+    const float* beta; float* mm; float* mv;
+    float momentum, eps; int relu;
+    float* Hout; long ldh; float* xhat; long ldx; float* inv_std;
+};
+
+__global__ __launch_bounds__(256) void bn_relu_apply_kernel(BnApplyArgs a) {
+    extern __shared__ float dyn[];               // [2][H]: mean, inv_std
+    float* s_mean = dyn;
+    float* s_inv = dyn + a.H;
+    for (int c = threadIdx.x; c < a.H; c += 256) {
+        float mean, var;
+        if (a.entries) {
+            double n, m, m2;
+            merge_entries(a.entries, a.counts, a.E, a.H, c, a.B, n, m, m2);
+            mean = (float)m;
+            var = (float)(m2 / n);                // biased variance
+            if (blockIdx.x == 0) {
+                // moving = moving - (moving - batch) * (1 - momentum)
+                a.mm[c] = a.mm[c] - (a.mm[c] - mean) * (1.f - a.momentum);
+                a.mv[c] = a.mv[c] - (a.mv[c] - var) * (1.f - a.momentum);
+            }
+        } else {
+            mean = a.mm[c]; var = a.mv[c];
+        }
+        const float inv = 1.f / sqrtf(var + a.eps);
+        s_mean[c] = mean; s_inv[c] = inv;
+        if (blockIdx.x == 0 && a.inv_std) a.inv_std[c] = inv;
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int r0 = blockIdx.x * kApplyRows, r1 = min(a.B, r0 + kApplyRows);
+    for (int c0 = 0; c0 < a.H; c0 += 64) {
+        const int c = c0 + tx;
+        if (c >= a.H) continue;
+        const float mean = s_mean[c], inv = s_inv[c], beta = a.beta ? a.beta[c] : 0.f;
+        for (int i = r0 + ty; i < r1; i += 4) {
+            const float xh = (a.Z[(long)i * a.ldz + c] - mean) * inv;
+            if (a.xhat) a.xhat[(long)i * a.ldx + c] = xh;
+            float y = xh + beta;
+            if (a.relu) y = fmaxf(y, 0.f);
+            a.Hout[(long)i * a.ldh + c] = y;
+        }
+    }
+}
+
+// part[r][0][c] = sum dy, part[r][1][c] = sum dy*xhat over the chunk's rows; dy = dh*[h>0]
+__global__ __launch_bounds__(256) void bn_bwd_sums_kernel(const float* dH, long ldd,
+                                                          const float* Hact, long ldh,
+                                                          const float* xhat, long ldx, int B, int H,
+                                                          float* part) {
+    __shared__ float sm[256];
+    const int R = gridDim.x, r = blockIdx.x;
+    const int cr = chunk_rows(B, R);
+    const int r0 = r * cr, r1 = min(B, r0 + cr);
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int c0 = 0; c0 < H; c0 += 64) {
+        const int c = c0 + tx;
+        float s1 = 0.f, s2 = 0.f;
+        if (c < H) for (int i = r0 + ty; i < r1; i += 4) {
+            const float dy = Hact[(long)i * ldh + c] > 0.f ? dH[(long)i * ldd + c] : 0.f;
+            s1 += dy; s2 += dy * xhat[(long)i * ldx + c];
+        }
+        const float t1 = wg_rowlane_sum(s1, sm);
+        const float t2 = wg_rowlane_sum(s2, sm);
+        if (c < H && ty == 0) {
+            part[((long)r * 2 + 0) * H + c] = t1;
+            part[((long)r * 2 + 1) * H + c] = t2;
+        }
+    }
+}
+
+struct BnBwdArgs {
+    const float* dH; long ldd; const float* Hact; long ldh; const float* xhat; long ldx;
+    const float* inv_std; const float* sums; int E; float n_total; int B, H;
+    float* dZ; long ldz; float* dbeta;
+};
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
+    extern __shared__ float dyn[];               // [2][H]: S1/n, S2/n
+    float* s1 = dyn;
+    float* s2 = dyn + a.H;
+    for (int c = threadIdx.x; c < a.H; c += 256) {
+        float v1 = 0.f, v2 = 0.f;
+        for (int e = 0; e < a.E; ++e) {
+            v1 += a.sums[((long)e * 2 + 0) * a.H + c];
+            v2 += a.sums[((long)e * 2 + 1) * a.H + c];
+        }
+        if (blockIdx.x == 0 && a.dbeta) a.dbeta[c] = v1;
+        s1[c] = v1 / a.n_total; s2[c] = v2 / a.n_total;
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int r0 = blockIdx.x * kApplyRows, r1 = min(a.B, r0 + kApplyRows);
+    for (int c0 = 0; c0 < a.H; c0 += 64) {
+        const int c = c0 + tx;
+        if (c >= a.H) continue;
+        const float m1 = s1[c], m2 = s2[c], inv = a.inv_std[c];
+        for (int i = r0 + ty; i < r1; i += 4) {
+            const float dy = a.Hact[(long)i * a.ldh + c] > 0.f ? a.dH[(long)i * a.ldd + c] : 0.f;
+            a.dZ[(long)i * a.ldz + c] = inv * (dy - m1 - a.xhat[(long)i * a.ldx + c] * m2);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* dH, long ldd, const float* Hact,
+                                                       long ldh, int B, int H, float* dZ, long ldz) {
+    const long total = (long)B * H;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int r = (int)(i / H), c = (int)(i - (long)r * H);
+        dZ[(long)r * ldz + c] = Hact[(long)r * ldh + c] > 0.f ? dH[(long)r * ldd + c] : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void colsum_chain_kernel(const float* x, long ldx, int B, int N,
+                                                           const float* theta_w, float* out) {
+    __shared__ float sm[256];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
+    float s = 0.f;
+    if (c < N) for (int i = ty; i < B; i += 4) s += x[(long)i * ldx + c];
+    const float tot = wg_rowlane_sum(s, sm);
+    if (c < N && ty == 0) {
+        float chain = 1.f;
+        if (theta_w) {                           // d clip(exp(w),1e-3,1e4) / dw
+            const float e = expf(theta_w[c]);
+            chain = (e >= 1e-3f && e <= 1e4f) ? e : 0.f;
+        }
+        out[c] = tot * chain;
+    }
+}
+
+__global__ __launch_bounds__(256) void rmsprop_clip_kernel(float* w, const float* g, float* ms,
+                                                           long n, const float* lrp, float rho,
+                                                           float eps, float clip) {
+    const float lr = *lrp;
+    const long nv = n >> 2;
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += stride) {
+        float4 gv = reinterpret_cast<const float4*>(g)[i];
+        float4 mv = reinterpret_cast<const float4*>(ms)[i];
+        float4 wv = reinterpret_cast<const float4*>(w)[i];
+        float* gp = &gv.x; float* mp = &mv.x; float* wp = &wv.x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float gj = gp[j];
+            if (clip > 0.f) gj = fminf(fmaxf(gj, -clip), clip);
+            mp[j] = rho * mp[j] + (1.f - rho) * gj * gj;
+            wp[j] = wp[j] - lr * gj / sqrtf(mp[j] + eps);
+        }
+        reinterpret_cast<float4*>(ms)[i] = mv;
+        reinterpret_cast<float4*>(w)[i] = wv;
+    }
+    for (long i = (nv << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        float gj = g[i];
+        if (clip > 0.f) gj = fminf(fmaxf(gj, -clip), clip);
+        const float m = rho * ms[i] + (1.f - rho) * gj * gj;
+        ms[i] = m;
+        w[i] = w[i] - lr * gj / sqrtf(m + eps);
+    }
+}
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int dcahip_col_moments_chunks(int B) { return n_chunks(B); }
+
+extern "C" int dcahip_col_moments(const float* Z, long ldz, int B, int H, float* part, void* stream) {
+    if (!Z || !part || B <= 0 || H <= 0) return DCAHIP_EINVAL;
+    hipLaunchKernelGGL(col_moments_kernel, dim3(n_chunks(B)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), Z, ldz, B, H, part);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dcahip_moments_combine(const float* entries, const float* counts, int E, int H,
+                                      float* out, void* stream) {
+    if (!entries || !counts || !out || E <= 0 || H <= 0) return DCAHIP_EINVAL;
+    hipLaunchKernelGGL(moments_combine_kernel, dim3((H + 255) / 256), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), entries, counts, E, H, out);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dcahip_bn_relu_apply(const float* Z, long ldz, int B, int H, const float* entries,
+                                    const float* counts, int E, const float* beta,
+                                    float* moving_mean, float* moving_var, float momentum, float eps,
+                                    int relu, float* Hout, long ldh, float* xhat, long ldx,
+                                    float* inv_std, void* stream) {
+    if (!Z || !Hout || !moving_mean || !moving_var || B <= 0 || H <= 0) return DCAHIP_EINVAL;
+    if (entries && E <= 0) return DCAHIP_EINVAL;
+    BnApplyArgs a{Z, ldz, B, H, entries, counts, E, beta, moving_mean, moving_var, momentum, eps,
+                  relu, Hout, ldh, xhat, ldx, inv_std};
+    const int grid = (B + kApplyRows - 1) / kApplyRows;
+    hipLaunchKernelGGL(bn_relu_apply_kernel, dim3(grid), dim3(256), 2 * H * sizeof(float),
+                       static_cast<hipStream_t>(stream), a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dcahip_bn_bwd_sums(const float* dH, long ldd, const float* Hact, long ldh,
+                                  const float* xhat, long ldx, int B, int H, float* part,
+                                  void* stream) {
+    if (!dH || !Hact || !xhat || !part || B <= 0 || H <= 0) return DCAHIP_EINVAL;
+    hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(n_chunks(B)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), dH, ldd, Hact, ldh, xhat, ldx, B, H, part);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dcahip_bn_bwd_apply(const float* dH, long ldd, const float* Hact, long ldh,
+                                   const float* xhat, long ldx, const float* inv_std,
+                                   const float* sums, int E, float n_total, int B, int H, float* dZ,
+                                   long ldz, float* dbeta, void* stream) {
+    if (!dH || !Hact || !xhat || !inv_std || !sums || !dZ || E <= 0 || B <= 0 || H <= 0)
+        return DCAHIP_EINVAL;
+    BnBwdArgs a{dH, ldd, Hact, ldh, xhat, ldx, inv_std, sums, E, n_total, B, H, dZ, ldz, dbeta};
+    const int grid = (B + kApplyRows - 1) / kApplyRows;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 2 * H * sizeof(float),
+                       static_cast<hipStream_t>(stream), a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dcahip_relu_bwd(const float* dH, long ldd, const float* Hact, long ldh, int B, int H,
+                               float* dZ, long ldz, void* stream) {
+    if (!dH || !Hact || !dZ || B <= 0 || H <= 0) return DCAHIP_EINVAL;
+    long g = ((long)B * H + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3((int)g), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       dH, ldd, Hact, ldh, B, H, dZ, ldz);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dcahip_colsum_chain(const float* x, long ldx, int B, int N, const float* theta_w,
+                                   float* out, void* stream) {
+    if (!x || !out || B <= 0 || N <= 0) return DCAHIP_EINVAL;
+    hipLaunchKernelGGL(colsum_chain_kernel, dim3((N + 63) / 64), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), x, ldx, B, N, theta_w, out);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dcahip_rmsprop_clip(float* w, const float* g, float* ms, long n, const float* lr,
+                                   float rho, float eps, float clip, void* stream) {
+    if (!w || !g || !ms || !lr || n <= 0) return DCAHIP_EINVAL;
+    if (!al16(w) || !al16(g) || !al16(ms)) return DCAHIP_EINVAL;
+    long grid = ((n >> 2) + 255) / 256;
+    if (grid > 2048) grid = 2048;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(rmsprop_clip_kernel, dim3((int)grid), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), w, g, ms, n, lr, rho, eps, clip);
+    return (int)hipGetLastError();
+}

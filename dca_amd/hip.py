@@ -1,0 +1,123 @@
+"""ctypes binding of libdcahip.so (include/dcahip.h) -- the only door to the HIP kernels.
+
+There is NO fallback: if the shared library is missing, or a kernel is asked to run on anything
+but device memory of an AMD GPU, this module raises.  PyTorch is used for what it is good at
+here -- owning device buffers and streams; tensors cross the boundary as raw device pointers.
+"""
+import ctypes
+import os
+
+import torch
+
+from . import build as _build
+
+_c = ctypes
+_f32p, _i32p, _i64p, _f64p, _vp = _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p
+
+NLL_HAS_PI = 1
+NLL_CONST_DISP = 2
+
+_SIGNATURES = {
+    'dcahip_version': (_c.c_int, []),
+    'dcahip_zinb_max_partials': (_c.c_int, []),
+    'dcahip_zinb_nll': (_c.c_int, [_f32p, _f32p, _f32p, _c.c_long, _f32p, _f32p, _c.c_long, _f32p,
+                                   _i32p, _i64p, _c.c_int, _c.c_int, _c.c_float, _c.c_float,
+                                   _c.c_int, _f32p, _f32p, _f32p, _c.c_long, _f64p,
+                                   _c.POINTER(_c.c_int), _vp]),
+    'dcahip_loss_finalize': (_c.c_int, [_f64p, _c.c_int, _c.c_double, _f32p, _vp]),
+    'dcahip_step_end': (_c.c_int, [_f32p, _c.c_double, _f32p, _c.c_int, _f64p, _i64p, _c.c_int, _vp]),
+    'dcahip_zinb_heads_infer': (_c.c_int, [_f32p, _f32p, _f32p, _c.c_long, _f32p, _c.c_int, _c.c_int,
+                                           _f32p, _f32p, _f32p, _c.c_long, _vp]),
+    'dcahip_sgemm': (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _f32p, _c.c_long,
+                                _f32p, _c.c_long, _f32p, _c.c_long, _f32p, _i32p, _i64p, _c.c_int,
+                                _c.c_int, _vp, _c.c_long, _vp]),
+    'dcahip_sgemm_workspace_bytes': (_c.c_long, [_c.c_int] * 7),
+    'dcahip_col_moments_chunks': (_c.c_int, [_c.c_int]),
+    'dcahip_col_moments': (_c.c_int, [_f32p, _c.c_long, _c.c_int, _c.c_int, _f32p, _vp]),
+    'dcahip_moments_combine': (_c.c_int, [_f32p, _f32p, _c.c_int, _c.c_int, _f32p, _vp]),
+    'dcahip_bn_relu_apply': (_c.c_int, [_f32p, _c.c_long, _c.c_int, _c.c_int, _f32p, _f32p, _c.c_int,
+                                        _f32p, _f32p, _f32p, _c.c_float, _c.c_float, _c.c_int,
+                                        _f32p, _c.c_long, _f32p, _c.c_long, _f32p, _vp]),
+    'dcahip_bn_bwd_sums': (_c.c_int, [_f32p, _c.c_long, _f32p, _c.c_long, _f32p, _c.c_long, _c.c_int,
+                                      _c.c_int, _f32p, _vp]),
+    'dcahip_bn_bwd_apply': (_c.c_int, [_f32p, _c.c_long, _f32p, _c.c_long, _f32p, _c.c_long, _f32p,
+                                       _f32p, _c.c_int, _c.c_float, _c.c_int, _c.c_int, _f32p,
+                                       _c.c_long, _f32p, _vp]),
+    'dcahip_relu_bwd': (_c.c_int, [_f32p, _c.c_long, _f32p, _c.c_long, _c.c_int, _c.c_int, _f32p,
+                                   _c.c_long, _vp]),
+    'dcahip_colsum_chain': (_c.c_int, [_f32p, _c.c_long, _c.c_int, _c.c_int, _f32p, _f32p, _vp]),
+    'dcahip_rmsprop_clip': (_c.c_int, [_f32p, _f32p, _f32p, _c.c_long, _f32p, _c.c_float,
+                                       _c.c_float, _c.c_float, _vp]),
+}
+
+# entry points added by later source files; bound when present in the library
+_OPTIONAL = {
+    'dcahip_prep_row_sums': (_c.c_int, [_f32p, _c.c_long, _c.c_int, _c.c_int, _f32p, _vp]),
+    'dcahip_prep_normalize_log1p': (_c.c_int, [_f32p, _c.c_long, _c.c_int, _c.c_int, _f32p, _c.c_int,
+                                               _c.c_int, _f32p, _c.c_long, _vp]),
+    'dcahip_prep_scale': (_c.c_int, [_f32p, _c.c_long, _c.c_int, _c.c_int, _f32p, _vp]),
+}
+
+_lib = None
+
+
+class HipExtensionMissing(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads libdcahip.so once (building it with hipcc first if it is absent or stale)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if _build.needs_build():
+        try:
+            _build.build_hip(verbose=False)
+        except Exception as e:  # noqa: BLE001
+            if not os.path.exists(path):
+                raise HipExtensionMissing(
+                    'dca_amd: libdcahip.so is missing and could not be built (%s). The HIP '
+                    'extension is mandatory; there is no CPU fallback.' % e) from e
+    try:
+        L = ctypes.CDLL(path)
+    except OSError as e:
+        raise HipExtensionMissing('dca_amd: cannot load %s: %s' % (path, e)) from e
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(L, name)          # AttributeError => header / library mismatch: loud
+        fn.restype, fn.argtypes = res, args
+    for name, (res, args) in _OPTIONAL.items():
+        if hasattr(L, name):
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+    assert L.dcahip_version() == 1
+    _lib = L
+    return L
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError('dca_amd: no AMD GPU visible (torch.cuda.is_available() is False); the '
+                           'training path runs on MI355X only -- there is no CPU fallback.')
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL). Refuses host memory."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError('dca_amd.hip: host tensor passed to a HIP kernel')
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError('dca_amd.hip: %s failed with code %d' % (what, rc))

@@ -1,0 +1,105 @@
+"""HipOps: tensor-level view of the C ABI (one method per entry point of include/dcahip.h).
+
+The training engine (engine.py) is written against this small interface.  The product always
+instantiates HipOps -- construction fails loudly without the HIP library or without a GPU.
+(Tests exercise the engine's host logic on CPU by injecting an oracle-backed object with the
+same methods; that object lives under oracle/ and is never imported from this package.)
+"""
+import ctypes
+
+from . import hip
+
+
+class HipOps:
+    name = 'hip'
+    device_type = 'cuda'
+
+    def __init__(self):
+        hip.require_gpu()
+        self.L = hip.lib()
+        self.max_partials = self.L.dcahip_zinb_max_partials()
+
+    # ------------------------------------------------------------------ loss
+    def zinb_nll(self, a_mean, a_disp, a_pi, lda, theta_w, Y, ldy, sf, perm, cursor, B, G, ridge,
+                 inv_n, flags, d_mean, d_disp, d_pi, ldd, partials):
+        n = ctypes.c_int(0)
+        p = hip.ptr
+        hip.check(self.L.dcahip_zinb_nll(p(a_mean), p(a_disp), p(a_pi), lda, p(theta_w), p(Y), ldy,
+                                         p(sf), p(perm), p(cursor), B, G, ridge, inv_n, flags,
+                                         p(d_mean), p(d_disp), p(d_pi), ldd, p(partials),
+                                         ctypes.byref(n), hip.stream()), 'zinb_nll')
+        return n.value
+
+    def loss_finalize(self, partials, n, scale, loss_out):
+        hip.check(self.L.dcahip_loss_finalize(hip.ptr(partials), n, scale, hip.ptr(loss_out),
+                                              hip.stream()), 'loss_finalize')
+
+    def step_end(self, loss, weight, hist, rows_per_slot, acc, cursor, advance):
+        p = hip.ptr
+        hip.check(self.L.dcahip_step_end(p(loss), weight, p(hist), rows_per_slot, p(acc), p(cursor),
+                                         advance, hip.stream()), 'step_end')
+
+    def heads_infer(self, a_mean, a_disp, a_pi, lda, sf, B, G, mean_sf, theta, pi, ldo):
+        p = hip.ptr
+        hip.check(self.L.dcahip_zinb_heads_infer(p(a_mean), p(a_disp), p(a_pi), lda, p(sf), B, G,
+                                                 p(mean_sf), p(theta), p(pi), ldo, hip.stream()),
+                  'heads_infer')
+
+    # ------------------------------------------------------------------ gemm
+    def sgemm_workspace_bytes(self, ta, tb, M, N, K, colsum_row=False, split_k=0):
+        return self.L.dcahip_sgemm_workspace_bytes(int(ta), int(tb), M, N, K, int(colsum_row), split_k)
+
+    def sgemm(self, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias=None, perm=None, cursor=None,
+              colsum_row=False, split_k=0, ws=None):
+        p = hip.ptr
+        wsb = ws.numel() * ws.element_size() if ws is not None else 0
+        hip.check(self.L.dcahip_sgemm(int(ta), int(tb), M, N, K, p(A), lda, p(B), ldb, p(C), ldc,
+                                      p(bias), p(perm), p(cursor), int(colsum_row), split_k, p(ws),
+                                      wsb, hip.stream()), 'sgemm')
+
+    # ------------------------------------------------------------------ batch norm
+    def col_moments_chunks(self, B):
+        return self.L.dcahip_col_moments_chunks(B)
+
+    def col_moments(self, Z, ldz, B, H, part):
+        hip.check(self.L.dcahip_col_moments(hip.ptr(Z), ldz, B, H, hip.ptr(part), hip.stream()),
+                  'col_moments')
+
+    def moments_combine(self, entries, counts, E, H, out):
+        hip.check(self.L.dcahip_moments_combine(hip.ptr(entries), hip.ptr(counts), E, H, hip.ptr(out),
+                                                hip.stream()), 'moments_combine')
+
+    def bn_relu_apply(self, Z, ldz, B, H, entries, counts, E, beta, mm, mv, momentum, eps, relu,
+                      Hout, ldh, xhat, ldx, inv_std):
+        p = hip.ptr
+        hip.check(self.L.dcahip_bn_relu_apply(p(Z), ldz, B, H, p(entries), p(counts), E, p(beta),
+                                              p(mm), p(mv), momentum, eps, int(relu), p(Hout), ldh,
+                                              p(xhat), ldx, p(inv_std), hip.stream()), 'bn_relu_apply')
+
+    def bn_bwd_sums(self, dH, ldd, Hact, ldh, xhat, ldx, B, H, part):
+        p = hip.ptr
+        hip.check(self.L.dcahip_bn_bwd_sums(p(dH), ldd, p(Hact), ldh, p(xhat), ldx, B, H, p(part),
+                                            hip.stream()), 'bn_bwd_sums')
+
+    def bn_bwd_apply(self, dH, ldd, Hact, ldh, xhat, ldx, inv_std, sums, E, n_total, B, H, dZ, ldz,
+                     dbeta):
+        p = hip.ptr
+        hip.check(self.L.dcahip_bn_bwd_apply(p(dH), ldd, p(Hact), ldh, p(xhat), ldx, p(inv_std),
+                                             p(sums), E, float(n_total), B, H, p(dZ), ldz, p(dbeta),
+                                             hip.stream()), 'bn_bwd_apply')
+
+    def relu_bwd(self, dH, ldd, Hact, ldh, B, H, dZ, ldz):
+        p = hip.ptr
+        hip.check(self.L.dcahip_relu_bwd(p(dH), ldd, p(Hact), ldh, B, H, p(dZ), ldz, hip.stream()),
+                  'relu_bwd')
+
+    def colsum_chain(self, x, ldx, B, N, theta_w, out):
+        p = hip.ptr
+        hip.check(self.L.dcahip_colsum_chain(p(x), ldx, B, N, p(theta_w), p(out), hip.stream()),
+                  'colsum_chain')
+
+    # ------------------------------------------------------------------ optimizer
+    def rmsprop_clip(self, w, g, ms, n, lr, rho, eps, clip):
+        p = hip.ptr
+        hip.check(self.L.dcahip_rmsprop_clip(p(w), p(g), p(ms), n, p(lr), rho, eps, clip,
+                                             hip.stream()), 'rmsprop_clip')

@@ -1,0 +1,176 @@
+/*
+ * dcahip.h -- C ABI of libdcahip.so: the MI355X (gfx950) kernels behind the DCA
+ * ZINB-autoencoder training path.
+ *
+ * The reference (theislab/dca v0.3.3) has NO native / FFI interface on this path: every
+ * FLOP is a stock TensorFlow CPU kernel reached through Keras.  Each entry
+ * point below therefore cites the reference Python call site(s) whose TensorFlow ops it
+ * replaces; a maintainer binds them with ctypes exactly as dca_amd/hip.py does (see
+ * INTEGRATION.md for the stub).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to row-major fp32 unless stated; the caller
+ *     (host code / PyTorch as allocator) owns every buffer, the library allocates nothing
+ *     and keeps no global state;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), re-entrant
+ *     across streams and capturable into a hipGraph (no host synchronisation inside);
+ *   - return value: 0 on success, otherwise the hipError_t of the failed launch or
+ *     DCAHIP_EINVAL for an argument the kernels cannot take (never throws, never aborts);
+ *   - "gather": kernels that consume a minibatch read row r of the batch from storage row
+ *     perm[*cursor + r] of the resident matrix, so the shuffled batch is never materialised
+ *     (reference: Keras slices index_array[batch_start:batch_end] on the host and feeds
+ *     copies, dca/train.py:91-98).  perm == NULL means identity (row r); cursor == NULL
+ *     means offset 0.  `cursor` lives in device memory so a captured step graph can be
+ *     replayed for every batch of an epoch.
+ */
+#ifndef DCAHIP_H
+#define DCAHIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DCAHIP_VERSION 1
+#define DCAHIP_EINVAL (-22)
+
+/* flags for dcahip_zinb_nll */
+#define DCAHIP_NLL_HAS_PI      1   /* ZINB (pi head present); otherwise plain NB          */
+#define DCAHIP_NLL_CONST_DISP  2   /* theta = clip(exp(theta_w[g]),1e-3,1e4) per gene      */
+
+int dcahip_version(void);
+
+/* Upper bound of `double` slots dcahip_zinb_nll writes to loss_partials. */
+int dcahip_zinb_max_partials(void);
+
+/*
+ * NB / ZINB negative log-likelihood of one minibatch and its gradient with respect to the
+ * head PRE-activations, one pass over the B x G tile (28 B/element: reads 3 pre-activation
+ * planes + y, writes 3 gradient planes).
+ * Replaces: MeanAct/DispAct/sigmoid (dca/network.py:38-39,369-380), ColwiseMultLayer
+ * (dca/layers.py:85), NB.loss (dca/loss.py:72-114), ZINB.loss (dca/loss.py:122-156),
+ * ConstantDispersionLayer.theta_exp (dca/layers.py:21) and TensorFlow's autodiff of them.
+ *
+ *   a_mean, a_disp, a_pi : [B, lda] pre-activations (a_disp NULL with CONST_DISP, a_pi NULL
+ *                          without HAS_PI)
+ *   theta_w              : [G] log-dispersion (CONST_DISP only)
+ *   y, ldy               : resident raw-count matrix (gathered by perm/cursor), sf: [n] size
+ *                          factors indexed by the same storage row
+ *   inv_n                : 1 / (B_global * G): the reduce_mean divisor folded into the grads
+ *   d_mean, d_disp, d_pi : [B, ldd] gradients out (all NULL => loss only, e.g. validation).
+ *                          With CONST_DISP d_disp receives d nll/d theta * inv_n per element
+ *                          (column-reduce it with dcahip_colsum_chain).
+ *                          Columns g in [G, ldd-plane width) are not touched; columns in the
+ *                          last partial quad (g >= G, < roundup4(G)) are written as 0.
+ *   loss_partials        : [>= dcahip_zinb_max_partials()] doubles; *n_partials_out (host
+ *                          int, may be NULL) = slots written = grid size (deterministic).
+ */
+int dcahip_zinb_nll(const float* a_mean, const float* a_disp, const float* a_pi, long lda,
+                    const float* theta_w,
+                    const float* y, long ldy, const float* sf,
+                    const int* perm, const long long* cursor,
+                    int B, int G, float ridge, float inv_n, int flags,
+                    float* d_mean, float* d_disp, float* d_pi, long ldd,
+                    double* loss_partials, int* n_partials_out, void* stream);
+
+/*
+ * Deterministic second stage of the loss reduction: loss = scale * sum(partials) with
+ * nan -> inf (dca/loss.py:148), written to *loss_out (fp32, device).
+ */
+int dcahip_loss_finalize(const double* partials, int n_partials, double scale,
+                         float* loss_out, void* stream);
+
+/*
+ * End-of-step bookkeeping in one tiny launch: hist[*cursor / rows_per_slot] = *loss (if
+ * hist), *acc += *loss * weight (Keras' sample-weighted epoch mean, if acc), *cursor += advance.
+ */
+int dcahip_step_end(const float* loss, double weight, float* hist, int rows_per_slot,
+                    double* acc, long long* cursor, int advance, void* stream);
+
+/*
+ * Inference heads: mean*sf, theta, pi from pre-activations (in-place allowed: out == in).
+ * Replaces model.predict / extra_models['dispersion'|'pi'].predict (dca/network.py:188-211,
+ * 395-405).  sf is indexed by batch row (no gather).  Outputs may be NULL.
+ */
+int dcahip_zinb_heads_infer(const float* a_mean, const float* a_disp, const float* a_pi,
+                            long lda, const float* sf, int B, int G,
+                            float* mean_sf, float* theta, float* pi, long ldo, void* stream);
+
+/*
+ * C[M,N] = op(A) * op(B) (+ bias) on the fp32 MFMA pipe (v_mfma_f32_32x32x2_f32), LDS-tiled,
+ * deterministic split-K through `workspace`.  Replaces the MatMul/BiasAdd kernels of every
+ * keras Dense layer forward and backward (dca/network.py:124-126,369-380 and autodiff).
+ *   ta == 0: A stored [M,K] (lda >= K)      ta == 1: A stored [K,M]   (C = A^T B, weight grads)
+ *   tb == 0: B stored [K,N]                 tb == 1: B stored [N,K]   (C = A B^T, input grads)
+ *   bias     : [N] added to every row of C, or NULL
+ *   perm/cursor : gather on A's STORAGE rows (batch rows: m index if ta==0, k index if ta==1)
+ *   colsum_row  : if non-zero (ta==1 only) additionally writes colsum_k B[k,:] into row M of
+ *                 C (C + M*ldc): the Dense bias gradient, free while B streams through LDS
+ *   split_k  : 0 = library heuristic (a pure function of the shape), else forced
+ *   workspace: >= dcahip_sgemm_workspace_bytes(...) bytes, may be NULL when that is 0
+ */
+int dcahip_sgemm(int ta, int tb, int M, int N, int K,
+                 const float* A, long lda, const float* B, long ldb, float* C, long ldc,
+                 const float* bias, const int* perm, const long long* cursor,
+                 int colsum_row, int split_k, void* workspace, long workspace_bytes,
+                 void* stream);
+long dcahip_sgemm_workspace_bytes(int ta, int tb, int M, int N, int K, int colsum_row, int split_k);
+
+/*
+ * Batch normalisation (center=True, scale=False, eps inside rsqrt) + ReLU, training mode.
+ * Replaces keras BatchNormalization + Activation('relu') (dca/network.py:127-135).
+ * Three stages so that data-parallel runs can exchange the statistics in between:
+ *  1. dcahip_col_moments: per row-chunk (mean, M2) of Z[B,H]  -> part[R][2][H], R returned
+ *  2. (DP only) dcahip_moments_combine: merge E entries (counts[e] rows each) into one
+ *  3. dcahip_bn_relu_apply: merge the E entries it is given (Chan et al.), then
+ *        xhat = (z - mean) * rsqrt(var + eps); h = max(xhat + beta, 0)
+ *     writes h, xhat (may be NULL), inv_std[H], and (training) updates
+ *        moving = moving - (moving - batch) * (1 - momentum)   (biased variance).
+ *     With entries == NULL it runs in INFERENCE mode on moving_mean / moving_var.
+ *     relu == 0 skips the activation (used for the latent 'center' output).
+ */
+int dcahip_col_moments_chunks(int B);
+int dcahip_col_moments(const float* Z, long ldz, int B, int H, float* part, void* stream);
+int dcahip_moments_combine(const float* entries, const float* counts, int E, int H,
+                           float* out /*[2][H]*/, void* stream);
+int dcahip_bn_relu_apply(const float* Z, long ldz, int B, int H,
+                         const float* entries, const float* counts, int E,
+                         const float* beta, float* moving_mean, float* moving_var,
+                         float momentum, float eps, int relu,
+                         float* Hout, long ldh, float* xhat, long ldx, float* inv_std,
+                         void* stream);
+
+/*
+ * Backward of ReLU + batch norm.  mask = the forward output h (h > 0 <=> pre-ReLU > 0).
+ *  1. dcahip_bn_bwd_sums: per row-chunk sums of dy and dy*xhat, dy = dh*[h>0] -> part[R][2][H]
+ *  2. (DP only) all-reduce the combined sums
+ *  3. dcahip_bn_bwd_apply: dz = inv_std * (dy - S1/n - xhat * S2/n), dbeta = S1
+ *     (sums: E entries [E][2][H] are added in order; n_total = global batch rows).
+ * Without batch norm use dcahip_relu_bwd (dz = dh*[h>0]).
+ */
+int dcahip_bn_bwd_sums(const float* dH, long ldd, const float* Hact, long ldh,
+                       const float* xhat, long ldx, int B, int H, float* part, void* stream);
+int dcahip_bn_bwd_apply(const float* dH, long ldd, const float* Hact, long ldh,
+                        const float* xhat, long ldx, const float* inv_std,
+                        const float* sums, int E, float n_total, int B, int H,
+                        float* dZ, long ldz, float* dbeta, void* stream);
+int dcahip_relu_bwd(const float* dH, long ldd, const float* Hact, long ldh, int B, int H,
+                    float* dZ, long ldz, void* stream);
+
+/* out[c] (+)= chain(c) * sum_r x[r, c]; chain = d clip(exp(w),1e-3,1e4)/dw if theta_w given
+ * (ConstantDispersionLayer gradient, dca/layers.py:17-21), else 1. */
+int dcahip_colsum_chain(const float* x, long ldx, int B, int N, const float* theta_w,
+                        float* out, void* stream);
+
+/*
+ * Keras clipvalue + tf.keras RMSprop on one flat parameter buffer:
+ *   g = clip(g, -clip, clip); ms = rho*ms + (1-rho)*g*g; w -= lr * g / sqrt(ms + eps)
+ * Replaces opt.RMSprop(lr, clipvalue) (dca/train.py:54-57).  *lr is read from device memory
+ * so ReduceLROnPlateau does not invalidate a captured graph.  clip <= 0 disables clipping.
+ */
+int dcahip_rmsprop_clip(float* w, const float* g, float* ms, long n, const float* lr,
+                        float rho, float eps, float clip, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCAHIP_H */

@@ -1,0 +1,338 @@
+"""Per-kernel parity: every HIP entry point against the numpy oracle on seeded inputs.
+
+All calls go through the C ABI (dca_amd.hip / dca_amd.ops).  Tolerances are stated against
+the fp64 oracle; the kernels compute in fp32.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import synth_counts
+from oracle import zinb_np as Z
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from dca_amd.ops import HipOps
+    return HipOps()
+
+
+def dev(a, dtype=torch.float32):
+    return torch.as_tensor(np.ascontiguousarray(a)).to(dtype).cuda()
+
+
+def pad_cols(a, ld):
+    out = np.zeros((a.shape[0], ld), a.dtype)
+    out[:, :a.shape[1]] = a
+    return out
+
+
+# ------------------------------------------------------------------------------- K-ZINB
+def _heads(B, G, seed, edge):
+    rng = np.random.RandomState(seed)
+    am = rng.normal(0, 1.5, (B, G)); ad = rng.normal(0, 2, (B, G)); ap = rng.normal(0, 2, (B, G))
+    y = synth_counts(B, G, seed)
+    sf = rng.lognormal(0, 0.3, B)
+    if edge:
+        am[0, :4] = [-14., 15., 0., 30.]
+        ad[1, :4] = [-12., 9500., 20., -3.]
+        ap[2, :4] = [-30., 30., 0., 12.]
+        y[3, :4] = [0, 1, 200, 5000]
+        am[3, :4] = [1., 1., 5., 8.]
+        y[4, :3] = [2.52, 0.5, 17.0]        # non-integer "counts" (check_counts=False inputs)
+        am[5, :2] = [95., -120.]            # exp overflow / underflow
+        ad[6, :3] = [9.3, 9.21, 100.]       # theta near / at the 1e4 clip
+    return [a.astype(np.float32).astype(np.float64) for a in (am, ad, ap, y, sf)]
+
+
+@pytest.mark.parametrize('flags', [1, 0, 3, 2])
+@pytest.mark.parametrize('B,G,edge', [(8, 40, True), (33, 1000, False), (5, 6, False), (16, 203, True)])
+def test_zinb_nll_vs_oracle(ops, flags, B, G, edge):
+    has_pi, cdisp = bool(flags & 1), bool(flags & 2)
+    am, ad, ap, y, sf = _heads(B, G, 11 + B, edge)
+    rng = np.random.RandomState(5)
+    tw = rng.normal(0, 1.5, G).astype(np.float32).astype(np.float64)
+    n_store = B + 7
+    perm = rng.permutation(n_store)[:B + 3].astype(np.int32)
+    cur = 3
+    rows = perm[cur:cur + B]
+    Gp = (G + 3) // 4 * 4
+    Yst = np.zeros((n_store, Gp)); Yst[rows, :G] = y
+    sfst = np.ones(n_store); sfst[rows] = sf
+    ridge = 0.05 if has_pi else 0.0
+    inv_n = 1.0 / (B * G)
+    if has_pi:
+        ls, lm, dm, dd, dp = Z.zinb_loss_and_grads(am, None if cdisp else ad, ap, y, sf, ridge,
+                                                   theta_w=tw if cdisp else None)
+    else:
+        ls, lm, dm, dd = Z.nb_loss_and_grads(am, None if cdisp else ad, y, sf,
+                                             theta_w=tw if cdisp else None)
+        dp = None
+    lda = 3 * Gp
+    A = np.zeros((B, lda)); A[:, :G] = am; A[:, Gp:Gp + G] = ad; A[:, 2 * Gp:2 * Gp + G] = ap
+    dA = dev(A); dD = torch.full((B, lda), 7.0, device='cuda')
+    dY, dsf, dperm = dev(Yst), dev(sfst), torch.as_tensor(perm).cuda()
+    dcur = torch.tensor([cur], dtype=torch.int64, device='cuda')
+    dtw = dev(tw)
+    part = torch.zeros(ops.max_partials, dtype=torch.float64, device='cuda')
+    a_mean, a_disp, a_pi = dA[:, 0:], dA[:, Gp:], dA[:, 2 * Gp:]
+    d_mean, d_disp, d_pi = dD[:, 0:], dD[:, Gp:], dD[:, 2 * Gp:]
+    n = ops.zinb_nll(a_mean, None if cdisp else a_disp, a_pi if has_pi else None, lda,
+                     dtw if cdisp else None, dY, Gp, dsf, dperm, dcur, B, G, ridge, inv_n, flags,
+                     d_mean, d_disp, d_pi if has_pi else None, lda, part)
+    loss = torch.zeros(1, device='cuda')
+    ops.loss_finalize(part, n, inv_n, loss)
+    torch.cuda.synchronize()
+    got = loss.item()
+    assert abs(got - lm) <= 3e-6 * abs(lm), (got, lm)
+    D = dD.cpu().numpy().astype(np.float64)
+
+    def close(g, ref, name):
+        scale = np.abs(ref).max()
+        err = np.abs(g - ref)
+        bad = err > (2e-4 * np.abs(ref) + 2e-6 * scale)
+        assert not bad.any(), (name, int(bad.sum()), np.argwhere(bad)[:5], g[bad][:5], ref[bad][:5])
+    close(D[:, :G], dm, 'd_mean')
+    if cdisp:
+        # per-element d nll/d theta * inv_n; the chain + column sum is dcahip_colsum_chain
+        out = torch.zeros(G, device='cuda')
+        ops.colsum_chain(d_disp, lda, B, G, dtw, out)
+        torch.cuda.synchronize()
+        close(out.cpu().numpy().astype(np.float64), dd, 'd_theta_w')
+    else:
+        close(D[:, Gp:Gp + G], dd, 'd_disp')
+    if has_pi:
+        close(D[:, 2 * Gp:2 * Gp + G], dp, 'd_pi')
+    # padded quad columns are written as zero, never garbage
+    if Gp > G:
+        assert (D[:, G:Gp] == 0).all()
+    # loss-only mode (validation) gives the same loss and touches no gradient buffer
+    part.zero_()
+    n2 = ops.zinb_nll(a_mean, None if cdisp else a_disp, a_pi if has_pi else None, lda,
+                      dtw if cdisp else None, dY, Gp, dsf, dperm, dcur, B, G, ridge, inv_n, flags,
+                      None, None, None, 0, part)
+    ops.loss_finalize(part, n2, inv_n, loss)
+    torch.cuda.synchronize()
+    assert abs(loss.item() - got) <= 1e-6 * abs(got)
+
+
+def test_zinb_nll_unaligned_scalar_path(ops):
+    """ld not a multiple of 4 -> the kernel must take its scalar path and still be right."""
+    B, G = 9, 37
+    am, ad, ap, y, sf = _heads(B, G, 3, False)
+    _, lm, dm, dd, dp = Z.zinb_loss_and_grads(am, ad, ap, y, sf, 0.0)
+    lda = 3 * G + 1
+    A = np.zeros((B, lda)); A[:, :G] = am; A[:, G:2 * G] = ad; A[:, 2 * G:3 * G] = ap
+    dA = dev(A); dD = torch.zeros((B, lda), device='cuda')
+    part = torch.zeros(ops.max_partials, dtype=torch.float64, device='cuda')
+    n = ops.zinb_nll(dA[:, 0:], dA[:, G:], dA[:, 2 * G:], lda, None, dev(y), G, dev(sf), None, None,
+                     B, G, 0.0, 1.0 / (B * G), 1, dD[:, 0:], dD[:, G:], dD[:, 2 * G:], lda, part)
+    loss = torch.zeros(1, device='cuda')
+    ops.loss_finalize(part, n, 1.0 / (B * G), loss)
+    torch.cuda.synchronize()
+    assert abs(loss.item() - lm) <= 3e-6 * abs(lm)
+    D = dD.cpu().numpy()
+    np.testing.assert_allclose(D[:, :G], dm, rtol=2e-4, atol=2e-6 * np.abs(dm).max())
+    np.testing.assert_allclose(D[:, 2 * G:3 * G], dp, rtol=2e-4, atol=2e-6 * np.abs(dp).max())
+
+
+def test_loss_nan_maps_to_inf_and_step_end(ops):
+    part = torch.tensor([1.0, float('nan')], dtype=torch.float64, device='cuda')
+    loss = torch.zeros(1, device='cuda')
+    ops.loss_finalize(part, 2, 1.0, loss)
+    torch.cuda.synchronize()
+    assert np.isinf(loss.item())
+    loss.fill_(2.5)
+    hist = torch.zeros(8, device='cuda'); acc = torch.zeros(1, dtype=torch.float64, device='cuda')
+    cur = torch.tensor([64], dtype=torch.int64, device='cuda')
+    ops.step_end(loss, 32.0, hist, 32, acc, cur, 32)
+    ops.step_end(loss, 7.0, hist, 32, acc, cur, 7)
+    torch.cuda.synchronize()
+    assert cur.item() == 103 and acc.item() == 2.5 * 39
+    assert hist.cpu().tolist() == [0, 0, 2.5, 2.5, 0, 0, 0, 0]
+
+
+def test_heads_infer(ops):
+    B, G = 7, 50
+    am, ad, ap, y, sf = _heads(B, G, 2, True)
+    Gp = 52
+    A = np.zeros((B, 3 * Gp)); A[:, :G] = am; A[:, Gp:Gp + G] = ad; A[:, 2 * Gp:2 * Gp + G] = ap
+    dA = dev(A)
+    mu, th, pi = Z.heads_forward(am, ad, ap, sf)
+    ops.heads_infer(dA[:, 0:], dA[:, Gp:], dA[:, 2 * Gp:], 3 * Gp, dev(sf), B, G,
+                    dA[:, 0:], dA[:, Gp:], dA[:, 2 * Gp:], 3 * Gp)     # in place
+    torch.cuda.synchronize()
+    O = dA.cpu().numpy()
+    np.testing.assert_allclose(O[:, :G], mu, rtol=3e-6)
+    np.testing.assert_allclose(O[:, Gp:Gp + G], th, rtol=3e-6)
+    np.testing.assert_allclose(O[:, 2 * Gp:2 * Gp + G], pi, rtol=3e-6, atol=1e-30)
+
+
+# ------------------------------------------------------------------------------- K-GEMM
+GEMM_SHAPES = [
+    # ta, tb, M, N, K, gather, bias, colsum, split
+    (0, 0, 32, 64, 1000, True, True, False, 0),      # enc0 fwd, B=32 (auto split-K)
+    (0, 0, 200, 64, 517, True, True, False, 3),      # ragged K, forced split
+    (0, 0, 32, 3000, 64, False, True, False, 0),     # heads fwd, small M (cfg 64x128)
+    (0, 0, 300, 1500, 64, False, True, False, 0),    # heads fwd, large M (cfg 128x128)
+    (0, 0, 45, 6, 3, False, True, False, 0),         # tiny odd (biochemists-like)
+    (1, 0, 64, 3000, 32, False, False, True, 0),     # dW heads + bias grad row
+    (1, 0, 64, 700, 300, False, False, True, 2),     # dW heads, split-K with colsum row
+    (1, 0, 1000, 64, 32, True, False, True, 0),      # dW0 with gathered K rows
+    (1, 0, 333, 33, 130, True, False, True, 0),      # odd sizes (scalar tails)
+    (1, 0, 150, 200, 260, False, False, True, 0),    # cfg 128x128, TN
+    (0, 1, 32, 64, 3000, False, False, False, 0),    # dH (NT), big K
+    (0, 1, 130, 32, 64, False, False, False, 0),     # dH mid layer
+    (0, 1, 257, 190, 99, False, False, False, 0),    # cfg 128x128, NT, odd
+    (0, 0, 17, 5, 9, False, False, False, 0),        # unaligned ld -> scalar loads
+]
+
+
+@pytest.mark.parametrize('ta,tb,M,N,K,gather,bias,colsum,split', GEMM_SHAPES)
+def test_sgemm_vs_numpy(ops, ta, tb, M, N, K, gather, bias, colsum, split):
+    rng = np.random.RandomState(M + N + K)
+    ra, ca = (K, M) if ta else (M, K)
+    rb, cb = (N, K) if tb else (K, N)
+    unaligned = (N == 5)
+    lda = ca + (1 if unaligned else (-ca) % 4)
+    ldb = cb + (1 if unaligned else (-cb) % 4)
+    n_store = ra + 9 if gather else ra
+    Ast = rng.uniform(-1, 1, (n_store, lda)).astype(np.float32)
+    Bm = rng.uniform(-1, 1, (rb, ldb)).astype(np.float32)
+    cur = 4
+    if gather:
+        perm = rng.permutation(n_store)[:ra + cur].astype(np.int32)
+        Arows = Ast[perm[cur:cur + ra]]
+    else:
+        perm = None
+        Arows = Ast
+    A = Arows[:, :ca].astype(np.float64)
+    Bv = Bm[:, :cb].astype(np.float64)
+    opA = A.T if ta else A
+    opB = Bv.T if tb else Bv
+    ref = opA @ opB
+    absref = np.abs(opA) @ np.abs(opB)
+    bvec = rng.uniform(-1, 1, N).astype(np.float32) if bias else None
+    if bias:
+        ref = ref + bvec.astype(np.float64)
+    ldc = N + (-N) % 4
+    Mo = M + (1 if colsum else 0)
+    C = torch.full((Mo + 1, ldc), 123.0, device='cuda')
+    wsb = ops.sgemm_workspace_bytes(ta, tb, M, N, K, colsum, split)
+    ws = torch.empty(max(wsb // 4, 1), device='cuda')
+    dcur = torch.tensor([cur], dtype=torch.int64, device='cuda') if gather else None
+    ops.sgemm(ta, tb, M, N, K, dev(Ast), lda, dev(Bm), ldb, C, ldc, bias=dev(bvec) if bias else None,
+              perm=torch.as_tensor(perm).cuda() if gather else None, cursor=dcur,
+              colsum_row=colsum, split_k=split, ws=ws)
+    torch.cuda.synchronize()
+    out = C.cpu().numpy().astype(np.float64)
+    err = np.abs(out[:M, :N] - ref)
+    tol = 2e-6 * absref + 1e-6
+    assert (err <= tol).all(), (err.max(), np.argwhere(err > tol)[:5])
+    if colsum:
+        cs = Bv.sum(axis=0)
+        np.testing.assert_allclose(out[M, :N], cs, rtol=0, atol=2e-6 * np.abs(Bv).sum(axis=0).max() + 1e-6)
+    # nothing outside the [Mo, N] window is touched
+    assert (out[Mo:, :] == 123.0).all() and (out[:, N:] == 123.0).all()
+
+
+# ------------------------------------------------------------------------------- batch norm
+@pytest.mark.parametrize('B,H', [(32, 64), (25, 32), (300, 64), (1000, 130), (8, 1)])
+def test_bn_forward_backward(ops, B, H):
+    rng = np.random.RandomState(B + H)
+    Zm = (rng.normal(0.3, 2.0, (B, H)) + rng.normal(0, 3, H)).astype(np.float32)
+    beta = rng.normal(0, .5, H).astype(np.float32)
+    mm0 = rng.normal(0, 1, H).astype(np.float32); mv0 = rng.uniform(.5, 2, H).astype(np.float32)
+    dHm = rng.normal(0, 1, (B, H)).astype(np.float32)
+    z = Zm.astype(np.float64)
+    mu = z.mean(0); var = ((z - mu) ** 2).mean(0)
+    inv = 1 / np.sqrt(var + 1e-3)
+    xh = (z - mu) * inv
+    yb = xh + beta
+    h = np.maximum(yb, 0)
+    dy = dHm * (yb > 0)
+    dz = inv * (dy - dy.mean(0) - xh * (dy * xh).mean(0))
+    ldz = H + (-H) % 4
+    dZ_in = dev(pad_cols(Zm, ldz))
+    R = ops.col_moments_chunks(B)
+    part = torch.zeros(R * 2 * H, device='cuda')
+    ops.col_moments(dZ_in, ldz, B, H, part)
+    Hout = torch.zeros(B, ldz, device='cuda'); xhat = torch.zeros(B, ldz, device='cuda')
+    inv_std = torch.zeros(H, device='cuda')
+    mm, mv = dev(mm0), dev(mv0)
+    ops.bn_relu_apply(dZ_in, ldz, B, H, part, None, R, dev(beta), mm, mv, 0.99, 1e-3, True,
+                      Hout, ldz, xhat, ldz, inv_std)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(Hout.cpu().numpy()[:, :H], h, rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(xhat.cpu().numpy()[:, :H], xh, rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(inv_std.cpu().numpy(), inv, rtol=1e-5)
+    np.testing.assert_allclose(mm.cpu().numpy(), mm0 - (mm0 - mu) * 0.01, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(mv.cpu().numpy(), mv0 - (mv0 - var) * 0.01, rtol=1e-5, atol=1e-6)
+    # backward
+    ddH = dev(pad_cols(dHm, ldz))
+    bpart = torch.zeros(R * 2 * H, device='cuda')
+    ops.bn_bwd_sums(ddH, ldz, Hout, ldz, xhat, ldz, B, H, bpart)
+    dZ = torch.zeros(B, ldz, device='cuda'); dbeta = torch.zeros(H, device='cuda')
+    ops.bn_bwd_apply(ddH, ldz, Hout, ldz, xhat, ldz, inv_std, bpart, R, float(B), B, H, dZ, ldz, dbeta)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(dZ.cpu().numpy()[:, :H], dz, rtol=1e-4, atol=2e-5 * np.abs(dz).max())
+    np.testing.assert_allclose(dbeta.cpu().numpy(), dy.sum(0), rtol=1e-4, atol=1e-4)
+    # inference mode uses the moving statistics and leaves them untouched
+    mm_b, mv_b = mm.clone(), mv.clone()
+    ops.bn_relu_apply(dZ_in, ldz, B, H, None, None, 0, dev(beta), mm, mv, 0.99, 1e-3, True,
+                      Hout, ldz, None, 0, None)
+    torch.cuda.synchronize()
+    ref = np.maximum((z - mm_b.cpu().numpy()) / np.sqrt(mv_b.cpu().numpy() + 1e-3) + beta, 0)
+    np.testing.assert_allclose(Hout.cpu().numpy()[:, :H], ref, rtol=2e-5, atol=2e-5)
+    assert torch.equal(mm, mm_b) and torch.equal(mv, mv_b)
+    # relu backward without batch norm
+    ops.relu_bwd(ddH, ldz, Hout, ldz, B, H, dZ, ldz)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(dZ.cpu().numpy()[:, :H], dHm * (ref > 0))
+
+
+def test_moments_combine_matches_global_stats(ops):
+    """SyncBN building block: merging per-rank (count, mean, M2) == statistics of the union."""
+    rng = np.random.RandomState(0)
+    H = 64
+    parts = [rng.normal(1 + r, 2, (b, H)).astype(np.float32) for r, b in enumerate([40, 17, 64])]
+    ent, cnt = [], []
+    for p in parts:
+        B = p.shape[0]
+        R = ops.col_moments_chunks(B)
+        part = torch.zeros(R * 2 * H, device='cuda')
+        ops.col_moments(dev(p), H, B, H, part)
+        cr = -(-B // R)
+        counts = dev(np.array([min(B, (r + 1) * cr) - r * cr for r in range(R)], np.float32))
+        out = torch.zeros(2 * H, device='cuda')
+        ops.moments_combine(part, counts, R, H, out)
+        ent.append(out); cnt.append(float(B))
+    allz = np.concatenate(parts).astype(np.float64)
+    Zd = dev(allz)
+    Hout = torch.zeros_like(Zd); inv_std = torch.zeros(H, device='cuda')
+    mm = torch.zeros(H, device='cuda'); mv = torch.ones(H, device='cuda')
+    ops.bn_relu_apply(Zd, H, allz.shape[0], H, torch.cat(ent), dev(np.array(cnt, np.float32)), 3,
+                      None, mm, mv, 0.99, 1e-3, False, Hout, H, None, 0, inv_std)
+    torch.cuda.synchronize()
+    mu = allz.mean(0); var = allz.var(0)
+    np.testing.assert_allclose(Hout.cpu().numpy(), (allz - mu) / np.sqrt(var + 1e-3), rtol=2e-5, atol=2e-5)
+
+
+# ------------------------------------------------------------------------------- optimizer
+def test_rmsprop_clip(ops):
+    rng = np.random.RandomState(1)
+    n = 4 * 1000 + 3
+    w = rng.normal(0, 1, n).astype(np.float32); g = (rng.normal(0, 4, n)).astype(np.float32)
+    ms = rng.uniform(0, 1, n).astype(np.float32)
+    g[:5] = [0, 1e-9, 7.5, -9, 5.0]
+    dw, dg, dms = dev(w), dev(g), dev(ms)
+    lr = torch.tensor([1e-3], device='cuda')
+    ops.rmsprop_clip(dw, dg, dms, n, lr, 0.9, 1e-7, 5.0)
+    torch.cuda.synchronize()
+    gc = np.clip(g.astype(np.float64), -5, 5)
+    ms_ref = 0.9 * ms + 0.1 * gc * gc
+    w_ref = w - 1e-3 * gc / np.sqrt(ms_ref + 1e-7)
+    np.testing.assert_allclose(dms.cpu().numpy(), ms_ref, rtol=1e-6)
+    np.testing.assert_allclose(dw.cpu().numpy(), w_ref, rtol=1e-6, atol=1e-7)
