@@ -122,8 +122,10 @@ __device__ __forceinline__ float nll_elem(const Heads& h, float y, float ridge,
         nll = t1 + t2;
         if (HAS_PI) nll -= logf(h.omp + kEps);         // loss.py:130
         if (GRAD) {
-            dmu = (theta + y) / (tp + mu) - y / (mu + kEps);
-            dth = -dpsi + l1p - (theta + y) * mu / (tp * (tp + mu)) + y / tp;
+            // (theta+y)/(tp+mu) - y/(mu+eps) and -(theta+y)mu/(tp(tp+mu)) + y/tp, combined over a
+            // common denominator: identical algebra, no cancellation between O(1) terms.
+            dmu = theta * (mu + kEps - y) / ((tp + mu) * (mu + kEps));
+            dth = -dpsi + l1p + (y * tp - theta * mu) / (tp * (tp + mu));
             dpi = HAS_PI ? 1.f / (h.omp + kEps) : 0.f;
         }
     }

@@ -1,0 +1,481 @@
+"""Device-resident training / inference engine of the DCA autoencoder (MI355X-first).
+
+Replaces the Keras model + session of the reference (dca/network.py:92-141, 366-393 build the
+graph; dca/train.py:54-98 compiles and fits it) with:
+
+* ONE flat fp32 parameter buffer (weights, biases, BN beta, per-gene log-dispersion) plus flat
+  gradient and RMSprop-slot buffers of the same layout -- the optimizer is a single launch and
+  the data-parallel exchange a single RCCL all-reduce bucket (the batch loss rides in its last
+  slot);
+* the count matrices resident in HBM ([n, ld] fp32, ld padded to 4): the shuffled minibatch is
+  never materialised -- kernels gather rows through a device permutation + device cursor, so a
+  step contains no host synchronisation and can be captured in a hipGraph;
+* hand-written HIP kernels for everything (ops.HipOps -> libdcahip.so).  No torch.nn, no
+  autograd, no CPU fallback.
+
+Layout of the three head matrices: one [h_L, nheads*Gp] weight block ([mean | dispersion | pi],
+Gp = G rounded up to 4) so the heads are ONE GEMM forward and TWO backward.
+"""
+import math
+
+import numpy as np
+import torch
+
+BN_MOMENTUM = 0.99   # keras BatchNormalization defaults (network.py:127-128)
+BN_EPS = 1e-3
+RMS_RHO = 0.9        # tf.keras RMSprop defaults (train.py:54-57)
+RMS_EPS = 1e-7
+
+AE_HEADS = {                      # ae_type -> (heads in the fused block, const dispersion?)
+    'zinb-conddisp': (('mean', 'disp', 'pi'), False),   # network.py:366-393
+    'zinb': (('mean', 'pi'), True),                      # network.py:496-516
+    'nb-conddisp': (('mean', 'disp'), False),            # network.py:293-318
+    'nb': (('mean',), True),                             # network.py:249-270
+}
+
+
+def _r4(x):
+    return (x + 3) // 4 * 4
+
+
+class SingleProcess:
+    """Communication stub for one GPU."""
+    world, rank = 1, 0
+
+    def all_reduce_sum(self, t):
+        return t
+
+    def all_gather(self, t):
+        return t.unsqueeze(0)
+
+
+class ParamLayout:
+    """Offsets of every tensor in the flat parameter / gradient / RMSprop buffers."""
+
+    def __init__(self, ae_type, input_size, output_size, hidden_size, batchnorm):
+        self.ae_type = ae_type
+        self.heads, self.const_disp = AE_HEADS[ae_type]
+        self.G_in, self.G_out = input_size, output_size
+        self.Gp = _r4(output_size)
+        self.NH = len(self.heads) * self.Gp
+        self.hidden = tuple(int(h) for h in hidden_size)
+        self.batchnorm = batchnorm
+        self.seg = {}
+        off = 0
+
+        def add(name, shape, align=False):
+            nonlocal off
+            if align:
+                off = _r4(off)
+            self.seg[name] = (off, shape)
+            off += int(np.prod(shape))
+
+        fan_in = input_size
+        for i, h in enumerate(self.hidden):
+            add('W%d' % i, (fan_in, h), align=True)     # Dense kernel [in, out]
+            add('b%d' % i, (h,))                        # bias right behind it: [in+1, out] block
+            if batchnorm:
+                add('beta%d' % i, (h,))
+            fan_in = h
+        add('Wh', (fan_in, self.NH), align=True)
+        add('bh', (self.NH,))
+        if self.const_disp:
+            add('theta_w', (self.Gp,), align=True)
+        self.P = _r4(off)
+        self.total = self.P + 4                         # [P] carries the batch loss
+
+    def view(self, flat, name):
+        off, shape = self.seg[name]
+        return flat[off:off + int(np.prod(shape))].view(*shape)
+
+    def head_cols(self, head):
+        k = self.heads.index(head)
+        return k * self.Gp, k * self.Gp + self.G_out
+
+
+class Engine:
+    def __init__(self, ae_type, input_size, output_size=None, hidden_size=(64, 32, 64),
+                 batchnorm=True, ridge=0.0, ops=None, comm=None, device=None):
+        if ae_type not in AE_HEADS:
+            raise NotImplementedError('ae_type %r is not available on the MI355X path yet '
+                                      '(supported: %s)' % (ae_type, ', '.join(AE_HEADS)))
+        if ops is None:
+            from .ops import HipOps
+            ops = HipOps()                              # raises without the HIP library / a GPU
+        self.ops = ops
+        self.comm = comm or SingleProcess()
+        self.dev = torch.device(device) if device is not None else (
+            torch.device('cuda', torch.cuda.current_device()) if ops.device_type == 'cuda'
+            else torch.device('cpu'))
+        output_size = input_size if output_size is None else output_size
+        self.lay = ParamLayout(ae_type, input_size, output_size, hidden_size, batchnorm)
+        self.ridge = float(ridge)
+        lay = self.lay
+        self.has_pi = 'pi' in lay.heads
+        self.flags = (1 if self.has_pi else 0) | (2 if lay.const_disp else 0)
+        self.center = int(np.floor(len(lay.hidden) / 2.0))          # network.py:102
+        f32 = dict(dtype=torch.float32, device=self.dev)
+        self.w = torch.zeros(lay.total, **f32)
+        self.g = torch.zeros(lay.total, **f32)
+        self.ms = torch.zeros(lay.total, **f32)
+        self.mm = [torch.zeros(h, **f32) for h in lay.hidden] if batchnorm else []
+        self.mv = [torch.ones(h, **f32) for h in lay.hidden] if batchnorm else []
+        self.lr = torch.full((1,), 1e-3, **f32)
+        self.cursor = torch.zeros(1, dtype=torch.int64, device=self.dev)
+        self.acc = torch.zeros(2, dtype=torch.float64, device=self.dev)   # [train, val] sums
+        self.partials = torch.zeros(ops.max_partials, dtype=torch.float64, device=self.dev)
+        self.val_loss_tmp = torch.zeros(1, **f32)
+        self.Bmax = 0
+        self.X = self.Y = self.sf = self.perm = None
+        self.hist = None
+
+    # ------------------------------------------------------------------ parameters
+    def init_params(self, seed=0):
+        """glorot_uniform kernels (keras default, network.py:57), zero biases / beta /
+        log-dispersion.  The stream is numpy RandomState(seed) (TensorFlow's initialiser stream
+        is not reproducible outside TensorFlow)."""
+        rng = np.random.RandomState(seed)
+        lay = self.lay
+        p = {}
+        fan_in = lay.G_in
+        for i, h in enumerate(lay.hidden):
+            lim = math.sqrt(6.0 / (fan_in + h))
+            p['W%d' % i] = rng.uniform(-lim, lim, size=(fan_in, h)).astype(np.float32)
+            fan_in = h
+        for hd in lay.heads:
+            lim = math.sqrt(6.0 / (fan_in + lay.G_out))
+            p['W_' + hd] = rng.uniform(-lim, lim, size=(fan_in, lay.G_out)).astype(np.float32)
+        self.set_params(p)
+
+    def set_params(self, p):
+        """Loads named numpy arrays (names as oracle.net_np.init_params); missing ones keep
+        their value."""
+        lay = self.lay
+        w = self.w.cpu()
+        for name, (off, shape) in lay.seg.items():
+            if name in ('Wh', 'bh', 'theta_w'):
+                continue
+            if name in p:
+                w[off:off + int(np.prod(shape))] = torch.as_tensor(
+                    np.asarray(p[name], dtype=np.float32).reshape(-1))
+        Wh = lay.view(w, 'Wh'); bh = lay.view(w, 'bh')
+        for hd in lay.heads:
+            c0, c1 = lay.head_cols(hd)
+            if 'W_' + hd in p:
+                Wh[:, c0:c1] = torch.as_tensor(np.asarray(p['W_' + hd], dtype=np.float32))
+            if 'b_' + hd in p:
+                bh[c0:c1] = torch.as_tensor(np.asarray(p['b_' + hd], dtype=np.float32))
+        if lay.const_disp and 'theta_w' in p:
+            lay.view(w, 'theta_w')[:lay.G_out] = torch.as_tensor(np.asarray(p['theta_w'], np.float32))
+        self.w.copy_(w)
+        for i in range(len(self.mm)):
+            if 'mm%d' % i in p:
+                self.mm[i].copy_(torch.as_tensor(np.asarray(p['mm%d' % i], np.float32)))
+            if 'mv%d' % i in p:
+                self.mv[i].copy_(torch.as_tensor(np.asarray(p['mv%d' % i], np.float32)))
+
+    def _named(self, flat):
+        lay = self.lay
+        f = flat.detach().cpu()
+        out = {}
+        for name in lay.seg:
+            if name in ('Wh', 'bh', 'theta_w'):
+                continue
+            out[name] = lay.view(f, name).numpy().copy()
+        Wh = lay.view(f, 'Wh'); bh = lay.view(f, 'bh')
+        for hd in lay.heads:
+            c0, c1 = lay.head_cols(hd)
+            out['W_' + hd] = Wh[:, c0:c1].numpy().copy()
+            out['b_' + hd] = bh[c0:c1].numpy().copy()
+        if lay.const_disp:
+            out['theta_w'] = lay.view(f, 'theta_w')[:lay.G_out].numpy().copy()
+        return out
+
+    def get_params(self):
+        out = self._named(self.w)
+        for i in range(len(self.mm)):
+            out['mm%d' % i] = self.mm[i].cpu().numpy().copy()
+            out['mv%d' % i] = self.mv[i].cpu().numpy().copy()
+        return out
+
+    def get_grads(self):
+        return self._named(self.g)
+
+    def set_lr(self, lr):
+        self.lr.fill_(float(np.float32(lr)))
+
+    # ------------------------------------------------------------------ data
+    def load_data(self, X, Y=None, sf=None, chunk_rows=8192):
+        """Uploads host matrices once into padded device buffers ([n, ld], ld % 4 == 0)."""
+        lay = self.lay
+        n = X.shape[0]
+        assert X.shape[1] == lay.G_in
+        self.n = n
+        self.ldx = _r4(lay.G_in)
+        self.X = torch.zeros(n, self.ldx, dtype=torch.float32, device=self.dev)
+        if Y is not None:
+            assert Y.shape == (n, lay.G_out)
+            self.ldy = lay.Gp
+            self.Y = torch.zeros(n, self.ldy, dtype=torch.float32, device=self.dev)
+        for s in range(0, n, chunk_rows):
+            e = min(n, s + chunk_rows)
+            xs = X[s:e]
+            xs = xs.toarray() if hasattr(xs, 'toarray') else np.asarray(xs)
+            self.X[s:e, :lay.G_in] = torch.as_tensor(np.ascontiguousarray(xs, dtype=np.float32)).to(self.dev)
+            if Y is not None:
+                ys = Y[s:e]
+                ys = ys.toarray() if hasattr(ys, 'toarray') else np.asarray(ys)
+                self.Y[s:e, :lay.G_out] = torch.as_tensor(np.ascontiguousarray(ys, dtype=np.float32)).to(self.dev)
+        sfv = np.ones(n, np.float32) if sf is None else np.asarray(sf, dtype=np.float32).reshape(-1)
+        self.sf = torch.as_tensor(sfv).to(self.dev)
+
+    def attach_device_data(self, X, Y, sf):
+        """Uses tensors that already live on the device (synthetic generators, bench)."""
+        lay = self.lay
+        assert X.shape[1] == _r4(lay.G_in) and (Y is None or Y.shape[1] == lay.Gp)
+        self.n, self.ldx, self.ldy = X.shape[0], X.shape[1], lay.Gp
+        self.X, self.Y, self.sf = X, Y, sf
+
+    # ------------------------------------------------------------------ work buffers
+    def reserve(self, B):
+        """Allocates every per-batch buffer for up to B rows (no allocation inside a step)."""
+        if B <= self.Bmax:
+            return
+        lay, ops = self.lay, self.ops
+        f32 = dict(dtype=torch.float32, device=self.dev)
+        self.Bmax = B
+        self.ldh = [_r4(h) for h in lay.hidden]
+        self.Z = [torch.zeros(B, l, **f32) for l in self.ldh]
+        self.XH = [torch.zeros(B, l, **f32) for l in self.ldh] if lay.batchnorm else []
+        self.H = [torch.zeros(B, l, **f32) for l in self.ldh]
+        self.dH = [torch.zeros(B, l, **f32) for l in self.ldh]
+        self.dZ = [torch.zeros(B, l, **f32) for l in self.ldh]
+        self.A = torch.zeros(B, lay.NH, **f32)
+        self.D = torch.zeros(B, lay.NH, **f32)
+        self.Dth = torch.zeros(B, lay.Gp, **f32) if lay.const_disp else None
+        R = ops.col_moments_chunks(B)
+        self.inv_std = [torch.zeros(h, **f32) for h in lay.hidden]
+        self.part = [torch.zeros(max(R, self.comm.world) * 2 * h, **f32) for h in lay.hidden]
+        self.bpart = [torch.zeros(R * 2 * h, **f32) for h in lay.hidden]
+        self.stat_local = [torch.zeros(2 * h, **f32) for h in lay.hidden]
+        self.counts_local = torch.zeros(kMaxCounts, **f32)
+        self.counts_world = torch.zeros(self.comm.world, **f32)
+        # split-K workspace: the maximum any GEMM of a step can ask for
+        need = 0
+        K = lay.G_in
+        for i, h in enumerate(lay.hidden):
+            need = max(need, ops.sgemm_workspace_bytes(0, 0, B, h, K))
+            need = max(need, ops.sgemm_workspace_bytes(1, 0, K, h, B, True))
+            if i > 0:
+                need = max(need, ops.sgemm_workspace_bytes(0, 1, B, K, h))
+            K = h
+        need = max(need, ops.sgemm_workspace_bytes(0, 0, B, lay.NH, K))
+        need = max(need, ops.sgemm_workspace_bytes(1, 0, K, lay.NH, B, True))
+        need = max(need, ops.sgemm_workspace_bytes(0, 1, B, K, lay.NH))
+        self.ws = torch.zeros(max(need // 4, 4), **f32)
+
+    # ------------------------------------------------------------------ forward pieces
+    def _hidden_forward(self, B, rows_from, training, counts=None):
+        """Dense -> BN -> ReLU stack (network.py:101-138).  rows_from: ('perm',) gathers the
+        batch through perm/cursor, ('range', r0) reads storage rows r0..r0+B."""
+        lay, ops = self.lay, self.ops
+        w = self.w
+        K = lay.G_in
+        for i, h in enumerate(lay.hidden):
+            Wi = lay.view(w, 'W%d' % i); bi = lay.view(w, 'b%d' % i)
+            if i == 0:
+                if rows_from[0] == 'perm':
+                    ops.sgemm(0, 0, B, h, K, self.X, self.ldx, Wi, h, self.Z[0], self.ldh[0], bias=bi,
+                              perm=self.perm, cursor=self.cursor, ws=self.ws)
+                else:
+                    ops.sgemm(0, 0, B, h, K, self.X[rows_from[1]:], self.ldx, Wi, h, self.Z[0],
+                              self.ldh[0], bias=bi, ws=self.ws)
+            else:
+                ops.sgemm(0, 0, B, h, K, self.H[i - 1], self.ldh[i - 1], Wi, h, self.Z[i],
+                          self.ldh[i], bias=bi, ws=self.ws)
+            if lay.batchnorm:
+                beta = lay.view(w, 'beta%d' % i)
+                if training:
+                    entries, cnts, E = self._batch_moments(i, B, h, counts)
+                    ops.bn_relu_apply(self.Z[i], self.ldh[i], B, h, entries, cnts, E, beta,
+                                      self.mm[i], self.mv[i], BN_MOMENTUM, BN_EPS, True, self.H[i],
+                                      self.ldh[i], self.XH[i], self.ldh[i], self.inv_std[i])
+                else:
+                    ops.bn_relu_apply(self.Z[i], self.ldh[i], B, h, None, None, 0, beta, self.mm[i],
+                                      self.mv[i], BN_MOMENTUM, BN_EPS, True, self.H[i], self.ldh[i],
+                                      None, 0, None)
+            else:
+                ops.relu_fwd(self.Z[i], self.ldh[i], B, h, self.H[i], self.ldh[i])
+            K = h
+        return K
+
+    def _batch_moments(self, i, B, h, counts):
+        """Batch statistics of layer i as (entries, counts, E) for bn_relu_apply.  One GPU: the
+        row-chunk partials directly.  Data parallel (SyncBN): merge local chunks, all-gather
+        one (count, mean, M2) triple per rank."""
+        ops = self.ops
+        if B > 0:
+            ops.col_moments(self.Z[i], self.ldh[i], B, h, self.part[i])
+        if self.comm.world == 1:
+            return self.part[i], None, ops.col_moments_chunks(B)
+        R = ops.col_moments_chunks(max(B, 1))
+        if B > 0:
+            cr = -(-B // R)
+            self.counts_local[:R] = torch.as_tensor(
+                [max(0, min(B, (r + 1) * cr) - r * cr) for r in range(R)], dtype=torch.float32)
+            ops.moments_combine(self.part[i], self.counts_local, R, h, self.stat_local[i])
+        else:
+            self.stat_local[i].zero_()
+        gathered = self.comm.all_gather(self.stat_local[i])          # [W, 2h]
+        self.part[i][:gathered.numel()].copy_(gathered.reshape(-1))
+        return self.part[i], counts, self.comm.world
+
+    def _heads_forward(self, B, K):
+        lay, ops = self.lay, self.ops
+        ops.sgemm(0, 0, B, lay.NH, K, self.H[-1], self.ldh[-1], lay.view(self.w, 'Wh'), lay.NH,
+                  self.A, lay.NH, bias=lay.view(self.w, 'bh'), ws=self.ws)
+
+    def _plane(self, buf, head):
+        lay = self.lay
+        if head not in lay.heads:
+            return None
+        return buf[:, lay.heads.index(head) * lay.Gp:]
+
+    def _nll(self, B, perm, cursor, Y, sf, inv_n, grad):
+        lay, ops = self.lay, self.ops
+        A, D = self.A, self.D
+        tw = lay.view(self.w, 'theta_w') if lay.const_disp else None
+        d_disp = (self.Dth if lay.const_disp else self._plane(D, 'disp')) if grad else None
+        return ops.zinb_nll(self._plane(A, 'mean'), self._plane(A, 'disp'), self._plane(A, 'pi'),
+                            lay.NH, tw, Y, self.ldy, sf, perm, cursor, B, lay.G_out, self.ridge,
+                            inv_n, self.flags, self._plane(D, 'mean') if grad else None, d_disp,
+                            self._plane(D, 'pi') if grad else None,
+                            (lay.Gp if lay.const_disp and False else lay.NH) if grad else 0,
+                            self.partials)
+
+    # ------------------------------------------------------------------ one training step
+    def train_step(self, B, B_global=None, world_counts=None, rows_per_slot=None):
+        """Forward + backward + clipvalue/RMSprop on the B rows perm[cursor : cursor+B].
+        Asynchronous: no host synchronisation (single GPU).  B may be 0 on a rank whose shard
+        is exhausted in the last step of a data-parallel epoch."""
+        lay, ops, comm = self.lay, self.ops, self.comm
+        Bg = B if B_global is None else B_global
+        inv_n = 1.0 / (float(Bg) * lay.G_out)
+        w, g = self.w, self.g
+        if comm.world > 1:
+            self.counts_world.copy_(torch.as_tensor(world_counts, dtype=torch.float32))
+        if B > 0:
+            self._forward_backward(B, Bg, inv_n)
+        else:
+            self._empty_step()
+        if comm.world > 1:
+            comm.all_reduce_sum(g[:lay.P + 1])
+        ops.rmsprop_clip(w, g, self.ms, lay.P, self.lr, RMS_RHO, RMS_EPS, self.clip)
+        ops.step_end(g[lay.P:], float(Bg), self.hist, rows_per_slot or max(self.Bmax, 1), self.acc,
+                     self.cursor, B)
+
+    def _empty_step(self):
+        lay = self.lay
+        self.g.zero_()
+        for i, h in enumerate(lay.hidden):
+            if lay.batchnorm:
+                self._batch_moments(i, 0, h, self.counts_world)
+        for i in reversed(range(len(lay.hidden))):
+            if lay.batchnorm:
+                self.bpart[i][:2 * h].zero_()
+                self.comm.all_reduce_sum(self.bpart[i][:2 * lay.hidden[i]])
+
+    def _forward_backward(self, B, Bg, inv_n):
+        lay, ops, comm = self.lay, self.ops, self.comm
+        w, g = self.w, self.g
+        KL = self._hidden_forward(B, ('perm',), True, self.counts_world)
+        self._heads_forward(B, KL)
+        n = self._nll(B, self.perm, self.cursor, self.Y, self.sf, inv_n, True)
+        ops.loss_finalize(self.partials, n, inv_n, g[lay.P:])
+        # ---- backward: heads
+        ops.sgemm(1, 0, KL, lay.NH, B, self.H[-1], self.ldh[-1], self.D, lay.NH, lay.view(g, 'Wh'),
+                  lay.NH, colsum_row=True, ws=self.ws)
+        if lay.const_disp:
+            ops.colsum_chain(self.Dth, lay.Gp, B, lay.G_out, lay.view(w, 'theta_w'),
+                             lay.view(g, 'theta_w'))
+        ops.sgemm(0, 1, B, KL, lay.NH, self.D, lay.NH, lay.view(w, 'Wh'), lay.NH, self.dH[-1],
+                  self.ldh[-1], ws=self.ws)
+        # ---- backward: hidden stack
+        L = len(lay.hidden)
+        for i in reversed(range(L)):
+            h = lay.hidden[i]
+            if lay.batchnorm:
+                ops.bn_bwd_sums(self.dH[i], self.ldh[i], self.H[i], self.ldh[i], self.XH[i],
+                                self.ldh[i], B, h, self.bpart[i])
+                E = ops.col_moments_chunks(B)
+                if comm.world > 1:
+                    E = self._reduce_bwd_sums(i, E, h)
+                ops.bn_bwd_apply(self.dH[i], self.ldh[i], self.H[i], self.ldh[i], self.XH[i],
+                                 self.ldh[i], self.inv_std[i], self.bpart[i], E, float(Bg), B, h,
+                                 self.dZ[i], self.ldh[i], lay.view(g, 'beta%d' % i))
+            else:
+                ops.relu_bwd(self.dH[i], self.ldh[i], self.H[i], self.ldh[i], B, h, self.dZ[i],
+                             self.ldh[i])
+            Kp = lay.G_in if i == 0 else lay.hidden[i - 1]
+            gW = lay.view(g, 'W%d' % i)
+            if i == 0:
+                ops.sgemm(1, 0, Kp, h, B, self.X, self.ldx, self.dZ[0], self.ldh[0], gW, h,
+                          perm=self.perm, cursor=self.cursor, colsum_row=True, ws=self.ws)
+            else:
+                ops.sgemm(1, 0, Kp, h, B, self.H[i - 1], self.ldh[i - 1], self.dZ[i], self.ldh[i], gW,
+                          h, colsum_row=True, ws=self.ws)
+                ops.sgemm(0, 1, B, Kp, h, self.dZ[i], self.ldh[i], lay.view(w, 'W%d' % i), h,
+                          self.dH[i - 1], self.ldh[i - 1], ws=self.ws)
+
+    def _reduce_bwd_sums(self, i, E, h):
+        """SyncBN backward: local chunk sums -> one [2h] vector -> all-reduce."""
+        s = self.bpart[i][:E * 2 * h].view(E, 2 * h).sum(dim=0)
+        self.comm.all_reduce_sum(s)
+        self.bpart[i][:2 * h].copy_(s)
+        return 1
+
+    # ------------------------------------------------------------------ evaluation / inference
+    def eval_loss_sum(self, r0, r1, scale, chunk=None):
+        """Adds scale * sum of element-wise NLL over storage rows [r0, r1) (inference mode) to
+        acc[1] (Keras validation pass, train.py:97)."""
+        lay, ops = self.lay, self.ops
+        chunk = chunk or self.Bmax
+        for s in range(r0, r1, chunk):
+            b = min(chunk, r1 - s)
+            KL = self._hidden_forward(b, ('range', s), False)
+            self._heads_forward(b, KL)
+            n = self._nll(b, None, None, self.Y[s:], self.sf[s:], 1.0, False)
+            ops.loss_finalize(self.partials, n, scale, self.val_loss_tmp)
+            ops.step_end(self.val_loss_tmp, 1.0, None, 0, self.acc[1:], None, 0)
+
+    def predict_chunk(self, r0, b, want):
+        """Inference forward over storage rows [r0, r0+b).  Returns device views (valid until
+        the next call): dict with 'mean' (mean*sf), 'dispersion', 'dropout', 'latent'."""
+        lay, ops = self.lay, self.ops
+        KL = self._hidden_forward(b, ('range', r0), False)
+        out = {}
+        if 'latent' in want:
+            out['latent'] = self.Z[self.center][:b, :lay.hidden[self.center]]
+        if want - {'latent'}:
+            self._heads_forward(b, KL)
+            A = self.A
+            m = self._plane(A, 'mean')
+            d = self._plane(A, 'disp') if 'dispersion' in want else None
+            p = self._plane(A, 'pi') if 'dropout' in want else None
+            ops.heads_infer(m, d, p, lay.NH, self.sf[r0:], b, lay.G_out,
+                            m if 'mean' in want else None, d, p, lay.NH)
+            if 'mean' in want:
+                out['mean'] = m[:b, :lay.G_out]
+            if d is not None:
+                out['dispersion'] = d[:b, :lay.G_out]
+            if p is not None:
+                out['dropout'] = p[:b, :lay.G_out]
+        return out
+
+    def const_dispersion(self):
+        """layers.py:21: theta = clip(exp(w), 1e-3, 1e4), per gene."""
+        tw = self.lay.view(self.w, 'theta_w')[:self.lay.G_out]
+        return torch.clamp(torch.exp(tw), 1e-3, 1e4).cpu().numpy()
+
+
+kMaxCounts = 256
