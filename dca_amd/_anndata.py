@@ -1,0 +1,135 @@
+"""Minimal AnnData stand-in.
+
+The reference API works on ``anndata.AnnData`` (dca/api.py:146).  anndata / scanpy are not
+installed in the build image; when the real package is importable it is used unchanged, and
+this class only exists so that the drop-in surface (and its tests) runs without it.  It
+implements exactly the members the DCA path touches: X, obs, var, obsm, uns, raw, n_obs,
+n_vars, obs_names, var_names, copy(), transpose(), boolean/slice row indexing and the
+``*_keys()`` helpers used by dca/test.py.
+"""
+import numpy as np
+import pandas as pd
+
+try:                                    # pragma: no cover - not available in the build image
+    import anndata as _real_anndata
+except Exception:                       # noqa: BLE001
+    _real_anndata = None
+
+
+class _Raw:
+    def __init__(self, X, var):
+        self.X = X
+        self.var = var
+
+    @property
+    def var_names(self):
+        return self.var.index
+
+    def copy(self):
+        return _Raw(self.X.copy(), self.var.copy())
+
+
+class MiniAnnData:
+    def __init__(self, X, obs=None, var=None, obsm=None, uns=None, raw=None, dtype=None):
+        X = X if hasattr(X, 'toarray') else np.asarray(X)
+        if dtype is not None and not hasattr(X, 'toarray'):
+            X = X.astype(dtype, copy=False)
+        self._X = X
+        n, g = X.shape
+        self.obs = obs.copy() if obs is not None else pd.DataFrame(index=pd.RangeIndex(n).astype(str))
+        self.var = var.copy() if var is not None else pd.DataFrame(index=pd.RangeIndex(g).astype(str))
+        assert len(self.obs) == n and len(self.var) == g
+        self.obsm = dict(obsm) if obsm else {}
+        self.uns = dict(uns) if uns else {}
+        self._raw = raw
+
+    # -- data
+    @property
+    def X(self):
+        return self._X
+
+    @X.setter
+    def X(self, v):
+        v = v if hasattr(v, 'toarray') else np.asarray(v)
+        assert v.shape == self._X.shape, 'X shape is fixed'
+        self._X = v
+
+    @property
+    def raw(self):
+        return self._raw
+
+    @raw.setter
+    def raw(self, ad):
+        self._raw = None if ad is None else (ad if isinstance(ad, _Raw) else _Raw(ad.X, ad.var))
+
+    @property
+    def n_obs(self):
+        return self._X.shape[0]
+
+    @property
+    def n_vars(self):
+        return self._X.shape[1]
+
+    @property
+    def shape(self):
+        return self._X.shape
+
+    @property
+    def obs_names(self):
+        return self.obs.index
+
+    @property
+    def var_names(self):
+        return self.var.index
+
+    def obsm_keys(self):
+        return list(self.obsm.keys())
+
+    def var_keys(self):
+        return list(self.var.columns)
+
+    def obs_keys(self):
+        return list(self.obs.columns)
+
+    def uns_keys(self):
+        return list(self.uns.keys())
+
+    # -- structure
+    def copy(self):
+        return MiniAnnData(self._X.copy(), self.obs, self.var,
+                           {k: np.array(v, copy=True) for k, v in self.obsm.items()},
+                           dict(self.uns), None if self._raw is None else self._raw.copy())
+
+    def transpose(self):
+        Xt = self._X.T
+        return MiniAnnData(Xt.copy() if not hasattr(Xt, 'toarray') else Xt.tocsr(), self.var, self.obs)
+
+    T = property(transpose)
+
+    def __getitem__(self, idx):
+        """Row subsetting (boolean mask / index array / slice), optionally (rows, cols)."""
+        cols = slice(None)
+        if isinstance(idx, tuple):
+            idx, cols = idx
+        if isinstance(idx, pd.Series):
+            idx = idx.values
+        idx = np.arange(self.n_obs)[idx]
+        cidx = np.arange(self.n_vars)[cols]
+        X = self._X[idx][:, cidx]
+        raw = None
+        if self._raw is not None:
+            raw = _Raw(self._raw.X[idx], self._raw.var)
+        return MiniAnnData(X, self.obs.iloc[idx], self.var.iloc[cidx],
+                           {k: np.asarray(v)[idx] for k, v in self.obsm.items()}, dict(self.uns), raw)
+
+    def __repr__(self):
+        return 'MiniAnnData object with n_obs x n_vars = %d x %d' % self.shape
+
+
+AnnData = _real_anndata.AnnData if _real_anndata is not None else MiniAnnData
+
+
+def is_anndata(obj):
+    if isinstance(obj, MiniAnnData):
+        return True
+    return _real_anndata is not None and isinstance(obj, _real_anndata.AnnData)

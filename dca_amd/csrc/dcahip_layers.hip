@@ -208,6 +208,15 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const float* dH, long ldd
     }
 }
 
+__global__ __launch_bounds__(256) void relu_fwd_kernel(const float* Z, long ldz, int B, int H,
+                                                       float* Hout, long ldh) {
+    const long total = (long)B * H;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int r = (int)(i / H), c = (int)(i - (long)r * H);
+        Hout[(long)r * ldh + c] = fmaxf(Z[(long)r * ldz + c], 0.f);
+    }
+}
+
 __global__ __launch_bounds__(256) void colsum_chain_kernel(const float* x, long ldx, int B, int N,
                                                            const float* theta_w, float* out) {
     __shared__ float sm[256];
@@ -321,6 +330,16 @@ extern "C" int dcahip_relu_bwd(const float* dH, long ldd, const float* Hact, lon
     if (g > 2048) g = 2048;
     hipLaunchKernelGGL(relu_bwd_kernel, dim3((int)g), dim3(256), 0, static_cast<hipStream_t>(stream),
                        dH, ldd, Hact, ldh, B, H, dZ, ldz);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dcahip_relu_fwd(const float* Z, long ldz, int B, int H, float* Hout, long ldh,
+                               void* stream) {
+    if (!Z || !Hout || B <= 0 || H <= 0) return DCAHIP_EINVAL;
+    long g = ((long)B * H + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(relu_fwd_kernel, dim3((int)g), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       Z, ldz, B, H, Hout, ldh);
     return (int)hipGetLastError();
 }
 

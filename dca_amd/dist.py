@@ -1,0 +1,71 @@
+"""Data-parallel plumbing: one process per GPU, torch.distributed (backend "nccl" == RCCL over
+xGMI on ROCm; "gloo" for the CPU tests).
+
+The reference is single-process: data parallelism over cells is a capability
+this implementation adds.  Cells are independent given the parameters, so the path shards by
+rows with exactly three exchanges per optimizer step:
+  1. one flat fp32 all-reduce of the gradient bucket (+ the batch loss in its last slot),
+  2. per BatchNormalization layer, forward: an all-gather of one (mean, M2) pair per rank
+     (merged with Chan's formula -> identical to single-GPU statistics of the global batch),
+  3. per BatchNormalization layer, backward: an all-reduce of [sum dy, sum dy*xhat].
+"""
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+class TorchDistComm:
+    def __init__(self, group=None):
+        assert dist.is_initialized()
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+
+    def all_reduce_sum(self, t):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def all_gather(self, t):
+        out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
+        return out
+
+
+def init_from_env(backend=None):
+    """Initialises torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun contract) and
+    binds this process to its GPU. Returns a communicator (SingleProcess if WORLD_SIZE <= 1)."""
+    from .engine import SingleProcess
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world <= 1:
+        return SingleProcess()
+    local_rank = int(os.environ.get('LOCAL_RANK', os.environ.get('RANK', '0')))
+    if backend is None:
+        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+    if backend == 'nccl':
+        torch.cuda.set_device(local_rank)
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    if not dist.is_initialized():
+        kw = {}
+        if backend == 'nccl':
+            kw['device_id'] = torch.device('cuda', local_rank)
+        dist.init_process_group(backend=backend, **kw)
+    return TorchDistComm()
+
+
+def shard(n, world, rank):
+    """Contiguous block partition of n rows: (start, count) of `rank`; sizes differ by <= 1."""
+    base, rem = divmod(n, world)
+    start = rank * base + min(rank, rem)
+    return start, base + (1 if rank < rem else 0)
+
+
+def local_order(global_perm, start, count):
+    """Order in which this rank visits its own rows: the subsequence of the global shuffled
+    index array that falls into [start, start+count), re-based to local row numbers.  With one
+    rank this is the reference's shuffled index_array itself."""
+    gp = np.asarray(global_perm)
+    m = (gp >= start) & (gp < start + count)
+    return (gp[m] - start).astype(np.int32)

@@ -125,6 +125,8 @@ class Engine:
         self.acc = torch.zeros(2, dtype=torch.float64, device=self.dev)   # [train, val] sums
         self.partials = torch.zeros(ops.max_partials, dtype=torch.float64, device=self.dev)
         self.val_loss_tmp = torch.zeros(1, **f32)
+        self.clip = 5.0                                   # train.py:37 clip_grad
+        self.ldD = lay.NH + (lay.Gp if lay.const_disp else 0)
         self.Bmax = 0
         self.X = self.Y = self.sf = self.perm = None
         self.hist = None
@@ -251,8 +253,9 @@ class Engine:
         self.dH = [torch.zeros(B, l, **f32) for l in self.ldh]
         self.dZ = [torch.zeros(B, l, **f32) for l in self.ldh]
         self.A = torch.zeros(B, lay.NH, **f32)
-        self.D = torch.zeros(B, lay.NH, **f32)
-        self.Dth = torch.zeros(B, lay.Gp, **f32) if lay.const_disp else None
+        # gradient planes of the heads (+ one d nll/d theta plane behind them for const-disp)
+        self.D = torch.zeros(B, self.ldD, **f32)
+        self.Dth = self.D[:, lay.NH:] if lay.const_disp else None
         R = ops.col_moments_chunks(B)
         self.inv_std = [torch.zeros(h, **f32) for h in lay.hidden]
         self.part = [torch.zeros(max(R, self.comm.world) * 2 * h, **f32) for h in lay.hidden]
@@ -349,8 +352,7 @@ class Engine:
         return ops.zinb_nll(self._plane(A, 'mean'), self._plane(A, 'disp'), self._plane(A, 'pi'),
                             lay.NH, tw, Y, self.ldy, sf, perm, cursor, B, lay.G_out, self.ridge,
                             inv_n, self.flags, self._plane(D, 'mean') if grad else None, d_disp,
-                            self._plane(D, 'pi') if grad else None,
-                            (lay.Gp if lay.const_disp and False else lay.NH) if grad else 0,
+                            self._plane(D, 'pi') if grad else None, self.ldD if grad else 0,
                             self.partials)
 
     # ------------------------------------------------------------------ one training step
@@ -382,8 +384,8 @@ class Engine:
                 self._batch_moments(i, 0, h, self.counts_world)
         for i in reversed(range(len(lay.hidden))):
             if lay.batchnorm:
-                self.bpart[i][:2 * h].zero_()
-                self.comm.all_reduce_sum(self.bpart[i][:2 * lay.hidden[i]])
+                s = torch.zeros(2 * lay.hidden[i], dtype=torch.float32, device=self.dev)
+                self.comm.all_reduce_sum(s)
 
     def _forward_backward(self, B, Bg, inv_n):
         lay, ops, comm = self.lay, self.ops, self.comm
@@ -393,12 +395,12 @@ class Engine:
         n = self._nll(B, self.perm, self.cursor, self.Y, self.sf, inv_n, True)
         ops.loss_finalize(self.partials, n, inv_n, g[lay.P:])
         # ---- backward: heads
-        ops.sgemm(1, 0, KL, lay.NH, B, self.H[-1], self.ldh[-1], self.D, lay.NH, lay.view(g, 'Wh'),
+        ops.sgemm(1, 0, KL, lay.NH, B, self.H[-1], self.ldh[-1], self.D, self.ldD, lay.view(g, 'Wh'),
                   lay.NH, colsum_row=True, ws=self.ws)
         if lay.const_disp:
-            ops.colsum_chain(self.Dth, lay.Gp, B, lay.G_out, lay.view(w, 'theta_w'),
+            ops.colsum_chain(self.Dth, self.ldD, B, lay.G_out, lay.view(w, 'theta_w'),
                              lay.view(g, 'theta_w'))
-        ops.sgemm(0, 1, B, KL, lay.NH, self.D, lay.NH, lay.view(w, 'Wh'), lay.NH, self.dH[-1],
+        ops.sgemm(0, 1, B, KL, lay.NH, self.D, self.ldD, lay.view(w, 'Wh'), lay.NH, self.dH[-1],
                   self.ldh[-1], ws=self.ws)
         # ---- backward: hidden stack
         L = len(lay.hidden)

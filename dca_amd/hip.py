@@ -45,6 +45,7 @@ _SIGNATURES = {
                                        _c.c_long, _f32p, _vp]),
     'dcahip_relu_bwd': (_c.c_int, [_f32p, _c.c_long, _f32p, _c.c_long, _c.c_int, _c.c_int, _f32p,
                                    _c.c_long, _vp]),
+    'dcahip_relu_fwd': (_c.c_int, [_f32p, _c.c_long, _c.c_int, _c.c_int, _f32p, _c.c_long, _vp]),
     'dcahip_colsum_chain': (_c.c_int, [_f32p, _c.c_long, _c.c_int, _c.c_int, _f32p, _f32p, _vp]),
     'dcahip_rmsprop_clip': (_c.c_int, [_f32p, _f32p, _f32p, _c.c_long, _f32p, _c.c_float,
                                        _c.c_float, _c.c_float, _vp]),

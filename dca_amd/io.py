@@ -1,0 +1,211 @@
+"""IO / preprocessing surface of the reference (dca/io.py:53-131), re-hosted on numpy / pandas.
+
+Same function names, arguments and outputs.  The reference delegates the arithmetic to scanpy
+(filter_genes / filter_cells / normalize_per_cell / log1p / scale) and scikit-learn
+(train_test_split); scanpy is not installable here, so its documented behaviour is restated
+below (citations per function); scikit-learn IS used directly, so the train/test split indices
+are bit-identical to the reference's.
+
+Works on real ``anndata.AnnData`` objects when anndata is installed and on the bundled
+MiniAnnData otherwise.
+"""
+import os
+import pickle
+
+import numpy as np
+import pandas as pd
+import scipy.sparse as sp_sparse
+
+from ._anndata import AnnData, MiniAnnData, is_anndata
+
+
+def _dense(X):
+    return X.toarray() if sp_sparse.issparse(X) else np.asarray(X)
+
+
+# ------------------------------------------------------------------ scanpy restatements
+def filter_genes_mask(X, min_counts=1):
+    """sc.pp.filter_genes(X, min_counts): keep genes whose total count >= min_counts.
+    Returns (gene_subset, number_per_gene) like scanpy does for array input (api.py:163)."""
+    number = np.asarray(X.sum(axis=0)).reshape(-1)
+    return number >= min_counts, number
+
+
+def filter_cells_mask(X, min_counts=1):
+    number = np.asarray(X.sum(axis=1)).reshape(-1)
+    return number >= min_counts, number
+
+
+def _subset(adata, rows=None, cols=None):
+    if isinstance(adata, MiniAnnData):
+        if rows is not None:
+            idx = np.where(rows)[0]
+            adata._X = adata._X[idx]
+            adata.obs = adata.obs.iloc[idx].copy()
+            adata.obsm = {k: np.asarray(v)[idx] for k, v in adata.obsm.items()}
+            if adata._raw is not None:      # anndata keeps .raw aligned along obs
+                adata._raw = type(adata._raw)(adata._raw.X[idx], adata._raw.var)
+        if cols is not None:
+            idx = np.where(cols)[0]
+            adata._X = adata._X[:, idx]
+            adata.var = adata.var.iloc[idx].copy()
+    else:                                   # real anndata
+        if rows is not None:
+            adata._inplace_subset_obs(rows)
+        if cols is not None:
+            adata._inplace_subset_var(cols)
+
+
+def filter_genes(adata, min_counts=1):
+    keep, number = filter_genes_mask(adata.X, min_counts)
+    adata.var['n_counts'] = number
+    _subset(adata, cols=keep)
+
+
+def filter_cells(adata, min_counts=1):
+    keep, number = filter_cells_mask(adata.X, min_counts)
+    adata.obs['n_counts'] = number
+    _subset(adata, rows=keep)
+
+
+def normalize_per_cell(adata):
+    """sc.pp.normalize_per_cell(adata): n_counts = row sums (stored in obs), cells with
+    n_counts < 1 are dropped, every row is divided by n_counts / median(n_counts)."""
+    X = adata.X
+    counts = np.asarray(X.sum(axis=1)).reshape(-1)
+    adata.obs['n_counts'] = counts
+    keep = counts >= 1
+    if not keep.all():
+        _subset(adata, rows=keep)
+        X = adata.X
+        counts = counts[keep]
+    after = np.median(counts)
+    counts = counts + (counts == 0)
+    fac = counts / after
+    if sp_sparse.issparse(X):
+        X = sp_sparse.diags(1.0 / fac) @ X
+        adata.X = X.astype(np.float32)
+    else:
+        X = np.asarray(X)
+        if np.issubdtype(X.dtype, np.integer):
+            X = X.astype(np.float32)
+        adata.X = (X / fac[:, None].astype(X.dtype)).astype(X.dtype)
+
+
+def log1p(adata):
+    X = adata.X
+    adata.X = X.log1p() if sp_sparse.issparse(X) else np.log1p(X)
+
+
+def scale(adata):
+    """sc.pp.scale(adata): per-gene z-score, zero centred, unbiased variance (ddof=1), no
+    clipping; genes with zero standard deviation are divided by 1."""
+    X = _dense(adata.X)
+    n = X.shape[0]
+    mean = X.mean(axis=0, dtype=np.float64)
+    mean_sq = np.multiply(X, X).mean(axis=0, dtype=np.float64)
+    var = (mean_sq - mean ** 2) * (n / (n - 1.0)) if n > 1 else np.zeros_like(mean)
+    std = np.sqrt(np.maximum(var, 0))
+    std[std == 0] = 1
+    dt = X.dtype if np.issubdtype(X.dtype, np.floating) else np.float32
+    adata.X = ((X - mean.astype(dt)) / std.astype(dt)).astype(dt)
+
+
+# ------------------------------------------------------------------ reference surface
+def read_text(filename, first_column_names=True):
+    """Stand-in for sc.read(path, first_column_names=True) on TSV/CSV (io.py:59)."""
+    sep = ',' if filename.endswith('.csv') else '\t'
+    df = pd.read_csv(filename, sep=sep, index_col=0 if first_column_names else None)
+    return AnnData(df.values.astype(np.float32),
+                   obs=pd.DataFrame(index=df.index.astype(str)),
+                   var=pd.DataFrame(index=df.columns.astype(str)))
+
+
+def read_dataset(adata, transpose=False, test_split=False, copy=False, check_counts=True):
+    """dca/io.py:53-85."""
+    if is_anndata(adata):
+        if copy:
+            adata = adata.copy()
+    elif isinstance(adata, str):
+        if adata.endswith('.h5ad'):
+            import anndata as _ad          # ImportError if unavailable, like the reference
+            adata = _ad.read_h5ad(adata)
+        else:
+            adata = read_text(adata, first_column_names=True)
+    else:
+        raise NotImplementedError
+
+    if check_counts:
+        # check if observations are unnormalized using first 10
+        X_subset = adata.X[:10]
+        norm_error = 'Make sure that the dataset (adata.X) contains unnormalized count data.'
+        if sp_sparse.issparse(X_subset):
+            assert (X_subset.astype(int) != X_subset).nnz == 0, norm_error
+        else:
+            assert np.all(X_subset.astype(int) == X_subset), norm_error
+
+    if transpose:
+        adata = adata.transpose()
+
+    if test_split:
+        from sklearn.model_selection import train_test_split
+        train_idx, test_idx = train_test_split(np.arange(adata.n_obs), test_size=0.1, random_state=42)
+        spl = pd.Series(['train'] * adata.n_obs)
+        spl.iloc[test_idx] = 'test'
+        adata.obs['dca_split'] = spl.values
+    else:
+        adata.obs['dca_split'] = 'train'
+
+    adata.obs['dca_split'] = adata.obs['dca_split'].astype('category')
+    print('dca: Successfully preprocessed {} genes and {} cells.'.format(adata.n_vars, adata.n_obs))
+    return adata
+
+
+def normalize(adata, filter_min_counts=True, size_factors=True, normalize_input=True,
+              logtrans_input=True):
+    """dca/io.py:88-111."""
+    if filter_min_counts:
+        filter_genes(adata, min_counts=1)
+        filter_cells(adata, min_counts=1)
+
+    if size_factors or normalize_input or logtrans_input:
+        adata.raw = adata.copy()
+    else:
+        adata.raw = adata
+
+    if size_factors:
+        normalize_per_cell(adata)
+        adata.obs['size_factors'] = adata.obs.n_counts / np.median(adata.obs.n_counts)
+    else:
+        adata.obs['size_factors'] = 1.0
+
+    if logtrans_input:
+        log1p(adata)
+
+    if normalize_input:
+        scale(adata)
+
+    return adata
+
+
+def read_genelist(filename):
+    genelist = list(set(open(filename, 'rt').read().strip().split('\n')))
+    assert len(genelist) > 0, 'No genes detected in genelist file'
+    print('dca: Subset of {} genes will be denoised.'.format(len(genelist)))
+    return genelist
+
+
+def write_text_matrix(matrix, filename, rownames=None, colnames=None, transpose=False):
+    """dca/io.py:120-129: TSV with '%.6f' floats; transpose swaps the name vectors too."""
+    if transpose:
+        matrix = matrix.T
+        rownames, colnames = colnames, rownames
+    pd.DataFrame(matrix, index=rownames, columns=colnames).to_csv(filename,
+                                                                  sep='\t',
+                                                                  index=(rownames is not None),
+                                                                  header=(colnames is not None),
+                                                                  float_format='%.6f')
+
+
+def read_pickle(inputfile):
+    return pickle.load(open(inputfile, "rb"))

@@ -1,0 +1,350 @@
+"""Autoencoder classes: the object protocol of dca/network.py on the device engine.
+
+``AE_types`` has the reference's keys (network.py:763-768).  Constructor arguments, ``build()``,
+``save()``, ``predict()``, ``write()``, ``load_weights()`` and the attributes used by
+``train()`` follow the reference; the Keras graph is replaced by ``self.engine``
+(dca_amd.engine.Engine): one flat parameter buffer + HIP kernels.  ``predict`` runs ONE
+inference forward per chunk of cells and emits mean*sf, dispersion, dropout and the latent
+code together (the reference runs 3-4 separate Keras predict passes, network.py:188-211,
+395-405).
+
+Implemented on the MI355X path: zinb-conddisp (the north-star class, network.py:366-421),
+zinb (:496-550), nb-conddisp (:293-339), nb (:249-290).  The remaining keys are registered
+and raise NotImplementedError at build() -- they are head-layout variants queued behind the
+hot path.
+"""
+import os
+import pickle
+
+import numpy as np
+import torch
+
+from . import engine as _engine
+from .io import write_text_matrix
+
+advanced_activations = ('PReLU', 'LeakyReLU')
+
+_test_ops_factory = None     # tests only: see override_ops()
+
+
+class override_ops:
+    """Context manager used by the CPU test-suite to inject an oracle-backed ops object into
+    networks built inside it.  Never used by the product: without it build() instantiates
+    HipOps, which raises when the HIP library or the GPU is missing."""
+
+    def __init__(self, factory):
+        self.factory = factory
+
+    def __enter__(self):
+        global _test_ops_factory
+        self.prev, _test_ops_factory = _test_ops_factory, self.factory
+
+    def __exit__(self, *a):
+        global _test_ops_factory
+        _test_ops_factory = self.prev
+
+
+class Autoencoder():
+    ae_type = 'normal'
+
+    def __init__(self,
+                 input_size,
+                 output_size=None,
+                 hidden_size=(64, 32, 64),
+                 l2_coef=0.,
+                 l1_coef=0.,
+                 l2_enc_coef=0.,
+                 l1_enc_coef=0.,
+                 ridge=0.,
+                 hidden_dropout=0.,
+                 input_dropout=0.,
+                 batchnorm=True,
+                 activation='relu',
+                 init='glorot_uniform',
+                 file_path=None,
+                 debug=False,
+                 comm=None):
+        self.input_size = input_size
+        self.output_size = output_size
+        self.hidden_size = hidden_size
+        self.l2_coef = l2_coef
+        self.l1_coef = l1_coef
+        self.l2_enc_coef = l2_enc_coef
+        self.l1_enc_coef = l1_enc_coef
+        self.ridge = ridge
+        self.hidden_dropout = hidden_dropout
+        self.input_dropout = input_dropout
+        self.batchnorm = batchnorm
+        self.activation = activation
+        self.init = init
+        self.loss = None
+        self.file_path = file_path
+        self.extra_models = {}
+        self.model = None
+        self.encoder = None
+        self.decoder = None
+        self.debug = debug
+        self.engine = None
+        self.comm = comm
+        self.seed = 0
+
+        if self.output_size is None:
+            self.output_size = input_size
+
+        if isinstance(self.hidden_dropout, list):
+            assert len(self.hidden_dropout) == len(self.hidden_size)
+        else:
+            self.hidden_dropout = [self.hidden_dropout] * len(self.hidden_size)
+
+    # ------------------------------------------------------------------ build
+    def _check_supported(self):
+        unsupported = []
+        if self.ae_type not in _engine.AE_HEADS:
+            unsupported.append('ae_type=%r' % self.ae_type)
+        if self.activation != 'relu':
+            unsupported.append('activation=%r' % self.activation)
+        if self.init != 'glorot_uniform':
+            unsupported.append('init=%r' % self.init)
+        if any(d > 0.0 for d in self.hidden_dropout) or self.input_dropout > 0.0:
+            unsupported.append('dropout')
+        if any(c != 0. for c in (self.l1_coef, self.l2_coef, self.l1_enc_coef, self.l2_enc_coef)):
+            unsupported.append('l1/l2 weight regularisation')
+        if unsupported:
+            raise NotImplementedError('not implemented on the MI355X path yet: ' + ', '.join(unsupported))
+
+    def build(self):
+        """network.py:92-141 + build_output: allocates the device engine and initialises the
+        weights (glorot_uniform kernels, zero biases)."""
+        self._check_supported()
+        ops = _test_ops_factory() if _test_ops_factory is not None else None
+        self.engine = _engine.Engine(self.ae_type, self.input_size, self.output_size,
+                                     self.hidden_size, self.batchnorm, self.ridge, ops=ops,
+                                     comm=self.comm)
+        self.engine.init_params(self.seed)
+        self.model = self.engine             # what train() drives (reference: the Keras Model)
+        self.encoder = self.engine
+        self.loss = self.ae_type
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        for k in ('engine', 'model', 'encoder', 'comm'):
+            d[k] = None
+        return d
+
+    def save(self):
+        """network.py:158-162: pickles the (unbuilt) configuration object."""
+        if self.file_path:
+            os.makedirs(self.file_path, exist_ok=True)
+            with open(os.path.join(self.file_path, 'model.pickle'), 'wb') as f:
+                pickle.dump(self, f)
+
+    def save_weights(self, filename):
+        np.savez(filename, **self.engine.get_params())
+
+    def load_weights(self, filename):
+        """network.py:164-167 (the reference reads Keras HDF5; here: the .npz of save_weights)."""
+        with np.load(filename) as z:
+            self.engine.set_params({k: z[k] for k in z.files})
+
+    # ------------------------------------------------------------------ inference
+    def _wanted(self, mode, return_info):
+        want = set()
+        if mode in ('latent', 'full'):
+            want.add('latent')
+        if mode in ('denoise', 'full'):
+            want.add('mean')
+        return want
+
+    def _run_predict(self, adata, want, chunk=4096):
+        """One inference pass over all cells; returns host arrays for the requested outputs."""
+        eng = self.engine
+        n = adata.n_obs
+        X = adata.X
+        sf = np.asarray(adata.obs['size_factors'].values, dtype=np.float32)
+        eng.load_data(X, None, sf)
+        chunk = min(chunk, n)
+        eng.reserve(chunk)
+        lay = eng.lay
+        outs = {}
+        for k in want:
+            cols = lay.hidden[eng.center] if k == 'latent' else lay.G_out
+            outs[k] = np.empty((n, cols), dtype=np.float32)
+        for s in range(0, n, chunk):
+            b = min(chunk, n - s)
+            res = eng.predict_chunk(s, b, want)
+            for k in want:
+                outs[k][s:s + b] = res[k].cpu().numpy()
+        return outs
+
+    def predict(self, adata, mode='denoise', return_info=False, copy=False):
+        """network.py:188-211."""
+        assert mode in ('denoise', 'latent', 'full'), 'Unknown mode'
+        adata = adata.copy() if copy else adata
+        want = self._wanted(mode, return_info)
+        if mode in ('latent', 'full'):
+            print('dca: Calculating low dimensional representations...')
+        if mode in ('denoise', 'full'):
+            print('dca: Calculating reconstructions...')
+        outs = self._run_predict(adata, want)
+        self._store(adata, outs, mode, return_info)
+        return adata if copy else None
+
+    def _store(self, adata, outs, mode, return_info):
+        if 'latent' in outs:
+            adata.obsm['X_dca'] = outs['latent']
+        if 'dispersion' in outs:
+            adata.obsm['X_dca_dispersion'] = outs['dispersion']
+        if 'dropout' in outs:
+            adata.obsm['X_dca_dropout'] = outs['dropout']
+        if mode in ('denoise', 'full'):
+            adata.X = outs['mean']
+        if mode == 'latent':
+            adata.X = adata.raw.X.copy()  # recover normalized expression values (network.py:208-209)
+
+    def write(self, adata, file_path, mode='denoise', colnames=None):
+        """network.py:213-231."""
+        colnames = adata.var_names.values if colnames is None else colnames
+        rownames = adata.obs_names.values
+        print('dca: Saving output(s)...')
+        os.makedirs(file_path, exist_ok=True)
+        if mode in ('denoise', 'full'):
+            print('dca: Saving denoised expression...')
+            write_text_matrix(adata.X, os.path.join(file_path, 'mean.tsv'),
+                              rownames=rownames, colnames=colnames, transpose=True)
+        if mode in ('latent', 'full'):
+            print('dca: Saving latent representations...')
+            write_text_matrix(adata.obsm['X_dca'], os.path.join(file_path, 'latent.tsv'),
+                              rownames=rownames, transpose=False)
+
+
+class PoissonAutoencoder(Autoencoder):
+    ae_type = 'poisson'
+
+
+class NBConstantDispAutoencoder(Autoencoder):
+    """network.py:249-290: NB loss, one trainable dispersion per gene."""
+    ae_type = 'nb'
+
+    def predict(self, adata, mode='denoise', return_info=False, copy=False):
+        res = super().predict(adata, mode, return_info, copy)
+        adata = res if copy else adata
+        if return_info:
+            adata.var['X_dca_dispersion'] = self.engine.const_dispersion()      # network.py:278
+        return adata if copy else None
+
+    def write(self, adata, file_path, mode='denoise', colnames=None):
+        colnames = adata.var_names.values if colnames is None else colnames
+        super().write(adata, file_path, mode, colnames=colnames)
+        if 'X_dca_dispersion' in adata.var_keys():
+            # the reference calls .reshape on a pandas Series here (network.py:288, a bug);
+            # the intended [1, G] row is written
+            write_text_matrix(np.asarray(adata.var['X_dca_dispersion']).reshape(1, -1),
+                              os.path.join(file_path, 'dispersion.tsv'),
+                              colnames=colnames, transpose=True)
+
+
+class NBAutoencoder(Autoencoder):
+    """network.py:293-339: NB loss, dispersion conditioned on the cell (a Dense head)."""
+    ae_type = 'nb-conddisp'
+
+    def _wanted(self, mode, return_info):
+        want = super()._wanted(mode, return_info)
+        if return_info:
+            want.add('dispersion')
+        return want
+
+    def write(self, adata, file_path, mode='denoise', colnames=None):
+        colnames = adata.var_names.values if colnames is None else colnames
+        super().write(adata, file_path, mode, colnames=colnames)
+        if 'X_dca_dispersion' in adata.obsm_keys():
+            write_text_matrix(adata.obsm['X_dca_dispersion'],
+                              os.path.join(file_path, 'dispersion.tsv'),
+                              colnames=colnames, transpose=True)
+
+
+class NBSharedAutoencoder(NBAutoencoder):
+    ae_type = 'nb-shared'
+
+
+class ZINBAutoencoder(Autoencoder):
+    """network.py:366-421: the north-star class (ae_type 'zinb-conddisp')."""
+    ae_type = 'zinb-conddisp'
+
+    def _wanted(self, mode, return_info):
+        want = super()._wanted(mode, return_info)
+        if return_info:
+            want |= {'dispersion', 'dropout'}
+        return want
+
+    def predict(self, adata, mode='denoise', return_info=False, copy=False, colnames=None):
+        return super().predict(adata, mode, return_info, copy)
+
+    def write(self, adata, file_path, mode='denoise', colnames=None):
+        colnames = adata.var_names.values if colnames is None else colnames
+        super().write(adata, file_path, mode, colnames=colnames)
+        if 'X_dca_dispersion' in adata.obsm_keys():
+            write_text_matrix(adata.obsm['X_dca_dispersion'],
+                              os.path.join(file_path, 'dispersion.tsv'),
+                              colnames=colnames, transpose=True)
+        if 'X_dca_dropout' in adata.obsm_keys():
+            write_text_matrix(adata.obsm['X_dca_dropout'],
+                              os.path.join(file_path, 'dropout.tsv'),
+                              colnames=colnames, transpose=True)
+
+
+class ZINBAutoencoderElemPi(ZINBAutoencoder):
+    ae_type = 'zinb-elempi'
+
+    def __init__(self, sharedpi=False, **kwds):
+        super().__init__(**kwds)
+        self.sharedpi = sharedpi
+
+
+class ZINBSharedAutoencoder(ZINBAutoencoder):
+    ae_type = 'zinb-shared'
+
+
+class ZINBConstantDispAutoencoder(Autoencoder):
+    """network.py:496-550: ZINB loss, one trainable dispersion per gene (ae_type 'zinb')."""
+    ae_type = 'zinb'
+
+    def _wanted(self, mode, return_info):
+        want = super()._wanted(mode, return_info)
+        if return_info:
+            want.add('dropout')
+        return want
+
+    def predict(self, adata, mode='denoise', return_info=False, copy=False):
+        res = super().predict(adata, mode, return_info, copy)
+        adata = res if copy else adata
+        if return_info:
+            adata.var['X_dca_dispersion'] = self.engine.const_dispersion()      # network.py:530
+        return adata if copy else None
+
+    def write(self, adata, file_path, mode='denoise', colnames=None):
+        colnames = adata.var_names.values if colnames is None else colnames
+        super().write(adata, file_path, mode, colnames=colnames)
+        if 'X_dca_dispersion' in adata.var_keys():
+            write_text_matrix(adata.var['X_dca_dispersion'].values.reshape(1, -1),
+                              os.path.join(file_path, 'dispersion.tsv'),
+                              colnames=colnames, transpose=True)
+        if 'X_dca_dropout' in adata.obsm_keys():
+            write_text_matrix(adata.obsm['X_dca_dropout'],
+                              os.path.join(file_path, 'dropout.tsv'),
+                              colnames=colnames, transpose=True)
+
+
+class ZINBForkAutoencoder(ZINBAutoencoder):
+    ae_type = 'zinb-fork'
+
+
+class NBForkAutoencoder(NBAutoencoder):
+    ae_type = 'nb-fork'
+
+
+AE_types = {'normal': Autoencoder, 'poisson': PoissonAutoencoder,
+            'nb': NBConstantDispAutoencoder, 'nb-conddisp': NBAutoencoder,
+            'nb-shared': NBSharedAutoencoder, 'nb-fork': NBForkAutoencoder,
+            'zinb': ZINBConstantDispAutoencoder, 'zinb-conddisp': ZINBAutoencoder,
+            'zinb-shared': ZINBSharedAutoencoder, 'zinb-fork': ZINBForkAutoencoder,
+            'zinb-elempi': ZINBAutoencoderElemPi}

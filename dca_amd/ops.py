@@ -93,6 +93,10 @@ class HipOps:
         hip.check(self.L.dcahip_relu_bwd(p(dH), ldd, p(Hact), ldh, B, H, p(dZ), ldz, hip.stream()),
                   'relu_bwd')
 
+    def relu_fwd(self, Z, ldz, B, H, Hout, ldh):
+        hip.check(self.L.dcahip_relu_fwd(hip.ptr(Z), ldz, B, H, hip.ptr(Hout), ldh, hip.stream()),
+                  'relu_fwd')
+
     def colsum_chain(self, x, ldx, B, N, theta_w, out):
         p = hip.ptr
         hip.check(self.L.dcahip_colsum_chain(p(x), ldx, B, N, p(theta_w), p(out), hip.stream()),

@@ -1,0 +1,216 @@
+"""Training driver: the reference's ``train()`` (dca/train.py:35-100) on the device engine.
+
+Same signature, same defaults, same return protocol (an object with ``.history`` holding
+``loss`` / ``val_loss`` / ``lr`` lists).  What Keras' ``model.fit`` did per batch on the host
+(slice index_array, copy the batch, session.run) is replaced by: the whole dataset resident in
+HBM, one int32 permutation upload per epoch, and an asynchronous stream of kernel launches --
+the host only reads two scalars back per epoch.
+
+Keras semantics restated here (source not vendored in the reference):
+validation_split takes the LAST rows before shuffling; each epoch shuffles a fresh arange with
+the numpy global RNG; the last partial batch is kept; the epoch loss is the sample-weighted
+mean of the batch losses; ReduceLROnPlateau(factor .1, min_delta 1e-4) and EarlyStopping
+(min_delta 0) both monitor val_loss.
+"""
+import math
+import os
+
+import numpy as np
+import torch
+
+from . import dist as ddist
+
+
+class History:
+    """Stand-in for keras.callbacks.History (api.py:205-206 reads ``.history``)."""
+
+    def __init__(self):
+        self.history = {'loss': [], 'val_loss': [], 'lr': []}
+        self.epoch = []
+        self.stopped_epoch = None
+
+
+class _ReduceLROnPlateau:     # keras defaults as used at train.py:70-72
+    def __init__(self, patience, verbose=False):
+        self.patience, self.factor, self.min_delta, self.min_lr = patience, 0.1, 1e-4, 0.0
+        self.best, self.wait, self.verbose = np.inf, 0, verbose
+
+    def step(self, epoch, val, lr):
+        if val < self.best - self.min_delta:
+            self.best, self.wait = val, 0
+            return lr
+        self.wait += 1
+        if self.wait >= self.patience:
+            if lr > self.min_lr:
+                lr = float(np.float32(max(lr * self.factor, self.min_lr)))
+                if self.verbose:
+                    print('\nEpoch %05d: ReduceLROnPlateau reducing learning rate to %s.' % (epoch + 1, lr))
+            self.wait = 0
+        return lr
+
+
+class _EarlyStopping:         # keras defaults as used at train.py:73-75
+    def __init__(self, patience):
+        self.patience, self.best, self.wait = patience, np.inf, 0
+
+    def step(self, val):
+        if val < self.best:
+            self.best, self.wait = val, 0
+            return False
+        self.wait += 1
+        return self.wait >= self.patience
+
+
+def fit_engine(eng, n_train_global, n_val_global, nt_local, nv_local, t0_global, *, epochs=300,
+               batch_size=32, learning_rate=None, clip_grad=5.0, reduce_lr=10, early_stop=15,
+               verbose=False, shuffle_rng=None, use_graph=None, on_epoch=None):
+    """Runs the Keras-equivalent fit loop on an engine whose storage rows are
+    [0, nt_local) = this rank's train shard and [nt_local, nt_local+nv_local) = its
+    validation shard.  Returns History."""
+    comm = eng.comm
+    W = comm.world
+    rng = np.random if shuffle_rng is None else shuffle_rng
+    if batch_size % W != 0:
+        raise ValueError('batch_size (%d) must be a multiple of the number of GPUs (%d)' % (batch_size, W))
+    b_local = batch_size // W
+    nt_all = [ddist.shard(n_train_global, W, r)[1] for r in range(W)]
+    steps = int(math.ceil(max(nt_all) / float(b_local))) if max(nt_all) > 0 else 0
+    counts = [[int(min(max(nt_all[r] - t * b_local, 0), b_local)) for r in range(W)] for t in range(steps)]
+    eng.clip = float(clip_grad) if clip_grad else 0.0
+    lr = float(np.float32(0.001 if learning_rate is None else learning_rate))
+    eng.set_lr(lr)
+    eng.reserve(max(b_local, min(1024, max(nv_local, 1))))     # validation runs in big chunks
+    dev = eng.dev
+    eng.perm = torch.zeros(max(nt_local, 1), dtype=torch.int32, device=dev)
+    eng.hist = torch.zeros(steps + 1, dtype=torch.float32, device=dev)
+    G = eng.lay.G_out
+    val_scale = 1.0 / (float(n_val_global) * G) if n_val_global > 0 else 0.0
+    rl = _ReduceLROnPlateau(reduce_lr, verbose) if reduce_lr else None
+    es = _EarlyStopping(early_stop) if early_stop else None
+    hist = History()
+    runner = _StepRunner(eng, use_graph)
+    for epoch in range(epochs):
+        idx = np.arange(n_train_global)
+        rng.shuffle(idx)                                       # numpy global RNG, like Keras
+        order = ddist.local_order(idx, t0_global, nt_local)
+        if nt_local > 0:
+            eng.perm[:nt_local].copy_(torch.as_tensor(order), non_blocking=False)
+        eng.cursor.zero_()
+        eng.acc.zero_()
+        for t in range(steps):
+            runner.step(counts[t][comm.rank], sum(counts[t]), counts[t], b_local)
+        if nv_local > 0:
+            eng.eval_loss_sum(nt_local, nt_local + nv_local, val_scale)
+        if W > 1:
+            comm.all_reduce_sum(eng.acc[1:])
+        acc = eng.acc.cpu().numpy()                            # the one host sync per epoch
+        loss = float(acc[0]) / n_train_global
+        hist.history['loss'].append(loss)
+        hist.history['lr'].append(lr)
+        hist.epoch.append(epoch)
+        stop = False
+        if n_val_global > 0:
+            val = float(acc[1])
+            hist.history['val_loss'].append(val)
+            if rl is not None:
+                new_lr = rl.step(epoch, val, lr)
+                if new_lr != lr:
+                    lr = new_lr
+                    eng.set_lr(lr)
+            if es is not None and es.step(val):
+                stop = True
+        if verbose and comm.rank == 0:
+            msg = 'Epoch %d/%d - loss: %.4f' % (epoch + 1, epochs, loss)
+            if n_val_global > 0:
+                msg += ' - val_loss: %.4f' % hist.history['val_loss'][-1]
+            print(msg, flush=True)
+        if on_epoch is not None:
+            on_epoch(epoch, hist)
+        if stop:
+            hist.stopped_epoch = epoch
+            if verbose and comm.rank == 0:
+                print('Epoch %05d: early stopping' % (epoch + 1))
+            break
+    if n_val_global == 0:
+        del hist.history['val_loss']
+    return hist
+
+
+class _StepRunner:
+    """Launches training steps; on one GPU the step (≈30 kernels, no host sync) is captured
+    once per distinct batch size into a hipGraph and replayed -- the device cursor makes the
+    same graph valid for every batch of every epoch."""
+
+    def __init__(self, eng, use_graph):
+        self.eng = eng
+        if use_graph is None:
+            use_graph = os.environ.get('DCA_AMD_GRAPH', '1') != '0'
+        self.use_graph = bool(use_graph) and eng.ops.device_type == 'cuda' and eng.comm.world == 1
+        self.graphs = {}
+
+    def step(self, b, b_global, world_counts, rows_per_slot):
+        eng = self.eng
+        if not self.use_graph or b == 0:
+            eng.train_step(b, b_global, world_counts, rows_per_slot)
+            return
+        g = self.graphs.get(b)
+        if g is None:
+            # first step of each batch size runs eagerly (loads the code objects outside a
+            # capture); the second one is captured, later ones replay
+            self.graphs[b] = 'seen'
+            eng.train_step(b, b_global, world_counts, rows_per_slot)
+            return
+        if g == 'seen':
+            g = torch.cuda.CUDAGraph()
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                with torch.cuda.graph(g, stream=s):
+                    eng.train_step(b, b_global, world_counts, rows_per_slot)
+            torch.cuda.current_stream().wait_stream(s)
+            self.graphs[b] = g
+        g.replay()
+
+
+def train(adata, network, output_dir=None, optimizer='RMSprop', learning_rate=None,
+          epochs=300, reduce_lr=10, output_subset=None, use_raw_as_output=True,
+          early_stop=15, batch_size=32, clip_grad=5., save_weights=False,
+          validation_split=0.1, tensorboard=False, verbose=True, threads=None,
+          **kwds):
+    """Signature and defaults of dca/train.py:35-39.  ``threads`` (TF CPU pools) and
+    ``tensorboard`` have no meaning on the GPU path and are accepted and ignored; optimizers
+    other than RMSprop are not implemented yet and raise."""
+    if optimizer.lower() != 'rmsprop':
+        raise NotImplementedError("optimizer %r: only 'RMSprop' (the reference default, "
+                                  'train.py:35) is implemented on the MI355X path' % optimizer)
+    eng = network.engine
+    if eng is None:
+        raise RuntimeError('network.build() must be called before train()')
+    if output_dir is not None:
+        os.makedirs(output_dir, exist_ok=True)
+
+    X = adata.X
+    sf = np.asarray(adata.obs['size_factors'].values, dtype=np.float32)       # train.py:83
+    if output_subset:                                                        # train.py:85-87
+        gene_idx = [np.where(adata.raw.var_names == x)[0][0] for x in output_subset]
+        Y = adata.raw.X[:, gene_idx] if use_raw_as_output else adata.X[:, gene_idx]
+    else:
+        Y = adata.raw.X if use_raw_as_output else adata.X
+
+    n = X.shape[0]
+    split_at = int(n * (1.0 - validation_split)) if validation_split and 0. < validation_split < 1. else n
+    n_train, n_val = split_at, n - split_at
+    comm = eng.comm
+    t0, nt = ddist.shard(n_train, comm.world, comm.rank)
+    v0, nv = ddist.shard(n_val, comm.world, comm.rank)
+    rows = np.r_[np.arange(t0, t0 + nt), split_at + np.arange(v0, v0 + nv)]
+    if comm.world == 1:
+        eng.load_data(X, Y, sf)
+    else:
+        eng.load_data(X[rows], Y[rows], sf[rows])
+    hist = fit_engine(eng, n_train, n_val, nt, nv, t0, epochs=epochs, batch_size=batch_size,
+                      learning_rate=learning_rate, clip_grad=clip_grad, reduce_lr=reduce_lr,
+                      early_stop=early_stop, verbose=verbose, **kwds)
+    if save_weights and output_dir is not None and comm.rank == 0:
+        network.save_weights(os.path.join(output_dir, 'weights.npz'))
+    return hist

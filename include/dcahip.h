@@ -155,6 +155,8 @@ int dcahip_bn_bwd_apply(const float* dH, long ldd, const float* Hact, long ldh,
                         float* dZ, long ldz, float* dbeta, void* stream);
 int dcahip_relu_bwd(const float* dH, long ldd, const float* Hact, long ldh, int B, int H,
                     float* dZ, long ldz, void* stream);
+/* h = max(z, 0): Activation('relu') of a stack built with batchnorm=False (network.py:132-135). */
+int dcahip_relu_fwd(const float* Z, long ldz, int B, int H, float* Hout, long ldh, void* stream);
 
 /* out[c] (+)= chain(c) * sum_r x[r, c]; chain = d clip(exp(w),1e-3,1e4)/dw if theta_w given
  * (ConstantDispersionLayer gradient, dca/layers.py:17-21), else 1. */

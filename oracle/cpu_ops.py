@@ -1,0 +1,238 @@
+"""Oracle (test infrastructure only): a CPU object with the SAME method interface as
+dca_amd.ops.HipOps, every method computed with numpy (fp64 inside, fp32 buffers) following
+the documented contract of include/dcahip.h.
+
+Purpose: lets tests/ run the engine's HOST logic (buffer layout, step orchestration, fit loop,
+data-parallel sharding + collectives over gloo) in a container without a GPU, and compare it
+with the straight-line oracle in net_np.py.  It is injected explicitly by tests
+(Engine(ops=CpuRefOps())); nothing in dca_amd/ imports it and the product never falls back to it.
+"""
+import numpy as np
+import torch
+
+from . import zinb_np as Z
+
+
+def _mat(t, rows, cols, ld):
+    """numpy view [rows, cols] with row stride ld starting at t's first element."""
+    if t is None:
+        return None
+    assert not t.is_cuda
+    return torch.as_strided(t, (rows, cols), (ld, 1)).numpy()
+
+
+def _vec(t, n):
+    return None if t is None else torch.as_strided(t, (n,), (1,)).numpy()
+
+
+def _chunks(B):
+    r = (B + 63) // 64
+    return max(1, min(256, r))
+
+
+class CpuRefOps:
+    name = 'cpu-oracle'
+    device_type = 'cpu'
+    max_partials = 2048
+
+    # ------------------------------------------------------------------ loss
+    def zinb_nll(self, a_mean, a_disp, a_pi, lda, theta_w, Y, ldy, sf, perm, cursor, B, G, ridge,
+                 inv_n, flags, d_mean, d_disp, d_pi, ldd, partials):
+        has_pi, cdisp = bool(flags & 1), bool(flags & 2)
+        c = int(cursor.item()) if cursor is not None else 0
+        rows = (perm[c:c + B].numpy().astype(np.int64) if perm is not None else np.arange(c, c + B))
+        n_store = int(rows.max()) + 1
+        y = _mat(Y, n_store, G, ldy)[rows].astype(np.float64)
+        sfv = _vec(sf, n_store)[rows].astype(np.float64)
+        am = _mat(a_mean, B, G, lda).astype(np.float64)
+        ad = None if cdisp else _mat(a_disp, B, G, lda).astype(np.float64)
+        tw = _vec(theta_w, G).astype(np.float64) if cdisp else None
+        n_total = 1.0 / inv_n
+        if has_pi:
+            ap = _mat(a_pi, B, G, lda).astype(np.float64)
+            if not cdisp:
+                ls, _, dm, dd, dp = Z.zinb_loss_and_grads(am, ad, ap, y, sfv, ridge, n_total, None)
+            else:       # per-element d nll / d theta * inv_n (chain applied by colsum_chain)
+                mu, _, pi = Z.heads_forward(am, None, ap, sfv)
+                th = np.broadcast_to(Z.const_disp(tw).reshape(1, -1), am.shape)
+                ls = Z.zinb_nll(y, mu, th, pi, ridge).sum()
+                dmu, dth, dpi = Z.zinb_grads(y, mu, th, pi, ridge)
+                gm, _ = Z._act_grads(am, None)
+                dm = dmu * sfv.reshape(-1, 1) * gm * inv_n
+                dd = dth * inv_n
+                dp = dpi * pi * (1 - pi) * inv_n
+        else:
+            if cdisp:
+                mu, _, _ = Z.heads_forward(am, None, None, sfv)
+                th = np.broadcast_to(Z.const_disp(tw).reshape(1, -1), am.shape)
+                ls = Z.nb_nll(y, mu, th).sum()
+                dmu, dth = Z.nb_grads(y, mu, th)
+                gm, _ = Z._act_grads(am, None)
+                dm = dmu * sfv.reshape(-1, 1) * gm * inv_n
+                dd = dth * inv_n
+            else:
+                ls, _, dm, dd = Z.nb_loss_and_grads(am, ad, y, sfv, n_total, None)
+            dp = None
+        if d_mean is not None:
+            _mat(d_mean, B, G, ldd)[:] = dm
+            _mat(d_disp, B, G, ldd)[:] = dd
+            if has_pi:
+                _mat(d_pi, B, G, ldd)[:] = dp
+        partials[0] = float(ls)
+        return 1
+
+    def loss_finalize(self, partials, n, scale, loss_out):
+        v = float(partials[:n].sum().item()) * scale
+        loss_out[0] = float(np.float32(np.inf if np.isnan(v) else v))
+
+    def step_end(self, loss, weight, hist, rows_per_slot, acc, cursor, advance):
+        c = int(cursor.item()) if cursor is not None else 0
+        if loss is not None:
+            lv = float(loss[0].item())
+            if hist is not None:
+                hist[c // rows_per_slot if rows_per_slot > 0 else 0] = lv
+            if acc is not None:
+                acc[0] += lv * weight
+        if cursor is not None:
+            cursor[0] = c + advance
+
+    def heads_infer(self, a_mean, a_disp, a_pi, lda, sf, B, G, mean_sf, theta, pi, ldo):
+        sfv = _vec(sf, B).astype(np.float64)
+        if mean_sf is not None:
+            _mat(mean_sf, B, G, ldo)[:] = Z.mean_act(_mat(a_mean, B, G, lda).astype(np.float64)) * sfv[:, None]
+        if theta is not None:
+            _mat(theta, B, G, ldo)[:] = Z.disp_act(_mat(a_disp, B, G, lda).astype(np.float64))
+        if pi is not None:
+            _mat(pi, B, G, ldo)[:] = Z.sigmoid(_mat(a_pi, B, G, lda).astype(np.float64))
+
+    # ------------------------------------------------------------------ gemm
+    def sgemm_workspace_bytes(self, ta, tb, M, N, K, colsum_row=False, split_k=0):
+        return 0
+
+    def sgemm(self, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias=None, perm=None, cursor=None,
+              colsum_row=False, split_k=0, ws=None):
+        ra, ca = (K, M) if ta else (M, K)
+        rb, cb = (N, K) if tb else (K, N)
+        if perm is not None:
+            c = int(cursor.item()) if cursor is not None else 0
+            rows = perm[c:c + ra].numpy().astype(np.int64)
+            a = _mat(A, int(rows.max()) + 1, ca, lda)[rows].astype(np.float64)
+        else:
+            a = _mat(A, ra, ca, lda).astype(np.float64)
+        b = _mat(B, rb, cb, ldb).astype(np.float64)
+        opa = a.T if ta else a
+        opb = b.T if tb else b
+        out = opa @ opb
+        if bias is not None:
+            out = out + _vec(bias, N).astype(np.float64)
+        _mat(C, M, N, ldc)[:] = out
+        if colsum_row:
+            torch.as_strided(C, (N,), (1,), C.storage_offset() + M * ldc).numpy()[:] = b.sum(axis=0)
+
+    # ------------------------------------------------------------------ batch norm
+    def col_moments_chunks(self, B):
+        return _chunks(B)
+
+    def col_moments(self, Zt, ldz, B, H, part):
+        R = _chunks(B)
+        cr = -(-B // R)
+        z = _mat(Zt, B, H, ldz).astype(np.float64)
+        p = _vec(part, R * 2 * H).reshape(R, 2, H)
+        for r in range(R):
+            blk = z[r * cr:min(B, (r + 1) * cr)]
+            if len(blk):
+                mu = blk.mean(0)
+                p[r, 0] = mu
+                p[r, 1] = ((blk - mu) ** 2).sum(0)
+            else:
+                p[r] = 0
+
+    @staticmethod
+    def _merge(ent, cnt):
+        n = 0.0
+        mean = np.zeros(ent.shape[2]); m2 = np.zeros(ent.shape[2])
+        for e in range(ent.shape[0]):
+            ne = float(cnt[e])
+            if ne <= 0:
+                continue
+            tot = n + ne
+            delta = ent[e, 0].astype(np.float64) - mean
+            mean = mean + delta * ne / tot
+            m2 = m2 + ent[e, 1].astype(np.float64) + delta * delta * n * ne / tot
+            n = tot
+        return n, mean, m2
+
+    def moments_combine(self, entries, counts, E, H, out):
+        n, mean, m2 = self._merge(_vec(entries, E * 2 * H).reshape(E, 2, H), _vec(counts, E))
+        o = _vec(out, 2 * H)
+        o[:H] = mean; o[H:] = m2
+
+    def bn_relu_apply(self, Zt, ldz, B, H, entries, counts, E, beta, mm, mv, momentum, eps, relu,
+                      Hout, ldh, xhat, ldx, inv_std):
+        z = _mat(Zt, B, H, ldz).astype(np.float64)
+        mmv, mvv = _vec(mm, H), _vec(mv, H)
+        if entries is not None:
+            if counts is None:
+                cr = -(-B // E)
+                cnt = [max(0, min(B, (r + 1) * cr) - r * cr) for r in range(E)]
+            else:
+                cnt = _vec(counts, E)
+            n, mean, m2 = self._merge(_vec(entries, E * 2 * H).reshape(E, 2, H), cnt)
+            mean = mean.astype(np.float32); var = (m2 / n).astype(np.float32)
+            mmv[:] = mmv - (mmv - mean) * np.float32(1 - momentum)
+            mvv[:] = mvv - (mvv - var) * np.float32(1 - momentum)
+        else:
+            mean, var = mmv.copy(), mvv.copy()
+        inv = (1 / np.sqrt(var.astype(np.float64) + eps))
+        xh = (z - mean) * inv
+        if xhat is not None:
+            _mat(xhat, B, H, ldx)[:] = xh
+        y = xh + (_vec(beta, H) if beta is not None else 0.0)
+        if relu:
+            y = np.maximum(y, 0)
+        _mat(Hout, B, H, ldh)[:] = y
+        if inv_std is not None:
+            _vec(inv_std, H)[:] = inv
+
+    def bn_bwd_sums(self, dH, ldd, Hact, ldh, xhat, ldx, B, H, part):
+        R = _chunks(B)
+        cr = -(-B // R)
+        dy = _mat(dH, B, H, ldd).astype(np.float64) * (_mat(Hact, B, H, ldh) > 0)
+        xh = _mat(xhat, B, H, ldx).astype(np.float64)
+        p = _vec(part, R * 2 * H).reshape(R, 2, H)
+        for r in range(R):
+            s = slice(r * cr, min(B, (r + 1) * cr))
+            p[r, 0] = dy[s].sum(0)
+            p[r, 1] = (dy[s] * xh[s]).sum(0)
+
+    def bn_bwd_apply(self, dH, ldd, Hact, ldh, xhat, ldx, inv_std, sums, E, n_total, B, H, dZ, ldz,
+                     dbeta):
+        s = _vec(sums, E * 2 * H).reshape(E, 2, H).astype(np.float64).sum(0)
+        dy = _mat(dH, B, H, ldd).astype(np.float64) * (_mat(Hact, B, H, ldh) > 0)
+        xh = _mat(xhat, B, H, ldx).astype(np.float64)
+        inv = _vec(inv_std, H).astype(np.float64)
+        _mat(dZ, B, H, ldz)[:] = inv * (dy - s[0] / n_total - xh * s[1] / n_total)
+        if dbeta is not None:
+            _vec(dbeta, H)[:] = s[0]
+
+    def relu_bwd(self, dH, ldd, Hact, ldh, B, H, dZ, ldz):
+        _mat(dZ, B, H, ldz)[:] = _mat(dH, B, H, ldd) * (_mat(Hact, B, H, ldh) > 0)
+
+    def relu_fwd(self, Zt, ldz, B, H, Hout, ldh):
+        _mat(Hout, B, H, ldh)[:] = np.maximum(_mat(Zt, B, H, ldz), 0)
+
+    def colsum_chain(self, x, ldx, B, N, theta_w, out):
+        s = _mat(x, B, N, ldx).astype(np.float64).sum(0)
+        if theta_w is not None:
+            e = np.exp(_vec(theta_w, N).astype(np.float64))
+            s = s * np.where((e >= 1e-3) & (e <= 1e4), e, 0.0)
+        _vec(out, N)[:] = s
+
+    # ------------------------------------------------------------------ optimizer
+    def rmsprop_clip(self, w, g, ms, n, lr, rho, eps, clip):
+        wv, gv, mv = _vec(w, n), _vec(g, n).astype(np.float64), _vec(ms, n)
+        if clip > 0:
+            gv = np.clip(gv, -clip, clip)
+        m = rho * mv.astype(np.float64) + (1 - rho) * gv * gv
+        mv[:] = m
+        wv[:] = wv - float(lr[0].item()) * gv / np.sqrt(m + eps)

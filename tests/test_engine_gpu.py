@@ -1,0 +1,102 @@
+"""End-to-end parity on the MI355X: the engine driving the HIP kernels through the C ABI against
+the fp64 oracle (oracle/net_np.py) with identical injected weights and batch order.
+
+Tolerances (fp32 kernels vs fp64 oracle):  batch / epoch loss 1e-4 relative (BASELINE.md
+target), gradients 2e-3 relative + 2e-5 of the tensor's max, outputs mean/dispersion/dropout
+1e-4 relative after training steps.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import net_np as N
+from helpers import make_problem, oracle_net, make_engine, assert_grads_close, run_single_step
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from dca_amd.ops import HipOps
+    return HipOps()
+
+
+@pytest.mark.parametrize('ae_type', N.AE_TYPES)
+@pytest.mark.parametrize('batchnorm', [True, False])
+@pytest.mark.parametrize('n,G,hs,B', [(300, 203, (64, 32, 64), 32), (40, 6, (1,), 25),
+                                      (600, 1000, (64, 32, 64), 300), (200, 130, (16, 5), 130)])
+def test_single_step_matches_oracle(ops, ae_type, batchnorm, n, G, hs, B):
+    ridge = 0.03 if ae_type.startswith('zinb') else 0.0
+    X, Y, sf, p = make_problem(n, G, hs, ae_type, batchnorm, seed=n)
+    rows = np.random.RandomState(1).permutation(n)[:B]
+    ref = oracle_net(ae_type, p, hs, batchnorm, ridge)
+    rl, rg = ref.loss_and_grads(X[rows].astype(np.float64), Y[rows].astype(np.float64),
+                                sf[rows].astype(np.float64))
+    ms = {}
+    N.rmsprop_step(ref.p, rg, ms, 1e-3)
+    eng = make_engine(ops, ae_type, G, hs, batchnorm, ridge, p, X, Y, sf)
+    loss, g, newp = run_single_step(eng, rows)
+    assert abs(loss - rl) < 1e-5 * abs(rl), (loss, rl)
+    assert_grads_close(g, rg)
+    if batchnorm:
+        for i in range(len(hs)):
+            np.testing.assert_allclose(newp['mm%d' % i], ref.p['mm%d' % i], rtol=1e-4, atol=1e-6)
+            np.testing.assert_allclose(newp['mv%d' % i], ref.p['mv%d' % i], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize('ae_type,use_graph', [('zinb-conddisp', True), ('zinb-conddisp', False),
+                                               ('zinb', True), ('nb-conddisp', True), ('nb', True)])
+def test_fit_epoch_losses_match_oracle(ops, ae_type, use_graph):
+    """BASELINE config 2 shape (2 000 x 1 000, 64-32-64, B=32): per-epoch loss / val_loss."""
+    from dca_amd.train import fit_engine
+    n, G, hs = 2000, 1000, (64, 32, 64)
+    epochs = 2
+    X, Y, sf, p = make_problem(n, G, hs, ae_type, True, seed=21)
+    ref = oracle_net(ae_type, p, hs, True)
+    rh = N.fit(ref, X.astype(np.float64), Y.astype(np.float64), sf.astype(np.float64), epochs=epochs,
+               batch_size=32, shuffle_rng=np.random.RandomState(5))
+    eng = make_engine(ops, ae_type, G, hs, True, 0.0, p, X, Y, sf)
+    n_train = int(n * 0.9)
+    h = fit_engine(eng, n_train, n - n_train, n_train, n - n_train, 0, epochs=epochs, batch_size=32,
+                   shuffle_rng=np.random.RandomState(5), use_graph=use_graph)
+    np.testing.assert_allclose(h.history['loss'], rh['loss'], rtol=1e-4)
+    np.testing.assert_allclose(h.history['val_loss'], rh['val_loss'], rtol=1e-4)
+    # outputs after training: mean / dispersion / dropout / latent
+    out_ref = ref.predict(X[:64].astype(np.float64), sf[:64].astype(np.float64))
+    eng.reserve(64)
+    want = {'mean', 'latent'} | ({'dispersion'} if 'disp' in eng.lay.heads else set()) \
+        | ({'dropout'} if 'pi' in eng.lay.heads else set())
+    out = eng.predict_chunk(0, 64, want)
+    torch.cuda.synchronize()
+    for k in want:
+        np.testing.assert_allclose(out[k].cpu().numpy(), out_ref[k], rtol=2e-3, atol=2e-4, err_msg=k)
+
+
+def test_graph_replay_equals_eager(ops):
+    from dca_amd.train import fit_engine
+    n, G, hs = 500, 200, (64, 32, 64)
+    X, Y, sf, p = make_problem(n, G, hs, 'zinb-conddisp', True, seed=2)
+    res = []
+    for use_graph in (False, True):
+        eng = make_engine(ops, 'zinb-conddisp', G, hs, True, 0.0, p, X, Y, sf)
+        h = fit_engine(eng, 450, 50, 450, 50, 0, epochs=3, batch_size=32,
+                       shuffle_rng=np.random.RandomState(1), use_graph=use_graph)
+        res.append((h.history, eng.get_params()))
+    assert res[0][0]['loss'] == res[1][0]['loss']            # same kernels, same order: bit-equal
+    assert res[0][0]['val_loss'] == res[1][0]['val_loss']
+    for k in res[0][1]:
+        np.testing.assert_array_equal(res[0][1][k], res[1][1][k])
+
+
+def test_large_batch_step(ops):
+    """Throughput regime (B = 2048 rows, G = 2000): split-K / 128x128 tile paths."""
+    n, G, hs, B = 2100, 2000, (64, 32, 64), 2048
+    X, Y, sf, p = make_problem(n, G, hs, 'zinb-conddisp', True, seed=3)
+    rows = np.random.RandomState(0).permutation(n)[:B]
+    ref = oracle_net('zinb-conddisp', p, hs, True)
+    rl, rg = ref.loss_and_grads(X[rows].astype(np.float64), Y[rows].astype(np.float64),
+                                sf[rows].astype(np.float64))
+    eng = make_engine(ops, 'zinb-conddisp', G, hs, True, 0.0, p, X, Y, sf)
+    loss, g, _ = run_single_step(eng, rows)
+    assert abs(loss - rl) < 1e-5 * abs(rl)
+    assert_grads_close(g, rg)
