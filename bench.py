@@ -1,0 +1,226 @@
+#!/usr/bin/env python
+"""bench.py -- training throughput of the ZINB-conddisp autoencoder on MI355X.
+
+Metric (BASELINE.json): cells/sec training, ZINB AE 64-32-64 on a synthetic 68 579 x 20 000
+count matrix (BASELINE configs[2], the configuration the metric is quoted on; it fits one GPU).
+A "step" = one pass of the hot path over one minibatch: forward (Dense/BN/ReLU x3, three
+heads), ZINB NLL + gradient, full backward, clipvalue + RMSprop.  Inputs are resident in HBM
+before the timed region starts.
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torchrun)
+
+Prints ONE JSON line on rank 0 (contract in the repository task statement), with
+  roofline      live HIP-event timing of the dominant kernel inside the timed region
+  cpu_baseline  the oracle's torch-CPU port of the same step on the host cores (rank 0, N=1)
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32 MFMA peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--cells', type=int, default=68579)
+    ap.add_argument('--genes', type=int, default=20000)
+    ap.add_argument('--hidden', type=str, default='64,32,64')
+    ap.add_argument('--batch-size', type=int, default=4096, help='cells per GPU per step')
+    ap.add_argument('--graph', type=str, default='auto', choices=['auto', 'on', 'off'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=15.0)
+    return ap.parse_args()
+
+
+def kernel_model(name, B, G, hidden, nheads=3):
+    """Algorithmic work of one launch: bytes for the HBM-bound
+    kernel, flops for the GEMMs."""
+    Gp = (G + 3) // 4 * 4
+    h1, hL = hidden[0], hidden[-1]
+    if name == 'zinb_nll':
+        return 'hbm', 28.0 * B * G                      # 3 pre-acts + y read, 3 grads written
+    if name == 'rmsprop_clip':
+        return 'hbm', None
+    fl = {'gemm_enc0_fwd': 2.0 * B * G * h1, 'gemm_enc0_dW': 2.0 * B * G * h1,
+          'gemm_heads_fwd': 2.0 * B * hL * nheads * Gp, 'gemm_heads_dW': 2.0 * B * hL * nheads * Gp,
+          'gemm_heads_dH': 2.0 * B * hL * nheads * Gp}
+    return 'mfma', fl.get(name)
+
+
+def cpu_baseline(Xh, Yh, sfh, params, hidden, B, budget_s):
+    """Times the oracle's torch-CPU port of the training step (oracle/torch_ref.py) on the host."""
+    from oracle.torch_ref import TorchAE
+    cores = os.cpu_count()
+    torch.set_num_threads(cores)
+    net = TorchAE('zinb-conddisp', params, hidden, True, dtype=torch.float32)
+    n = Xh.shape[0]
+    nb = max(n // B, 1)
+    X, Y, S = torch.as_tensor(Xh), torch.as_tensor(Yh), torch.as_tensor(sfh)
+    net.train_step(X[:B], Y[:B], S[:B])                   # warm-up
+    t0 = time.perf_counter(); steps = 0
+    while True:
+        s = (steps % nb) * B
+        net.train_step(X[s:s + B], Y[s:s + B], S[s:s + B])
+        steps += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or steps >= 200:
+            break
+    return {'value': steps * B / el, 'unit': 'cells/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d steps of batch %d on the first %d cells of the same synthetic matrix, '
+                      'oracle/torch_ref.py (torch-CPU fp32, %d threads), %.1f s'
+                      % (steps, B, min(n, nb * B), cores, el),
+            'ms_per_step': 1e3 * el / steps}
+
+
+def main():
+    args = parse()
+    from dca_amd import dist as ddist, synth
+    from dca_amd.engine import Engine, EventProfiler
+    comm = ddist.init_from_env()
+    W, rank = comm.world, comm.rank
+    if args.gpus != W:
+        if W == 1 and args.gpus > 1:
+            raise SystemExit('bench.py --gpus %d must be launched with torch.distributed.run' % args.gpus)
+    dev = torch.device('cuda', torch.cuda.current_device())
+    hidden = tuple(int(x) for x in args.hidden.split(','))
+    G, B = args.genes, args.batch_size
+    n_train_global = int(args.cells * 0.9)               # validation_split=0.1 tail is not trained on
+    t0, n_local = ddist.shard(n_train_global, W, rank)
+    n_local = n_train_global // W                         # equal shards (all-gather of stats)
+
+    # ---- synthetic data, generated and normalised in HBM (not timed)
+    Y = synth.generate_counts(n_local, G, device=dev, row_offset=rank)
+    X, sf = synth.normalize_on_device(Y, G, comm if W > 1 else None)
+    eng = Engine('zinb-conddisp', G, G, hidden, True, 0.0, comm=comm)
+    eng.init_params(0)
+    eng.attach_device_data(X, Y, sf)
+    eng.reserve(B)
+    eng.clip = 5.0
+    eng.set_lr(1e-3)
+    total_steps = args.warmup + args.steps
+    # shuffled row order: as many reshuffles of the shard as the run needs
+    gen = torch.Generator(device='cpu'); gen.manual_seed(1234 + rank)
+    need = total_steps * B
+    perms = []
+    while sum(p.numel() for p in perms) < need:
+        perms.append(torch.randperm(n_local, generator=gen, dtype=torch.int32) if n_local >= B
+                     else torch.randint(0, n_local, (B,), generator=gen, dtype=torch.int32))
+    eng.perm = torch.cat(perms)[:need].to(dev)
+    eng.hist = torch.zeros(total_steps + 1, dtype=torch.float32, device=dev)
+    eng.cursor.zero_(); eng.acc.zero_()
+    counts = [B] * W
+    use_graph = (args.graph == 'on') or (args.graph == 'auto' and B <= 256 and W == 1)
+    use_graph = use_graph and W == 1
+
+    def barrier():
+        if W > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    graph = None
+    for i in range(args.warmup):
+        if use_graph and i == 1:
+            graph = torch.cuda.CUDAGraph()
+            s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                with torch.cuda.graph(graph, stream=s):
+                    eng.train_step(B, B * W, counts, B)
+            torch.cuda.current_stream().wait_stream(s)
+        if graph is not None:
+            graph.replay()
+        else:
+            eng.train_step(B, B * W, counts, B)
+    if use_graph and graph is None:
+        use_graph = False
+    prof = None
+    if not use_graph:
+        prof = EventProfiler(); eng.prof = prof
+    barrier()
+    t_start = time.perf_counter()
+    for i in range(args.steps):
+        if graph is not None:
+            graph.replay()
+        else:
+            eng.train_step(B, B * W, counts, B)
+    barrier()
+    el = time.perf_counter() - t_start
+    elt = torch.tensor([el], dtype=torch.float64, device=dev)
+    if W > 1:
+        torch.distributed.all_reduce(elt, op=torch.distributed.ReduceOp.MAX)
+    el = float(elt.item())
+    eng.prof = None
+    losses = eng.hist[:total_steps].cpu().numpy()
+
+    # ---- per-kernel timing (HIP events on the launch stream)
+    ksum = prof.summary() if prof is not None else {}
+    if use_graph:
+        # graph replay hides individual launches: time the dominant kernels in isolation
+        eng.prof = EventProfiler()
+        eng.cursor.zero_()
+        for i in range(min(args.steps, 20)):
+            eng.train_step(B, B * W, counts, B)
+        ksum = eng.prof.summary(); eng.prof = None
+    kernels = []
+    for name, st in ksum.items():
+        bound, work = kernel_model(name, B, G, hidden)
+        ent = {'kernel': name, 'mean_ms': st['mean_ms'], 'share_of_step': st['total_ms'] / st['count'] / (1e3 * el / args.steps)}
+        if work:
+            if bound == 'hbm':
+                ent.update(bound='hbm', achieved=work / (st['mean_ms'] * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit='GB/s')
+            else:
+                ent.update(bound='mfma', achieved=work / (st['mean_ms'] * 1e-3) / 1e12, peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s')
+            ent['frac'] = ent['achieved'] / ent['peak']
+        kernels.append(ent)
+    kernels.sort(key=lambda e: -e['mean_ms'])
+    roof = None
+    for e in kernels:
+        if 'frac' in e:
+            roof = {'kernel': e['kernel'], 'bound': e['bound'], 'achieved': e['achieved'], 'peak': e['peak'],
+                    'unit': e['unit'], 'frac': e['frac'], 'traffic': None,
+                    'timing': 'HIP events around each launch, ' + ('isolated eager steps after the graph-replayed timed region' if use_graph else 'inside the timed region')}
+            break
+
+    if rank == 0:
+        out = {
+            'metric': 'cells/sec training (ZINB AE, 68k x 20k)',
+            'value': args.steps * B * W / el, 'unit': 'cells/s', 'n_gpus': W, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': 1e3 * el / args.steps, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'zinb-conddisp autoencoder %s on synthetic %d x %d counts '
+                                   '(BASELINE configs[2]); train rows %d sharded over %d GPU(s)'
+                                   % ('-'.join(map(str, hidden)), args.cells, G, n_train_global, W),
+                       'batch_per_gpu': B, 'global_batch': B * W, 'hidden': list(hidden),
+                       'parallelism': 'dp%d' % W, 'launch': 'hipGraph replay' if use_graph else 'eager',
+                       'optimizer': 'RMSprop+clipvalue', 'params': int(eng.lay.P)},
+            'loss_first': float(losses[0]), 'loss_last': float(losses[total_steps - 1]),
+            'roofline': roof, 'kernels': kernels,
+        }
+        if not args.no_cpu_baseline and W == 1:
+            nb = min(n_local, max(B, 4 * B))
+            p = eng.get_params()
+            # host copy of a bounded sample of the same matrix; weights = current device weights
+            out['cpu_baseline'] = cpu_baseline(X[:nb, :G].cpu().numpy(), Y[:nb, :G].cpu().numpy(),
+                                               sf[:nb].cpu().numpy(), p, hidden, B, args.cpu_seconds)
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out), flush=True)
+    if W > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -291,11 +291,13 @@ extern "C" int dcahip_bn_relu_apply(const float* Z, long ldz, int B, int H, cons
                                     float* moving_mean, float* moving_var, float momentum, float eps,
                                     int relu, float* Hout, long ldh, float* xhat, long ldx,
                                     float* inv_std, void* stream) {
-    if (!Z || !Hout || !moving_mean || !moving_var || B <= 0 || H <= 0) return DCAHIP_EINVAL;
+    // B == 0 is legal: a data-parallel rank whose shard is exhausted still has to fold the
+    // global batch statistics into its moving averages
+    if (!Z || !Hout || !moving_mean || !moving_var || B < 0 || H <= 0) return DCAHIP_EINVAL;
     if (entries && E <= 0) return DCAHIP_EINVAL;
     BnApplyArgs a{Z, ldz, B, H, entries, counts, E, beta, moving_mean, moving_var, momentum, eps,
                   relu, Hout, ldh, xhat, ldx, inv_std};
-    const int grid = (B + kApplyRows - 1) / kApplyRows;
+    const int grid = B > 0 ? (B + kApplyRows - 1) / kApplyRows : 1;
     hipLaunchKernelGGL(bn_relu_apply_kernel, dim3(grid), dim3(256), 2 * H * sizeof(float),
                        static_cast<hipStream_t>(stream), a);
     return (int)hipGetLastError();

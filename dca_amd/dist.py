@@ -28,9 +28,10 @@ class TorchDistComm:
         return t
 
     def all_gather(self, t):
-        out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-        dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
-        return out
+        flat = t.contiguous().view(-1)
+        out = torch.empty(self.world * flat.numel(), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, flat, group=self.group)
+        return out.view((self.world,) + tuple(t.shape))
 
 
 def init_from_env(backend=None):

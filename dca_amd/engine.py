@@ -38,6 +38,53 @@ def _r4(x):
     return (x + 3) // 4 * 4
 
 
+class _NullSection:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+_NULL = _NullSection()
+
+
+class EventProfiler:
+    """Per-kernel timing with HIP events on the launch stream (bench.py's live roofline leg)."""
+
+    class _Sec:
+        def __init__(self, prof, name):
+            self.prof, self.name = prof, name
+
+        def __enter__(self):
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.e = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+            return self
+
+        def __exit__(self, *a):
+            self.e.record()
+            self.prof.ev.setdefault(self.name, []).append((self.s, self.e))
+            return False
+
+    def __init__(self):
+        self.ev = {}
+
+    def section(self, name):
+        return EventProfiler._Sec(self, name)
+
+    def reset(self):
+        self.ev = {}
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for k, lst in self.ev.items():
+            ms = [s.elapsed_time(e) for s, e in lst]
+            out[k] = {'count': len(ms), 'mean_ms': float(np.mean(ms)), 'total_ms': float(np.sum(ms))}
+        return out
+
+
 class SingleProcess:
     """Communication stub for one GPU."""
     world, rank = 1, 0
@@ -130,6 +177,10 @@ class Engine:
         self.Bmax = 0
         self.X = self.Y = self.sf = self.perm = None
         self.hist = None
+        self.prof = None            # EventProfiler or None
+
+    def _t(self, name):
+        return self.prof.section(name) if self.prof is not None else _NULL
 
     # ------------------------------------------------------------------ parameters
     def init_params(self, seed=0):
@@ -288,8 +339,9 @@ class Engine:
             Wi = lay.view(w, 'W%d' % i); bi = lay.view(w, 'b%d' % i)
             if i == 0:
                 if rows_from[0] == 'perm':
-                    ops.sgemm(0, 0, B, h, K, self.X, self.ldx, Wi, h, self.Z[0], self.ldh[0], bias=bi,
-                              perm=self.perm, cursor=self.cursor, ws=self.ws)
+                    with self._t('gemm_enc0_fwd'):
+                        ops.sgemm(0, 0, B, h, K, self.X, self.ldx, Wi, h, self.Z[0], self.ldh[0],
+                                  bias=bi, perm=self.perm, cursor=self.cursor, ws=self.ws)
                 else:
                     ops.sgemm(0, 0, B, h, K, self.X[rows_from[1]:], self.ldx, Wi, h, self.Z[0],
                               self.ldh[0], bias=bi, ws=self.ws)
@@ -335,8 +387,9 @@ class Engine:
 
     def _heads_forward(self, B, K):
         lay, ops = self.lay, self.ops
-        ops.sgemm(0, 0, B, lay.NH, K, self.H[-1], self.ldh[-1], lay.view(self.w, 'Wh'), lay.NH,
-                  self.A, lay.NH, bias=lay.view(self.w, 'bh'), ws=self.ws)
+        with self._t('gemm_heads_fwd'):
+            ops.sgemm(0, 0, B, lay.NH, K, self.H[-1], self.ldh[-1], lay.view(self.w, 'Wh'), lay.NH,
+                      self.A, lay.NH, bias=lay.view(self.w, 'bh'), ws=self.ws)
 
     def _plane(self, buf, head):
         lay = self.lay
@@ -372,7 +425,8 @@ class Engine:
             self._empty_step()
         if comm.world > 1:
             comm.all_reduce_sum(g[:lay.P + 1])
-        ops.rmsprop_clip(w, g, self.ms, lay.P, self.lr, RMS_RHO, RMS_EPS, self.clip)
+        with self._t('rmsprop_clip'):
+            ops.rmsprop_clip(w, g, self.ms, lay.P, self.lr, RMS_RHO, RMS_EPS, self.clip)
         ops.step_end(g[lay.P:], float(Bg), self.hist, rows_per_slot or max(self.Bmax, 1), self.acc,
                      self.cursor, B)
 
@@ -380,8 +434,11 @@ class Engine:
         lay = self.lay
         self.g.zero_()
         for i, h in enumerate(lay.hidden):
-            if lay.batchnorm:
-                self._batch_moments(i, 0, h, self.counts_world)
+            if lay.batchnorm:      # take part in the statistics exchange, update moving averages
+                entries, cnts, E = self._batch_moments(i, 0, h, self.counts_world)
+                self.ops.bn_relu_apply(self.Z[i], self.ldh[i], 0, h, entries, cnts, E,
+                                       lay.view(self.w, 'beta%d' % i), self.mm[i], self.mv[i],
+                                       BN_MOMENTUM, BN_EPS, True, self.H[i], self.ldh[i], None, 0, None)
         for i in reversed(range(len(lay.hidden))):
             if lay.batchnorm:
                 s = torch.zeros(2 * lay.hidden[i], dtype=torch.float32, device=self.dev)
@@ -392,16 +449,19 @@ class Engine:
         w, g = self.w, self.g
         KL = self._hidden_forward(B, ('perm',), True, self.counts_world)
         self._heads_forward(B, KL)
-        n = self._nll(B, self.perm, self.cursor, self.Y, self.sf, inv_n, True)
+        with self._t('zinb_nll'):
+            n = self._nll(B, self.perm, self.cursor, self.Y, self.sf, inv_n, True)
         ops.loss_finalize(self.partials, n, inv_n, g[lay.P:])
         # ---- backward: heads
-        ops.sgemm(1, 0, KL, lay.NH, B, self.H[-1], self.ldh[-1], self.D, self.ldD, lay.view(g, 'Wh'),
-                  lay.NH, colsum_row=True, ws=self.ws)
+        with self._t('gemm_heads_dW'):
+            ops.sgemm(1, 0, KL, lay.NH, B, self.H[-1], self.ldh[-1], self.D, self.ldD,
+                      lay.view(g, 'Wh'), lay.NH, colsum_row=True, ws=self.ws)
         if lay.const_disp:
             ops.colsum_chain(self.Dth, self.ldD, B, lay.G_out, lay.view(w, 'theta_w'),
                              lay.view(g, 'theta_w'))
-        ops.sgemm(0, 1, B, KL, lay.NH, self.D, self.ldD, lay.view(w, 'Wh'), lay.NH, self.dH[-1],
-                  self.ldh[-1], ws=self.ws)
+        with self._t('gemm_heads_dH'):
+            ops.sgemm(0, 1, B, KL, lay.NH, self.D, self.ldD, lay.view(w, 'Wh'), lay.NH, self.dH[-1],
+                      self.ldh[-1], ws=self.ws)
         # ---- backward: hidden stack
         L = len(lay.hidden)
         for i in reversed(range(L)):
@@ -421,8 +481,9 @@ class Engine:
             Kp = lay.G_in if i == 0 else lay.hidden[i - 1]
             gW = lay.view(g, 'W%d' % i)
             if i == 0:
-                ops.sgemm(1, 0, Kp, h, B, self.X, self.ldx, self.dZ[0], self.ldh[0], gW, h,
-                          perm=self.perm, cursor=self.cursor, colsum_row=True, ws=self.ws)
+                with self._t('gemm_enc0_dW'):
+                    ops.sgemm(1, 0, Kp, h, B, self.X, self.ldx, self.dZ[0], self.ldh[0], gW, h,
+                              perm=self.perm, cursor=self.cursor, colsum_row=True, ws=self.ws)
             else:
                 ops.sgemm(1, 0, Kp, h, B, self.H[i - 1], self.ldh[i - 1], self.dZ[i], self.ldh[i], gW,
                           h, colsum_row=True, ws=self.ws)

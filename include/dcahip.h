@@ -126,7 +126,8 @@ long dcahip_sgemm_workspace_bytes(int ta, int tb, int M, int N, int K, int colsu
  *     writes h, xhat (may be NULL), inv_std[H], and (training) updates
  *        moving = moving - (moving - batch) * (1 - momentum)   (biased variance).
  *     With entries == NULL it runs in INFERENCE mode on moving_mean / moving_var.
- *     relu == 0 skips the activation (used for the latent 'center' output).
+ *     relu == 0 skips the activation.  B == 0 is legal (only the moving statistics are
+ *     updated): a data-parallel rank with an exhausted shard still joins the exchange.
  */
 int dcahip_col_moments_chunks(int B);
 int dcahip_col_moments(const float* Z, long ldz, int B, int H, float* part, void* stream);

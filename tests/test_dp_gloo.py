@@ -1,0 +1,134 @@
+"""Data-parallel path on CPU: 2 processes over gloo running the engine's DP step (row shards,
+SyncBN statistics exchange, flat gradient all-reduce) must reproduce the single-process run on
+the same global batches, and both must match the straight-line oracle."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import net_np as N
+from oracle.cpu_ops import CpuRefOps
+from helpers import make_problem, oracle_net
+from dca_amd import dist as ddist
+
+
+class FixedOrders:
+    """shuffle_rng stand-in that replays prescribed index orders (one per epoch)."""
+
+    def __init__(self, orders):
+        self.orders = list(orders)
+        self.k = 0
+
+    def shuffle(self, idx):
+        idx[:] = self.orders[self.k]
+        self.k += 1
+
+
+def dp_equivalent_orders(n_train, W, b_local, epochs, seed):
+    """The single-process index order that visits, batch by batch, exactly the samples the W
+    ranks visit together (rank-major inside each global batch)."""
+    rs = np.random.RandomState(seed)
+    out = []
+    for _ in range(epochs):
+        idx = np.arange(n_train)
+        rs.shuffle(idx)
+        loc = []
+        for r in range(W):
+            s, c = ddist.shard(n_train, W, r)
+            loc.append(ddist.local_order(idx, s, c) + s)
+        steps = int(np.ceil(max(len(l) for l in loc) / b_local))
+        order = []
+        for t in range(steps):
+            for r in range(W):
+                order.extend(loc[r][t * b_local:(t + 1) * b_local].tolist())
+        out.append(np.array(order))
+    return out
+
+
+def _run(rank, world, port, cfg, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from dca_amd.engine import Engine
+        from dca_amd.train import fit_engine
+        n, G, hs, ae, bn, B, epochs, seed = cfg
+        X, Y, sf, p = make_problem(n, G, hs, ae, bn, seed=3)
+        n_train = int(n * 0.9)
+        n_val = n - n_train
+        comm = ddist.TorchDistComm()
+        t0, nt = ddist.shard(n_train, world, rank)
+        v0, nv = ddist.shard(n_val, world, rank)
+        rows = np.r_[np.arange(t0, t0 + nt), n_train + np.arange(v0, v0 + nv)]
+        eng = Engine(ae, G, G, hs, bn, 0.0, ops=CpuRefOps(), comm=comm)
+        eng.set_params(p)
+        eng.load_data(X[rows], Y[rows], sf[rows])
+        h = fit_engine(eng, n_train, n_val, nt, nv, t0, epochs=epochs, batch_size=B,
+                       shuffle_rng=np.random.RandomState(seed), reduce_lr=1, early_stop=0)
+        if rank == 0:
+            q.put((h.history, eng.get_params()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]; s.close()
+    return p
+
+
+@pytest.mark.parametrize('ae,bn,n,B', [('zinb-conddisp', True, 60, 16), ('zinb-conddisp', True, 38, 16), ('zinb-conddisp', True, 37, 16),
+                                       ('nb', True, 50, 8), ('zinb', False, 60, 16)])
+def test_two_rank_dp_equals_single_process_and_oracle(ae, bn, n, B):
+    G, hs, epochs, seed, W = 14, (6, 3, 6), 3, 17, 2
+    cfg = (n, G, hs, ae, bn, B, epochs, seed)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_run, args=(r, W, port, cfg, q)) for r in range(W)]
+    for pr in procs:
+        pr.start()
+    hist_dp, p_dp = q.get(timeout=120)
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+
+    # single process, same global batches
+    from dca_amd.engine import Engine
+    from dca_amd.train import fit_engine
+    X, Y, sf, p = make_problem(n, G, hs, ae, bn, seed=3)
+    n_train = int(n * 0.9)
+    orders = dp_equivalent_orders(n_train, W, B // W, epochs, seed)
+    eng = Engine(ae, G, G, hs, bn, 0.0, ops=CpuRefOps())
+    eng.set_params(p)
+    eng.load_data(X, Y, sf)
+    h1 = fit_engine(eng, n_train, n - n_train, n_train, n - n_train, 0, epochs=epochs, batch_size=B,
+                    shuffle_rng=FixedOrders(orders), reduce_lr=1, early_stop=0)
+    # fp32 buffers on both sides; the only difference is the association order of the BN
+    # statistics merge and of the gradient sum across ranks
+    np.testing.assert_allclose(hist_dp['loss'], h1.history['loss'], rtol=3e-5)
+    np.testing.assert_allclose(hist_dp['val_loss'], h1.history['val_loss'], rtol=3e-5)
+    assert hist_dp['lr'] == h1.history['lr']
+    p1 = eng.get_params()
+    for k in p1:
+        np.testing.assert_allclose(p_dp[k], p1[k], rtol=2e-3, atol=2e-3, err_msg=k)  # RMSprop: |step| <= lr/sqrt(1-rho) per update
+
+    # and the oracle on the same order
+    ref = oracle_net(ae, p, hs, bn)
+    rh = N.fit(ref, X.astype(np.float64), Y.astype(np.float64), sf.astype(np.float64), epochs=epochs,
+               batch_size=B, shuffle_rng=FixedOrders(orders), reduce_lr=1, early_stop=0)
+    np.testing.assert_allclose(hist_dp['loss'], rh['loss'], rtol=1e-4)
+    np.testing.assert_allclose(hist_dp['val_loss'], rh['val_loss'], rtol=1e-4)
+
+
+def test_shard_and_local_order():
+    assert [ddist.shard(10, 3, r) for r in range(3)] == [(0, 4), (4, 3), (7, 3)]
+    idx = np.array([5, 0, 9, 3, 7, 1, 8, 2, 6, 4])
+    assert ddist.local_order(idx, 4, 3).tolist() == [1, 2, 0]        # 5, 6, 4 in visiting order
+    assert ddist.local_order(idx, 0, 10).tolist() == idx.tolist()    # one rank: the reference order

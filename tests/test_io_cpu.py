@@ -1,0 +1,92 @@
+"""IO / preprocessing surface (dca_amd/io.py == dca/io.py): index outputs bit-exact, floats
+against an independent restatement."""
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from conftest import synth_counts
+from dca_amd import io
+from dca_amd._anndata import AnnData
+from oracle import preproc_np as P
+
+
+def _adata(n=60, G=40, seed=0, dtype=np.float32):
+    y = synth_counts(n, G, seed).astype(dtype)
+    return AnnData(y, obs=pd.DataFrame(index=['c%d' % i for i in range(n)]),
+                   var=pd.DataFrame(index=['g%d' % i for i in range(G)]))
+
+
+def test_filter_masks_bit_exact():
+    rng = np.random.RandomState(0)
+    y = synth_counts(50, 30, 1)
+    y[:, [3, 17]] = 0          # all-zero genes
+    y[[5, 44], :] = 0          # all-zero cells
+    keep_g, num = io.filter_genes_mask(y, 1)
+    assert (keep_g == P.gene_keep_mask(y)).all() and keep_g.sum() == 28
+    keep_c, _ = io.filter_cells_mask(y, 1)
+    assert (keep_c == P.cell_keep_mask(y)).all() and keep_c.sum() == 48
+    ad = AnnData(y.astype(np.float32))
+    ad = io.read_dataset(ad, check_counts=True)
+    ad = io.normalize(ad, filter_min_counts=True)
+    # genes filtered first, then cells (io.py:91-92); raw keeps the filtered counts
+    assert ad.shape == (48, 28) and ad.raw.X.shape == (48, 28)
+    np.testing.assert_array_equal(ad.raw.X, y[keep_c][:, keep_g].astype(np.float32))
+    assert list(ad.var.index) == [str(j) for j in np.where(keep_g)[0]]
+    assert list(ad.obs.index) == [str(i) for i in np.where(keep_c)[0]]
+
+
+def test_normalize_matches_independent_restatement():
+    ad = _adata(80, 50, 3)
+    y = ad.X.copy()
+    ad = io.read_dataset(ad)
+    ad = io.normalize(ad, filter_min_counts=False)
+    x, sf, nc = P.normalize(y)
+    np.testing.assert_array_equal(ad.obs['n_counts'].values, nc.astype(np.float32))
+    np.testing.assert_allclose(ad.obs['size_factors'].values, sf, rtol=1e-6)
+    np.testing.assert_allclose(ad.X, x, rtol=2e-4, atol=2e-5)
+    np.testing.assert_array_equal(ad.raw.X, y)
+    assert (ad.obs['dca_split'] == 'train').all() and str(ad.obs['dca_split'].dtype) == 'category'
+    # switches
+    ad2 = io.normalize(io.read_dataset(_adata(80, 50, 3)), filter_min_counts=False,
+                       size_factors=False, normalize_input=False, logtrans_input=True)
+    np.testing.assert_allclose(ad2.X, np.log1p(y), rtol=1e-6)
+    assert (ad2.obs['size_factors'] == 1.0).all()
+
+
+def test_test_split_indices_are_sklearns():
+    from sklearn.model_selection import train_test_split
+    ad = io.read_dataset(_adata(101, 10, 2), test_split=True)
+    tr, te = train_test_split(np.arange(101), test_size=0.1, random_state=42)
+    got_te = np.where(ad.obs['dca_split'].values == 'test')[0]
+    assert sorted(te.tolist()) == got_te.tolist()
+    assert (ad.obs['dca_split'].values == 'train').sum() == len(tr)
+
+
+def test_check_counts_and_errors():
+    ad = _adata(20, 8, 1)
+    ad.X[3, 2] = 0.5
+    with pytest.raises(AssertionError, match='unnormalized count data'):
+        io.read_dataset(ad)
+    io.read_dataset(ad, check_counts=False)
+    with pytest.raises(NotImplementedError):
+        io.read_dataset(12345)
+
+
+def test_read_text_transpose_and_write_text_matrix(tmp_path):
+    y = synth_counts(6, 4, 0)
+    df = pd.DataFrame(y.T, index=['g%d' % i for i in range(4)], columns=['c%d' % i for i in range(6)])
+    f = str(tmp_path / 'counts.tsv')
+    df.to_csv(f, sep='\t')
+    ad = io.read_dataset(f, transpose=True)             # gene x cell file -> cells x genes
+    assert ad.shape == (6, 4) and list(ad.var_names) == ['g0', 'g1', 'g2', 'g3']
+    np.testing.assert_array_equal(ad.X, y.astype(np.float32))
+    out = str(tmp_path / 'm.tsv')
+    io.write_text_matrix(np.array([[1.0, 2.5], [3.25, 4.1234567]]), out, rownames=['r0', 'r1'],
+                         colnames=['a', 'b'], transpose=True)
+    txt = open(out).read().splitlines()
+    assert txt[0] == '\tr0\tr1' and txt[1] == 'a\t1.000000\t3.250000' and txt[2] == 'b\t2.500000\t4.123457'
+    g = str(tmp_path / 'genes.txt')
+    open(g, 'w').write('g1\ng3\ng1\n')
+    assert sorted(io.read_genelist(g)) == ['g1', 'g3']
