@@ -28,12 +28,55 @@ __constant__ float kLogFact[kSmallY + 1] = {
     12.801827480081469f, 15.104412573075516f, 17.502307845873887f, 19.987214495661885f,
     22.552163853123425f, 25.191221182738680f, 27.899271383840890f, 30.671860106080672f};
 
+// ---- elementary functions on the transcendental unit (v_exp_f32 / v_log_f32 / v_rcp_f32, 1 ulp
+// each) with first-order compensation of the range step, so that no IEEE division or libm call
+// sits on the per-element path.  exp: the rounding of x*log2(e) is re-applied as a correction
+// term; log: log2 result times ln2 in two pieces; log1p / expm1 use Kahan's exact-ratio forms.
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+__device__ __forceinline__ float fexp(float x) {
+    x = fminf(fmaxf(x, -104.f), 88.7f);
+    const float L = 1.44269504088896340736f, Llo = 1.92596299112661746e-8f;
+    const float t = x * L;
+    const float r = fmaf(x, Llo, fmaf(x, L, -t));
+    const float e = __builtin_amdgcn_exp2f(t);
+    return fmaf(e, r * 0.69314718055994531f, e);
+}
+
+__device__ __forceinline__ float flog(float x) {           // x > 0, normal
+    const float y = __builtin_amdgcn_logf(x);              // log2(x)
+    const float C = 0.693147182464599609375f, Clo = -1.90465429995776804e-9f;
+    const float r = y * C;
+    return r + fmaf(y, Clo, fmaf(y, C, -r));
+}
+
+__device__ __forceinline__ float flog1p(float t) {         // t >= 0
+    const float u = 1.f + t;
+    const float d = u - 1.f;
+    const float l = flog(u);
+    return d == 0.f ? t : l * (t * frcp(d));
+}
+
+__device__ __forceinline__ float fexpm1_neg(float x, float ex) {   // x <= 0, ex = fexp(x)
+    const float d = ex - 1.f;
+    const float k = d * x * frcp(flog(ex));
+    return x < -17.f ? -1.f : (d == 0.f ? x : k);
+}
+
 __device__ __forceinline__ float digamma_pos(float x) {
-    // x > 0: upward recurrence to x >= 6, then the asymptotic series
+    // x > 0: upward recurrence to x >= 6, then the asymptotic series (rare generic path)
     float r = 0.f;
     while (x < 6.f) { r -= 1.f / x; x += 1.f; }
     const float xi = 1.f / x, xi2 = xi * xi;
     return r + logf(x) - 0.5f * xi - xi2 * (1.f / 12.f - xi2 * (1.f / 120.f - xi2 * (1.f / 252.f)));
+}
+
+// lgamma / digamma route for non-integer or large counts: rare, kept out of line so the hot
+// loop stays small (registers, instruction cache)
+template <bool GRAD>
+__device__ __attribute__((noinline)) float nb_t1_generic(float tp, float y, float* dpsi) {
+    if (GRAD) *dpsi = digamma_pos(y + tp) - digamma_pos(tp);
+    return lgammaf(tp) + lgammaf(y + 1.f) - lgammaf(y + tp);
 }
 
 struct Heads {       // activations of one element
@@ -45,25 +88,27 @@ struct Heads {       // activations of one element
 template <bool HAS_PI, bool CONST_DISP>
 __device__ __forceinline__ Heads head_acts(float am, float ad, float ap, float sf) {
     Heads h;
-    const float e = expf(am);                                   // network.py:38
+    const float e = fexp(am);                                   // network.py:38
     const bool mwin = (e >= 1e-5f) && (e <= 1e6f);
     h.mu = fminf(fmaxf(e, 1e-5f), 1e6f) * sf;                   // layers.py:85
     h.gm = mwin ? e * sf : 0.f;
     if (CONST_DISP) {                                           // layers.py:21 (ad = theta_w[g])
-        h.theta = fminf(fmaxf(expf(ad), 1e-3f), 1e4f);
+        h.theta = fminf(fmaxf(fexp(ad), 1e-3f), 1e4f);
         h.gd = 1.f;                                             // chained in dcahip_colsum_chain
     } else {                                                    // network.py:39
-        const float ex = expf(-fabsf(ad));
-        const float sp = fmaxf(ad, 0.f) + log1pf(ex);
+        const float ex = fexp(-fabsf(ad));
+        const float u = 1.f + ex, d = u - 1.f;
+        const float s = frcp(u);
+        const float l1 = d == 0.f ? ex : flog(u) * (ex * frcp(d));      // log1p(ex)
+        const float sp = fmaxf(ad, 0.f) + l1;
         const bool dwin = (sp >= 1e-4f) && (sp <= 1e4f);
         h.theta = fminf(fmaxf(sp, 1e-4f), 1e4f);
-        const float s = 1.f / (1.f + ex);
         h.gd = dwin ? (ad >= 0.f ? s : ex * s) : 0.f;
     }
     h.theta = fminf(h.theta, kThetaMax);                        // loss.py:85
     if (HAS_PI) {
-        const float ex = expf(-fabsf(ap));
-        const float s = 1.f / (1.f + ex);
+        const float ex = fexp(-fabsf(ap));
+        const float s = frcp(1.f + ex);
         h.pi = ap >= 0.f ? s : ex * s;
         h.omp = ap >= 0.f ? ex * s : s;
     } else {
@@ -82,27 +127,27 @@ __device__ __forceinline__ float nll_elem(const Heads& h, float y, float ridge,
     if (HAS_PI && y < kZeroThresh) {
         // zero_case = -log(pi + (1-pi) * (theta/(theta+mu+eps))^theta + eps)   loss.py:136-137
         const float den = theta + mu + kEps;
-        const float t = (mu + kEps) / theta;           // theta/den = 1/(1+t)
-        const float logq = -log1pf(t);
+        const float rden = frcp(den);
+        const float t = (mu + kEps) * frcp(theta);     // theta/den = 1/(1+t)
+        const float logq = -flog1p(t);
         const float tl = theta * logq;
-        const float z = expf(tl);
+        const float z = fexp(tl);
         const float D = h.pi + h.omp * z + kEps;
-        nll = -logf(D);
+        nll = -flog(D);
         if (GRAD) {
-            const float invD = 1.f / D;
-            dmu = h.omp * theta * z / den * invD;
+            const float invD = frcp(D);
+            const float oz = h.omp * z * invD;
+            dmu = oz * theta * rden;
             // log q + 1 - q = -log1p(t) + t/(1+t): series below t = 2^-5 (cancellation)
-            float f;
-            if (t < 0.03125f)
-                f = -t * t * (0.5f - t * (2.f / 3.f - t * (0.75f - t * (0.8f - t * (5.f / 6.f)))));
-            else
-                f = logq + (mu + kEps) / den;
-            dth = -h.omp * z * f * invD;
-            dpi = expm1f(tl) * invD;                   // -(1 - z)/D
+            const float fs = -t * t * (0.5f - t * (2.f / 3.f - t * (0.75f - t * (0.8f - t * (5.f / 6.f)))));
+            const float fl = logq + (mu + kEps) * rden;
+            dth = -oz * (t < 0.03125f ? fs : fl);
+            dpi = fexpm1_neg(tl, z) * invD;            // -(1 - z)/D
         }
     } else {
         // NB.loss: t1 + t2, loss.py:87-88
-        const float l1p = log1pf(mu / tp);
+        const float rtp = frcp(tp);
+        const float l1p = flog1p(mu * rtp);
         float t1, dpsi = 0.f;
         if (y == floorf(y) && y <= (float)kSmallY) {
             // lgamma(y+tp) - lgamma(tp) = log prod_{i<y}(tp+i); psi difference = sum 1/(tp+i)
@@ -111,22 +156,23 @@ __device__ __forceinline__ float nll_elem(const Heads& h, float y, float ridge,
             for (int i = 0; i < n; ++i) {
                 const float x = tp + (float)i;
                 if (i < 8) p1 *= x; else p2 *= x;
-                if (GRAD) dpsi += 1.f / x;
+                if (GRAD) dpsi += frcp(x);
             }
-            t1 = kLogFact[n] - (logf(p1) + logf(p2));
+            t1 = kLogFact[n] - (flog(p1) + (n > 8 ? flog(p2) : 0.f));
         } else {
-            t1 = lgammaf(tp) + lgammaf(y + 1.f) - lgammaf(y + tp);
-            if (GRAD) dpsi = digamma_pos(y + tp) - digamma_pos(tp);
+            t1 = nb_t1_generic<GRAD>(tp, y, &dpsi);
         }
-        const float t2 = (theta + y) * l1p + y * (logf(tp) - logf(mu + kEps));
+        const float mue = mu + kEps;
+        const float t2 = (theta + y) * l1p + y * (flog(tp) - flog(mue));
         nll = t1 + t2;
-        if (HAS_PI) nll -= logf(h.omp + kEps);         // loss.py:130
+        if (HAS_PI) nll -= flog(h.omp + kEps);         // loss.py:130
         if (GRAD) {
             // (theta+y)/(tp+mu) - y/(mu+eps) and -(theta+y)mu/(tp(tp+mu)) + y/tp, combined over a
             // common denominator: identical algebra, no cancellation between O(1) terms.
-            dmu = theta * (mu + kEps - y) / ((tp + mu) * (mu + kEps));
-            dth = -dpsi + l1p + (y * tp - theta * mu) / (tp * (tp + mu));
-            dpi = HAS_PI ? 1.f / (h.omp + kEps) : 0.f;
+            const float rtm = frcp(tp + mu);
+            dmu = theta * (mue - y) * rtm * frcp(mue);
+            dth = -dpsi + l1p + (y * tp - theta * mu) * rtp * rtm;
+            dpi = HAS_PI ? frcp(h.omp + kEps) : 0.f;
         }
     }
     if (HAS_PI) {
@@ -176,49 +222,53 @@ __device__ __forceinline__ void stv(float* p, const float (&o)[V]) {
 
 template <bool HAS_PI, bool CONST_DISP, bool GRAD, int V>
 __global__ __launch_bounds__(256) void zinb_nll_kernel(NllArgs a) {
+    // grid.x walks the gene segments (256 lanes x V genes), grid.y strides over the batch rows:
+    // no integer division on the path, the per-row gather index and size factor are scalar loads
     const int nvec = (a.G + V - 1) / V;              // lanes' work units per row
     const int nseg = (nvec + 255) >> 8;
-    const long total = (long)a.B * nseg;
     const long long cur = a.cursor ? *a.cursor : 0;
     double dacc = 0.0;
-    for (long item = blockIdx.x; item < total; item += gridDim.x) {
-        const int row = (int)(item / nseg);
-        const int q = (int)(item - (long)row * nseg) * 256 + threadIdx.x;
+    for (int seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
+        const int q = seg * 256 + threadIdx.x;
         if (q >= nvec) continue;
-        const long srow = a.perm ? (long)a.perm[cur + row] : (long)(cur + row);
-        const float sf = a.sf[srow];
         const int g = q * V;
-        const long ao = (long)row * a.lda + g;
-        float vm[V], vd[V], vp[V], vy[V];
-        ldv<V>(a.a_mean + ao, vm);
-        if (CONST_DISP) ldv<V>(a.theta_w + g, vd); else ldv<V>(a.a_disp + ao, vd);
-        if (HAS_PI) ldv<V>(a.a_pi + ao, vp);
-        ldv<V>(a.y + srow * a.ldy + g, vy);
-        float om[V], od[V], op[V];
-        float lacc = 0.f;
+        float vd[V];
+        if (CONST_DISP) ldv<V>(a.theta_w + g, vd);
+        for (int row = blockIdx.y; row < a.B; row += gridDim.y) {
+            const long srow = a.perm ? (long)a.perm[cur + row] : (long)(cur + row);
+            const float sf = a.sf[srow];
+            const long ao = (long)row * a.lda + g;
+            float vm[V], vp[V], vy[V];
+            ldv<V>(a.a_mean + ao, vm);
+            if (!CONST_DISP) ldv<V>(a.a_disp + ao, vd);
+            if (HAS_PI) ldv<V>(a.a_pi + ao, vp);
+            ldv<V>(a.y + srow * a.ldy + g, vy);
+            float om[V], od[V], op[V];
+            float lacc = 0.f;
 #pragma unroll
-        for (int j = 0; j < V; ++j) {
-            float dmu = 0.f, dth = 0.f, dpi = 0.f;
-            const Heads h = head_acts<HAS_PI, CONST_DISP>(vm[j], vd[j], HAS_PI ? vp[j] : 0.f, sf);
-            const float nll = nll_elem<HAS_PI, GRAD>(h, vy[j], a.ridge, dmu, dth, dpi);
-            const bool valid = (g + j) < a.G;
-            lacc += valid ? nll : 0.f;
-            if (GRAD) {
-                om[j] = valid ? dmu * h.gm * a.inv_n : 0.f;
-                od[j] = valid ? dth * h.gd * a.inv_n : 0.f;
-                op[j] = valid ? dpi * h.pi * h.omp * a.inv_n : 0.f;
+            for (int j = 0; j < V; ++j) {
+                float dmu = 0.f, dth = 0.f, dpi = 0.f;
+                const Heads h = head_acts<HAS_PI, CONST_DISP>(vm[j], vd[j], HAS_PI ? vp[j] : 0.f, sf);
+                const float nll = nll_elem<HAS_PI, GRAD>(h, vy[j], a.ridge, dmu, dth, dpi);
+                const bool valid = (g + j) < a.G;
+                lacc += valid ? nll : 0.f;
+                if (GRAD) {
+                    om[j] = valid ? dmu * h.gm * a.inv_n : 0.f;
+                    od[j] = valid ? dth * h.gd * a.inv_n : 0.f;
+                    op[j] = valid ? dpi * h.pi * h.omp * a.inv_n : 0.f;
+                }
             }
-        }
-        dacc += (double)lacc;
-        if (GRAD) {
-            const long dof = (long)row * a.ldd + g;
-            stv<V>(a.d_mean + dof, om);
-            stv<V>(a.d_disp + dof, od);
-            if (HAS_PI) stv<V>(a.d_pi + dof, op);
+            dacc += (double)lacc;
+            if (GRAD) {
+                const long dof = (long)row * a.ldd + g;
+                stv<V>(a.d_mean + dof, om);
+                stv<V>(a.d_disp + dof, od);
+                if (HAS_PI) stv<V>(a.d_pi + dof, op);
+            }
         }
     }
     const double r = block_reduce_sum(dacc);
-    if (threadIdx.x == 0) a.partials[blockIdx.x] = r;
+    if (threadIdx.x == 0) a.partials[blockIdx.y * gridDim.x + blockIdx.x] = r;
 }
 
 __global__ __launch_bounds__(256) void loss_finalize_kernel(const double* partials, int n,
@@ -298,9 +348,9 @@ __global__ __launch_bounds__(256) void heads_infer_kernel(InferArgs a) {
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 template <bool HAS_PI, bool CONST_DISP, bool GRAD>
-int launch_nll(const NllArgs& a, bool vec, int grid, hipStream_t s) {
-    if (vec) hipLaunchKernelGGL((zinb_nll_kernel<HAS_PI, CONST_DISP, GRAD, 4>), dim3(grid), dim3(256), 0, s, a);
-    else     hipLaunchKernelGGL((zinb_nll_kernel<HAS_PI, CONST_DISP, GRAD, 1>), dim3(grid), dim3(256), 0, s, a);
+int launch_nll(const NllArgs& a, bool vec, dim3 grid, hipStream_t s) {
+    if (vec) hipLaunchKernelGGL((zinb_nll_kernel<HAS_PI, CONST_DISP, GRAD, 4>), grid, dim3(256), 0, s, a);
+    else     hipLaunchKernelGGL((zinb_nll_kernel<HAS_PI, CONST_DISP, GRAD, 1>), grid, dim3(256), 0, s, a);
     return (int)hipGetLastError();
 }
 
@@ -328,9 +378,13 @@ extern "C" int dcahip_zinb_nll(const float* a_mean, const float* a_disp, const f
               d_mean, d_disp, d_pi, loss_partials, B, G, ridge, inv_n};
     const int V = vec ? 4 : 1;
     const int nvec = (G + V - 1) / V;
-    const long total = (long)B * ((nvec + 255) / 256);
-    const int grid = (int)(total < kMaxPartials ? total : kMaxPartials);
-    if (n_partials_out) *n_partials_out = grid;
+    const int nseg = (nvec + 255) / 256;
+    const int gx = nseg < kMaxPartials ? nseg : kMaxPartials;
+    int gy = kMaxPartials / gx;
+    if (gy > B) gy = B;
+    if (gy < 1) gy = 1;
+    const dim3 grid(gx, gy);
+    if (n_partials_out) *n_partials_out = gx * gy;
     hipStream_t s = static_cast<hipStream_t>(stream);
 #define DCA_DISPATCH(P, C)                                                  \
     return grad ? launch_nll<P, C, true>(a, vec, grid, s) : launch_nll<P, C, false>(a, vec, grid, s)

@@ -86,7 +86,10 @@ def test_zinb_nll_vs_oracle(ops, flags, B, G, edge):
     ops.loss_finalize(part, n, inv_n, loss)
     torch.cuda.synchronize()
     got = loss.item()
-    assert abs(got - lm) <= 3e-6 * abs(lm), (got, lm)
+    # fp32 kernel vs fp64 oracle: 3e-6 relative on realistic data; the edge set holds y = 5000
+    # / 200 next to theta ~ 1e4, where one ulp of an fp32 lgamma/log term is already ~4e-3
+    # absolute (the reference's own fp32 TensorFlow evaluation is no better there): 3e-5.
+    assert abs(got - lm) <= (3e-5 if edge else 3e-6) * abs(lm), (got, lm)
     D = dD.cpu().numpy().astype(np.float64)
 
     def close(g, ref, name):
