@@ -41,7 +41,7 @@ def parse():
     ap.add_argument('--batch-size', type=int, default=4096, help='cells per GPU per step')
     ap.add_argument('--graph', type=str, default='auto', choices=['auto', 'on', 'off'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-seconds', type=float, default=15.0)
+    ap.add_argument('--cpu-seconds', type=float, default=20.0)
     return ap.parse_args()
 
 
@@ -61,28 +61,42 @@ def kernel_model(name, B, G, hidden, nheads=3):
 
 
 def cpu_baseline(Xh, Yh, sfh, params, hidden, B, budget_s):
-    """Times the oracle's torch-CPU port of the training step (oracle/torch_ref.py) on the host."""
+    """Times the oracle's torch-CPU port of the training step (oracle/torch_ref.py) on the host:
+    at the reference's default batch size 32 (train.py:37 -- also the CPU's best throughput)
+    and at the batch size of the GPU run, on a bounded sample of the same matrix."""
     from oracle.torch_ref import TorchAE
-    cores = os.cpu_count()
-    torch.set_num_threads(cores)
-    net = TorchAE('zinb-conddisp', params, hidden, True, dtype=torch.float32)
+    # torch's CPU kernels stop scaling (and then collapse) far below the box's core count on
+    # this op mix; 16 threads measured best on the 256-core host (tools/cpu_sweep.py)
+    threads = max(1, min(16, os.cpu_count() or 1))
+    torch.set_num_threads(threads)
     n = Xh.shape[0]
-    nb = max(n // B, 1)
     X, Y, S = torch.as_tensor(Xh), torch.as_tensor(Yh), torch.as_tensor(sfh)
-    net.train_step(X[:B], Y[:B], S[:B])                   # warm-up
-    t0 = time.perf_counter(); steps = 0
-    while True:
-        s = (steps % nb) * B
-        net.train_step(X[s:s + B], Y[s:s + B], S[s:s + B])
-        steps += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s or steps >= 200:
-            break
-    return {'value': steps * B / el, 'unit': 'cells/s', 'cores': cores, 'kind': 'port',
-            'sample': '%d steps of batch %d on the first %d cells of the same synthetic matrix, '
-                      'oracle/torch_ref.py (torch-CPU fp32, %d threads), %.1f s'
-                      % (steps, B, min(n, nb * B), cores, el),
-            'ms_per_step': 1e3 * el / steps}
+
+    def run(b, budget, max_steps):
+        net = TorchAE('zinb-conddisp', params, hidden, True, dtype=torch.float32)
+        nb = max(n // b, 1)
+        if b <= 256:
+            net.train_step(X[:b], Y[:b], S[:b])               # warm-up
+        t0 = time.perf_counter(); steps = 0
+        while True:
+            s = (steps % nb) * b
+            net.train_step(X[s:s + b], Y[s:s + b], S[s:s + b])
+            steps += 1
+            el = time.perf_counter() - t0
+            if el >= budget or steps >= max_steps:
+                break
+        return steps, el
+
+    s32, e32 = run(32, 0.45 * budget_s, 400)
+    sB, eB = run(B, 0.55 * budget_s, 50) if B != 32 else (s32, e32)
+    v32, vB = s32 * 32 / e32, sB * B / eB
+    return {'value': max(v32, vB), 'unit': 'cells/s', 'cores': threads, 'kind': 'port',
+            'sample': 'oracle/torch_ref.py (torch-CPU fp32 autograd port of the step, %d threads) on the '
+                      'first %d cells of the same synthetic matrix: batch 32 (reference default): %d '
+                      'steps in %.1f s = %.0f cells/s; batch %d (as the GPU run): %d steps in %.1f s = '
+                      '%.0f cells/s; value = the better of the two'
+                      % (threads, n, s32, e32, v32, B, sB, eB, vB),
+            'cells_per_s_batch32': v32, 'cells_per_s_bench_batch': vB, 'host_cores': os.cpu_count()}
 
 
 def main():

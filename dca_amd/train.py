@@ -214,3 +214,80 @@ def train(adata, network, output_dir=None, optimizer='RMSprop', learning_rate=No
     if save_weights and output_dir is not None and comm.rank == 0:
         network.save_weights(os.path.join(output_dir, 'weights.npz'))
     return hist
+
+
+def train_with_args(args):
+    """The CLI pipeline of dca/train.py:103-191 (seed 42, read -> normalize with count filtering
+    -> build -> train -> predict(mode='full', return_info=True) -> write TSVs)."""
+    import random
+    from . import io
+    from .network import AE_types
+
+    random.seed(42)
+    np.random.seed(42)
+    os.environ['PYTHONHASHSEED'] = '0'
+
+    if args.hyper:
+        raise NotImplementedError('--hyper needs kopt/hyperopt (dca/hyper.py); not available on this path')
+
+    adata = io.read_dataset(args.input,
+                            transpose=(not args.transpose),  # assume gene x cell by default
+                            check_counts=args.checkcounts,
+                            test_split=args.testsplit)
+    adata = io.normalize(adata,
+                         size_factors=args.sizefactors,
+                         logtrans_input=args.loginput,
+                         normalize_input=args.norminput)
+
+    if args.denoisesubset:
+        genelist = list(set(io.read_genelist(args.denoisesubset)))
+        assert len(set(genelist) - set(adata.var_names.values)) == 0, \
+            'Gene list is not overlapping with genes from the dataset'
+        output_size = len(genelist)
+    else:
+        genelist = None
+        output_size = adata.n_vars
+
+    hidden_size = [int(x) for x in args.hiddensize.split(',')]
+    hidden_dropout = [float(x) for x in args.dropoutrate.split(',')]
+    if len(hidden_dropout) == 1:
+        hidden_dropout = hidden_dropout[0]
+
+    assert args.type in AE_types, 'loss type not supported'
+    net = AE_types[args.type](input_size=adata.n_vars,
+                              output_size=output_size,
+                              hidden_size=hidden_size,
+                              l2_coef=args.l2, l1_coef=args.l1,
+                              l2_enc_coef=args.l2enc, l1_enc_coef=args.l1enc,
+                              ridge=args.ridge,
+                              hidden_dropout=hidden_dropout,
+                              input_dropout=args.inputdropout,
+                              batchnorm=args.batchnorm,
+                              activation=args.activation,
+                              init=args.init,
+                              debug=args.debug,
+                              file_path=args.outputdir)
+    net.seed = 42
+    net.save()
+    net.build()
+
+    mask = (adata.obs.dca_split == 'train').values
+    train(adata[mask], net,
+          output_dir=args.outputdir,
+          learning_rate=args.learningrate,
+          epochs=args.epochs, batch_size=args.batchsize,
+          early_stop=args.earlystop,
+          reduce_lr=args.reducelr,
+          output_subset=genelist,
+          optimizer=args.optimizer,
+          clip_grad=args.gradclip,
+          save_weights=args.saveweights,
+          tensorboard=args.tensorboard)
+
+    if genelist:
+        predict_columns = adata.var_names[[np.where(adata.var_names == x)[0][0] for x in genelist]]
+    else:
+        predict_columns = adata.var_names
+
+    net.predict(adata, mode='full', return_info=True)
+    net.write(adata, args.outputdir, mode='full', colnames=predict_columns)
