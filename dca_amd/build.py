@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(CSRC, 'libdcahip.so')
-SOURCES = ['dcahip_zinb.hip', 'dcahip_gemm.hip', 'dcahip_layers.hip', 'dcahip_prep.hip']
+SOURCES = ['dcahip_zinb.hip', 'dcahip_gemm.hip', 'dcahip_layers.hip']
 ARCH = 'gfx950'
 
 
