@@ -54,6 +54,8 @@ def kernel_model(name, B, G, hidden, nheads=3):
         return 'hbm', 28.0 * B * G                      # 3 pre-acts + y read, 3 grads written
     if name == 'rmsprop_clip':
         return 'hbm', None
+    if name == 'heads_fused':                           # heads forward + dW + dH in one launch
+        return 'mfma', 6.0 * B * hL * nheads * Gp
     fl = {'gemm_enc0_fwd': 2.0 * B * G * h1, 'gemm_enc0_dW': 2.0 * B * G * h1,
           'gemm_heads_fwd': 2.0 * B * hL * nheads * Gp, 'gemm_heads_dW': 2.0 * B * hL * nheads * Gp,
           'gemm_heads_dH': 2.0 * B * hL * nheads * Gp}

@@ -15,7 +15,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(CSRC, 'libdcahip.so')
-SOURCES = ['dcahip_zinb.hip', 'dcahip_gemm.hip', 'dcahip_layers.hip']
+SOURCES = ['dcahip_zinb.hip', 'dcahip_gemm.hip', 'dcahip_layers.hip', 'dcahip_heads.hip']
+HEADERS = ['zinb_math.hpp']
 ARCH = 'gfx950'
 
 
@@ -30,7 +31,7 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(ROOT, 'include', 'dcahip.h')]
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.join(ROOT, 'include', 'dcahip.h')]
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 

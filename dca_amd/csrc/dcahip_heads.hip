@@ -1,0 +1,641 @@
+// K-HEADS: the output heads of the autoencoder as ONE kernel -- forward GEMM of the three
+// Dense heads, NB / ZINB negative log-likelihood + gradient, weight/bias gradient and input
+// gradient -- so that the [cells x genes] pre-activation and gradient planes never exist in
+// HBM.  gfx950 (MI355X), wave64, fp32 MFMA (v_mfma_f32_32x32x2_f32, exact fp32).
+//
+// Reference path replaced: dca/network.py:369-385 (pi / dispersion / mean Dense heads,
+// ColwiseMultLayer, SliceLayer, ZINB loss closure), dca/network.py:38-39, dca/layers.py:21,85,
+// dca/loss.py:72-156 and TensorFlow's autodiff of all of it.
+//
+// Work decomposition (gene-stationary):
+//   * a wave owns one 32-gene tile of every head and a strided set of 32-row batch tiles;
+//     a workgroup = kWG gene tiles x WR row slots; the [hL x 32 genes x heads] slice of the
+//     head weights sits in LDS for the lifetime of the workgroup, the wave's weight-gradient
+//     slice ([hL x 32] per head) in MFMA accumulators for the lifetime of the wave.
+//   * per (row tile, gene tile):
+//       F   pre-activations  A = H W + b        32 rows x 32 genes x heads, K = hL
+//       Z   NLL + d NLL / d A   element-wise, through a wave-private LDS staging tile
+//       Bk  dW += H^T D   (D read from staging in exactly the MFMA B-operand layout)
+//           dH  = D W^T   (D read transposed from the same staging tile) -> partial per gene tile
+//     No workgroup barrier inside the loop: waves drift apart, so one wave's transcendental
+//     (VALU) phase overlaps its SIMD partner's MFMA phases.
+//   * HBM traffic per element: y (4 B) + the dH partial (8 B written, 8 B re-read by the
+//     reduce) instead of 36 B for materialised pre-activations / gradients + 28 B K-ZINB.
+//   * deterministic: fixed summation orders everywhere (no atomics).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "dcahip.h"
+#include "zinb_math.hpp"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int kTG = 32;        // genes per wave tile
+constexpr int kTR = 32;        // batch rows per tile
+constexpr int kLdS = 33;       // odd LDS row stride: both operand orientations conflict-free
+constexpr int kWG = 2;         // gene tiles per workgroup
+constexpr int kMaxGrid = 2048; // = dcahip_zinb_max_partials()
+constexpr int kCUs = 256;
+constexpr int kZU = 4;        // staged rows per Z group (two groups per loop iteration)
+constexpr int kQCap = 320;     // non-zero queue entries per wave (< 64 left over + 4 x 64 pushed)
+constexpr int kLdH = 65;       // row stride of the H tile parked in the staging buffer
+
+#ifdef DCA_HEADS_TIMING
+#define TSTAMP(i) { const long long now_ = __builtin_readcyclecounter(); tacc[i] += now_ - tlast; tlast = now_; }
+#else
+#define TSTAMP(i)
+#endif
+
+struct HeadsArgs {
+    long long* timing;                // debug builds only: per-wave phase cycle sums
+    const float* H;  long ldh;
+    const float* Wh; long ldw;
+    const float* bh;
+    const float* theta_w;
+    const float* y;  long ldy;
+    const float* sf;
+    const int* perm;
+    const long long* cursor;
+    float* ws_dw;  long dw_stride;   // [S][(hL + 2)][ldws]
+    float* ws_dh;                     // [ntg][NT*32][KT]
+    double* partials;
+    long plane, ldws;
+    int B, hL, G;
+    int S, NT;
+    float ridge, inv_n;
+};
+
+__device__ __forceinline__ int rowmap(int e, int hi) { return (e & 3) + 8 * (e >> 2) + 4 * hi; }
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <bool HAS_PI, bool CONST_DISP, int HLB, int WR>
+__global__ __launch_bounds__(64 * kWG * WR) void heads_fused_kernel(HeadsArgs p) {
+    constexpr int NH = 1 + (CONST_DISP ? 0 : 1) + (HAS_PI ? 1 : 0);
+    constexpr int PI_H = NH - 1;                 // plane of the pi head (when present)
+    constexpr int KT = HLB * 32;                 // padded hidden width
+    constexpr int KH = HLB * 16;                 // k per half-wave in the forward
+    constexpr int WS_TILE = NH * KT * kLdS;      // floats of one gene tile's weights
+    constexpr int ST_PLANE = kTG * kLdS;
+    constexpr int NP = NH + (CONST_DISP ? 1 : 0);  // staging planes (+ d nll / d theta for const-disp)
+    constexpr int TH_P = NH;                        // that extra plane
+    constexpr int ST_WAVE = NP * ST_PLANE > kTR * kLdH ? NP * ST_PLANE : kTR * kLdH;
+    constexpr int NTHREADS = 64 * kWG * WR;
+    constexpr int NRED = NH * HLB * 16 + NH + 1; // registers a wave hands over in the dW reduce
+    constexpr int LDS_FLOATS = kWG * WS_TILE + kWG * WR * (ST_WAVE + kQCap);
+    static_assert(WR == 1 || (kWG * WR / 2) * NRED * 64 <= LDS_FLOATS, "dW reduce scratch");
+    static_assert(kTR * kLdH <= ST_WAVE, "H tile must fit the staging buffer");
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    __shared__ double lred[kWG * WR];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int g = wave / WR, r = wave % WR;
+    const int s = blockIdx.x % p.S, gb = blockIdx.x / p.S;
+    const int gt = gb * kWG + g;
+    const int g0 = gt * kTG;
+    const int gene = g0 + l31;
+    const bool tile_ok = g0 < p.G;
+    const bool gvalid = gene < p.G;
+    const long long cur = p.cursor ? *p.cursor : 0;
+
+    float* Ws = lds;
+    float* Wsg = Ws + g * WS_TILE;
+    float* St = lds + kWG * WS_TILE + wave * ST_WAVE;
+    unsigned* Q = reinterpret_cast<unsigned*>(lds + kWG * WS_TILE + kWG * WR * ST_WAVE) + wave * kQCap;
+
+    // ---- head weights of this workgroup's genes -> LDS, [tile][head][k][33]
+    {
+        constexpr int NT4 = kWG * NH * KT * (kTG / 4);
+        for (int idx = tid; idx < NT4; idx += NTHREADS) {
+            const int c4 = idx & 7;
+            int rest = idx >> 3;
+            const int k = rest % KT; rest /= KT;
+            const int h = rest % NH;
+            const int gg = rest / NH;
+            const int gcol = (gb * kWG + gg) * kTG + c4 * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < p.hL && gcol < p.plane)
+                v = *reinterpret_cast<const float4*>(p.Wh + (long)k * p.ldw + (long)h * p.plane + gcol);
+            float* d = Ws + ((gg * NH + h) * KT + k) * kLdS + c4 * 4;
+            d[0] = gcol + 0 < p.G ? v.x : 0.f;
+            d[1] = gcol + 1 < p.G ? v.y : 0.f;
+            d[2] = gcol + 2 < p.G ? v.z : 0.f;
+            d[3] = gcol + 3 < p.G ? v.w : 0.f;
+        }
+    }
+    __syncthreads();
+
+    f32x16 dW[NH][HLB];
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int ib = 0; ib < HLB; ++ib)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) dW[h][ib][e] = 0.f;
+    float bsum[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) bsum[h] = 0.f;
+    float thsum = 0.f;
+    double dacc = 0.0;
+
+    if (tile_ok) {
+        float bias[NH];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) bias[h] = gvalid ? p.bh[(long)h * p.plane + gene] : 0.f;
+        const float thw = (CONST_DISP && gvalid) ? p.theta_w[gene] : 0.f;
+
+        const int hl4 = (p.hL + 3) & ~3;
+        const int gene_c = gvalid ? gene : p.G - 1;         // clamped: loads stay unconditional
+        // Software pipeline across tiles: the row indices (perm), size factors, H rows and the
+        // first count groups of tile t+1 are requested while tile t is in its Z / Bk phases.
+        const int tstep = p.S * WR;
+        int t = s * WR + r;
+        int srow_l = 0;
+        float sf_l = 1.f;
+        float4 hv[KH / 4];
+        float yA[kZU], yB[kZU];
+        auto row_clamped = [&](int tt) { const int rl = tt * kTR + l31; return rl < p.B ? rl : p.B - 1; };
+        auto load_srow = [&](int tt) { const int rlc = row_clamped(tt); return p.perm ? p.perm[cur + rlc] : (int)(cur + rlc); };
+        auto load_hv = [&](int tt) {
+            const float* hp = p.H + (long)row_clamped(tt) * p.ldh;
+#pragma unroll
+            for (int c = 0; c < KH / 4; ++c) {
+                const int k = hi * KH + 4 * c;
+                const int kc = k < hl4 ? k : hl4 - 4;
+                hv[c] = *reinterpret_cast<const float4*>(hp + kc);
+            }
+        };
+        if (t < p.NT) {
+            srow_l = load_srow(t);
+            sf_l = p.sf[srow_l];
+            load_hv(t);
+#pragma unroll
+            for (int j = 0; j < kZU; ++j) {
+                const int sr = __shfl(srow_l, rowmap(j, hi), 64);
+                yA[j] = p.y[(long)sr * p.ldy + gene_c];
+            }
+        }
+#ifdef DCA_HEADS_TIMING
+        long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        long long tlast = __builtin_readcyclecounter();
+#endif
+        for (; t < p.NT; t += tstep) {
+            TSTAMP(0)
+            const int row0 = t * kTR;
+            const bool rv = row0 + l31 < p.B;
+            const int tn = t + tstep < p.NT ? t + tstep : t;     // next tile (or a harmless re-read)
+            // ---- this tile's rows of H -> the (still unused) staging tile, [row][k] with an odd
+            // row stride: the forward's A operands are then plain conflict-free ds_reads
+#pragma unroll
+            for (int c = 0; c < KH / 4; ++c) {
+                const int k = hi * KH + 4 * c;
+                float* d = St + l31 * kLdH + k;
+                d[0] = (rv && k + 0 < p.hL) ? hv[c].x : 0.f;
+                d[1] = (rv && k + 1 < p.hL) ? hv[c].y : 0.f;
+                d[2] = (rv && k + 2 < p.hL) ? hv[c].z : 0.f;
+                d[3] = (rv && k + 3 < p.hL) ? hv[c].w : 0.f;
+            }
+            wave_sync();
+            TSTAMP(1)
+            // ---- F: pre-activations.  Lane half hi covers k in [hi*KH, hi*KH+KH): the MFMA's
+            // k order is free as long as A and B agree.
+            f32x16 acc[NH];
+#pragma unroll
+            for (int h = 0; h < NH; ++h)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[h][e] = 0.f;    // bias joins at the staging store
+#pragma unroll
+            for (int kk = 0; kk < KH; ++kk) {
+                const float a = St[l31 * kLdH + hi * KH + kk];
+#pragma unroll
+                for (int h = 0; h < NH; ++h) {
+                    const float b = Wsg[(h * KT + hi * KH + kk) * kLdS + l31];
+                    acc[h] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[h], 0, 0, 0);
+                }
+            }
+            wave_sync();
+            TSTAMP(2)
+            // ---- stage [gene][row] (row stride 1, gene stride 33)
+#pragma unroll
+            for (int h = 0; h < NH; ++h)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    St[h * ST_PLANE + l31 * kLdS + rowmap(e, hi)] = acc[h][e] + bias[h];
+            const int srow_n = load_srow(tn);       // in flight during the Z loop
+            wave_sync();
+            TSTAMP(3)
+
+            // ---- Z: element-wise likelihood and gradient.  16 staged rows = 4 groups of 4; the
+            // counts of group g+1 are in flight while group g is evaluated (two named buffers,
+            // no register rotation: a rotation would have to wait for the load it just issued).
+            // The last request already belongs to the next tile.
+            // Counts are ~93 % zeros: the dense pass evaluates the y = 0 formulas for every
+            // element and queues the positions of the non-zero ones; the queue is drained 64
+            // entries at a time by the NB branch (lgamma / digamma differences), which therefore
+            // runs ~2x per tile instead of 16x with 5 % of its lanes alive.
+            float lacc = 0.f;
+            int qn = 0;
+            auto z_dense = [&](int grp, const float (&yv)[kZU]) {
+#pragma unroll
+                for (int j = 0; j < kZU; ++j) {
+                    const int row = rowmap(grp * kZU + j, hi);
+                    const float sfr = __shfl(sf_l, row, 64);
+                    const bool valid = (row0 + row < p.B) && gvalid;
+                    const int idx = l31 * kLdS + row;
+                    const float am = St[idx];
+                    const float ad = CONST_DISP ? thw : St[ST_PLANE + idx];
+                    const float ap = HAS_PI ? St[PI_H * ST_PLANE + idx] : 0.f;
+                    const float yj = yv[j];
+                    const bool nz = valid && (HAS_PI ? !(yj < kZeroThresh) : (yj != 0.f));
+                    float dmu = 0.f, dth = 0.f, dpi = 0.f;
+                    const Heads hd = head_acts<HAS_PI, CONST_DISP>(am, ad, ap, sfr);
+                    const float nll = nll_elem<HAS_PI, true>(hd, 0.f, p.ridge, dmu, dth, dpi);
+                    lacc += (valid && !nz) ? nll : 0.f;
+                    const float om = valid ? dmu * hd.gm * p.inv_n : 0.f;
+                    const float od = valid ? dth * hd.gd * p.inv_n : 0.f;
+                    const float op = (HAS_PI && valid) ? dpi * hd.pi * hd.omp * p.inv_n : 0.f;
+                    const unsigned long long m = __ballot(nz);
+                    const int slot = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                    if (nz) {
+                        Q[slot] = (unsigned)idx | ((unsigned)row << 11) | ((unsigned)l31 << 16);
+                    } else {                 // pre-activations of queued elements stay in place
+                        St[idx] = om;
+                        if (CONST_DISP) St[TH_P * ST_PLANE + idx] = od; else St[ST_PLANE + idx] = od;
+                        if (HAS_PI) St[PI_H * ST_PLANE + idx] = op;
+                    }
+                    qn += __popcll(m);
+                }
+            };
+            auto z_sparse = [&](int q0, int cnt) {
+                const bool act = lane < cnt;
+                const unsigned e = Q[q0 + (act ? lane : 0)];
+                const int idx = e & 2047, row = (e >> 11) & 31, gq = (e >> 16) & 31;
+                const float sfr = __shfl(sf_l, row, 64);
+                const int sr = __shfl(srow_l, row, 64);
+                const float am = St[idx];
+                const float ad = CONST_DISP ? __shfl(thw, gq, 64) : St[ST_PLANE + idx];
+                const float ap = HAS_PI ? St[PI_H * ST_PLANE + idx] : 0.f;
+                const float yq = p.y[(long)sr * p.ldy + g0 + gq];
+                float dmu = 0.f, dth = 0.f, dpi = 0.f;
+                const Heads hd = head_acts<HAS_PI, CONST_DISP>(am, ad, ap, sfr);
+                const float nll = nll_elem<HAS_PI, true, true>(hd, yq, p.ridge, dmu, dth, dpi);
+                lacc += act ? nll : 0.f;
+                if (act) {
+                    St[idx] = dmu * hd.gm * p.inv_n;
+                    const float od = dth * hd.gd * p.inv_n;
+                    if (CONST_DISP) St[TH_P * ST_PLANE + idx] = od; else St[ST_PLANE + idx] = od;
+                    if (HAS_PI) St[PI_H * ST_PLANE + idx] = dpi * hd.pi * hd.omp * p.inv_n;
+                }
+            };
+            auto z_flush = [&](bool last) {
+                while (qn >= 64 || (last && qn > 0)) {
+                    const int c = qn < 64 ? qn : 64;
+                    wave_sync();
+                    z_sparse(qn - c, c);
+                    qn -= c;
+                }
+            };
+            auto load_y = [&](int srow_src, int grp, float (&yv)[kZU]) {
+#pragma unroll
+                for (int j = 0; j < kZU; ++j) {
+                    const int sr = __shfl(srow_src, rowmap(grp * kZU + j, hi), 64);
+                    yv[j] = p.y[(long)sr * p.ldy + gene_c];
+                }
+            };
+#pragma unroll 1
+            for (int it = 0; it < 16 / (2 * kZU); ++it) {
+                const bool last = it + 1 == 16 / (2 * kZU);
+                load_y(srow_l, 2 * it + 1, yB);
+                z_dense(2 * it, yA);
+                z_flush(false);
+                if (!last) load_y(srow_l, 2 * it + 2, yA);
+                else load_y(srow_n, 0, yA);              // next tile's first group
+                z_dense(2 * it + 1, yB);
+                z_flush(last);
+            }
+            dacc += (double)lacc;
+            // next tile: size factors + H rows; this tile: A operands of the weight-gradient
+            // product (H rows, lanes along the hidden units) -- all in flight during the dH MFMAs
+            const float sf_n = p.sf[srow_n];
+            load_hv(tn);
+            float Hd[HLB][16];
+#pragma unroll
+            for (int ib = 0; ib < HLB; ++ib)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = row0 + rowmap(e, hi);
+                    const int i = ib * 32 + l31;
+                    const int rc = row < p.B ? row : p.B - 1;
+                    const int ic = i < hl4 ? i : hl4 - 1;
+                    Hd[ib][e] = p.H[(long)rc * p.ldh + ic];
+                }
+            wave_sync();
+            TSTAMP(4)
+
+            // ---- Bk (1): dH[row, i] = sum_genes D[row, gene] W[i, gene] (this gene tile's share;
+            // D read transposed from the staging tile)
+            {
+                f32x16 dHa[HLB];
+#pragma unroll
+                for (int jb = 0; jb < HLB; ++jb)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) dHa[jb][e] = 0.f;
+#pragma unroll
+                for (int h = 0; h < NH; ++h)
+#pragma unroll
+                    for (int kk = 0; kk < 16; ++kk) {
+                        const int gl = 16 * hi + kk;
+                        const float a = St[h * ST_PLANE + gl * kLdS + l31];
+#pragma unroll
+                        for (int jb = 0; jb < HLB; ++jb) {
+                            const float b = Wsg[(h * KT + jb * 32 + l31) * kLdS + gl];
+                            dHa[jb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, dHa[jb], 0, 0, 0);
+                        }
+                    }
+                float* dst = p.ws_dh + ((long)gt * p.NT * kTR + row0) * KT + l31;   // rows padded to tiles
+#pragma unroll
+                for (int jb = 0; jb < HLB; ++jb)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) dst[rowmap(e, hi) * KT + jb * 32] = dHa[jb][e];
+            }
+            TSTAMP(5)
+            // ---- Bk (2): dW[i, gene] += sum_rows H[row, i] D[row, gene]; the staged D column
+            // of a lane IS its B operand (k slot = lane half), A = H rows of this tile
+#pragma unroll
+            for (int h = 0; h < NH; ++h)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float b = St[h * ST_PLANE + l31 * kLdS + rowmap(e, hi)];
+                    bsum[h] += b;                    // bias gradient = column sum of D
+#pragma unroll
+                    for (int ib = 0; ib < HLB; ++ib) {
+                        const bool ok = (row0 + rowmap(e, hi) < p.B) && (ib * 32 + l31 < p.hL);
+                        dW[h][ib] = __builtin_amdgcn_mfma_f32_32x32x2f32(ok ? Hd[ib][e] : 0.f, b, dW[h][ib], 0, 0, 0);
+                    }
+                }
+            if (CONST_DISP) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) thsum += St[TH_P * ST_PLANE + l31 * kLdS + rowmap(e, hi)];
+            }
+            srow_l = srow_n;
+            sf_l = sf_n;
+            wave_sync();
+            TSTAMP(6)
+        }
+#ifdef DCA_HEADS_TIMING
+        if (p.timing && lane == 0)
+            for (int i = 0; i < 8; ++i) p.timing[((long)blockIdx.x * (kWG * WR) + wave) * 8 + i] = tacc[i];
+#endif
+    }
+
+    // ---- loss: wave -> workgroup -> one partial per workgroup
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) dacc += __shfl_down(dacc, off, 64);
+    if (lane == 0) lred[wave] = dacc;
+    __syncthreads();                      // also: every wave is done with the LDS weights / staging
+    if (tid == 0) {
+        double v = 0.0;
+        for (int w = 0; w < kWG * WR; ++w) v += lred[w];
+        p.partials[blockIdx.x] = v;
+    }
+
+    // ---- dW / bias-gradient sums of the WR row slots of a gene tile: ordered tree through LDS
+    if (WR > 1) {
+        float* red = lds;
+#pragma unroll
+        for (int step = 1; step < WR; step *= 2) {
+            const int slot = g * (WR / 2) + r / (2 * step);
+            float* rs = red + (long)slot * NRED * 64 + lane;
+            if (r % (2 * step) == step) {
+                int n = 0;
+#pragma unroll
+                for (int h = 0; h < NH; ++h)
+#pragma unroll
+                    for (int ib = 0; ib < HLB; ++ib)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) rs[(n++) * 64] = dW[h][ib][e];
+#pragma unroll
+                for (int h = 0; h < NH; ++h) rs[(n++) * 64] = bsum[h];
+                rs[(n++) * 64] = thsum;
+            }
+            __syncthreads();
+            if (r % (2 * step) == 0 && r + step < WR) {
+                int n = 0;
+#pragma unroll
+                for (int h = 0; h < NH; ++h)
+#pragma unroll
+                    for (int ib = 0; ib < HLB; ++ib)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) dW[h][ib][e] += rs[(n++) * 64];
+#pragma unroll
+                for (int h = 0; h < NH; ++h) bsum[h] += rs[(n++) * 64];
+                thsum += rs[(n++) * 64];
+            }
+            __syncthreads();
+        }
+    }
+    if (r == 0 && tile_ok) {
+        float* out = p.ws_dw + (long)s * p.dw_stride;
+        const bool cw = gene < p.plane;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+#pragma unroll
+            for (int ib = 0; ib < HLB; ++ib)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int i = ib * 32 + rowmap(e, hi);
+                    if (cw && i < p.hL) out[(long)i * p.ldws + (long)h * p.plane + gene] = dW[h][ib][e];
+                }
+            const float bv = bsum[h] + __shfl_xor(bsum[h], 32, 64);
+            if (cw && hi == 0) out[(long)p.hL * p.ldws + (long)h * p.plane + gene] = bv;
+        }
+        if (CONST_DISP) {
+            const float tv = thsum + __shfl_xor(thsum, 32, 64);
+            if (cw && hi == 0) out[(long)(p.hL + 1) * p.ldws + gene] = tv;
+        }
+    }
+}
+
+// gW[i, col] = sum_s ws[s][i][col], i = 0..hL (row hL = bias gradient), then the
+// ConstantDispersionLayer chain (dca/layers.py:17-21) on the per-gene theta sums.
+__global__ __launch_bounds__(256) void heads_reduce_dw_kernel(const float* ws, int S, long stride,
+                                                              int hL, long ldws, long ncols,
+                                                              float* gW, long ldg,
+                                                              const float* theta_w, float* g_theta,
+                                                              int G) {
+    const long total = (long)(hL + 1) * ncols;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long i = idx / ncols, c = idx - i * ncols;
+        float v = 0.f;
+        for (int s = 0; s < S; ++s) v += ws[(long)s * stride + i * ldws + c];
+        gW[i * ldg + c] = v;
+    }
+    if (g_theta) {
+        for (long c = (long)blockIdx.x * 256 + threadIdx.x; c < G; c += (long)gridDim.x * 256) {
+            float v = 0.f;
+            for (int s = 0; s < S; ++s) v += ws[(long)s * stride + (long)(hL + 1) * ldws + c];
+            const float e = expf(theta_w[c]);
+            g_theta[c] = (e >= 1e-3f && e <= 1e4f) ? v * e : 0.f;
+        }
+    }
+}
+
+// dH[row, i] = sum over gene tiles of ws[gt][row][i]; GL threads split the gene tiles of one
+// output quad, combined in fixed order through LDS.
+template <int GL>
+__global__ __launch_bounds__(256) void heads_reduce_dh_kernel(const float* ws, int ntg, int B, int Bpad,
+                                                              int KT, int hL, float* dH, long lddh) {
+    constexpr int OUT = 256 / GL;
+    __shared__ float4 red[256];
+    const int o = threadIdx.x % OUT, gl = threadIdx.x / OUT;
+    const int q4 = KT / 4;
+    const long nq = (long)B * q4;
+    const long quad = (long)blockIdx.x * OUT + o;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (quad < nq) {
+        const float4* src = reinterpret_cast<const float4*>(ws) + quad;
+#pragma unroll 4
+        for (int gt = gl; gt < ntg; gt += GL) {
+            const float4 x = src[(long)gt * Bpad * q4];
+            v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+        }
+    }
+    red[threadIdx.x] = v;
+    __syncthreads();
+    if (gl == 0 && quad < nq) {
+#pragma unroll
+        for (int k = 1; k < GL; ++k) {
+            const float4 x = red[k * OUT + o];
+            v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+        }
+        const long row = quad / q4;
+        const int i = (int)(quad - row * q4) * 4;
+        float* d = dH + row * lddh + i;
+        if (i + 0 < hL) d[0] = v.x;
+        if (i + 1 < hL) d[1] = v.y;
+        if (i + 2 < hL) d[2] = v.z;
+        if (i + 3 < hL) d[3] = v.w;
+    }
+}
+
+struct HeadsPlan {
+    int HLB, WR, S, NT, ntg, ngb, grid;
+    long ldws, dw_stride, dw_bytes, dh_bytes;
+};
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// a pure function of the shape: row slots per workgroup, batch splits, workspace layout
+bool make_heads_plan(int B, int hL, int G, long plane, int flags, HeadsPlan* out) {
+    if (B <= 0 || G <= 0 || hL <= 0 || hL > 64 || plane < G || (plane & 3) || plane > ((G + 31) & ~31)) return false;
+    const bool has_pi = flags & DCAHIP_NLL_HAS_PI, cdisp = flags & DCAHIP_NLL_CONST_DISP;
+    const int NH = 1 + (cdisp ? 0 : 1) + (has_pi ? 1 : 0);
+    HeadsPlan p;
+    p.HLB = 2;
+    p.NT = (B + kTR - 1) / kTR;
+    p.ntg = (G + kTG - 1) / kTG;
+    p.ngb = (p.ntg + kWG - 1) / kWG;
+    if (p.ngb > kMaxGrid) return false;
+    p.WR = p.NT >= 4 ? 4 : 1;
+    const int smax = (p.NT + p.WR - 1) / p.WR;
+    double best = 1e300;
+    p.S = 1;
+    for (int S = 1; S <= smax && (long)S * p.ngb <= kMaxGrid; ++S) {
+        const long items = (long)S * p.ngb;
+        const long rounds = (items + kCUs - 1) / kCUs;
+        const int tiles = (p.NT + S * p.WR - 1) / (S * p.WR);
+        const double cost = (double)rounds * (tiles + 0.75);
+        if (cost < best - 1e-9) { best = cost; p.S = S; }
+    }
+    p.grid = p.S * p.ngb;
+    p.ldws = (long)NH * plane;
+    p.dw_stride = (long)(hL + 2) * p.ldws;
+    p.dw_bytes = (long)p.S * p.dw_stride * (long)sizeof(float);
+    p.dh_bytes = (long)p.ntg * p.NT * kTR * (p.HLB * 32) * (long)sizeof(float);
+    *out = p;
+    return true;
+}
+
+long long* g_timing = nullptr;
+
+template <bool P, bool C>
+void launch_fused(const HeadsPlan& pl, const HeadsArgs& a, hipStream_t s) {
+    if (pl.WR == 4) hipLaunchKernelGGL((heads_fused_kernel<P, C, 2, 4>), dim3(pl.grid), dim3(64 * kWG * 4), 0, s, a);
+    else            hipLaunchKernelGGL((heads_fused_kernel<P, C, 2, 1>), dim3(pl.grid), dim3(64 * kWG * 1), 0, s, a);
+}
+
+}  // namespace
+
+// sufficient for every batch of at most B rows (the plan of a smaller batch may split more)
+extern "C" long dcahip_heads_fused_workspace_bytes(int B, int hL, int G, long plane, int flags) {
+    HeadsPlan p;
+    if (!make_heads_plan(B, hL, G, plane, flags, &p)) return 0;
+    long smax = kMaxGrid / p.ngb;
+    if (smax > p.NT) smax = p.NT;
+    if (smax < 1) smax = 1;
+    return smax * p.dw_stride * (long)sizeof(float) + p.dh_bytes;
+}
+
+#ifdef DCA_HEADS_TIMING
+extern "C" void dcahip_heads_set_timing(long long* buf) { g_timing = buf; }
+#endif
+
+extern "C" int dcahip_heads_fused(const float* H, long ldh, const float* Wh, long ldw,
+                                  const float* bh, long plane, const float* theta_w,
+                                  const float* y, long ldy, const float* sf, const int* perm,
+                                  const long long* cursor, int B, int hL, int G, float ridge,
+                                  float inv_n, int flags, float* gW, long ldg, float* g_theta,
+                                  float* dH, long lddh, double* loss_partials, int* n_partials_out,
+                                  void* workspace, long workspace_bytes, void* stream) {
+    const bool has_pi = flags & DCAHIP_NLL_HAS_PI, cdisp = flags & DCAHIP_NLL_CONST_DISP;
+    HeadsPlan pl;
+    if (!make_heads_plan(B, hL, G, plane, flags, &pl)) return DCAHIP_EINVAL;
+    if (!H || !Wh || !bh || !y || !sf || !gW || !dH || !loss_partials || !workspace) return DCAHIP_EINVAL;
+    if (cdisp && (!theta_w || !g_theta)) return DCAHIP_EINVAL;
+    if (workspace_bytes < pl.dw_bytes + pl.dh_bytes) return DCAHIP_EINVAL;
+    if (!al16(H) || !al16(Wh) || !al16(workspace) || (ldh & 3) || (ldw & 3) || ldh < ((hL + 3) & ~3))
+        return DCAHIP_EINVAL;
+    const int NH = 1 + (cdisp ? 0 : 1) + (has_pi ? 1 : 0);
+    if (ldw < (long)NH * plane || ldg < (long)NH * plane) return DCAHIP_EINVAL;
+    float* ws_dh = static_cast<float*>(workspace);
+    float* ws_dw = ws_dh + pl.dh_bytes / sizeof(float);
+    HeadsArgs a{g_timing, H, ldh, Wh, ldw, bh, theta_w, y, ldy, sf, perm, cursor, ws_dw, pl.dw_stride, ws_dh,
+                loss_partials, plane, pl.ldws, B, hL, G, pl.S, pl.NT, ridge, inv_n};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (has_pi && cdisp) launch_fused<true, true>(pl, a, s);
+    else if (has_pi) launch_fused<true, false>(pl, a, s);
+    else if (cdisp) launch_fused<false, true>(pl, a, s);
+    else launch_fused<false, false>(pl, a, s);
+    int rc = (int)hipGetLastError();
+    if (rc != 0) return rc;
+    if (n_partials_out) *n_partials_out = pl.grid;
+    {
+        const long total = (long)(hL + 1) * pl.ldws;
+        long gr = (total + 255) / 256;
+        if (gr > 2048) gr = 2048;
+        hipLaunchKernelGGL(heads_reduce_dw_kernel, dim3((int)gr), dim3(256), 0, s, ws_dw, pl.S,
+                           pl.dw_stride, hL, pl.ldws, pl.ldws, gW, ldg, cdisp ? theta_w : nullptr,
+                           cdisp ? g_theta : nullptr, G);
+        rc = (int)hipGetLastError();
+        if (rc != 0) return rc;
+    }
+    {
+        const int KT = pl.HLB * 32;
+        const long nq = (long)B * (KT / 4);
+        if (nq >= 64L * 512) {
+            hipLaunchKernelGGL(heads_reduce_dh_kernel<4>, dim3((int)((nq + 63) / 64)), dim3(256), 0, s,
+                               ws_dh, pl.ntg, B, pl.NT * kTR, KT, hL, dH, lddh);
+        } else {
+            hipLaunchKernelGGL(heads_reduce_dh_kernel<16>, dim3((int)((nq + 15) / 16)), dim3(256), 0, s,
+                               ws_dh, pl.ntg, B, pl.NT * kTR, KT, hL, dH, lddh);
+        }
+        rc = (int)hipGetLastError();
+    }
+    return rc;
+}

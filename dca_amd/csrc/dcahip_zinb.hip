@@ -12,175 +12,11 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include "dcahip.h"
+#include "zinb_math.hpp"
 
 namespace {
 
-constexpr float kEps = 1e-10f;        // loss.py:65
-constexpr float kThetaMax = 1e6f;     // loss.py:85
-constexpr float kZeroThresh = 1e-8f;  // loss.py:138
 constexpr int kMaxPartials = 2048;    // 256 CUs x 8 blocks
-constexpr int kSmallY = 16;
-
-// log(n!) for n = 0..16
-__constant__ float kLogFact[kSmallY + 1] = {
-    0.0f, 0.0f, 0.69314718055994531f, 1.7917594692280550f, 3.1780538303479458f,
-    4.7874917427820458f, 6.5792512120101012f, 8.5251613610654147f, 10.604602902745251f,
-    12.801827480081469f, 15.104412573075516f, 17.502307845873887f, 19.987214495661885f,
-    22.552163853123425f, 25.191221182738680f, 27.899271383840890f, 30.671860106080672f};
-
-// ---- elementary functions on the transcendental unit (v_exp_f32 / v_log_f32 / v_rcp_f32, 1 ulp
-// each) with first-order compensation of the range step, so that no IEEE division or libm call
-// sits on the per-element path.  exp: the rounding of x*log2(e) is re-applied as a correction
-// term; log: log2 result times ln2 in two pieces; log1p / expm1 use Kahan's exact-ratio forms.
-__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
-
-__device__ __forceinline__ float fexp(float x) {
-    x = fminf(fmaxf(x, -104.f), 88.7f);
-    const float L = 1.44269504088896340736f, Llo = 1.92596299112661746e-8f;
-    const float t = x * L;
-    const float r = fmaf(x, Llo, fmaf(x, L, -t));
-    const float e = __builtin_amdgcn_exp2f(t);
-    return fmaf(e, r * 0.69314718055994531f, e);
-}
-
-__device__ __forceinline__ float flog(float x) {           // x > 0, normal
-    const float y = __builtin_amdgcn_logf(x);              // log2(x)
-    const float C = 0.693147182464599609375f, Clo = -1.90465429995776804e-9f;
-    const float r = y * C;
-    return r + fmaf(y, Clo, fmaf(y, C, -r));
-}
-
-__device__ __forceinline__ float flog1p(float t) {         // t >= 0
-    const float u = 1.f + t;
-    const float d = u - 1.f;
-    const float l = flog(u);
-    return d == 0.f ? t : l * (t * frcp(d));
-}
-
-__device__ __forceinline__ float fexpm1_neg(float x, float ex) {   // x <= 0, ex = fexp(x)
-    const float d = ex - 1.f;
-    const float k = d * x * frcp(flog(ex));
-    return x < -17.f ? -1.f : (d == 0.f ? x : k);
-}
-
-__device__ __forceinline__ float digamma_pos(float x) {
-    // x > 0: upward recurrence to x >= 6, then the asymptotic series (rare generic path)
-    float r = 0.f;
-    while (x < 6.f) { r -= 1.f / x; x += 1.f; }
-    const float xi = 1.f / x, xi2 = xi * xi;
-    return r + logf(x) - 0.5f * xi - xi2 * (1.f / 12.f - xi2 * (1.f / 120.f - xi2 * (1.f / 252.f)));
-}
-
-// lgamma / digamma route for non-integer or large counts: rare, kept out of line so the hot
-// loop stays small (registers, instruction cache)
-template <bool GRAD>
-__device__ __attribute__((noinline)) float nb_t1_generic(float tp, float y, float* dpsi) {
-    if (GRAD) *dpsi = digamma_pos(y + tp) - digamma_pos(tp);
-    return lgammaf(tp) + lgammaf(y + 1.f) - lgammaf(y + tp);
-}
-
-struct Heads {       // activations of one element
-    float mu, gm;    // mean * sf,            d mu / d a_mean          (0 outside the clip window)
-    float theta, gd; // dispersion,           d theta / d a_disp
-    float pi, omp;   // dropout prob, 1 - pi (computed directly, no cancellation)
-};
-
-template <bool HAS_PI, bool CONST_DISP>
-__device__ __forceinline__ Heads head_acts(float am, float ad, float ap, float sf) {
-    Heads h;
-    const float e = fexp(am);                                   // network.py:38
-    const bool mwin = (e >= 1e-5f) && (e <= 1e6f);
-    h.mu = fminf(fmaxf(e, 1e-5f), 1e6f) * sf;                   // layers.py:85
-    h.gm = mwin ? e * sf : 0.f;
-    if (CONST_DISP) {                                           // layers.py:21 (ad = theta_w[g])
-        h.theta = fminf(fmaxf(fexp(ad), 1e-3f), 1e4f);
-        h.gd = 1.f;                                             // chained in dcahip_colsum_chain
-    } else {                                                    // network.py:39
-        const float ex = fexp(-fabsf(ad));
-        const float u = 1.f + ex, d = u - 1.f;
-        const float s = frcp(u);
-        const float l1 = d == 0.f ? ex : flog(u) * (ex * frcp(d));      // log1p(ex)
-        const float sp = fmaxf(ad, 0.f) + l1;
-        const bool dwin = (sp >= 1e-4f) && (sp <= 1e4f);
-        h.theta = fminf(fmaxf(sp, 1e-4f), 1e4f);
-        h.gd = dwin ? (ad >= 0.f ? s : ex * s) : 0.f;
-    }
-    h.theta = fminf(h.theta, kThetaMax);                        // loss.py:85
-    if (HAS_PI) {
-        const float ex = fexp(-fabsf(ap));
-        const float s = frcp(1.f + ex);
-        h.pi = ap >= 0.f ? s : ex * s;
-        h.omp = ap >= 0.f ? ex * s : s;
-    } else {
-        h.pi = 0.f; h.omp = 1.f;
-    }
-    return h;
-}
-
-// One element of the loss and (GRAD) its gradient w.r.t. (mu, theta, pi).
-template <bool HAS_PI, bool GRAD>
-__device__ __forceinline__ float nll_elem(const Heads& h, float y, float ridge,
-                                          float& dmu, float& dth, float& dpi) {
-    const float theta = h.theta, mu = h.mu;
-    const float tp = theta + kEps;
-    float nll;
-    if (HAS_PI && y < kZeroThresh) {
-        // zero_case = -log(pi + (1-pi) * (theta/(theta+mu+eps))^theta + eps)   loss.py:136-137
-        const float den = theta + mu + kEps;
-        const float rden = frcp(den);
-        const float t = (mu + kEps) * frcp(theta);     // theta/den = 1/(1+t)
-        const float logq = -flog1p(t);
-        const float tl = theta * logq;
-        const float z = fexp(tl);
-        const float D = h.pi + h.omp * z + kEps;
-        nll = -flog(D);
-        if (GRAD) {
-            const float invD = frcp(D);
-            const float oz = h.omp * z * invD;
-            dmu = oz * theta * rden;
-            // log q + 1 - q = -log1p(t) + t/(1+t): series below t = 2^-5 (cancellation)
-            const float fs = -t * t * (0.5f - t * (2.f / 3.f - t * (0.75f - t * (0.8f - t * (5.f / 6.f)))));
-            const float fl = logq + (mu + kEps) * rden;
-            dth = -oz * (t < 0.03125f ? fs : fl);
-            dpi = fexpm1_neg(tl, z) * invD;            // -(1 - z)/D
-        }
-    } else {
-        // NB.loss: t1 + t2, loss.py:87-88
-        const float rtp = frcp(tp);
-        const float l1p = flog1p(mu * rtp);
-        float t1, dpsi = 0.f;
-        if (y == floorf(y) && y <= (float)kSmallY) {
-            // lgamma(y+tp) - lgamma(tp) = log prod_{i<y}(tp+i); psi difference = sum 1/(tp+i)
-            const int n = (int)y;
-            float p1 = 1.f, p2 = 1.f;
-            for (int i = 0; i < n; ++i) {
-                const float x = tp + (float)i;
-                if (i < 8) p1 *= x; else p2 *= x;
-                if (GRAD) dpsi += frcp(x);
-            }
-            t1 = kLogFact[n] - (flog(p1) + (n > 8 ? flog(p2) : 0.f));
-        } else {
-            t1 = nb_t1_generic<GRAD>(tp, y, &dpsi);
-        }
-        const float mue = mu + kEps;
-        const float t2 = (theta + y) * l1p + y * (flog(tp) - flog(mue));
-        nll = t1 + t2;
-        if (HAS_PI) nll -= flog(h.omp + kEps);         // loss.py:130
-        if (GRAD) {
-            // (theta+y)/(tp+mu) - y/(mu+eps) and -(theta+y)mu/(tp(tp+mu)) + y/tp, combined over a
-            // common denominator: identical algebra, no cancellation between O(1) terms.
-            const float rtm = frcp(tp + mu);
-            dmu = theta * (mue - y) * rtm * frcp(mue);
-            dth = -dpsi + l1p + (y * tp - theta * mu) * rtp * rtm;
-            dpi = HAS_PI ? frcp(h.omp + kEps) : 0.f;
-        }
-    }
-    if (HAS_PI) {
-        nll += ridge * h.pi * h.pi;                    // loss.py:139-140
-        if (GRAD) dpi += 2.f * ridge * h.pi;
-    }
-    return nll;
-}
 
 struct NllArgs {
     const float *a_mean, *a_disp, *a_pi, *theta_w, *y, *sf;

@@ -17,6 +17,7 @@ Layout of the three head matrices: one [h_L, nheads*Gp] weight block ([mean | di
 Gp = G rounded up to 4) so the heads are ONE GEMM forward and TWO backward.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -178,6 +179,10 @@ class Engine:
         self.X = self.Y = self.sf = self.perm = None
         self.hist = None
         self.prof = None            # EventProfiler or None
+        # K-HEADS (heads forward + NLL + both backward products in one kernel) whenever the
+        # library supports the shape; DCA_AMD_FUSED_HEADS=0 forces the separate kernels
+        self.use_fused = os.environ.get('DCA_AMD_FUSED_HEADS', '1') != '0'
+        self.ws_heads = None
 
     def _t(self, name):
         return self.prof.section(name) if self.prof is not None else _NULL
@@ -327,6 +332,8 @@ class Engine:
         need = max(need, ops.sgemm_workspace_bytes(1, 0, K, lay.NH, B, True))
         need = max(need, ops.sgemm_workspace_bytes(0, 1, B, K, lay.NH))
         self.ws = torch.zeros(max(need // 4, 4), **f32)
+        nb = ops.heads_fused_workspace_bytes(B, K, lay.G_out, lay.Gp, self.flags) if self.use_fused else 0
+        self.ws_heads = torch.zeros(nb // 4, **f32) if nb > 0 else None
 
     # ------------------------------------------------------------------ forward pieces
     def _hidden_forward(self, B, rows_from, training, counts=None):
@@ -448,20 +455,18 @@ class Engine:
         lay, ops, comm = self.lay, self.ops, self.comm
         w, g = self.w, self.g
         KL = self._hidden_forward(B, ('perm',), True, self.counts_world)
-        self._heads_forward(B, KL)
-        with self._t('zinb_nll'):
-            n = self._nll(B, self.perm, self.cursor, self.Y, self.sf, inv_n, True)
-        ops.loss_finalize(self.partials, n, inv_n, g[lay.P:])
-        # ---- backward: heads
-        with self._t('gemm_heads_dW'):
-            ops.sgemm(1, 0, KL, lay.NH, B, self.H[-1], self.ldh[-1], self.D, self.ldD,
-                      lay.view(g, 'Wh'), lay.NH, colsum_row=True, ws=self.ws)
-        if lay.const_disp:
-            ops.colsum_chain(self.Dth, self.ldD, B, lay.G_out, lay.view(w, 'theta_w'),
-                             lay.view(g, 'theta_w'))
-        with self._t('gemm_heads_dH'):
-            ops.sgemm(0, 1, B, KL, lay.NH, self.D, self.ldD, lay.view(w, 'Wh'), lay.NH, self.dH[-1],
-                      self.ldh[-1], ws=self.ws)
+        if self.ws_heads is not None:
+            with self._t('heads_fused'):
+                n = ops.heads_fused(self.H[-1], self.ldh[-1], lay.view(w, 'Wh'), lay.NH,
+                                    lay.view(w, 'bh'), lay.Gp,
+                                    lay.view(w, 'theta_w') if lay.const_disp else None, self.Y,
+                                    self.ldy, self.sf, self.perm, self.cursor, B, KL, lay.G_out,
+                                    self.ridge, inv_n, self.flags, lay.view(g, 'Wh'), lay.NH,
+                                    lay.view(g, 'theta_w') if lay.const_disp else None,
+                                    self.dH[-1], self.ldh[-1], self.partials, self.ws_heads)
+            ops.loss_finalize(self.partials, n, inv_n, g[lay.P:])
+        else:
+            self._heads_backward_unfused(B, KL, inv_n)
         # ---- backward: hidden stack
         L = len(lay.hidden)
         for i in reversed(range(L)):
@@ -489,6 +494,25 @@ class Engine:
                           h, colsum_row=True, ws=self.ws)
                 ops.sgemm(0, 1, B, Kp, h, self.dZ[i], self.ldh[i], lay.view(w, 'W%d' % i), h,
                           self.dH[i - 1], self.ldh[i - 1], ws=self.ws)
+
+    def _heads_backward_unfused(self, B, KL, inv_n):
+        """Heads as separate launches: GEMM forward, K-ZINB, weight-gradient GEMM (+ bias column
+        sums), per-gene dispersion chain, input-gradient GEMM."""
+        lay, ops = self.lay, self.ops
+        w, g = self.w, self.g
+        self._heads_forward(B, KL)
+        with self._t('zinb_nll'):
+            n = self._nll(B, self.perm, self.cursor, self.Y, self.sf, inv_n, True)
+        ops.loss_finalize(self.partials, n, inv_n, g[lay.P:])
+        with self._t('gemm_heads_dW'):
+            ops.sgemm(1, 0, KL, lay.NH, B, self.H[-1], self.ldh[-1], self.D, self.ldD,
+                      lay.view(g, 'Wh'), lay.NH, colsum_row=True, ws=self.ws)
+        if lay.const_disp:
+            ops.colsum_chain(self.Dth, self.ldD, B, lay.G_out, lay.view(w, 'theta_w'),
+                             lay.view(g, 'theta_w'))
+        with self._t('gemm_heads_dH'):
+            ops.sgemm(0, 1, B, KL, lay.NH, self.D, self.ldD, lay.view(w, 'Wh'), lay.NH, self.dH[-1],
+                      self.ldh[-1], ws=self.ws)
 
     def _reduce_bwd_sums(self, i, E, h):
         """SyncBN backward: local chunk sums -> one [2h] vector -> all-reduce."""

@@ -28,6 +28,12 @@ _SIGNATURES = {
     'dcahip_step_end': (_c.c_int, [_f32p, _c.c_double, _f32p, _c.c_int, _f64p, _i64p, _c.c_int, _vp]),
     'dcahip_zinb_heads_infer': (_c.c_int, [_f32p, _f32p, _f32p, _c.c_long, _f32p, _c.c_int, _c.c_int,
                                            _f32p, _f32p, _f32p, _c.c_long, _vp]),
+    'dcahip_heads_fused_workspace_bytes': (_c.c_long, [_c.c_int, _c.c_int, _c.c_int, _c.c_long, _c.c_int]),
+    'dcahip_heads_fused': (_c.c_int, [_f32p, _c.c_long, _f32p, _c.c_long, _f32p, _c.c_long, _f32p,
+                                      _f32p, _c.c_long, _f32p, _i32p, _i64p, _c.c_int, _c.c_int,
+                                      _c.c_int, _c.c_float, _c.c_float, _c.c_int, _f32p, _c.c_long,
+                                      _f32p, _f32p, _c.c_long, _f64p, _c.POINTER(_c.c_int), _vp,
+                                      _c.c_long, _vp]),
     'dcahip_sgemm': (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _f32p, _c.c_long,
                                 _f32p, _c.c_long, _f32p, _c.c_long, _f32p, _i32p, _i64p, _c.c_int,
                                 _c.c_int, _vp, _c.c_long, _vp]),

@@ -45,6 +45,21 @@ class HipOps:
                                                  p(mean_sf), p(theta), p(pi), ldo, hip.stream()),
                   'heads_infer')
 
+    # ------------------------------------------------------------------ fused heads
+    def heads_fused_workspace_bytes(self, B, hL, G, plane, flags):
+        return self.L.dcahip_heads_fused_workspace_bytes(B, hL, G, plane, flags)
+
+    def heads_fused(self, H, ldh, Wh, ldw, bh, plane, theta_w, Y, ldy, sf, perm, cursor, B, hL, G,
+                    ridge, inv_n, flags, gW, ldg, g_theta, dH, lddh, partials, ws):
+        n = ctypes.c_int(0)
+        p = hip.ptr
+        hip.check(self.L.dcahip_heads_fused(p(H), ldh, p(Wh), ldw, p(bh), plane, p(theta_w), p(Y), ldy,
+                                            p(sf), p(perm), p(cursor), B, hL, G, ridge, inv_n, flags,
+                                            p(gW), ldg, p(g_theta), p(dH), lddh, p(partials),
+                                            ctypes.byref(n), p(ws), ws.numel() * ws.element_size(),
+                                            hip.stream()), 'heads_fused')
+        return n.value
+
     # ------------------------------------------------------------------ gemm
     def sgemm_workspace_bytes(self, ta, tb, M, N, K, colsum_row=False, split_k=0):
         return self.L.dcahip_sgemm_workspace_bytes(int(ta), int(tb), M, N, K, int(colsum_row), split_k)

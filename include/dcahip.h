@@ -96,6 +96,39 @@ int dcahip_zinb_heads_infer(const float* a_mean, const float* a_disp, const floa
                             float* mean_sf, float* theta, float* pi, long ldo, void* stream);
 
 /*
+ * K-HEADS: the output heads of one training step in a single pass -- forward GEMM of the heads
+ * (pre-activations = H Wh + bh), NB / ZINB NLL + gradient, weight + bias gradient, input
+ * gradient -- without materialising the [B, G] pre-activation / gradient planes in HBM.
+ * Equivalent to dcahip_sgemm(NN, bias) + dcahip_zinb_nll + dcahip_sgemm(TN, colsum_row) +
+ * dcahip_colsum_chain + dcahip_sgemm(NT) on the same operands.
+ * Replaces: dca/network.py:369-385 (the three Dense heads, ColwiseMultLayer, SliceLayer, loss
+ * closure), dca/loss.py:72-156 and TensorFlow's autodiff of them.
+ *
+ *   H [B, ldh]      : decoder output (last hidden activation), 16-byte aligned, ldh % 4 == 0
+ *   Wh [hL, ldw]    : head weights, head planes in the order [mean | dispersion | pi] (absent
+ *                     heads skipped), `plane` columns apart (plane % 4 == 0, G <= plane <=
+ *                     roundup32(G)); bh [nheads*plane] the biases in the same layout
+ *   theta_w [G]     : log-dispersion (CONST_DISP only)
+ *   y, ldy, sf, perm, cursor, ridge, inv_n, flags : as dcahip_zinb_nll
+ *   gW [hL+1, ldg]  : OUT weight gradient in the layout of Wh; row hL = bias gradient
+ *   g_theta [G]     : OUT d loss / d theta_w (CONST_DISP only)
+ *   dH [B, lddh]    : OUT gradient w.r.t. H (columns < hL)
+ *   loss_partials   : as dcahip_zinb_nll (finish with dcahip_loss_finalize)
+ *   workspace       : >= dcahip_heads_fused_workspace_bytes(...) bytes, 16-byte aligned
+ * Supported: 1 <= hL <= 64 (workspace_bytes query returns 0 otherwise -> use the separate
+ * kernels).  Deterministic (fixed summation order, no atomics).
+ */
+long dcahip_heads_fused_workspace_bytes(int B, int hL, int G, long plane, int flags);
+int dcahip_heads_fused(const float* H, long ldh, const float* Wh, long ldw, const float* bh,
+                       long plane, const float* theta_w,
+                       const float* y, long ldy, const float* sf,
+                       const int* perm, const long long* cursor,
+                       int B, int hL, int G, float ridge, float inv_n, int flags,
+                       float* gW, long ldg, float* g_theta, float* dH, long lddh,
+                       double* loss_partials, int* n_partials_out,
+                       void* workspace, long workspace_bytes, void* stream);
+
+/*
  * C[M,N] = op(A) * op(B) (+ bias) on the fp32 MFMA pipe (v_mfma_f32_32x32x2_f32), LDS-tiled,
  * deterministic split-K through `workspace`.  Replaces the MatMul/BiasAdd kernels of every
  * keras Dense layer forward and backward (dca/network.py:124-126,369-380 and autodiff).

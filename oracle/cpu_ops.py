@@ -105,6 +105,32 @@ class CpuRefOps:
         if pi is not None:
             _mat(pi, B, G, ldo)[:] = Z.sigmoid(_mat(a_pi, B, G, lda).astype(np.float64))
 
+    # ------------------------------------------------------------------ fused heads
+    def heads_fused_workspace_bytes(self, B, hL, G, plane, flags):
+        return 16 if 1 <= hL <= 64 else 0
+
+    def heads_fused(self, H, ldh, Wh, ldw, bh, plane, theta_w, Y, ldy, sf, perm, cursor, B, hL, G,
+                    ridge, inv_n, flags, gW, ldg, g_theta, dH, lddh, partials, ws):
+        """Contract of dcahip_heads_fused = the composition of the separate entry points."""
+        has_pi, cdisp = bool(flags & 1), bool(flags & 2)
+        nh = 1 + (0 if cdisp else 1) + (1 if has_pi else 0)
+        NH = nh * plane
+        A = torch.zeros(B, NH, dtype=torch.float32)
+        D = torch.zeros(B, NH + plane, dtype=torch.float32)
+        self.sgemm(0, 0, B, NH, hL, H, ldh, Wh, ldw, A, NH, bias=bh)
+        k_pi = nh - 1
+        a_disp = None if cdisp else A[:, plane:]
+        a_pi = A[:, k_pi * plane:] if has_pi else None
+        d_disp = D[:, NH:] if cdisp else D[:, plane:]
+        d_pi = D[:, k_pi * plane:] if has_pi else None
+        n = self.zinb_nll(A, a_disp, a_pi, NH, theta_w, Y, ldy, sf, perm, cursor, B, G, ridge, inv_n,
+                          flags, D, d_disp, d_pi, NH + plane, partials)
+        self.sgemm(1, 0, hL, NH, B, H, ldh, D, NH + plane, gW, ldg, colsum_row=True)
+        if cdisp:
+            self.colsum_chain(d_disp, NH + plane, B, G, theta_w, g_theta)
+        self.sgemm(0, 1, B, hL, NH, D, NH + plane, Wh, ldw, dH, lddh)
+        return n
+
     # ------------------------------------------------------------------ gemm
     def sgemm_workspace_bytes(self, ta, tb, M, N, K, colsum_row=False, split_k=0):
         return 0

@@ -1,0 +1,150 @@
+"""K-HEADS parity: dcahip_heads_fused (heads forward + NLL + weight / bias / input gradients in
+one kernel) against the fp64 oracle -- numpy matmuls around oracle.zinb_np -- on seeded inputs,
+through the C ABI.  Tolerances against fp64; the kernel computes in fp32 (MFMA, exact fp32).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import synth_counts
+from oracle import zinb_np as Z
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from dca_amd.ops import HipOps
+    return HipOps()
+
+
+def dev(a, dtype=torch.float32):
+    return torch.as_tensor(np.ascontiguousarray(a)).to(dtype).cuda()
+
+
+def reference(Hm, W, b, tw, y, sf, flags, ridge, n_total):
+    """fp64: A = H W + b per head -> loss / grads -> gW, gb, dH, (g_theta)."""
+    has_pi, cdisp = bool(flags & 1), bool(flags & 2)
+    heads = ['mean'] + ([] if cdisp else ['disp']) + (['pi'] if has_pi else [])
+    A = {h: Hm @ W[h] + b[h] for h in heads}
+    if has_pi:
+        ls, lm, dm, dd, dp = Z.zinb_loss_and_grads(A['mean'], A.get('disp'), A['pi'], y, sf, ridge,
+                                                   n_total, tw if cdisp else None)
+    else:
+        ls, lm, dm, dd = Z.nb_loss_and_grads(A['mean'], A.get('disp'), y, sf, n_total,
+                                             tw if cdisp else None)
+        dp = None
+    D = {'mean': dm}
+    if not cdisp:
+        D['disp'] = dd
+    if has_pi:
+        D['pi'] = dp
+    gW = {h: Hm.T @ D[h] for h in heads}
+    gb = {h: D[h].sum(0) for h in heads}
+    dH = sum(D[h] @ W[h].T for h in heads)
+    return heads, ls / n_total, gW, gb, dH, (dd if cdisp else None)
+
+
+def run_case(ops, flags, B, G, hL, seed, ridge=0.0, use_perm=True):
+    has_pi, cdisp = bool(flags & 1), bool(flags & 2)
+    rng = np.random.RandomState(seed)
+    f = lambda a: a.astype(np.float32).astype(np.float64)
+    heads = ['mean'] + ([] if cdisp else ['disp']) + (['pi'] if has_pi else [])
+    nh = len(heads)
+    Hm = f(np.maximum(rng.normal(0.3, 1.0, (B, hL)), 0))          # post-ReLU activations
+    W = {h: f(rng.normal(0, 0.25, (hL, G))) for h in heads}
+    b = {h: f(rng.normal(0, 0.3, G)) for h in heads}
+    tw = f(rng.normal(0, 1.5, G))
+    y = f(synth_counts(B, G, seed))
+    sf = f(rng.lognormal(0, 0.3, B))
+    n_total = float(B * G)
+    _, lm, gW, gb, dH, dth = reference(Hm, W, b, tw, y, sf, flags, ridge, n_total)
+
+    Gp = (G + 3) // 4 * 4
+    NH = nh * Gp
+    ldh = (hL + 3) // 4 * 4
+    Wh = np.zeros((hL + 1, NH))
+    for k, h in enumerate(heads):
+        Wh[:hL, k * Gp:k * Gp + G] = W[h]
+        Wh[hL, k * Gp:k * Gp + G] = b[h]
+    Hp = np.zeros((B, ldh)); Hp[:, :hL] = Hm
+    n_store = B + 5
+    if use_perm:
+        perm = rng.permutation(n_store)[:B + 2].astype(np.int32); cur = 2
+        rows = perm[cur:cur + B]
+    else:
+        perm = None; cur = 1
+        rows = np.arange(cur, cur + B)
+    Yst = np.zeros((n_store, Gp)); Yst[rows, :G] = y
+    sfst = np.ones(n_store); sfst[rows] = sf
+
+    dWh = dev(Wh)
+    dHp, dY, dsf = dev(Hp), dev(Yst), dev(sfst)
+    dperm = torch.as_tensor(perm).cuda() if perm is not None else None
+    dcur = torch.tensor([cur], dtype=torch.int64, device='cuda')
+    dtw = dev(np.concatenate([tw, np.zeros(Gp - G)]))
+    gWd = torch.full((hL + 1, NH), 7.0, device='cuda')
+    gth = torch.full((Gp,), 7.0, device='cuda')
+    dHd = torch.full((B, ldh), 7.0, device='cuda')
+    part = torch.zeros(ops.max_partials, dtype=torch.float64, device='cuda')
+    nb = ops.heads_fused_workspace_bytes(B, hL, G, Gp, flags)
+    assert nb > 0
+    ws = torch.full((nb // 4,), float('nan'), device='cuda')      # every slot read must be written
+    n = ops.heads_fused(dHp, ldh, dWh, NH, dWh[hL], Gp, dtw if cdisp else None, dY, Gp, dsf, dperm,
+                        dcur, B, hL, G, ridge, 1.0 / n_total, flags, gWd, NH,
+                        gth if cdisp else None, dHd, ldh, part, ws)
+    loss = torch.zeros(1, device='cuda')
+    ops.loss_finalize(part, n, 1.0 / n_total, loss)
+    torch.cuda.synchronize()
+    out = {'loss': (loss.item(), lm)}
+    gWn = gWd.cpu().numpy().astype(np.float64)
+    for k, h in enumerate(heads):
+        out['gW_' + h] = (gWn[:hL, k * Gp:k * Gp + G], gW[h])
+        out['gb_' + h] = (gWn[hL, k * Gp:k * Gp + G], gb[h])
+        if Gp > G:
+            out['pad_' + h] = (gWn[:, k * Gp + G:(k + 1) * Gp], np.zeros((hL + 1, Gp - G)))
+    out['dH'] = (dHd.cpu().numpy().astype(np.float64)[:, :hL], dH)
+    if cdisp:
+        e = np.exp(tw)
+        chain = np.where((e >= 1e-3) & (e <= 1e4), e, 0.0)
+        # oracle returns d loss / d theta_w already chained when theta_w is given
+        out['g_theta'] = (gth.cpu().numpy().astype(np.float64)[:G], dth)
+    return out
+
+
+def check(out, edge=False):
+    got, ref = out['loss']
+    assert abs(got - ref) <= (3e-5 if edge else 3e-6) * abs(ref), ('loss', got, ref)
+    for k, (g, r) in out.items():
+        if k == 'loss':
+            continue
+        scale = max(np.abs(r).max(), 1e-30)
+        err = np.abs(g - r)
+        if k.startswith('pad_'):
+            assert (g == 0).all(), k
+            continue
+        # sums of B (or 3G) fp32 terms: 2e-4 relative + 2e-5 of the tensor's scale
+        bad = err > 2e-4 * np.abs(r) + 2e-5 * scale
+        assert not bad.any(), (k, int(bad.sum()), float(err.max()), float(scale), np.argwhere(bad)[:4].tolist())
+
+
+@pytest.mark.parametrize('flags', [1, 0, 3, 2])
+@pytest.mark.parametrize('B,G,hL', [(8, 40, 64), (33, 1000, 64), (5, 6, 16), (150, 203, 50), (260, 333, 64)])
+def test_heads_fused_vs_oracle(ops, flags, B, G, hL):
+    out = run_case(ops, flags, B, G, hL, seed=B + G, ridge=0.05 if flags & 1 else 0.0)
+    check(out)
+
+
+def test_heads_fused_no_perm_and_determinism(ops):
+    a = run_case(ops, 1, 200, 500, 64, seed=3, use_perm=False)
+    check(a)
+    b = run_case(ops, 1, 200, 500, 64, seed=3, use_perm=False)
+    for k in a:
+        assert np.array_equal(np.asarray(a[k][0]), np.asarray(b[k][0])), k
+
+
+def test_heads_fused_matches_separate_kernels(ops):
+    """Same operands through the separate entry points (sgemm + zinb_nll + sgemm x2)."""
+    B, G, hL = 192, 777, 64
+    out = run_case(ops, 1, B, G, hL, seed=9)
+    check(out)
