@@ -281,9 +281,12 @@ Plan make_plan(int M, int N, int K, int split_k) {
     int S = split_k;
     if (S <= 0) {
         const long tiles = (long)p.mtiles * p.ntiles;
+        // ~4 workgroups per CU (256 CUs), never more: measured on the step's skinny shapes at
+        // B = 4096 (tools/bench_gemm.py): 4096x64x20000 best at 32 tiles x 32 splits = 1024
+        // workgroups (0.147 ms vs 0.239 at 384), 20000x64x4096 at 157 x 6 = 942 (0.160 vs 0.214)
         S = 1;
-        if (tiles < 256) {
-            S = (int)((384 + tiles - 1) / tiles);
+        if (tiles < 1024) {
+            S = (int)(1024 / tiles);
             if (S > nchunks / 2) S = nchunks / 2;
             if (S > 128) S = 128;
             if (S < 1) S = 1;

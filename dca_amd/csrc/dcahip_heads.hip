@@ -320,10 +320,9 @@ __global__ __launch_bounds__(64 * kWG * WR) void heads_fused_kernel(HeadsArgs p)
                 z_flush(last);
             }
             dacc += (double)lacc;
-            // next tile: size factors + H rows; this tile: A operands of the weight-gradient
+            // next tile: size factors; this tile: A operands of the weight-gradient
             // product (H rows, lanes along the hidden units) -- all in flight during the dH MFMAs
             const float sf_n = p.sf[srow_n];
-            load_hv(tn);
             float Hd[HLB][16];
 #pragma unroll
             for (int ib = 0; ib < HLB; ++ib)
@@ -364,6 +363,7 @@ __global__ __launch_bounds__(64 * kWG * WR) void heads_fused_kernel(HeadsArgs p)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) dst[rowmap(e, hi) * KT + jb * 32] = dHa[jb][e];
             }
+            load_hv(tn);                           // next tile's H rows: in flight during the dW MFMAs
             TSTAMP(5)
             // ---- Bk (2): dW[i, gene] += sum_rows H[row, i] D[row, gene]; the staged D column
             // of a lane IS its B operand (k slot = lane half), A = H rows of this tile

@@ -81,6 +81,52 @@ __device__ __forceinline__ void merge_entries(const float* entries, const float*
     n_out = n; mean_out = mean; m2_out = m2;
 }
 
+
+// Workgroup version of the merge for the apply kernel: the E entries of a column are split over
+// the 4 row lanes (ty), combined through LDS.  Two passes in fp64 -- N = sum n_e,
+// mean = sum n_e mean_e / N, M2 = sum (M2_e + n_e (mean_e - mean)^2) -- no division inside the
+// loops (the sequential Chan merge spent ~20 us per launch on fp64 divisions at 64 entries).
+__device__ __forceinline__ double entry_count(const float* counts, int e, int E, int Bfallback) {
+    if (counts) return (double)counts[e];
+    const int cr = chunk_rows(Bfallback, E);
+    const int r0 = e * cr;
+    int r1 = r0 + cr;
+    if (r1 > Bfallback) r1 = Bfallback;
+    return r1 > r0 ? (double)(r1 - r0) : 0.0;
+}
+
+__device__ __forceinline__ void merge_entries_wg(const float* entries, const float* counts, int E,
+                                                 int H, int c, int Bfallback, double* sm /*[2][256]*/,
+                                                 double& n_out, double& mean_out, double& m2_out) {
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    double n = 0.0, sw = 0.0;
+    if (c < H)
+        for (int e = ty; e < E; e += 4) {
+            const double ne = entry_count(counts, e, E, Bfallback);
+            n += ne;
+            sw += ne * (double)entries[((long)e * 2 + 0) * H + c];
+        }
+    __syncthreads();
+    sm[ty * 64 + tx] = n; sm[256 + ty * 64 + tx] = sw;
+    __syncthreads();
+    n = (sm[tx] + sm[64 + tx]) + (sm[128 + tx] + sm[192 + tx]);
+    sw = (sm[256 + tx] + sm[320 + tx]) + (sm[384 + tx] + sm[448 + tx]);
+    const double mean = n > 0.0 ? sw / n : 0.0;
+    double q = 0.0;
+    if (c < H)
+        for (int e = ty; e < E; e += 4) {
+            const double ne = entry_count(counts, e, E, Bfallback);
+            if (ne <= 0.0) continue;
+            const double d = (double)entries[((long)e * 2 + 0) * H + c] - mean;
+            q += (double)entries[((long)e * 2 + 1) * H + c] + ne * d * d;
+        }
+    __syncthreads();
+    sm[ty * 64 + tx] = q;
+    __syncthreads();
+    n_out = n; mean_out = mean;
+    m2_out = (sm[tx] + sm[64 + tx]) + (sm[128 + tx] + sm[192 + tx]);
+}
+
 __global__ __launch_bounds__(256) void moments_combine_kernel(const float* entries,
                                                               const float* counts, int E, int H,
                                                               float* out) {
@@ -104,24 +150,28 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(BnApplyArgs a) {
     extern __shared__ float dyn[];               // [2][H]: mean, inv_std
     float* s_mean = dyn;
     float* s_inv = dyn + a.H;
-    for (int c = threadIdx.x; c < a.H; c += 256) {
-        float mean, var;
+    __shared__ double smd[512];
+    for (int c0 = 0; c0 < a.H; c0 += 64) {
+        const int c = c0 + (threadIdx.x & 63);
+        float mean = 0.f, var = 1.f;
         if (a.entries) {
             double n, m, m2;
-            merge_entries(a.entries, a.counts, a.E, a.H, c, a.B, n, m, m2);
+            merge_entries_wg(a.entries, a.counts, a.E, a.H, c, a.B, smd, n, m, m2);
             mean = (float)m;
             var = (float)(m2 / n);                // biased variance
-            if (blockIdx.x == 0) {
+            if (blockIdx.x == 0 && threadIdx.x < 64 && c < a.H) {
                 // moving = moving - (moving - batch) * (1 - momentum)
                 a.mm[c] = a.mm[c] - (a.mm[c] - mean) * (1.f - a.momentum);
                 a.mv[c] = a.mv[c] - (a.mv[c] - var) * (1.f - a.momentum);
             }
-        } else {
+        } else if (c < a.H) {
             mean = a.mm[c]; var = a.mv[c];
         }
-        const float inv = 1.f / sqrtf(var + a.eps);
-        s_mean[c] = mean; s_inv[c] = inv;
-        if (blockIdx.x == 0 && a.inv_std) a.inv_std[c] = inv;
+        if (threadIdx.x < 64 && c < a.H) {
+            const float inv = 1.f / sqrtf(var + a.eps);
+            s_mean[c] = mean; s_inv[c] = inv;
+            if (blockIdx.x == 0 && a.inv_std) a.inv_std[c] = inv;
+        }
     }
     __syncthreads();
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -176,14 +226,21 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
     extern __shared__ float dyn[];               // [2][H]: S1/n, S2/n
     float* s1 = dyn;
     float* s2 = dyn + a.H;
-    for (int c = threadIdx.x; c < a.H; c += 256) {
+    __shared__ float smf[256];
+    for (int c0 = 0; c0 < a.H; c0 += 64) {
+        const int c = c0 + (threadIdx.x & 63);
         float v1 = 0.f, v2 = 0.f;
-        for (int e = 0; e < a.E; ++e) {
-            v1 += a.sums[((long)e * 2 + 0) * a.H + c];
-            v2 += a.sums[((long)e * 2 + 1) * a.H + c];
+        if (c < a.H)
+            for (int e = threadIdx.x >> 6; e < a.E; e += 4) {
+                v1 += a.sums[((long)e * 2 + 0) * a.H + c];
+                v2 += a.sums[((long)e * 2 + 1) * a.H + c];
+            }
+        v1 = wg_rowlane_sum(v1, smf);
+        v2 = wg_rowlane_sum(v2, smf);
+        if (threadIdx.x < 64 && c < a.H) {
+            if (blockIdx.x == 0 && a.dbeta) a.dbeta[c] = v1;
+            s1[c] = v1 / a.n_total; s2[c] = v2 / a.n_total;
         }
-        if (blockIdx.x == 0 && a.dbeta) a.dbeta[c] = v1;
-        s1[c] = v1 / a.n_total; s2[c] = v2 / a.n_total;
     }
     __syncthreads();
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;

@@ -319,18 +319,21 @@ class Engine:
         self.stat_local = [torch.zeros(2 * h, **f32) for h in lay.hidden]
         self.counts_local = torch.zeros(kMaxCounts, **f32)
         self.counts_world = torch.zeros(self.comm.world, **f32)
-        # split-K workspace: the maximum any GEMM of a step can ask for
+        # split-K workspace: the maximum any GEMM of a step can ask for, over every batch size up
+        # to B (the split plan is a function of the shape: a smaller last batch may split more)
+        cand = sorted({B} | {b for k in range(0, B // 64 + 2) for b in (64 * k, 64 * k + 1) if 1 <= b <= B})
         need = 0
-        K = lay.G_in
-        for i, h in enumerate(lay.hidden):
-            need = max(need, ops.sgemm_workspace_bytes(0, 0, B, h, K))
-            need = max(need, ops.sgemm_workspace_bytes(1, 0, K, h, B, True))
-            if i > 0:
-                need = max(need, ops.sgemm_workspace_bytes(0, 1, B, K, h))
-            K = h
-        need = max(need, ops.sgemm_workspace_bytes(0, 0, B, lay.NH, K))
-        need = max(need, ops.sgemm_workspace_bytes(1, 0, K, lay.NH, B, True))
-        need = max(need, ops.sgemm_workspace_bytes(0, 1, B, K, lay.NH))
+        for b in cand:
+            K = lay.G_in
+            for i, h in enumerate(lay.hidden):
+                need = max(need, ops.sgemm_workspace_bytes(0, 0, b, h, K))
+                need = max(need, ops.sgemm_workspace_bytes(1, 0, K, h, b, True))
+                if i > 0:
+                    need = max(need, ops.sgemm_workspace_bytes(0, 1, b, K, h))
+                K = h
+            need = max(need, ops.sgemm_workspace_bytes(0, 0, b, lay.NH, K))
+            need = max(need, ops.sgemm_workspace_bytes(1, 0, K, lay.NH, b, True))
+            need = max(need, ops.sgemm_workspace_bytes(0, 1, b, K, lay.NH))
         self.ws = torch.zeros(max(need // 4, 4), **f32)
         nb = ops.heads_fused_workspace_bytes(B, K, lay.G_out, lay.Gp, self.flags) if self.use_fused else 0
         self.ws_heads = torch.zeros(nb // 4, **f32) if nb > 0 else None
