@@ -201,12 +201,25 @@ def main():
             ent['frac'] = ent['achieved'] / ent['peak']
         kernels.append(ent)
     kernels.sort(key=lambda e: -e['mean_ms'])
+    pmc = {}
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as f:
+            pmc = json.load(f)
+    except (OSError, ValueError):
+        pass
     roof = None
     for e in kernels:
         if 'frac' in e:
             roof = {'kernel': e['kernel'], 'bound': e['bound'], 'achieved': e['achieved'], 'peak': e['peak'],
                     'unit': e['unit'], 'frac': e['frac'], 'traffic': None,
+                    'traffic_source': None,
                     'timing': 'HIP events around each launch, ' + ('isolated eager steps after the graph-replayed timed region' if use_graph else 'inside the timed region')}
+            m = pmc.get(e['kernel'])
+            if m and m['shape']['B'] == B and m['shape']['G'] == G and m['shape']['hL'] == hidden[-1]:
+                roof['traffic'] = m['traffic_bytes']
+                roof['traffic_source'] = ('rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same kernel and shape '
+                                          '(profiles/pmc_traffic.json, profiles/r01_pmc/): bytes per launch; '
+                                          'algorithmic HBM bytes %.0f' % m['algorithmic_hbm_bytes'])
             break
 
     if rank == 0:
