@@ -4,7 +4,8 @@ xGMI on ROCm; "gloo" for the CPU tests).
 The reference is single-process: data parallelism over cells is a capability
 this implementation adds.  Cells are independent given the parameters, so the path shards by
 rows with exactly three exchanges per optimizer step:
-  1. one flat fp32 all-reduce of the gradient bucket (+ the batch loss in its last slot),
+  1. the flat fp32 gradient buffer in two all-reduce buckets: [heads | loss] as soon as the heads'
+     backward is done (overlaps the hidden stack's backward), [hidden layers] at the end,
   2. per BatchNormalization layer, forward: an all-gather of one (mean, M2) pair per rank
      (merged with Chan's formula -> identical to single-GPU statistics of the global batch),
   3. per BatchNormalization layer, backward: an all-reduce of [sum dy, sum dy*xhat].
@@ -22,10 +23,20 @@ class TorchDistComm:
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        # a second communicator (its own RCCL stream) for the bulk gradient bucket: on the main
+        # one it would queue the small SyncBN exchanges of the backward pass behind 15 MB
+        self.bulk = dist.new_group(ranks=list(range(dist.get_world_size())) if group is None else None) \
+            if group is None else group
 
     def all_reduce_sum(self, t):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
+
+    def all_reduce_sum_async(self, t):
+        """Starts the all-reduce on the communication stream and returns a handle; wait() makes
+        the current stream wait for it.  Lets the head-gradient bucket (75 % of the bytes, ready
+        first) travel over xGMI while the hidden stack's backward still computes."""
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.bulk, async_op=True)
 
     def all_gather(self, t):
         flat = t.contiguous().view(-1)
@@ -43,9 +54,13 @@ def init_from_env(backend=None):
         return SingleProcess()
     local_rank = int(os.environ.get('LOCAL_RANK', os.environ.get('RANK', '0')))
     if backend is None:
-        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
-    if backend == 'nccl':
-        torch.cuda.set_device(local_rank)
+        # DCA_AMD_DIST_BACKEND=gloo: functional multi-rank runs on a box with fewer GPUs than ranks
+        backend = os.environ.get('DCA_AMD_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+    if torch.cuda.is_available():
+        ndev = torch.cuda.device_count()
+        if backend == 'nccl' and local_rank >= ndev:
+            raise RuntimeError('rank %d has no GPU (%d visible): RCCL needs one GPU per rank' % (local_rank, ndev))
+        torch.cuda.set_device(local_rank % ndev)
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     if not dist.is_initialized():

@@ -96,6 +96,9 @@ class SingleProcess:
     def all_gather(self, t):
         return t.unsqueeze(0)
 
+    def all_reduce_sum_async(self, t):
+        return None
+
 
 class ParamLayout:
     """Offsets of every tensor in the flat parameter / gradient / RMSprop buffers."""
@@ -183,6 +186,7 @@ class Engine:
         # library supports the shape; DCA_AMD_FUSED_HEADS=0 forces the separate kernels
         self.use_fused = os.environ.get('DCA_AMD_FUSED_HEADS', '1') != '0'
         self.ws_heads = None
+        self._pending = None        # in-flight all-reduce of the heads bucket (data parallel)
 
     def _t(self, name):
         return self.prof.section(name) if self.prof is not None else _NULL
@@ -434,11 +438,23 @@ class Engine:
         else:
             self._empty_step()
         if comm.world > 1:
-            comm.all_reduce_sum(g[:lay.P + 1])
+            # bucket 2: hidden layers; bucket 1 (heads + loss) has been travelling since the heads'
+            # backward finished (_launch_heads_bucket)
+            comm.all_reduce_sum(g[:lay.seg['Wh'][0]])
+            if self._pending is not None:
+                self._pending.wait()
+                self._pending = None
         with self._t('rmsprop_clip'):
             ops.rmsprop_clip(w, g, self.ms, lay.P, self.lr, RMS_RHO, RMS_EPS, self.clip)
         ops.step_end(g[lay.P:], float(Bg), self.hist, rows_per_slot or max(self.Bmax, 1), self.acc,
                      self.cursor, B)
+
+    def _launch_heads_bucket(self):
+        """Data parallel: all-reduce of g[Wh .. P] (head weights, biases, log-dispersion, batch
+        loss) starts now, asynchronously."""
+        if self.comm.world > 1:
+            lay = self.lay
+            self._pending = self.comm.all_reduce_sum_async(self.g[lay.seg['Wh'][0]:lay.P + 1])
 
     def _empty_step(self):
         lay = self.lay
@@ -449,6 +465,7 @@ class Engine:
                 self.ops.bn_relu_apply(self.Z[i], self.ldh[i], 0, h, entries, cnts, E,
                                        lay.view(self.w, 'beta%d' % i), self.mm[i], self.mv[i],
                                        BN_MOMENTUM, BN_EPS, True, self.H[i], self.ldh[i], None, 0, None)
+        self._launch_heads_bucket()
         for i in reversed(range(len(lay.hidden))):
             if lay.batchnorm:
                 s = torch.zeros(2 * lay.hidden[i], dtype=torch.float32, device=self.dev)
@@ -470,6 +487,7 @@ class Engine:
             ops.loss_finalize(self.partials, n, inv_n, g[lay.P:])
         else:
             self._heads_backward_unfused(B, KL, inv_n)
+        self._launch_heads_bucket()
         # ---- backward: hidden stack
         L = len(lay.hidden)
         for i in reversed(range(L)):
