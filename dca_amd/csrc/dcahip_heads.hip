@@ -41,6 +41,12 @@ constexpr int kZU = 4;        // staged rows per Z group (two groups per loop it
 constexpr int kQCap = 320;     // non-zero queue entries per wave (< 64 left over + 4 x 64 pushed)
 constexpr int kLdH = 65;       // row stride of the H tile parked in the staging buffer
 
+#ifdef DCA_EXP_NOMFMA
+#define MFMA(a, b, c) (c)
+#else
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0)
+#endif
+
 #ifdef DCA_HEADS_TIMING
 #define TSTAMP(i) { const long long now_ = __builtin_readcyclecounter(); tacc[i] += now_ - tlast; tlast = now_; }
 #else
@@ -74,7 +80,9 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <bool HAS_PI, bool CONST_DISP, int HLB, int WR>
+// FULLK: hL == 32 * HLB exactly (the default 64-wide decoder): no k / hidden-unit guards at all,
+// which also keeps a dozen loop-invariant clamped offsets and predicates out of the register file.
+template <bool HAS_PI, bool CONST_DISP, int HLB, int WR, bool FULLK>
 __global__ __launch_bounds__(64 * kWG * WR) void heads_fused_kernel(HeadsArgs p) {
     constexpr int NH = 1 + (CONST_DISP ? 0 : 1) + (HAS_PI ? 1 : 0);
     constexpr int PI_H = NH - 1;                 // plane of the pi head (when present)
@@ -167,7 +175,7 @@ __global__ __launch_bounds__(64 * kWG * WR) void heads_fused_kernel(HeadsArgs p)
 #pragma unroll
             for (int c = 0; c < KH / 4; ++c) {
                 const int k = hi * KH + 4 * c;
-                const int kc = k < hl4 ? k : hl4 - 4;
+                const int kc = (FULLK || k < hl4) ? k : hl4 - 4;
                 hv[c] = *reinterpret_cast<const float4*>(hp + kc);
             }
         };
@@ -196,10 +204,10 @@ __global__ __launch_bounds__(64 * kWG * WR) void heads_fused_kernel(HeadsArgs p)
             for (int c = 0; c < KH / 4; ++c) {
                 const int k = hi * KH + 4 * c;
                 float* d = St + l31 * kLdH + k;
-                d[0] = (rv && k + 0 < p.hL) ? hv[c].x : 0.f;
-                d[1] = (rv && k + 1 < p.hL) ? hv[c].y : 0.f;
-                d[2] = (rv && k + 2 < p.hL) ? hv[c].z : 0.f;
-                d[3] = (rv && k + 3 < p.hL) ? hv[c].w : 0.f;
+                d[0] = (rv && (FULLK || k + 0 < p.hL)) ? hv[c].x : 0.f;
+                d[1] = (rv && (FULLK || k + 1 < p.hL)) ? hv[c].y : 0.f;
+                d[2] = (rv && (FULLK || k + 2 < p.hL)) ? hv[c].z : 0.f;
+                d[3] = (rv && (FULLK || k + 3 < p.hL)) ? hv[c].w : 0.f;
             }
             wave_sync();
             TSTAMP(1)
@@ -216,7 +224,7 @@ __global__ __launch_bounds__(64 * kWG * WR) void heads_fused_kernel(HeadsArgs p)
 #pragma unroll
                 for (int h = 0; h < NH; ++h) {
                     const float b = Wsg[(h * KT + hi * KH + kk) * kLdS + l31];
-                    acc[h] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[h], 0, 0, 0);
+                    acc[h] = MFMA(a, b, acc[h]);
                 }
             }
             wave_sync();
@@ -242,32 +250,65 @@ __global__ __launch_bounds__(64 * kWG * WR) void heads_fused_kernel(HeadsArgs p)
             float lacc = 0.f;
             int qn = 0;
             auto z_dense = [&](int grp, const float (&yv)[kZU]) {
+                // (1) all staged inputs of the group first: the kZU element chains below are then
+                // independent (no LDS store between their loads) and interleave
+                float i_sf[kZU], i_am[kZU], i_ad[kZU], i_ap[kZU];
 #pragma unroll
                 for (int j = 0; j < kZU; ++j) {
                     const int row = rowmap(grp * kZU + j, hi);
-                    const float sfr = __shfl(sf_l, row, 64);
-                    const bool valid = (row0 + row < p.B) && gvalid;
                     const int idx = l31 * kLdS + row;
-                    const float am = St[idx];
-                    const float ad = CONST_DISP ? thw : St[ST_PLANE + idx];
-                    const float ap = HAS_PI ? St[PI_H * ST_PLANE + idx] : 0.f;
+                    i_sf[j] = __shfl(sf_l, row, 64);
+                    i_am[j] = St[idx];
+                    i_ad[j] = CONST_DISP ? thw : St[ST_PLANE + idx];
+                    i_ap[j] = HAS_PI ? St[PI_H * ST_PLANE + idx] : 0.f;
+                }
+                // (2) arithmetic
+                float o_m[kZU], o_d[kZU], o_p[kZU];
+                bool o_nz[kZU];
+#pragma unroll
+                for (int j = 0; j < kZU; ++j) {
+                    const int row = rowmap(grp * kZU + j, hi);
+                    const bool valid = (row0 + row < p.B) && gvalid;
                     const float yj = yv[j];
+#if defined(DCA_EXP_NOZ)
+                    const bool nz = false;
+                    lacc += valid ? yj : 0.f;
+                    o_m[j] = i_am[j] * i_sf[j]; o_d[j] = i_ad[j]; o_p[j] = i_ap[j];
+                    o_nz[j] = nz;
+#else
+#if defined(DCA_EXP_NOSPARSE)
+                    const bool nz = false;
+#else
                     const bool nz = valid && (HAS_PI ? !(yj < kZeroThresh) : (yj != 0.f));
+#endif
                     float dmu = 0.f, dth = 0.f, dpi = 0.f;
-                    const Heads hd = head_acts<HAS_PI, CONST_DISP>(am, ad, ap, sfr);
+                    const Heads hd = head_acts<HAS_PI, CONST_DISP>(i_am[j], i_ad[j], i_ap[j], i_sf[j]);
                     const float nll = nll_elem<HAS_PI, true>(hd, 0.f, p.ridge, dmu, dth, dpi);
                     lacc += (valid && !nz) ? nll : 0.f;
-                    const float om = valid ? dmu * hd.gm * p.inv_n : 0.f;
-                    const float od = valid ? dth * hd.gd * p.inv_n : 0.f;
-                    const float op = (HAS_PI && valid) ? dpi * hd.pi * hd.omp * p.inv_n : 0.f;
+                    o_m[j] = valid ? dmu * hd.gm * p.inv_n : 0.f;
+                    o_d[j] = valid ? dth * hd.gd * p.inv_n : 0.f;
+                    o_p[j] = (HAS_PI && valid) ? dpi * hd.pi * hd.omp * p.inv_n : 0.f;
+                    o_nz[j] = nz;
+#endif
+                }
+                // (3) results / queue
+#pragma unroll
+                for (int j = 0; j < kZU; ++j) {
+                    const int row = rowmap(grp * kZU + j, hi);
+                    const int idx = l31 * kLdS + row;
+                    const bool nz = o_nz[j];
                     const unsigned long long m = __ballot(nz);
                     const int slot = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
                     if (nz) {
-                        Q[slot] = (unsigned)idx | ((unsigned)row << 11) | ((unsigned)l31 << 16);
+                        // entry = staging index | count as uint16 (0xFFFF: not representable --
+                        // re-read from memory by the sparse pass)
+                        const float yj = yv[j];
+                        const unsigned y16 = (yj < 65535.f && yj == floorf(yj)) ? (unsigned)yj : 0xFFFFu;
+                        Q[slot] = (unsigned)idx | (y16 << 16);
                     } else {                 // pre-activations of queued elements stay in place
-                        St[idx] = om;
-                        if (CONST_DISP) St[TH_P * ST_PLANE + idx] = od; else St[ST_PLANE + idx] = od;
-                        if (HAS_PI) St[PI_H * ST_PLANE + idx] = op;
+                        St[idx] = o_m[j];
+                        if (CONST_DISP) St[TH_P * ST_PLANE + idx] = o_d[j]; else St[ST_PLANE + idx] = o_d[j];
+                        if (HAS_PI) St[PI_H * ST_PLANE + idx] = o_p[j];
                     }
                     qn += __popcll(m);
                 }
@@ -275,13 +316,16 @@ __global__ __launch_bounds__(64 * kWG * WR) void heads_fused_kernel(HeadsArgs p)
             auto z_sparse = [&](int q0, int cnt) {
                 const bool act = lane < cnt;
                 const unsigned e = Q[q0 + (act ? lane : 0)];
-                const int idx = e & 2047, row = (e >> 11) & 31, gq = (e >> 16) & 31;
+                const int idx = e & 2047;
+                const int gq = (idx * 1986) >> 16;          // idx / 33 for idx < 1056
+                const int row = idx - gq * kLdS;
                 const float sfr = __shfl(sf_l, row, 64);
                 const int sr = __shfl(srow_l, row, 64);
                 const float am = St[idx];
                 const float ad = CONST_DISP ? __shfl(thw, gq, 64) : St[ST_PLANE + idx];
                 const float ap = HAS_PI ? St[PI_H * ST_PLANE + idx] : 0.f;
-                const float yq = p.y[(long)sr * p.ldy + g0 + gq];
+                float yq = (float)(e >> 16);
+                if ((e >> 16) == 0xFFFFu) yq = p.y[(long)sr * p.ldy + g0 + gq];
                 float dmu = 0.f, dth = 0.f, dpi = 0.f;
                 const Heads hd = head_acts<HAS_PI, CONST_DISP>(am, ad, ap, sfr);
                 const float nll = nll_elem<HAS_PI, true, true>(hd, yq, p.ridge, dmu, dth, dpi);
@@ -331,7 +375,7 @@ __global__ __launch_bounds__(64 * kWG * WR) void heads_fused_kernel(HeadsArgs p)
                     const int row = row0 + rowmap(e, hi);
                     const int i = ib * 32 + l31;
                     const int rc = row < p.B ? row : p.B - 1;
-                    const int ic = i < hl4 ? i : hl4 - 1;
+                    const int ic = (FULLK || i < hl4) ? i : hl4 - 1;
                     Hd[ib][e] = p.H[(long)rc * p.ldh + ic];
                 }
             wave_sync();
@@ -354,7 +398,7 @@ __global__ __launch_bounds__(64 * kWG * WR) void heads_fused_kernel(HeadsArgs p)
 #pragma unroll
                         for (int jb = 0; jb < HLB; ++jb) {
                             const float b = Wsg[(h * KT + jb * 32 + l31) * kLdS + gl];
-                            dHa[jb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, dHa[jb], 0, 0, 0);
+                            dHa[jb] = MFMA(a, b, dHa[jb]);
                         }
                     }
                 float* dst = p.ws_dh + ((long)gt * p.NT * kTR + row0) * KT + l31;   // rows padded to tiles
@@ -375,8 +419,8 @@ __global__ __launch_bounds__(64 * kWG * WR) void heads_fused_kernel(HeadsArgs p)
                     bsum[h] += b;                    // bias gradient = column sum of D
 #pragma unroll
                     for (int ib = 0; ib < HLB; ++ib) {
-                        const bool ok = (row0 + rowmap(e, hi) < p.B) && (ib * 32 + l31 < p.hL);
-                        dW[h][ib] = __builtin_amdgcn_mfma_f32_32x32x2f32(ok ? Hd[ib][e] : 0.f, b, dW[h][ib], 0, 0, 0);
+                        const bool ok = (row0 + rowmap(e, hi) < p.B) && (FULLK || ib * 32 + l31 < p.hL);
+                        dW[h][ib] = MFMA(ok ? Hd[ib][e] : 0.f, b, dW[h][ib]);
                     }
                 }
             if (CONST_DISP) {
@@ -450,7 +494,7 @@ __global__ __launch_bounds__(64 * kWG * WR) void heads_fused_kernel(HeadsArgs p)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int i = ib * 32 + rowmap(e, hi);
-                    if (cw && i < p.hL) out[(long)i * p.ldws + (long)h * p.plane + gene] = dW[h][ib][e];
+                    if (cw && (FULLK || i < p.hL)) out[(long)i * p.ldws + (long)h * p.plane + gene] = dW[h][ib][e];
                 }
             const float bv = bsum[h] + __shfl_xor(bsum[h], 32, 64);
             if (cw && hi == 0) out[(long)p.hL * p.ldws + (long)h * p.plane + gene] = bv;
@@ -566,8 +610,11 @@ long long* g_timing = nullptr;
 
 template <bool P, bool C>
 void launch_fused(const HeadsPlan& pl, const HeadsArgs& a, hipStream_t s) {
-    if (pl.WR == 4) hipLaunchKernelGGL((heads_fused_kernel<P, C, 2, 4>), dim3(pl.grid), dim3(64 * kWG * 4), 0, s, a);
-    else            hipLaunchKernelGGL((heads_fused_kernel<P, C, 2, 1>), dim3(pl.grid), dim3(64 * kWG * 1), 0, s, a);
+    const bool full = a.hL == 32 * pl.HLB;
+#define DCA_LF(WRV, FK) hipLaunchKernelGGL((heads_fused_kernel<P, C, 2, WRV, FK>), dim3(pl.grid), dim3(64 * kWG * WRV), 0, s, a)
+    if (pl.WR == 4) { if (full) DCA_LF(4, true); else DCA_LF(4, false); }
+    else            { if (full) DCA_LF(1, true); else DCA_LF(1, false); }
+#undef DCA_LF
 }
 
 }  // namespace

@@ -45,7 +45,7 @@ def reference(Hm, W, b, tw, y, sf, flags, ridge, n_total):
     return heads, ls / n_total, gW, gb, dH, (dd if cdisp else None)
 
 
-def run_case(ops, flags, B, G, hL, seed, ridge=0.0, use_perm=True):
+def run_case(ops, flags, B, G, hL, seed, ridge=0.0, use_perm=True, odd_counts=False):
     has_pi, cdisp = bool(flags & 1), bool(flags & 2)
     rng = np.random.RandomState(seed)
     f = lambda a: a.astype(np.float32).astype(np.float64)
@@ -56,6 +56,9 @@ def run_case(ops, flags, B, G, hL, seed, ridge=0.0, use_perm=True):
     b = {h: f(rng.normal(0, 0.3, G)) for h in heads}
     tw = f(rng.normal(0, 1.5, G))
     y = f(synth_counts(B, G, seed))
+    if odd_counts:        # non-integer 'counts' (check_counts=False), large and > 65535 counts
+        y[0, :6] = [2.52, 0.5, 17.0, 70000.0, 200.0, 5000.0]
+        y[1, 1:4] = [16.0, 16.5, 65535.0]
     sf = f(rng.lognormal(0, 0.3, B))
     n_total = float(B * G)
     _, lm, gW, gb, dH, dth = reference(Hm, W, b, tw, y, sf, flags, ridge, n_total)
@@ -133,6 +136,14 @@ def check(out, edge=False):
 def test_heads_fused_vs_oracle(ops, flags, B, G, hL):
     out = run_case(ops, flags, B, G, hL, seed=B + G, ridge=0.05 if flags & 1 else 0.0)
     check(out)
+
+
+@pytest.mark.parametrize('flags', [1, 0, 3, 2])
+def test_heads_fused_odd_counts(ops, flags):
+    """Non-integer counts (libm lgamma route), counts above 16 (Stirling route), counts that do
+    not fit the 16-bit queue slot (re-read from memory)."""
+    out = run_case(ops, flags, 40, 70, 64, seed=5, odd_counts=True)
+    check(out, edge=True)
 
 
 def test_heads_fused_no_perm_and_determinism(ops):
