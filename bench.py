@@ -119,7 +119,15 @@ def main():
 
     # ---- synthetic data, generated and normalised in HBM (not timed)
     Y = synth.generate_counts(n_local, G, device=dev, row_offset=rank)
-    X, sf = synth.normalize_on_device(Y, G, comm if W > 1 else None)
+    # K-PREP (dca_amd/prep.py): size factors, log1p, per-gene z-score on the resident counts;
+    # with N ranks the median library size and the gene statistics are global
+    from dca_amd import prep
+    from dca_amd.ops import HipOps
+    pops = HipOps()
+    counts = prep.cell_counts(pops, Y, n_local, G)
+    med = (comm.all_gather(counts).flatten() if W > 1 else counts).median()
+    sf = counts / med
+    X = prep.transform(pops, Y, n_local, G, sf, True, True, comm if W > 1 else None)
     eng = Engine('zinb-conddisp', G, G, hidden, True, 0.0, comm=comm)
     eng.init_params(0)
     eng.attach_device_data(X, Y, sf)

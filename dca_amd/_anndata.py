@@ -119,8 +119,13 @@ class MiniAnnData:
         raw = None
         if self._raw is not None:
             raw = _Raw(self._raw.X[idx], self._raw.var)
-        return MiniAnnData(X, self.obs.iloc[idx], self.var.iloc[cidx],
-                           {k: np.asarray(v)[idx] for k, v in self.obsm.items()}, dict(self.uns), raw)
+        out = MiniAnnData(X, self.obs.iloc[idx], self.var.iloc[cidx],
+                          {k: np.asarray(v)[idx] for k, v in self.obsm.items()}, dict(self.uns), raw)
+        dd = getattr(self, '_dca_device', None)
+        if dd is not None and len(idx) == self.n_obs and len(cidx) == self.n_vars and \
+                (idx == np.arange(self.n_obs)).all() and (cidx == np.arange(self.n_vars)).all():
+            out._dca_device = dd          # identity selection: the device-resident tensors still match
+        return out
 
     def __repr__(self):
         return 'MiniAnnData object with n_obs x n_vars = %d x %d' % self.shape

@@ -53,16 +53,14 @@ _SIGNATURES = {
                                    _c.c_long, _vp]),
     'dcahip_relu_fwd': (_c.c_int, [_f32p, _c.c_long, _c.c_int, _c.c_int, _f32p, _c.c_long, _vp]),
     'dcahip_colsum_chain': (_c.c_int, [_f32p, _c.c_long, _c.c_int, _c.c_int, _f32p, _f32p, _vp]),
+    'dcahip_prep_chunks': (_c.c_int, [_c.c_int]),
+    'dcahip_prep_row_sums': (_c.c_int, [_f32p, _c.c_long, _c.c_int, _c.c_int, _f32p, _vp]),
+    'dcahip_prep_col_pass': (_c.c_int, [_f32p, _c.c_long, _c.c_int, _c.c_int, _f32p, _c.c_int, _f32p,
+                                        _c.c_long, _f64p, _vp]),
+    'dcahip_prep_col_finish': (_c.c_int, [_f64p, _c.c_int, _c.c_int, _c.c_double, _f32p, _f32p, _f32p, _vp]),
+    'dcahip_prep_scale': (_c.c_int, [_f32p, _c.c_long, _c.c_int, _c.c_int, _f32p, _f32p, _vp]),
     'dcahip_rmsprop_clip': (_c.c_int, [_f32p, _f32p, _f32p, _c.c_long, _f32p, _c.c_float,
                                        _c.c_float, _c.c_float, _vp]),
-}
-
-# entry points added by later source files; bound when present in the library
-_OPTIONAL = {
-    'dcahip_prep_row_sums': (_c.c_int, [_f32p, _c.c_long, _c.c_int, _c.c_int, _f32p, _vp]),
-    'dcahip_prep_normalize_log1p': (_c.c_int, [_f32p, _c.c_long, _c.c_int, _c.c_int, _f32p, _c.c_int,
-                                               _c.c_int, _f32p, _c.c_long, _vp]),
-    'dcahip_prep_scale': (_c.c_int, [_f32p, _c.c_long, _c.c_int, _c.c_int, _f32p, _vp]),
 }
 
 _lib = None
@@ -93,10 +91,6 @@ def lib():
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(L, name)          # AttributeError => header / library mismatch: loud
         fn.restype, fn.argtypes = res, args
-    for name, (res, args) in _OPTIONAL.items():
-        if hasattr(L, name):
-            fn = getattr(L, name)
-            fn.restype, fn.argtypes = res, args
     assert L.dcahip_version() == 1
     _lib = L
     return L

@@ -161,9 +161,29 @@ def read_dataset(adata, transpose=False, test_split=False, copy=False, check_cou
     return adata
 
 
+def _device_prep_available():
+    if os.environ.get('DCA_AMD_DEVICE_PREP', '1') == '0':
+        return False
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except ImportError:
+        return False
+
+
 def normalize(adata, filter_min_counts=True, size_factors=True, normalize_input=True,
-              logtrans_input=True):
-    """dca/io.py:88-111."""
+              logtrans_input=True, device='auto'):
+    """dca/io.py:88-111.  With a GPU present the arithmetic runs on the device (K-PREP,
+    dca_amd/prep.py): one upload of the raw counts, the training tensors stay in HBM and are
+    handed to ``train`` through ``adata._dca_device``; the AnnData receives exactly what this
+    host restatement would leave behind.  ``device=False`` (or DCA_AMD_DEVICE_PREP=0) forces the
+    host path, which is the reference's own (scanpy on the CPU)."""
+    if device is True or (device == 'auto' and _device_prep_available()):
+        from . import prep
+        adata, dd = prep.normalize_device(adata, filter_min_counts, size_factors, normalize_input,
+                                          logtrans_input)
+        adata._dca_device = dd
+        return adata
     if filter_min_counts:
         filter_genes(adata, min_counts=1)
         filter_cells(adata, min_counts=1)

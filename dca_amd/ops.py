@@ -117,6 +117,28 @@ class HipOps:
         hip.check(self.L.dcahip_colsum_chain(p(x), ldx, B, N, p(theta_w), p(out), hip.stream()),
                   'colsum_chain')
 
+    # ------------------------------------------------------------------ preprocessing
+    def prep_chunks(self, n):
+        return self.L.dcahip_prep_chunks(n)
+
+    def prep_row_sums(self, Y, ldy, n, G, out):
+        hip.check(self.L.dcahip_prep_row_sums(hip.ptr(Y), ldy, n, G, hip.ptr(out), hip.stream()),
+                  'prep_row_sums')
+
+    def prep_col_pass(self, Y, ldy, n, G, fac, do_log, X, ldx, col_part):
+        p = hip.ptr
+        hip.check(self.L.dcahip_prep_col_pass(p(Y), ldy, n, G, p(fac), int(do_log), p(X), ldx,
+                                              p(col_part), hip.stream()), 'prep_col_pass')
+
+    def prep_col_finish(self, col_part, R, G, n_total, sums, mean, stdv):
+        p = hip.ptr
+        hip.check(self.L.dcahip_prep_col_finish(p(col_part), R, G, float(n_total), p(sums), p(mean),
+                                                p(stdv), hip.stream()), 'prep_col_finish')
+
+    def prep_scale(self, X, ldx, n, G, mean, stdv):
+        p = hip.ptr
+        hip.check(self.L.dcahip_prep_scale(p(X), ldx, n, G, p(mean), p(stdv), hip.stream()), 'prep_scale')
+
     # ------------------------------------------------------------------ optimizer
     def rmsprop_clip(self, w, g, ms, n, lr, rho, eps, clip):
         p = hip.ptr

@@ -1,0 +1,147 @@
+"""K-PREP driver: dca/io.py:88-111 (``normalize``) on the GPU.
+
+The reference preprocesses on the host with scanpy (filter_genes / filter_cells /
+normalize_per_cell / log1p / scale), then Keras copies batches of the result to the device.
+Here the raw counts are uploaded ONCE; gene / cell counts, size factors, log1p and the per-gene
+z-score are streaming passes over the resident matrix (dcahip_prep_*), and the tensors the
+training engine needs (X, Y, size factors) never leave HBM.  The host AnnData still receives
+what the reference's ``normalize`` leaves behind -- ``adata.X`` (normalised), ``adata.raw``
+(counts), ``obs['n_counts', 'size_factors']``, ``var['n_counts']`` -- so the function is a
+drop-in for ``dca_amd.io.normalize``.
+
+Index outputs (which genes / cells survive the filters) are bit-exact with the host path: the
+sums are exact integer arithmetic.  The median of the library sizes is taken on the host
+(``np.median`` over n values), exactly as the reference does.
+"""
+import numpy as np
+import torch
+
+
+class DeviceData:
+    """Preprocessed tensors resident on the device: X [n, ldx] (network input), Y [n, ldy]
+    (raw counts, the loss target), sf [n]."""
+
+    def __init__(self, X, Y, sf, n, G):
+        self.X, self.Y, self.sf, self.n, self.G = X, Y, sf, n, G
+
+
+def _r4(x):
+    return (x + 3) // 4 * 4
+
+
+def _upload(X, dev, chunk_rows=8192):
+    n, G = X.shape
+    out = torch.zeros(n, _r4(G), dtype=torch.float32, device=dev)
+    for s in range(0, n, chunk_rows):
+        e = min(n, s + chunk_rows)
+        xs = X[s:e]
+        xs = xs.toarray() if hasattr(xs, 'toarray') else np.asarray(xs)
+        out[s:e, :G] = torch.as_tensor(np.ascontiguousarray(xs, dtype=np.float32)).to(dev)
+    return out
+
+
+def gene_counts(ops, Y, n, G):
+    dev = Y.device
+    R = ops.prep_chunks(n)
+    part = torch.zeros(R * 2 * _r4(G), dtype=torch.float64, device=dev)
+    sums = torch.zeros(G, dtype=torch.float32, device=dev)
+    ops.prep_col_pass(Y, Y.shape[1], n, G, None, False, None, 0, part)
+    ops.prep_col_finish(part, R, G, float(n), sums, None, None)
+    return sums
+
+
+def cell_counts(ops, Y, n, G):
+    out = torch.zeros(n, dtype=torch.float32, device=Y.device)
+    ops.prep_row_sums(Y, Y.shape[1], n, G, out)
+    return out
+
+
+def transform(ops, Y, n, G, fac, logtrans_input, normalize_input, comm=None):
+    """X = scale(log1p(Y / fac)) on the device (each step optional).  With a communicator the
+    per-gene statistics are those of all ranks' shards (data-parallel preprocessing)."""
+    dev = Y.device
+    ld = Y.shape[1]
+    X = torch.zeros(n, ld, dtype=torch.float32, device=dev)
+    R = ops.prep_chunks(n)
+    Gp = _r4(G)
+    part = torch.zeros(R * 2 * Gp, dtype=torch.float64, device=dev)
+    ops.prep_col_pass(Y, ld, n, G, fac, logtrans_input, X, ld, part)
+    if normalize_input:
+        mean = torch.zeros(Gp, dtype=torch.float32, device=dev)
+        std = torch.ones(Gp, dtype=torch.float32, device=dev)
+        n_total = float(n)
+        if comm is not None and comm.world > 1:
+            tot = part.view(R, 2 * Gp).sum(dim=0)
+            cnt = torch.tensor([n_total], dtype=torch.float64, device=dev)
+            comm.all_reduce_sum(tot); comm.all_reduce_sum(cnt)
+            n_total = float(cnt.item())
+            ops.prep_col_finish(tot, 1, G, n_total, None, mean, std)
+        else:
+            ops.prep_col_finish(part, R, G, n_total, None, mean, std)
+        ops.prep_scale(X, ld, n, G, mean, std)
+    return X
+
+
+def normalize_device(adata, filter_min_counts=True, size_factors=True, normalize_input=True,
+                     logtrans_input=True, ops=None, device=None, to_host=True):
+    """``io.normalize`` with the arithmetic on the device.  Returns (adata, DeviceData)."""
+    from . import io as _io
+    if ops is None:
+        from .ops import HipOps
+        ops = HipOps()
+    dev = torch.device(device) if device is not None else (
+        torch.device('cuda', torch.cuda.current_device()) if ops.device_type == 'cuda' else torch.device('cpu'))
+    n, G = adata.X.shape
+    Y = _upload(adata.X, dev)
+
+    if filter_min_counts:                                         # io.py:90-92
+        gc = gene_counts(ops, Y, n, G).cpu().numpy()
+        adata.var['n_counts'] = gc
+        keep = gc >= 1
+        if not keep.all():
+            _io._subset(adata, cols=keep)
+            idx = torch.as_tensor(np.nonzero(keep)[0], device=dev)
+            G = int(keep.sum())
+            Yn = torch.zeros(n, _r4(G), dtype=torch.float32, device=dev)
+            Yn[:, :G] = Y.index_select(1, idx)
+            Y = Yn
+        cc = cell_counts(ops, Y, n, G).cpu().numpy()
+        adata.obs['n_counts'] = cc
+        keep = cc >= 1
+        if not keep.all():
+            _io._subset(adata, rows=keep)
+            Y = Y.index_select(0, torch.as_tensor(np.nonzero(keep)[0], device=dev)).contiguous()
+            n = int(keep.sum())
+
+    if size_factors or normalize_input or logtrans_input:         # io.py:94-97
+        adata.raw = adata.copy()
+    else:
+        adata.raw = adata
+
+    fac_d = None
+    if size_factors:                                              # io.py:99-101 (normalize_per_cell)
+        counts = cell_counts(ops, Y, n, G).cpu().numpy()
+        adata.obs['n_counts'] = counts
+        keep = counts >= 1
+        if not keep.all():
+            _io._subset(adata, rows=keep)
+            Y = Y.index_select(0, torch.as_tensor(np.nonzero(keep)[0], device=dev)).contiguous()
+            counts = counts[keep]
+            n = int(keep.sum())
+        after = np.median(counts)
+        c2 = counts + (counts == 0)
+        fac = (c2 / after).astype(np.float32)
+        adata.obs['size_factors'] = adata.obs.n_counts / np.median(adata.obs.n_counts)
+        fac_d = torch.as_tensor(fac).to(dev)
+        sf_d = torch.as_tensor(np.asarray(adata.obs['size_factors'].values, dtype=np.float32)).to(dev)
+    else:
+        adata.obs['size_factors'] = 1.0
+        sf_d = torch.ones(n, dtype=torch.float32, device=dev)
+
+    if fac_d is not None or logtrans_input or normalize_input:
+        X = transform(ops, Y, n, G, fac_d, logtrans_input, normalize_input)
+    else:
+        X = Y
+    if to_host:
+        adata.X = X[:, :G].cpu().numpy()
+    return adata, DeviceData(X, Y, sf_d, n, G)

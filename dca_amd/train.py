@@ -204,7 +204,12 @@ def train(adata, network, output_dir=None, optimizer='RMSprop', learning_rate=No
     t0, nt = ddist.shard(n_train, comm.world, comm.rank)
     v0, nv = ddist.shard(n_val, comm.world, comm.rank)
     rows = np.r_[np.arange(t0, t0 + nt), split_at + np.arange(v0, v0 + nv)]
-    if comm.world == 1:
+    dd = getattr(adata, '_dca_device', None)
+    if comm.world == 1 and dd is not None and not output_subset and use_raw_as_output and \
+            dd.n == n and dd.G == X.shape[1] == eng.lay.G_in == eng.lay.G_out and \
+            dd.X.device == eng.dev:
+        eng.attach_device_data(dd.X, dd.Y, dd.sf)      # K-PREP left the tensors in HBM
+    elif comm.world == 1:
         eng.load_data(X, Y, sf)
     else:
         eng.load_data(X[rows], Y[rows], sf[rows])

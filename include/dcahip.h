@@ -198,6 +198,29 @@ int dcahip_colsum_chain(const float* x, long ldx, int B, int N, const float* the
                         float* out, void* stream);
 
 /*
+ * K-PREP: dca/io.py:88-111 (normalize: scanpy filter counts, normalize_per_cell, log1p, scale)
+ * on the resident count matrix Y [n, ldy].
+ *   dcahip_prep_row_sums   out[r] = sum_g Y[r, g]                 (n_counts; exact for counts)
+ *   dcahip_prep_col_pass   x = Y[r, g]; if fac: x /= fac[r]; if do_log: x = log1p(x);
+ *                          X[r, g] = x (X may be NULL, may alias Y); per-gene sums of x and of
+ *                          fl32(x*x) in fp64 per row chunk -> col_part[R][2][roundup4(G)],
+ *                          R = dcahip_prep_chunks(n)
+ *   dcahip_prep_col_finish ordered sum of the R chunks (x E ranks' all-reduced partials:
+ *                          pass the summed [1][2][Gp] block with R = 1): sums[g] (gene counts
+ *                          of filter_genes, may be NULL) and/or mean[g], std[g] exactly as
+ *                          sc.pp.scale: var = (E[x^2] - E[x]^2) n/(n-1), std 0 -> 1
+ *   dcahip_prep_scale      X = (X - mean) / std in place (fp32 division)
+ */
+int dcahip_prep_chunks(int n);
+int dcahip_prep_row_sums(const float* Y, long ldy, int n, int G, float* out, void* stream);
+int dcahip_prep_col_pass(const float* Y, long ldy, int n, int G, const float* fac, int do_log,
+                         float* X, long ldx, double* col_part, void* stream);
+int dcahip_prep_col_finish(const double* col_part, int R, int G, double n_total,
+                           float* sums, float* mean, float* stdv, void* stream);
+int dcahip_prep_scale(float* X, long ldx, int n, int G, const float* mean, const float* stdv,
+                      void* stream);
+
+/*
  * Keras clipvalue + tf.keras RMSprop on one flat parameter buffer:
  *   g = clip(g, -clip, clip); ms = rho*ms + (1-rho)*g*g; w -= lr * g / sqrt(ms + eps)
  * Replaces opt.RMSprop(lr, clipvalue) (dca/train.py:54-57).  *lr is read from device memory

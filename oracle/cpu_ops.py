@@ -254,6 +254,46 @@ class CpuRefOps:
             s = s * np.where((e >= 1e-3) & (e <= 1e4), e, 0.0)
         _vec(out, N)[:] = s
 
+    # ------------------------------------------------------------------ preprocessing
+    def prep_chunks(self, n):
+        return max(1, min(512, (n + 127) // 128))
+
+    def prep_row_sums(self, Y, ldy, n, G, out):
+        _vec(out, n)[:] = _mat(Y, n, G, ldy).astype(np.float64).sum(axis=1)
+
+    def prep_col_pass(self, Y, ldy, n, G, fac, do_log, X, ldx, col_part):
+        x = _mat(Y, n, G, ldy).astype(np.float32)
+        if fac is not None:
+            x = (x / _vec(fac, n).astype(np.float32)[:, None]).astype(np.float32)
+        if do_log:
+            x = np.log1p(x).astype(np.float32)
+        if X is not None:
+            _mat(X, n, G, ldx)[:] = x
+        R = self.prep_chunks(n)
+        Gp = (G + 3) // 4 * 4
+        cr = -(-n // R)
+        part = torch.as_strided(col_part, (R, 2, Gp), (2 * Gp, Gp, 1)).numpy()
+        for r in range(R):
+            blk = x[r * cr:min(n, (r + 1) * cr)]
+            part[r, 0, :G] = blk.sum(axis=0, dtype=np.float64)
+            part[r, 1, :G] = np.multiply(blk, blk).sum(axis=0, dtype=np.float64)
+
+    def prep_col_finish(self, col_part, R, G, n_total, sums, mean, stdv):
+        Gp = (G + 3) // 4 * 4
+        part = torch.as_strided(col_part, (R, 2, Gp), (2 * Gp, Gp, 1)).numpy()
+        s1 = part[:, 0, :G].sum(axis=0); s2 = part[:, 1, :G].sum(axis=0)
+        if sums is not None:
+            _vec(sums, G)[:] = s1
+        if mean is not None:
+            m = s1 / n_total
+            var = (s2 / n_total - m * m) * (n_total / (n_total - 1.0)) if n_total > 1 else np.zeros_like(m)
+            sd = np.sqrt(np.maximum(var, 0)); sd[sd == 0] = 1
+            _vec(mean, G)[:] = m; _vec(stdv, G)[:] = sd
+
+    def prep_scale(self, X, ldx, n, G, mean, stdv):
+        x = _mat(X, n, G, ldx)
+        x[:] = (x - _vec(mean, G).astype(np.float32)) / _vec(stdv, G).astype(np.float32)
+
     # ------------------------------------------------------------------ optimizer
     def rmsprop_clip(self, w, g, ms, n, lr, rho, eps, clip):
         wv, gv, mv = _vec(w, n), _vec(g, n).astype(np.float64), _vec(ms, n)
