@@ -237,8 +237,10 @@ def main():
             'warmup': args.warmup, 'ms_per_step': 1e3 * el / args.steps, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'zinb-conddisp autoencoder %s on synthetic %d x %d counts '
-                                   '(BASELINE configs[2]); train rows %d sharded over %d GPU(s)'
-                                   % ('-'.join(map(str, hidden)), args.cells, G, n_train_global, W),
+                                   '(%s); train rows %d sharded over %d GPU(s)'
+                                   % ('-'.join(map(str, hidden)), args.cells, G,
+                                      'BASELINE configs[2]' if (args.cells, G, hidden) == (68579, 20000, (64, 32, 64))
+                                      else 'not a BASELINE shape: ad-hoc run', n_train_global, W),
                        'batch_per_gpu': B, 'global_batch': B * W, 'hidden': list(hidden),
                        'parallelism': 'dp%d' % W, 'launch': 'hipGraph replay' if use_graph else 'eager',
                        'optimizer': 'RMSprop+clipvalue', 'params': int(eng.lay.P)},

@@ -129,6 +129,22 @@ def test_graph_replay_equals_eager(ops):
         np.testing.assert_array_equal(res[0][1][k], res[1][1][k])
 
 
+def test_wide_network_step(ops):
+    """BASELINE configs[4] architecture (512-256-128-256-512) at test size: decoder width > 64,
+    i.e. the heads run as separate kernels (GEMM + K-ZINB + 2 GEMMs), MFMA-bound regime."""
+    n, G, hs, B = 700, 1500, (512, 256, 128, 256, 512), 640
+    X, Y, sf, p = make_problem(n, G, hs, 'zinb-conddisp', True, seed=5)
+    rows = np.random.RandomState(0).permutation(n)[:B]
+    ref = oracle_net('zinb-conddisp', p, hs, True)
+    rl, rg = ref.loss_and_grads(X[rows].astype(np.float64), Y[rows].astype(np.float64),
+                                sf[rows].astype(np.float64))
+    eng = make_engine(ops, 'zinb-conddisp', G, hs, True, 0.0, p, X, Y, sf)
+    loss, g, _ = run_single_step(eng, rows)
+    assert eng.ws_heads is None
+    assert abs(loss - rl) < 1e-5 * abs(rl)
+    assert_grads_close(g, rg)
+
+
 def test_large_batch_step(ops):
     """Throughput regime (B = 2048 rows, G = 2000): split-K / 128x128 tile paths."""
     n, G, hs, B = 2100, 2000, (64, 32, 64), 2048
