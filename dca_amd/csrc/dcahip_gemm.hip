@@ -248,17 +248,35 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     }
 }
 
-// C[m,n] = bias[n] + sum_s ws[s][m][n]  (ordered: deterministic)
+// C[m,n] = bias[n] + sum_s ws[s][m][n]  (ordered: deterministic).  GL threads split the S slabs of
+// one output (many slabs of a small C: the batch-32 regime), combined in fixed order through LDS.
+template <int GL>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, int S, int Mo, int N,
                                                             const float* bias, int Mbias,
                                                             float* C, long ldc) {
+    constexpr int OUT = 256 / GL;
+    __shared__ float red[256];
     const long total = (long)Mo * N;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int m = (int)(i / N), n = (int)(i - (long)m * N);
+    const int o = threadIdx.x % OUT, gl = threadIdx.x / OUT;
+    for (long base = (long)blockIdx.x * OUT; base < total; base += (long)gridDim.x * OUT) {
+        const long i = base + o;
         float v = 0.f;
-        for (int s = 0; s < S; ++s) v += ws[(long)s * total + i];
-        if (bias && m < Mbias) v += bias[n];
-        C[(long)m * ldc + n] = v;
+        if (i < total)
+            for (int s = gl; s < S; s += GL) v += ws[(long)s * total + i];
+        if (GL > 1) {
+            __syncthreads();
+            red[threadIdx.x] = v;
+            __syncthreads();
+            if (gl == 0) {
+#pragma unroll
+                for (int k = 1; k < GL; ++k) v += red[k * OUT + o];
+            }
+        }
+        if (gl == 0 && i < total) {
+            const int m = (int)(i / N), n = (int)(i - (long)m * N);
+            if (bias && m < Mbias) v += bias[n];
+            C[(long)m * ldc + n] = v;
+        }
     }
 }
 
@@ -350,8 +368,15 @@ extern "C" int dcahip_sgemm(int ta, int tb, int M, int N, int K, const float* A,
         const long total = (long)Mo * N;
         long g = (total + 255) / 256;
         if (g > 4096) g = 4096;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)g), dim3(256), 0, s, a.ws, p.split, Mo, N,
-                           bias, M, C, ldc);
+        if (p.split >= 16 && total <= 65536) {
+            long g16 = (total + 15) / 16;
+            if (g16 > 4096) g16 = 4096;
+            hipLaunchKernelGGL(splitk_reduce_kernel<16>, dim3((int)g16), dim3(256), 0, s, a.ws, p.split, Mo, N,
+                               bias, M, C, ldc);
+        } else {
+            hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3((int)g), dim3(256), 0, s, a.ws, p.split, Mo, N,
+                               bias, M, C, ldc);
+        }
         rc = (int)hipGetLastError();
     }
     return rc;

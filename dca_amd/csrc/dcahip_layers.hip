@@ -18,10 +18,10 @@
 namespace {
 
 constexpr int kMaxChunks = 256;
-constexpr int kApplyRows = 64;   // rows per workgroup in the apply kernels
+constexpr int kApplyRows = 16;   // rows per workgroup in the apply kernels (256 workgroups at B = 4096)
 
 __host__ __device__ inline int n_chunks(int B) {
-    int r = (B + 63) / 64;
+    int r = (B + 15) / 16;           // short row loops: these kernels are latency-bound
     return r < 1 ? 1 : (r > kMaxChunks ? kMaxChunks : r);
 }
 __host__ __device__ inline int chunk_rows(int B, int R) { return (B + R - 1) / R; }

@@ -15,7 +15,7 @@ constexpr float kZeroThresh = 1e-8f;  // loss.py:138
 constexpr int kSmallY = 16;
 
 // log(n!) for n = 0..16
-__constant__ float kLogFact[kSmallY + 1] = {
+__constant__ float kLogFact[17] = {
     0.0f, 0.0f, 0.69314718055994531f, 1.7917594692280550f, 3.1780538303479458f,
     4.7874917427820458f, 6.5792512120101012f, 8.5251613610654147f, 10.604602902745251f,
     12.801827480081469f, 15.104412573075516f, 17.502307845873887f, 19.987214495661885f,

@@ -26,7 +26,7 @@ def _vec(t, n):
 
 
 def _chunks(B):
-    r = (B + 63) // 64
+    r = (B + 15) // 16
     return max(1, min(256, r))
 
 
