@@ -44,6 +44,10 @@ class override_ops:
         _test_ops_factory = self.prev
 
 
+def lay_G(eng):
+    return eng.lay.G_in
+
+
 class Autoencoder():
     ae_type = 'normal'
 
@@ -161,7 +165,11 @@ class Autoencoder():
         n = adata.n_obs
         X = adata.X
         sf = np.asarray(adata.obs['size_factors'].values, dtype=np.float32)
-        eng.load_data(X, None, sf)
+        dd = getattr(adata, '_dca_device', None)
+        if dd is not None and dd.n == n and dd.G == lay_G(eng) and dd.X.device == eng.dev:
+            eng.attach_device_data(dd.X, dd.Y, dd.sf)      # K-PREP's tensors are still in HBM
+        else:
+            eng.load_data(X, None, sf)
         chunk = min(chunk, n)
         eng.reserve(chunk)
         lay = eng.lay
@@ -173,7 +181,7 @@ class Autoencoder():
             b = min(chunk, n - s)
             res = eng.predict_chunk(s, b, want)
             for k in want:
-                outs[k][s:s + b] = res[k].cpu().numpy()
+                torch.from_numpy(outs[k][s:s + b]).copy_(res[k])      # D2H straight into the result
         return outs
 
     def predict(self, adata, mode='denoise', return_info=False, copy=False):

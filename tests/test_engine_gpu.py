@@ -157,3 +157,49 @@ def test_large_batch_step(ops):
     loss, g, _ = run_single_step(eng, rows)
     assert abs(loss - rl) < 1e-5 * abs(rl)
     assert_grads_close(g, rg)
+
+
+def test_full_size_step_fused_equals_separate(ops):
+    """BASELINE configs[2] at FULL size (68 579 x 20 000 resident, batch 4096): the oracle cannot
+    run here in seconds, so parity is carried by a size-independent property -- the fused K-HEADS
+    step and the separate-kernel step (both checked against the oracle at small sizes above) must
+    agree on the loss and on every gradient from the same state -- plus finiteness and the
+    NLL's known scale on this generator."""
+    from dca_amd import synth, prep
+    from dca_amd.engine import Engine
+    n, G, hs, B = 68579, 20000, (64, 32, 64), 4096
+    dev = torch.device('cuda')
+    Y = synth.generate_counts(n, G, device=dev)
+    counts = prep.cell_counts(ops, Y, n, G)
+    sf = counts / counts.median()
+    X = prep.transform(ops, Y, n, G, sf, True, True)
+    engs = []
+    for fused in (True, False):
+        e = Engine('zinb-conddisp', G, G, hs, True, 0.0, ops=ops)
+        e.use_fused = fused
+        e.init_params(0)
+        e.attach_device_data(X, Y, sf)
+        e.reserve(B)
+        e.set_lr(1e-3)
+        e.perm = torch.randperm(n, generator=torch.Generator().manual_seed(1), dtype=torch.int32)[:B].to(dev)
+        e.hist = torch.zeros(4, dtype=torch.float32, device=dev)
+        e.cursor.zero_(); e.acc.zero_()
+        e.train_step(B, rows_per_slot=B)
+        engs.append(e)
+    torch.cuda.synchronize()
+    ef, eu = engs
+    assert ef.ws_heads is not None and eu.ws_heads is None
+    P = ef.lay.P
+    lf, lu = ef.g[P].item(), eu.g[P].item()
+    assert np.isfinite(lf) and 0.3 < lf < 0.6                    # reduce_mean NLL of this generator at init
+    assert abs(lf - lu) <= 2e-6 * abs(lu), (lf, lu)
+    gf, gu = ef.g[:P], eu.g[:P]
+    assert torch.isfinite(gf).all()
+    for name, (off, shape) in ef.lay.seg.items():
+        m = int(np.prod(shape))
+        a, b = gf[off:off + m], gu[off:off + m]
+        scale = b.abs().max().item()
+        if name[0] == 'b' and name[1:].isdigit():
+            assert scale < 1e-6 * gu.abs().max().item()         # Dense bias feeding BatchNorm: identically 0
+            continue
+        assert (a - b).abs().max().item() <= 5e-5 * scale, (name, (a - b).abs().max().item(), scale)
