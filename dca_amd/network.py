@@ -177,11 +177,33 @@ class Autoencoder():
         for k in want:
             cols = lay.hidden[eng.center] if k == 'latent' else lay.G_out
             outs[k] = np.empty((n, cols), dtype=np.float32)
-        for s in range(0, n, chunk):
+        # results leave through two pinned staging buffers per output: the device -> host copy of
+        # chunk i runs asynchronously while the host moves chunk i-1 into the result arrays
+        pinned = eng.dev.type == 'cuda'
+        stage = {k: [torch.empty((chunk, outs[k].shape[1]), dtype=torch.float32, pin_memory=pinned)
+                     for _ in range(2)] for k in want}
+        events = [torch.cuda.Event() for _ in range(2)] if pinned else None
+        prev = None
+        for ci, s in enumerate(range(0, n, chunk)):
             b = min(chunk, n - s)
             res = eng.predict_chunk(s, b, want)
             for k in want:
-                torch.from_numpy(outs[k][s:s + b]).copy_(res[k])      # D2H straight into the result
+                stage[k][ci % 2][:b].copy_(res[k], non_blocking=pinned)
+            if pinned:
+                events[ci % 2].record()
+            if prev is not None:
+                pi, ps, pb = prev
+                if pinned:
+                    events[pi].synchronize()
+                for k in want:
+                    outs[k][ps:ps + pb] = stage[k][pi][:pb].numpy()
+            prev = (ci % 2, s, b)
+        if prev is not None:
+            pi, ps, pb = prev
+            if pinned:
+                events[pi].synchronize()
+            for k in want:
+                outs[k][ps:ps + pb] = stage[k][pi][:pb].numpy()
         return outs
 
     def predict(self, adata, mode='denoise', return_info=False, copy=False):
