@@ -130,12 +130,14 @@ __device__ __forceinline__ void merge_entries_wg(const float* entries, const flo
 __global__ __launch_bounds__(256) void moments_combine_kernel(const float* entries,
                                                               const float* counts, int E, int H,
                                                               float* out) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= H) return;
+    __shared__ double smd[512];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     double n, mean, m2;
-    merge_entries(entries, counts, E, H, c, 0, n, mean, m2);
-    out[c] = (float)mean;
-    out[H + c] = (float)m2;
+    merge_entries_wg(entries, counts, E, H, c, 0, smd, n, mean, m2);
+    if (threadIdx.x < 64 && c < H) {
+        out[c] = (float)mean;
+        out[H + c] = (float)m2;
+    }
 }
 
 struct BnApplyArgs {
@@ -338,7 +340,7 @@ extern "C" int dcahip_col_moments(const float* Z, long ldz, int B, int H, float*
 extern "C" int dcahip_moments_combine(const float* entries, const float* counts, int E, int H,
                                       float* out, void* stream) {
     if (!entries || !counts || !out || E <= 0 || H <= 0) return DCAHIP_EINVAL;
-    hipLaunchKernelGGL(moments_combine_kernel, dim3((H + 255) / 256), dim3(256), 0,
+    hipLaunchKernelGGL(moments_combine_kernel, dim3((H + 63) / 64), dim3(256), 0,
                        static_cast<hipStream_t>(stream), entries, counts, E, H, out);
     return (int)hipGetLastError();
 }

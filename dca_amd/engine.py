@@ -187,6 +187,7 @@ class Engine:
         self.use_fused = os.environ.get('DCA_AMD_FUSED_HEADS', '1') != '0'
         self.ws_heads = None
         self._pending = None        # in-flight all-reduce of the heads bucket (data parallel)
+        self._counts_local_key = self._counts_world_key = None
 
     def _t(self, name):
         return self.prof.section(name) if self.prof is not None else _NULL
@@ -323,6 +324,7 @@ class Engine:
         self.stat_local = [torch.zeros(2 * h, **f32) for h in lay.hidden]
         self.counts_local = torch.zeros(kMaxCounts, **f32)
         self.counts_world = torch.zeros(self.comm.world, **f32)
+        self._counts_local_key = self._counts_world_key = None
         # split-K workspace: the maximum any GEMM of a step can ask for, over every batch size up
         # to B (the split plan is a function of the shape: a smaller last batch may split more)
         cand = sorted({B} | {b for k in range(0, B // 64 + 2) for b in (64 * k, 64 * k + 1) if 1 <= b <= B})
@@ -390,8 +392,10 @@ class Engine:
         R = ops.col_moments_chunks(max(B, 1))
         if B > 0:
             cr = -(-B // R)
-            self.counts_local[:R] = torch.as_tensor(
-                [max(0, min(B, (r + 1) * cr) - r * cr) for r in range(R)], dtype=torch.float32)
+            if self._counts_local_key != (B, R):        # host -> device only when the batch size changes
+                self.counts_local[:R] = torch.as_tensor(
+                    [max(0, min(B, (r + 1) * cr) - r * cr) for r in range(R)], dtype=torch.float32)
+                self._counts_local_key = (B, R)
             ops.moments_combine(self.part[i], self.counts_local, R, h, self.stat_local[i])
         else:
             self.stat_local[i].zero_()
@@ -432,7 +436,10 @@ class Engine:
         inv_n = 1.0 / (float(Bg) * lay.G_out)
         w, g = self.w, self.g
         if comm.world > 1:
-            self.counts_world.copy_(torch.as_tensor(world_counts, dtype=torch.float32))
+            key = tuple(world_counts)
+            if self._counts_world_key != key:
+                self.counts_world.copy_(torch.as_tensor(world_counts, dtype=torch.float32))
+                self._counts_world_key = key
         if B > 0:
             self._forward_backward(B, Bg, inv_n)
         else:
