@@ -56,7 +56,8 @@ __device__ __forceinline__ void stv(float* p, const float (&o)[V]) {
     else *p = o[0];
 }
 
-template <bool HAS_PI, bool CONST_DISP, bool GRAD, int V>
+// LOSS: 0 = NB / ZINB, 1 = Poisson, 2 = squared error (mean head only)
+template <bool HAS_PI, bool CONST_DISP, bool GRAD, int V, int LOSS = 0>
 __global__ __launch_bounds__(256) void zinb_nll_kernel(NllArgs a) {
     // grid.x walks the gene segments (256 lanes x V genes), grid.y strides over the batch rows:
     // no integer division on the path, the per-row gather index and size factor are scalar loads
@@ -76,17 +77,25 @@ __global__ __launch_bounds__(256) void zinb_nll_kernel(NllArgs a) {
             const long ao = (long)row * a.lda + g;
             float vm[V], vp[V], vy[V];
             ldv<V>(a.a_mean + ao, vm);
-            if (!CONST_DISP) ldv<V>(a.a_disp + ao, vd);
+            if (!CONST_DISP && LOSS == 0) ldv<V>(a.a_disp + ao, vd);
             if (HAS_PI) ldv<V>(a.a_pi + ao, vp);
             ldv<V>(a.y + srow * a.ldy + g, vy);
             float om[V], od[V], op[V];
             float lacc = 0.f;
 #pragma unroll
             for (int j = 0; j < V; ++j) {
+                const bool valid = (g + j) < a.G;
+                if (LOSS != 0) {
+                    float d_am;
+                    const float nll = LOSS == 1 ? poisson_elem(vm[j], sf, vy[j], d_am)
+                                                : mse_elem(vm[j], sf, vy[j], d_am);
+                    lacc += valid ? nll : 0.f;
+                    if (GRAD) om[j] = valid ? d_am * a.inv_n : 0.f;
+                    continue;
+                }
                 float dmu = 0.f, dth = 0.f, dpi = 0.f;
                 const Heads h = head_acts<HAS_PI, CONST_DISP>(vm[j], vd[j], HAS_PI ? vp[j] : 0.f, sf);
                 const float nll = nll_elem<HAS_PI, GRAD>(h, vy[j], a.ridge, dmu, dth, dpi);
-                const bool valid = (g + j) < a.G;
                 lacc += valid ? nll : 0.f;
                 if (GRAD) {
                     om[j] = valid ? dmu * h.gm * a.inv_n : 0.f;
@@ -98,7 +107,7 @@ __global__ __launch_bounds__(256) void zinb_nll_kernel(NllArgs a) {
             if (GRAD) {
                 const long dof = (long)row * a.ldd + g;
                 stv<V>(a.d_mean + dof, om);
-                stv<V>(a.d_disp + dof, od);
+                if (LOSS == 0) stv<V>(a.d_disp + dof, od);
                 if (HAS_PI) stv<V>(a.d_pi + dof, op);
             }
         }
@@ -138,6 +147,7 @@ struct InferArgs {
     float *mean_sf, *theta, *pi;
     long lda, ldo;
     int B, G;
+    int linear_mean;
 };
 
 template <int V>
@@ -156,7 +166,7 @@ __global__ __launch_bounds__(256) void heads_infer_kernel(InferArgs a) {
         if (a.mean_sf) {
             ldv<V>(a.a_mean + ao, v);
 #pragma unroll
-            for (int j = 0; j < V; ++j) o[j] = fminf(fmaxf(expf(v[j]), 1e-5f), 1e6f) * sf;
+            for (int j = 0; j < V; ++j) o[j] = a.linear_mean ? v[j] * sf : fminf(fmaxf(expf(v[j]), 1e-5f), 1e6f) * sf;
             stv<V>(a.mean_sf + oo, o);
         }
         if (a.theta) {
@@ -190,6 +200,13 @@ int launch_nll(const NllArgs& a, bool vec, dim3 grid, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
+template <int LOSS, bool GRAD>
+int launch_nll_simple(const NllArgs& a, bool vec, dim3 grid, hipStream_t s) {
+    if (vec) hipLaunchKernelGGL((zinb_nll_kernel<false, false, GRAD, 4, LOSS>), grid, dim3(256), 0, s, a);
+    else     hipLaunchKernelGGL((zinb_nll_kernel<false, false, GRAD, 1, LOSS>), grid, dim3(256), 0, s, a);
+    return (int)hipGetLastError();
+}
+
 }  // namespace
 
 extern "C" int dcahip_version(void) { return DCAHIP_VERSION; }
@@ -202,14 +219,16 @@ extern "C" int dcahip_zinb_nll(const float* a_mean, const float* a_disp, const f
                                long ldd, double* loss_partials, int* n_partials_out, void* stream) {
     const bool has_pi = flags & DCAHIP_NLL_HAS_PI, cdisp = flags & DCAHIP_NLL_CONST_DISP;
     const bool grad = d_mean != nullptr;
+    const int loss = (flags & DCAHIP_NLL_POISSON) ? 1 : ((flags & DCAHIP_NLL_MSE) ? 2 : 0);
     if (B <= 0 || G <= 0 || !a_mean || !y || !sf || !loss_partials) return DCAHIP_EINVAL;
+    if (loss != 0 && (has_pi || cdisp)) return DCAHIP_EINVAL;
     if (has_pi && !a_pi) return DCAHIP_EINVAL;
-    if (cdisp ? (theta_w == nullptr) : (a_disp == nullptr)) return DCAHIP_EINVAL;
-    if (grad && (!d_disp || (has_pi && !d_pi))) return DCAHIP_EINVAL;
+    if (loss == 0 && (cdisp ? (theta_w == nullptr) : (a_disp == nullptr))) return DCAHIP_EINVAL;
+    if (grad && loss == 0 && (!d_disp || (has_pi && !d_pi))) return DCAHIP_EINVAL;
     bool vec = (lda % 4 == 0) && (ldy % 4 == 0) && al16(a_mean) && al16(y) &&
-               (cdisp ? al16(theta_w) : al16(a_disp)) && (!has_pi || al16(a_pi)) &&
+               (loss != 0 || (cdisp ? al16(theta_w) : al16(a_disp))) && (!has_pi || al16(a_pi)) &&
                lda >= ((G + 3) & ~3) && ldy >= ((G + 3) & ~3);
-    if (grad) vec = vec && (ldd % 4 == 0) && ldd >= ((G + 3) & ~3) && al16(d_mean) && al16(d_disp) && (!has_pi || al16(d_pi));
+    if (grad) vec = vec && (ldd % 4 == 0) && ldd >= ((G + 3) & ~3) && al16(d_mean) && (loss != 0 || al16(d_disp)) && (!has_pi || al16(d_pi));
     NllArgs a{a_mean, a_disp, a_pi, theta_w, y, sf, perm, cursor, lda, ldy, ldd,
               d_mean, d_disp, d_pi, loss_partials, B, G, ridge, inv_n};
     const int V = vec ? 4 : 1;
@@ -222,6 +241,8 @@ extern "C" int dcahip_zinb_nll(const float* a_mean, const float* a_disp, const f
     const dim3 grid(gx, gy);
     if (n_partials_out) *n_partials_out = gx * gy;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (loss == 1) return grad ? launch_nll_simple<1, true>(a, vec, grid, s) : launch_nll_simple<1, false>(a, vec, grid, s);
+    if (loss == 2) return grad ? launch_nll_simple<2, true>(a, vec, grid, s) : launch_nll_simple<2, false>(a, vec, grid, s);
 #define DCA_DISPATCH(P, C)                                                  \
     return grad ? launch_nll<P, C, true>(a, vec, grid, s) : launch_nll<P, C, false>(a, vec, grid, s)
     if (has_pi && cdisp) { DCA_DISPATCH(true, true); }
@@ -248,14 +269,14 @@ extern "C" int dcahip_step_end(const float* loss, double weight, float* hist, in
 
 extern "C" int dcahip_zinb_heads_infer(const float* a_mean, const float* a_disp, const float* a_pi,
                                        long lda, const float* sf, int B, int G, float* mean_sf,
-                                       float* theta, float* pi, long ldo, void* stream) {
+                                       float* theta, float* pi, long ldo, int flags, void* stream) {
     if (B <= 0 || G <= 0 || !sf) return DCAHIP_EINVAL;
     if ((mean_sf && !a_mean) || (theta && !a_disp) || (pi && !a_pi)) return DCAHIP_EINVAL;
     const int Gp = (G + 3) & ~3;
     bool vec = (lda % 4 == 0) && (ldo % 4 == 0) && lda >= Gp && ldo >= Gp;
     const void* ps[6] = {a_mean, a_disp, a_pi, mean_sf, theta, pi};
     for (const void* p : ps) vec = vec && (p == nullptr || al16(p));
-    InferArgs a{a_mean, a_disp, a_pi, sf, mean_sf, theta, pi, lda, ldo, B, G};
+    InferArgs a{a_mean, a_disp, a_pi, sf, mean_sf, theta, pi, lda, ldo, B, G, (flags & DCAHIP_NLL_MSE) ? 1 : 0};
     const int V = vec ? 4 : 1;
     const long total = (long)B * (((G + V - 1) / V + 255) / 256);
     const int grid = (int)(total < 4096 ? total : 4096);

@@ -105,6 +105,35 @@ __device__ __forceinline__ void nb_t1_large(float tp, float y, float& t1, float&
     }
 }
 
+// lgamma(y + 1) for the Poisson likelihood's constant term (dca/loss.py:52): table for integer
+// counts <= 16, Stirling above (next omitted term 1/(1260 z^5) < 6e-10 at z = 17), libm otherwise.
+__device__ __forceinline__ float lgamma_yp1(float y) {
+    if (y > 16.f) {
+        const float z = y + 1.f, r = frcp(z), r2 = r * r;
+        return (y + 0.5f) * flog(z) - z + 0.91893853320467274178f + r * (1.f / 12.f - r2 * (1.f / 360.f));
+    }
+    if (y == floorf(y) && y >= 0.f) return kLogFact[(int)y];
+    return lgammaf(y + 1.f);
+}
+
+// Poisson (dca/loss.py:36-55 with MeanAct, dca/network.py:233-246) and squared error
+// (dca/loss.py:24-27 on the linear mean head, dca/network.py:143-156): loss of one element and
+// d loss / d pre-activation (unscaled).
+__device__ __forceinline__ float poisson_elem(float am, float sf, float y, float& d_am) {
+    const float e = fexp(am);
+    const bool win = (e >= 1e-5f) && (e <= 1e6f);
+    const float mu = fminf(fmaxf(e, 1e-5f), 1e6f) * sf;
+    const float mue = mu + kEps;
+    d_am = win ? (1.f - y / mue) * e * sf : 0.f;
+    return mu - y * flog(mue) + lgamma_yp1(y);
+}
+
+__device__ __forceinline__ float mse_elem(float am, float sf, float y, float& d_am) {
+    const float diff = am * sf - y;
+    d_am = 2.f * diff * sf;
+    return diff * diff;
+}
+
 struct Heads {       // activations of one element
     float mu, gm;    // mean * sf,            d mu / d a_mean          (0 outside the clip window)
     float theta, gd; // dispersion,           d theta / d a_disp

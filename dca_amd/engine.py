@@ -32,7 +32,10 @@ AE_HEADS = {                      # ae_type -> (heads in the fused block, const 
     'zinb': (('mean', 'pi'), True),                      # network.py:496-516
     'nb-conddisp': (('mean', 'disp'), False),            # network.py:293-318
     'nb': (('mean',), True),                             # network.py:249-270
+    'poisson': (('mean',), False),                       # network.py:233-246 (poisson_loss)
+    'normal': (('mean',), False),                        # network.py:143-156 (mse_loss, linear mean)
 }
+AE_LOSS_FLAG = {'poisson': 4, 'normal': 8}              # DCAHIP_NLL_POISSON / DCAHIP_NLL_MSE
 
 
 def _r4(x):
@@ -163,7 +166,7 @@ class Engine:
         self.ridge = float(ridge)
         lay = self.lay
         self.has_pi = 'pi' in lay.heads
-        self.flags = (1 if self.has_pi else 0) | (2 if lay.const_disp else 0)
+        self.flags = (1 if self.has_pi else 0) | (2 if lay.const_disp else 0) | AE_LOSS_FLAG.get(ae_type, 0)
         self.center = int(np.floor(len(lay.hidden) / 2.0))          # network.py:102
         f32 = dict(dtype=torch.float32, device=self.dev)
         self.w = torch.zeros(lay.total, **f32)
@@ -578,7 +581,7 @@ class Engine:
             d = self._plane(A, 'disp') if 'dispersion' in want else None
             p = self._plane(A, 'pi') if 'dropout' in want else None
             ops.heads_infer(m, d, p, lay.NH, self.sf[r0:], b, lay.G_out,
-                            m if 'mean' in want else None, d, p, lay.NH)
+                            m if 'mean' in want else None, d, p, lay.NH, self.flags & 8)
             if 'mean' in want:
                 out['mean'] = m[:b, :lay.G_out]
             if d is not None:

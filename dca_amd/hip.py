@@ -16,6 +16,8 @@ _f32p, _i32p, _i64p, _f64p, _vp = _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_vo
 
 NLL_HAS_PI = 1
 NLL_CONST_DISP = 2
+NLL_POISSON = 4
+NLL_MSE = 8
 
 _SIGNATURES = {
     'dcahip_version': (_c.c_int, []),
@@ -27,7 +29,7 @@ _SIGNATURES = {
     'dcahip_loss_finalize': (_c.c_int, [_f64p, _c.c_int, _c.c_double, _f32p, _vp]),
     'dcahip_step_end': (_c.c_int, [_f32p, _c.c_double, _f32p, _c.c_int, _f64p, _i64p, _c.c_int, _vp]),
     'dcahip_zinb_heads_infer': (_c.c_int, [_f32p, _f32p, _f32p, _c.c_long, _f32p, _c.c_int, _c.c_int,
-                                           _f32p, _f32p, _f32p, _c.c_long, _vp]),
+                                           _f32p, _f32p, _f32p, _c.c_long, _c.c_int, _vp]),
     'dcahip_heads_fused_workspace_bytes': (_c.c_long, [_c.c_int, _c.c_int, _c.c_int, _c.c_long, _c.c_int]),
     'dcahip_heads_fused': (_c.c_int, [_f32p, _c.c_long, _f32p, _c.c_long, _f32p, _c.c_long, _f32p,
                                       _f32p, _c.c_long, _f32p, _i32p, _i64p, _c.c_int, _c.c_int,

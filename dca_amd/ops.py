@@ -39,10 +39,10 @@ class HipOps:
         hip.check(self.L.dcahip_step_end(p(loss), weight, p(hist), rows_per_slot, p(acc), p(cursor),
                                          advance, hip.stream()), 'step_end')
 
-    def heads_infer(self, a_mean, a_disp, a_pi, lda, sf, B, G, mean_sf, theta, pi, ldo):
+    def heads_infer(self, a_mean, a_disp, a_pi, lda, sf, B, G, mean_sf, theta, pi, ldo, flags=0):
         p = hip.ptr
         hip.check(self.L.dcahip_zinb_heads_infer(p(a_mean), p(a_disp), p(a_pi), lda, p(sf), B, G,
-                                                 p(mean_sf), p(theta), p(pi), ldo, hip.stream()),
+                                                 p(mean_sf), p(theta), p(pi), ldo, flags, hip.stream()),
                   'heads_infer')
 
     # ------------------------------------------------------------------ fused heads

@@ -36,6 +36,8 @@ extern "C" {
 /* flags for dcahip_zinb_nll */
 #define DCAHIP_NLL_HAS_PI      1   /* ZINB (pi head present); otherwise plain NB          */
 #define DCAHIP_NLL_CONST_DISP  2   /* theta = clip(exp(theta_w[g]),1e-3,1e4) per gene      */
+#define DCAHIP_NLL_POISSON     4   /* mean head only: poisson_loss, dca/loss.py:36-55     */
+#define DCAHIP_NLL_MSE         8   /* linear mean head only: mse_loss, dca/loss.py:24-27  */
 
 int dcahip_version(void);
 
@@ -49,6 +51,8 @@ int dcahip_zinb_max_partials(void);
  * Replaces: MeanAct/DispAct/sigmoid (dca/network.py:38-39,369-380), ColwiseMultLayer
  * (dca/layers.py:85), NB.loss (dca/loss.py:72-114), ZINB.loss (dca/loss.py:122-156),
  * ConstantDispersionLayer.theta_exp (dca/layers.py:21) and TensorFlow's autodiff of them.
+ * With DCAHIP_NLL_POISSON / DCAHIP_NLL_MSE (ae_type 'poisson' / 'normal', dca/network.py:143-156,
+ * 233-246) only a_mean / d_mean are used: poisson_loss on clip(exp(a)) * sf, mse_loss on a * sf.
  *
  *   a_mean, a_disp, a_pi : [B, lda] pre-activations (a_disp NULL with CONST_DISP, a_pi NULL
  *                          without HAS_PI)
@@ -89,11 +93,13 @@ int dcahip_step_end(const float* loss, double weight, float* hist, int rows_per_
 /*
  * Inference heads: mean*sf, theta, pi from pre-activations (in-place allowed: out == in).
  * Replaces model.predict / extra_models['dispersion'|'pi'].predict (dca/network.py:188-211,
- * 395-405).  sf is indexed by batch row (no gather).  Outputs may be NULL.
+ * 395-405).  sf is indexed by batch row (no gather).  Outputs may be NULL.  flags &
+ * DCAHIP_NLL_MSE: the mean head is linear (ae_type 'normal': mean_sf = a_mean * sf).
  */
 int dcahip_zinb_heads_infer(const float* a_mean, const float* a_disp, const float* a_pi,
                             long lda, const float* sf, int B, int G,
-                            float* mean_sf, float* theta, float* pi, long ldo, void* stream);
+                            float* mean_sf, float* theta, float* pi, long ldo, int flags,
+                            void* stream);
 
 /*
  * K-HEADS: the output heads of one training step in a single pass -- forward GEMM of the heads

@@ -45,9 +45,16 @@ class CpuRefOps:
         y = _mat(Y, n_store, G, ldy)[rows].astype(np.float64)
         sfv = _vec(sf, n_store)[rows].astype(np.float64)
         am = _mat(a_mean, B, G, lda).astype(np.float64)
-        ad = None if cdisp else _mat(a_disp, B, G, lda).astype(np.float64)
+        ad = None if (cdisp or a_disp is None) else _mat(a_disp, B, G, lda).astype(np.float64)
         tw = _vec(theta_w, G).astype(np.float64) if cdisp else None
         n_total = 1.0 / inv_n
+        if flags & 12:                       # Poisson / squared error: mean head only
+            fn = Z.poisson_loss_and_grads if flags & 4 else Z.mse_loss_and_grads
+            ls, _, dm = fn(am, y, sfv, n_total)
+            if d_mean is not None:
+                _mat(d_mean, B, G, ldd)[:] = dm
+            partials[0] = float(ls)
+            return 1
         if has_pi:
             ap = _mat(a_pi, B, G, lda).astype(np.float64)
             if not cdisp:
@@ -96,10 +103,11 @@ class CpuRefOps:
         if cursor is not None:
             cursor[0] = c + advance
 
-    def heads_infer(self, a_mean, a_disp, a_pi, lda, sf, B, G, mean_sf, theta, pi, ldo):
+    def heads_infer(self, a_mean, a_disp, a_pi, lda, sf, B, G, mean_sf, theta, pi, ldo, flags=0):
         sfv = _vec(sf, B).astype(np.float64)
         if mean_sf is not None:
-            _mat(mean_sf, B, G, ldo)[:] = Z.mean_act(_mat(a_mean, B, G, lda).astype(np.float64)) * sfv[:, None]
+            am = _mat(a_mean, B, G, lda).astype(np.float64)
+            _mat(mean_sf, B, G, ldo)[:] = (am if flags & 8 else Z.mean_act(am)) * sfv[:, None]
         if theta is not None:
             _mat(theta, B, G, ldo)[:] = Z.disp_act(_mat(a_disp, B, G, lda).astype(np.float64))
         if pi is not None:
@@ -107,7 +115,7 @@ class CpuRefOps:
 
     # ------------------------------------------------------------------ fused heads
     def heads_fused_workspace_bytes(self, B, hL, G, plane, flags):
-        return 16 if 1 <= hL <= 64 else 0
+        return 16 if (1 <= hL <= 64 and not flags & 12) else 0
 
     def heads_fused(self, H, ldh, Wh, ldw, bh, plane, theta_w, Y, ldy, sf, perm, cursor, B, hL, G,
                     ridge, inv_n, flags, gW, ldg, g_theta, dH, lddh, partials, ws):

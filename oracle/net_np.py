@@ -27,7 +27,7 @@ from . import zinb_np as Z
 
 BN_MOMENTUM = 0.99
 BN_EPS = 1e-3
-AE_TYPES = ('zinb-conddisp', 'zinb', 'nb-conddisp', 'nb')
+AE_TYPES = ('zinb-conddisp', 'zinb', 'nb-conddisp', 'nb', 'poisson', 'normal')
 
 
 def glorot_uniform(rng, fan_in, fan_out, dtype):
@@ -117,6 +117,12 @@ class OracleAE:
 
     def _loss_grads(self, c, Y, n_total):
         tw = self.p.get('theta_w')
+        if self.ae_type == 'poisson':
+            ls, lm, dm = Z.poisson_loss_and_grads(c['a_mean'], Y, c['sf'], n_total)
+            return ls, lm, dm, None, None
+        if self.ae_type == 'normal':
+            ls, lm, dm = Z.mse_loss_and_grads(c['a_mean'], Y, c['sf'], n_total)
+            return ls, lm, dm, None, None
         if self.ae_type.startswith('zinb'):
             ls, lm, dm, dd, dpi = Z.zinb_loss_and_grads(c['a_mean'], c['a_disp'], c['a_pi'], Y,
                                                         c['sf'], self.ridge, n_total, tw)
@@ -139,7 +145,7 @@ class OracleAE:
             g['W_disp'] = HL.T @ d_disp
             g['b_disp'] = d_disp.sum(axis=0)
             dH = dH + d_disp @ p['W_disp'].T
-        else:
+        elif 'theta_w' in p:
             g['theta_w'] = d_disp
         if 'W_pi' in p:
             g['W_pi'] = HL.T @ d_pi
@@ -168,6 +174,9 @@ class OracleAE:
     def predict(self, X, sf):
         """network.py:188-211, 395-405: mean*sf, theta, pi, latent (centre Dense output)."""
         c = self.forward(X, sf, training=False)
+        if self.ae_type == 'normal':                             # linear mean head (network.py:146-149)
+            return {'mean': c['a_mean'] * c['sf'].reshape(-1, 1), 'dispersion': None, 'dropout': None,
+                    'latent': c['Z'][self.center]}
         mu, theta, pi = Z.heads_forward(c['a_mean'], c['a_disp'], c['a_pi'], c['sf'])
         if 'theta_w' in self.p:
             theta = Z.const_disp(self.p['theta_w'])          # layers.py:21, per gene

@@ -77,7 +77,13 @@ class TorchAE:
                     mu, var = p['mm%d' % i], p['mv%d' % i]
                 Zi = (Zi - mu) * torch.rsqrt(var + BN_EPS) + p['beta%d' % i]
             H = torch.relu(Zi)
+        if self.ae_type == 'normal':         # dca/network.py:146-149 + dca/loss.py:24-27
+            el = torch.square((H @ p['W_mean'] + p['b_mean']) * sf.reshape(-1, 1) - Y)
+            return el.mean() if n_total is None else el.sum() / n_total
         mean = mean_act(H @ p['W_mean'] + p['b_mean']) * sf.reshape(-1, 1)
+        if self.ae_type == 'poisson':        # dca/network.py:236-240 + dca/loss.py:52
+            el = mean - Y * torch.log(mean + EPS) + torch.lgamma(Y + 1.0)
+            return el.mean() if n_total is None else el.sum() / n_total
         if 'W_disp' in p:
             theta = disp_act(H @ p['W_disp'] + p['b_disp'])
         else:

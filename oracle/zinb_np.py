@@ -219,3 +219,36 @@ def nb_loss_and_grads(a_mean, a_disp, y, sf, n_total=None, theta_w=None):
     else:
         d_disp = dth * g_disp * inv
     return loss_sum, loss_sum / dt.type(n), d_mean, d_disp
+
+
+# ------------------------------------------------------------------ Poisson / squared error
+def poisson_nll(y, mu):
+    """dca/loss.py:36-55: y_pred - y*log(y_pred + 1e-10) + lgamma(y + 1)."""
+    from scipy.special import gammaln
+    return mu - y * np.log(mu + _c(1e-10, mu)) + gammaln(y + 1).astype(mu.dtype)
+
+
+def poisson_loss_and_grads(a_mean, y, sf, n_total=None):
+    """ae_type 'poisson' (dca/network.py:233-246): MeanAct head * size factors, poisson_loss."""
+    dt = a_mean.dtype
+    sfc = sf.reshape(-1, 1).astype(dt)
+    mu = mean_act(a_mean) * sfc
+    yy = y.astype(dt)
+    el = poisson_nll(yy, mu)
+    n = el.size if n_total is None else n_total
+    g_mean, _ = _act_grads(a_mean, None)
+    d_mean = (1 - yy / (mu + _c(1e-10, mu))) * sfc * g_mean * dt.type(1.0 / n)
+    ls = el.sum(dtype=dt)
+    return ls, ls / dt.type(n), d_mean
+
+
+def mse_loss_and_grads(a_mean, y, sf, n_total=None):
+    """ae_type 'normal' (dca/network.py:143-156): linear mean head * size factors, mse_loss
+    (dca/loss.py:24-27)."""
+    dt = a_mean.dtype
+    sfc = sf.reshape(-1, 1).astype(dt)
+    diff = a_mean * sfc - y.astype(dt)
+    el = np.square(diff)
+    n = el.size if n_total is None else n_total
+    ls = el.sum(dtype=dt)
+    return ls, ls / dt.type(n), 2 * diff * sfc * dt.type(1.0 / n)

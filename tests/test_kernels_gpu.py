@@ -121,6 +121,35 @@ def test_zinb_nll_vs_oracle(ops, flags, B, G, edge):
     assert abs(loss.item() - got) <= 1e-6 * abs(got)
 
 
+@pytest.mark.parametrize('flag,B,G', [(4, 8, 40), (4, 33, 1000), (8, 16, 203), (8, 5, 6)])
+def test_poisson_and_mse_vs_oracle(ops, flag, B, G):
+    """DCAHIP_NLL_POISSON / DCAHIP_NLL_MSE (ae_types 'poisson', 'normal'): loss and d loss / d a_mean."""
+    am, _, _, y, sf = _heads(B, G, 7 + B, edge=(G == 40))
+    if flag == 4:
+        ls, lm, dm = Z.poisson_loss_and_grads(am, y, sf)
+    else:
+        ls, lm, dm = Z.mse_loss_and_grads(am, y, sf)
+    Gp = (G + 3) // 4 * 4
+    dA = dev(pad_cols(am, Gp)); dD = torch.full((B, Gp), 7.0, device='cuda')
+    part = torch.zeros(ops.max_partials, dtype=torch.float64, device='cuda')
+    inv_n = 1.0 / (B * G)
+    n = ops.zinb_nll(dA, None, None, Gp, None, dev(pad_cols(y, Gp)), Gp, dev(sf), None, None, B, G, 0.0,
+                     inv_n, flag, dD, None, None, Gp, part)
+    loss = torch.zeros(1, device='cuda')
+    ops.loss_finalize(part, n, inv_n, loss)
+    torch.cuda.synchronize()
+    assert abs(loss.item() - lm) <= 3e-6 * abs(lm), (loss.item(), lm)
+    D = dD.cpu().numpy().astype(np.float64)[:, :G]
+    scale = np.abs(dm).max()
+    assert (np.abs(D - dm) <= 2e-4 * np.abs(dm) + 2e-6 * scale).all()
+    # inference heads: linear mean for 'normal'
+    out = torch.zeros(B, Gp, device='cuda')
+    ops.heads_infer(dA, None, None, Gp, dev(sf), B, G, out, None, None, Gp, flag & 8)
+    torch.cuda.synchronize()
+    ref = (am if flag == 8 else Z.mean_act(am)) * sf[:, None]
+    np.testing.assert_allclose(out.cpu().numpy()[:, :G], ref, rtol=2e-6, atol=1e-30)
+
+
 def test_zinb_nll_unaligned_scalar_path(ops):
     """ld not a multiple of 4 -> the kernel must take its scalar path and still be right."""
     B, G = 9, 37
