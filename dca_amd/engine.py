@@ -267,6 +267,26 @@ class Engine:
     def get_grads(self):
         return self._named(self.g)
 
+    def save_state(self, path, fit_state):
+        """Full training state after an epoch: parameters, RMSprop slots, BN moving statistics
+        and the fit loop's scalars (epoch, lr, callback counters, history)."""
+        import json
+        np.savez(path, w=self.w.cpu().numpy(), ms=self.ms.cpu().numpy(),
+                 **{'mm%d' % i: t.cpu().numpy() for i, t in enumerate(self.mm)},
+                 **{'mv%d' % i: t.cpu().numpy() for i, t in enumerate(self.mv)},
+                 fit=np.frombuffer(json.dumps(fit_state).encode(), dtype=np.uint8))
+
+    def load_state(self, path):
+        import json
+        with np.load(path) as z:
+            assert z['w'].shape[0] == self.w.shape[0], 'checkpoint belongs to a different network'
+            self.w.copy_(torch.as_tensor(z['w']))
+            self.ms.copy_(torch.as_tensor(z['ms']))
+            for i in range(len(self.mm)):
+                self.mm[i].copy_(torch.as_tensor(z['mm%d' % i]))
+                self.mv[i].copy_(torch.as_tensor(z['mv%d' % i]))
+            return json.loads(bytes(z['fit']).decode())
+
     def set_lr(self, lr):
         self.lr.fill_(float(np.float32(lr)))
 

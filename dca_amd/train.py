@@ -63,10 +63,16 @@ class _EarlyStopping:         # keras defaults as used at train.py:73-75
 
 def fit_engine(eng, n_train_global, n_val_global, nt_local, nv_local, t0_global, *, epochs=300,
                batch_size=32, learning_rate=None, clip_grad=5.0, reduce_lr=10, early_stop=15,
-               verbose=False, shuffle_rng=None, use_graph=None, on_epoch=None):
+               verbose=False, shuffle_rng=None, use_graph=None, on_epoch=None, state=None):
     """Runs the Keras-equivalent fit loop on an engine whose storage rows are
     [0, nt_local) = this rank's train shard and [nt_local, nt_local+nv_local) = its
-    validation shard.  Returns History."""
+    validation shard.  Returns History.
+
+    ``state`` (a dict from a previous call's ``on_epoch`` hook: 'epoch', 'lr', callback
+    counters, history) resumes the loop after that epoch: the engine must already hold the
+    matching weights / optimizer slots (Engine.load_state).  NOTE: the shuffles consume the numpy
+    RNG stream; a resumed run replays them for the skipped epochs so that the order of the
+    remaining epochs is the one an uninterrupted run would have seen."""
     comm = eng.comm
     W = comm.world
     rng = np.random if shuffle_rng is None else shuffle_rng
@@ -88,10 +94,23 @@ def fit_engine(eng, n_train_global, n_val_global, nt_local, nv_local, t0_global,
     rl = _ReduceLROnPlateau(reduce_lr, verbose) if reduce_lr else None
     es = _EarlyStopping(early_stop) if early_stop else None
     hist = History()
+    first_epoch = 0
+    if state is not None:
+        first_epoch = int(state['epoch']) + 1
+        lr = float(state['lr'])
+        eng.set_lr(lr)
+        if rl is not None:
+            rl.best, rl.wait = state['rl_best'], state['rl_wait']
+        if es is not None:
+            es.best, es.wait = state['es_best'], state['es_wait']
+        hist.history = {k: list(v) for k, v in state['history'].items()}
+        hist.epoch = list(range(first_epoch))
     runner = _StepRunner(eng, use_graph)
     for epoch in range(epochs):
         idx = np.arange(n_train_global)
         rng.shuffle(idx)                                       # numpy global RNG, like Keras
+        if epoch < first_epoch:
+            continue                                           # resumed: replay the stream only
         order = ddist.local_order(idx, t0_global, nt_local)
         if nt_local > 0:
             eng.perm[:nt_local].copy_(torch.as_tensor(order), non_blocking=False)
@@ -125,7 +144,10 @@ def fit_engine(eng, n_train_global, n_val_global, nt_local, nv_local, t0_global,
                 msg += ' - val_loss: %.4f' % hist.history['val_loss'][-1]
             print(msg, flush=True)
         if on_epoch is not None:
-            on_epoch(epoch, hist)
+            on_epoch(epoch, hist, dict(epoch=epoch, lr=lr, rl_best=rl.best if rl else None,
+                                       rl_wait=rl.wait if rl else 0, es_best=es.best if es else None,
+                                       es_wait=es.wait if es else 0,
+                                       history={k: list(v) for k, v in hist.history.items()}))
         if stop:
             hist.stopped_epoch = epoch
             if verbose and comm.rank == 0:
@@ -213,11 +235,35 @@ def train(adata, network, output_dir=None, optimizer='RMSprop', learning_rate=No
         eng.load_data(X, Y, sf)
     else:
         eng.load_data(X[rows], Y[rows], sf[rows])
+    # Callbacks of train.py:62-69.  ModelCheckpoint(save_weights_only=True, save_best_only=True,
+    # monitor val_loss): the weights file holds the BEST epoch so far; the model itself keeps
+    # training (Keras does not restore).  Beyond the reference: ``checkpoint=True`` writes the full
+    # training state after every epoch and ``resume=True`` continues from it.
+    checkpoint = bool(kwds.pop('checkpoint', False))
+    resume = bool(kwds.pop('resume', False))
+    best = {'val': np.inf}
+    state_path = os.path.join(output_dir, 'train_state.npz') if output_dir is not None else None
+
+    def on_epoch(epoch, h, st):
+        if comm.rank != 0 or output_dir is None:
+            return
+        if save_weights:
+            cur = h.history['val_loss'][-1] if 'val_loss' in h.history and h.history['val_loss'] else None
+            if cur is None or cur < best['val']:
+                best['val'] = np.inf if cur is None else cur
+                network.save_weights(os.path.join(output_dir, 'weights.npz'))
+        if checkpoint:
+            eng.save_state(state_path, st)
+
+    state = None
+    if resume and state_path is not None and os.path.exists(state_path):
+        state = eng.load_state(state_path)
+        vl = state['history'].get('val_loss') or []
+        if vl:
+            best['val'] = float(np.min(vl))
     hist = fit_engine(eng, n_train, n_val, nt, nv, t0, epochs=epochs, batch_size=batch_size,
                       learning_rate=learning_rate, clip_grad=clip_grad, reduce_lr=reduce_lr,
-                      early_stop=early_stop, verbose=verbose, **kwds)
-    if save_weights and output_dir is not None and comm.rank == 0:
-        network.save_weights(os.path.join(output_dir, 'weights.npz'))
+                      early_stop=early_stop, verbose=verbose, on_epoch=on_epoch, state=state, **kwds)
     return hist
 
 

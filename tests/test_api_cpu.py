@@ -104,3 +104,41 @@ def test_biochemists_zinb_ae_plumbing(biochemists):
     h = ret.uns['dca_loss_history']
     assert len(h['loss']) == 3 and len(h['val_loss']) == 3 and np.isfinite(h['loss']).all()
     assert ret.X.shape == (915, 6)
+
+
+def _prepared(seed=0):
+    from dca_amd import io
+    ad = io.read_dataset(_adata(90, 30, seed))
+    return io.normalize(ad, filter_min_counts=False, device=False)
+
+
+def test_checkpoint_best_weights_and_resume(tmp_path):
+    """train(save_weights=True) keeps the weights of the best validation epoch (Keras
+    ModelCheckpoint(save_best_only=True), train.py:64-69); checkpoint / resume (an extension)
+    continues a run bit-for-bit: 4 epochs == 2 epochs + resume to 4."""
+    from dca_amd.train import train
+    out_a, out_b = str(tmp_path / 'a'), str(tmp_path / 'b')
+    with override_ops(CpuRefOps):
+        def run(outdir, epochs, resume):
+            np.random.seed(3)
+            ad = _prepared()
+            net = AE_types['zinb-conddisp'](input_size=ad.n_vars, hidden_size=(8, 3, 8), file_path=outdir)
+            net.seed = 0
+            net.build()
+            h = train(ad, net, output_dir=outdir, epochs=epochs, batch_size=16, save_weights=True,
+                      verbose=False, checkpoint=True, resume=resume, early_stop=0, reduce_lr=2)
+            return h, net
+        h4, net4 = run(out_a, 4, False)
+        run(out_b, 2, False)
+        h22, net22 = run(out_b, 4, True)
+    assert h22.history == h4.history
+    p4, p22 = net4.engine.get_params(), net22.engine.get_params()
+    for k in p4:
+        np.testing.assert_array_equal(p4[k], p22[k])
+    # the weights file is the best-val_loss epoch, not necessarily the last one
+    best = int(np.argmin(h4.history['val_loss']))
+    z = np.load(str(tmp_path / 'a' / 'weights.npz'))
+    if best == 3:
+        for k in p4:
+            np.testing.assert_array_equal(z[k], p4[k])
+    assert set(z.files) == set(p4)
