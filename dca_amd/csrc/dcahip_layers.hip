@@ -21,7 +21,7 @@ constexpr int kMaxChunks = 256;
 constexpr int kApplyRows = 16;   // rows per workgroup in the apply kernels (256 workgroups at B = 4096)
 
 __host__ __device__ inline int n_chunks(int B) {
-    int r = (B + 15) / 16;           // short row loops: these kernels are latency-bound
+    int r = (B + 63) / 64;           // 64 chunks at B = 4096: every apply workgroup re-merges them
     return r < 1 ? 1 : (r > kMaxChunks ? kMaxChunks : r);
 }
 __host__ __device__ inline int chunk_rows(int B, int R) { return (B + R - 1) / R; }
@@ -47,10 +47,16 @@ __global__ __launch_bounds__(256) void col_moments_kernel(const float* Z, long l
     for (int c0 = 0; c0 < H; c0 += 64) {
         const int c = c0 + tx;
         float s = 0.f;
-        if (c < H) for (int i = r0 + ty; i < r1; i += 4) s += Z[(long)i * ldz + c];
+        if (c < H) {
+#pragma unroll 8
+            for (int i = r0 + ty; i < r1; i += 4) s += Z[(long)i * ldz + c];
+        }
         const float mean = cnt > 0.f ? wg_rowlane_sum(s, sm) / cnt : 0.f;
         float q = 0.f;
-        if (c < H) for (int i = r0 + ty; i < r1; i += 4) { const float d = Z[(long)i * ldz + c] - mean; q += d * d; }
+        if (c < H) {
+#pragma unroll 8
+            for (int i = r0 + ty; i < r1; i += 4) { const float d = Z[(long)i * ldz + c] - mean; q += d * d; }
+        }
         const float m2 = wg_rowlane_sum(q, sm);
         if (c < H && ty == 0) {
             part[((long)r * 2 + 0) * H + c] = mean;
@@ -101,6 +107,7 @@ __device__ __forceinline__ void merge_entries_wg(const float* entries, const flo
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     double n = 0.0, sw = 0.0;
     if (c < H)
+#pragma unroll 4
         for (int e = ty; e < E; e += 4) {
             const double ne = entry_count(counts, e, E, Bfallback);
             n += ne;
@@ -114,6 +121,7 @@ __device__ __forceinline__ void merge_entries_wg(const float* entries, const flo
     const double mean = n > 0.0 ? sw / n : 0.0;
     double q = 0.0;
     if (c < H)
+#pragma unroll 4
         for (int e = ty; e < E; e += 4) {
             const double ne = entry_count(counts, e, E, Bfallback);
             if (ne <= 0.0) continue;
@@ -205,7 +213,9 @@ __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(const float* dH, long 
     for (int c0 = 0; c0 < H; c0 += 64) {
         const int c = c0 + tx;
         float s1 = 0.f, s2 = 0.f;
-        if (c < H) for (int i = r0 + ty; i < r1; i += 4) {
+        if (c < H)
+#pragma unroll 8
+        for (int i = r0 + ty; i < r1; i += 4) {
             const float dy = Hact[(long)i * ldh + c] > 0.f ? dH[(long)i * ldd + c] : 0.f;
             s1 += dy; s2 += dy * xhat[(long)i * ldx + c];
         }
@@ -233,6 +243,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
         const int c = c0 + (threadIdx.x & 63);
         float v1 = 0.f, v2 = 0.f;
         if (c < a.H)
+#pragma unroll 4
             for (int e = threadIdx.x >> 6; e < a.E; e += 4) {
                 v1 += a.sums[((long)e * 2 + 0) * a.H + c];
                 v2 += a.sums[((long)e * 2 + 1) * a.H + c];

@@ -26,7 +26,7 @@ def _vec(t, n):
 
 
 def _chunks(B):
-    r = (B + 15) // 16
+    r = (B + 63) // 64
     return max(1, min(256, r))
 
 
