@@ -36,3 +36,29 @@ def test_product_path_fails_loudly_without_gpu():
         pytest.skip('GPU present')
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         HipOps()
+
+
+def test_heads_kernel_stays_inside_its_scratch_budget():
+    """K-HEADS runs at 2 waves/SIMD with 256 VGPRs; builds whose spills pushed the private segment of
+    the main variants above 96 bytes/lane showed sporadic 3x slow launches on the MI355X (the runtime's
+    scratch handling), so the budget is part of the contract: zinb-conddisp / 4 row slots / hL = 64
+    must stay <= 96 bytes/lane, every other 64-wide variant <= 32."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    src = os.path.join(ROOT, 'dca_amd', 'csrc', 'dcahip_heads.hip')
+    out = subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-I' + os.path.join(ROOT, 'include'),
+                          '--cuda-device-only', '-c', src, '-o', os.devnull, '-Rpass-analysis=kernel-resource-usage'],
+                         capture_output=True, text=True, check=True).stderr
+    names = re.findall(r'Function Name: (\S+)', out)
+    scratch = [int(x) for x in re.findall(r'ScratchSize \[bytes/lane\]: (\d+)', out)]
+    lds = [int(x) for x in re.findall(r'LDS Size \[bytes/block\]: (\d+)', out)]
+    assert len(names) == len(scratch) == len(lds) and len(names) >= 16
+    for n, s, l in zip(names, scratch, lds):
+        if 'heads_fused_kernel' not in n:
+            continue
+        assert l <= 163840, (n, l)
+        if n.endswith('ELb1EEEvNS_9HeadsArgsE'):                      # FULLK variants (hL == 64)
+            limit = 96 if 'ILb1ELb0ELi2ELi4E' in n else 32
+            assert s <= limit, (n, s)
