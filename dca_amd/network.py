@@ -9,9 +9,9 @@ code together (the reference runs 3-4 separate Keras predict passes, network.py:
 395-405).
 
 Implemented on the MI355X path: zinb-conddisp (the north-star class, network.py:366-421),
-zinb (:496-550), nb-conddisp (:293-339), nb (:249-290).  The remaining keys are registered
-and raise NotImplementedError at build() -- they are head-layout variants queued behind the
-hot path.
+zinb (:496-550), nb-conddisp (:293-339), nb (:249-290), poisson (:233-246), normal (:143-156).
+The remaining keys (*-shared, *-fork, zinb-elempi) are registered and raise NotImplementedError
+at build() -- head-layout variants queued behind the hot path.
 """
 import os
 import pickle

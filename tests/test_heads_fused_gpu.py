@@ -108,8 +108,6 @@ def run_case(ops, flags, B, G, hL, seed, ridge=0.0, use_perm=True, odd_counts=Fa
             out['pad_' + h] = (gWn[:, k * Gp + G:(k + 1) * Gp], np.zeros((hL + 1, Gp - G)))
     out['dH'] = (dHd.cpu().numpy().astype(np.float64)[:, :hL], dH)
     if cdisp:
-        e = np.exp(tw)
-        chain = np.where((e >= 1e-3) & (e <= 1e4), e, 0.0)
         # oracle returns d loss / d theta_w already chained when theta_w is given
         out['g_theta'] = (gth.cpu().numpy().astype(np.float64)[:G], dth)
     return out
@@ -154,8 +152,7 @@ def test_heads_fused_no_perm_and_determinism(ops):
         assert np.array_equal(np.asarray(a[k][0]), np.asarray(b[k][0])), k
 
 
-def test_heads_fused_matches_separate_kernels(ops):
-    """Same operands through the separate entry points (sgemm + zinb_nll + sgemm x2)."""
-    B, G, hL = 192, 777, 64
-    out = run_case(ops, 1, B, G, hL, seed=9)
+def test_heads_fused_ragged_shapes(ops):
+    """Batch and gene counts that end inside a tile (192 = 6 row tiles, 777 genes = 24.3 gene tiles)."""
+    out = run_case(ops, 1, 192, 777, 64, seed=9)
     check(out)
