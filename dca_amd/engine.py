@@ -190,6 +190,11 @@ class Engine:
         self.use_fused = os.environ.get('DCA_AMD_FUSED_HEADS', '1') != '0'
         self.ws_heads = None
         self._pending = None        # in-flight all-reduce of the heads bucket (data parallel)
+        self.opt_kind = 'rmsprop'   # train.py:54-57 picks the Keras optimizer by name
+        self.slot2 = None
+        self.opt_iter = torch.zeros(1, dtype=torch.int64, device=self.dev)
+        self.reg = None             # l1 / l2 kernel regularisers (network.py:114-126)
+        self.reg_ws = None
         self._counts_local_key = self._counts_world_key = None
 
     def _t(self, name):
@@ -267,11 +272,48 @@ class Engine:
     def get_grads(self):
         return self._named(self.g)
 
+    def set_optimizer(self, name):
+        """Keras optimizer by name with its default hyper-parameters; resets the slots."""
+        name = name.lower()
+        if name not in ('sgd', 'rmsprop', 'adagrad', 'adadelta', 'adam', 'adamax'):
+            raise NotImplementedError('optimizer %r is not implemented on the MI355X path (available: SGD, '
+                                      'RMSprop, Adagrad, Adadelta, Adam, Adamax)' % name)
+        self.opt_kind = name
+        self.ms.fill_(0.1 if name == 'adagrad' else 0.0)       # tf.keras initial_accumulator_value
+        self.slot2 = torch.zeros_like(self.ms) if name in ('adadelta', 'adam', 'adamax') else None
+        self.opt_iter.zero_()
+
+    def set_regularizers(self, l1=0., l2=0., l1_enc=0., l2_enc=0.):
+        """kernel_regularizer=l1_l2(..) of every Dense kernel (network.py:114-126, 144-146, 369-380):
+        encoder / centre layers take the *_enc coefficients when those are non-zero."""
+        lay = self.lay
+        center = int(np.floor(len(lay.hidden) / 2.0))
+        segs = []
+        for i in range(len(lay.hidden)):
+            a = l1_enc if (i <= center and l1_enc != 0.) else l1
+            b = l2_enc if (i <= center and l2_enc != 0.) else l2
+            off, shape = lay.seg['W%d' % i]
+            segs.append((off, off + int(np.prod(shape)), a, b))
+        off, shape = lay.seg['Wh']
+        segs.append((off, off + int(np.prod(shape)), l1, l2))
+        segs = [sg for sg in segs if sg[2] != 0. or sg[3] != 0.]
+        self.reg = self.ops.reg_desc(segs) if segs else None
+        self.reg_ws = torch.zeros(self.ops.l1l2_workspace_doubles(), dtype=torch.float64, device=self.dev) \
+            if segs else None
+
+    def add_val_penalty(self):
+        """Keras reports val_loss including the regularisation losses: adds them to acc[1]."""
+        if self.reg is not None and self.comm.rank == 0:
+            self.val_loss_tmp.zero_()
+            self.ops.l1l2_apply(self.reg, self.w, None, self.val_loss_tmp, self.reg_ws)
+            self.ops.step_end(self.val_loss_tmp, 1.0, None, 0, self.acc[1:], None, 0)
+
     def save_state(self, path, fit_state):
         """Full training state after an epoch: parameters, RMSprop slots, BN moving statistics
         and the fit loop's scalars (epoch, lr, callback counters, history)."""
         import json
-        np.savez(path, w=self.w.cpu().numpy(), ms=self.ms.cpu().numpy(),
+        extra = {} if self.slot2 is None else {'slot2': self.slot2.cpu().numpy()}
+        np.savez(path, w=self.w.cpu().numpy(), ms=self.ms.cpu().numpy(), opt_iter=self.opt_iter.cpu().numpy(), **extra,
                  **{'mm%d' % i: t.cpu().numpy() for i, t in enumerate(self.mm)},
                  **{'mv%d' % i: t.cpu().numpy() for i, t in enumerate(self.mv)},
                  fit=np.frombuffer(json.dumps(fit_state).encode(), dtype=np.uint8))
@@ -282,6 +324,10 @@ class Engine:
             assert z['w'].shape[0] == self.w.shape[0], 'checkpoint belongs to a different network'
             self.w.copy_(torch.as_tensor(z['w']))
             self.ms.copy_(torch.as_tensor(z['ms']))
+            if 'opt_iter' in z.files:
+                self.opt_iter.copy_(torch.as_tensor(z['opt_iter']))
+            if self.slot2 is not None and 'slot2' in z.files:
+                self.slot2.copy_(torch.as_tensor(z['slot2']))
             for i in range(len(self.mm)):
                 self.mm[i].copy_(torch.as_tensor(z['mm%d' % i]))
                 self.mv[i].copy_(torch.as_tensor(z['mv%d' % i]))
@@ -474,8 +520,15 @@ class Engine:
             if self._pending is not None:
                 self._pending.wait()
                 self._pending = None
-        with self._t('rmsprop_clip'):
-            ops.rmsprop_clip(w, g, self.ms, lay.P, self.lr, RMS_RHO, RMS_EPS, self.clip)
+        if self.reg is not None:           # after the exchange: every rank adds the same terms once
+            ops.l1l2_apply(self.reg, w, g, g[lay.P:], self.reg_ws)
+        if self.opt_kind == 'rmsprop':
+            with self._t('rmsprop_clip'):
+                ops.rmsprop_clip(w, g, self.ms, lay.P, self.lr, RMS_RHO, RMS_EPS, self.clip)
+        else:
+            ops.optimizer_step(self.opt_kind, w, g, None if self.opt_kind == 'sgd' else self.ms,
+                               self.slot2, lay.P, self.lr, self.opt_iter, self.clip)
+            ops.counter_add(self.opt_iter, 1)
         ops.step_end(g[lay.P:], float(Bg), self.hist, rows_per_slot or max(self.Bmax, 1), self.acc,
                      self.cursor, B)
 

@@ -19,6 +19,17 @@ NLL_CONST_DISP = 2
 NLL_POISSON = 4
 NLL_MSE = 8
 
+REG_MAX_SEGS = 16
+
+
+class RegDesc(_c.Structure):
+    """dcahip_reg_desc (include/dcahip.h)."""
+    _fields_ = [('nseg', _c.c_int), ('start', _c.c_long * REG_MAX_SEGS), ('end', _c.c_long * REG_MAX_SEGS),
+                ('l1', _c.c_float * REG_MAX_SEGS), ('l2', _c.c_float * REG_MAX_SEGS)]
+
+
+OPT_KINDS = {'sgd': 0, 'rmsprop': 1, 'adagrad': 2, 'adadelta': 3, 'adam': 4, 'adamax': 5}
+
 _SIGNATURES = {
     'dcahip_version': (_c.c_int, []),
     'dcahip_zinb_max_partials': (_c.c_int, []),
@@ -55,6 +66,11 @@ _SIGNATURES = {
                                    _c.c_long, _vp]),
     'dcahip_relu_fwd': (_c.c_int, [_f32p, _c.c_long, _c.c_int, _c.c_int, _f32p, _c.c_long, _vp]),
     'dcahip_colsum_chain': (_c.c_int, [_f32p, _c.c_long, _c.c_int, _c.c_int, _f32p, _f32p, _vp]),
+    'dcahip_optimizer_step': (_c.c_int, [_c.c_int, _f32p, _f32p, _f32p, _f32p, _c.c_long, _f32p, _i64p,
+                                         _c.c_float, _vp]),
+    'dcahip_counter_add': (_c.c_int, [_i64p, _c.c_int, _vp]),
+    'dcahip_l1l2_workspace_doubles': (_c.c_int, []),
+    'dcahip_l1l2_apply': (_c.c_int, [_c.POINTER(RegDesc), _f32p, _f32p, _f32p, _f64p, _vp]),
     'dcahip_prep_chunks': (_c.c_int, [_c.c_int]),
     'dcahip_prep_row_sums': (_c.c_int, [_f32p, _c.c_long, _c.c_int, _c.c_int, _f32p, _vp]),
     'dcahip_prep_col_pass': (_c.c_int, [_f32p, _c.c_long, _c.c_int, _c.c_int, _f32p, _c.c_int, _f32p,

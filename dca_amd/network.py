@@ -111,8 +111,6 @@ class Autoencoder():
             unsupported.append('init=%r' % self.init)
         if any(d > 0.0 for d in self.hidden_dropout) or self.input_dropout > 0.0:
             unsupported.append('dropout')
-        if any(c != 0. for c in (self.l1_coef, self.l2_coef, self.l1_enc_coef, self.l2_enc_coef)):
-            unsupported.append('l1/l2 weight regularisation')
         if unsupported:
             raise NotImplementedError('not implemented on the MI355X path yet: ' + ', '.join(unsupported))
 
@@ -125,6 +123,7 @@ class Autoencoder():
                                      self.hidden_size, self.batchnorm, self.ridge, ops=ops,
                                      comm=self.comm)
         self.engine.init_params(self.seed)
+        self.engine.set_regularizers(self.l1_coef, self.l2_coef, self.l1_enc_coef, self.l2_enc_coef)
         self.model = self.engine             # what train() drives (reference: the Keras Model)
         self.encoder = self.engine
         self.loss = self.ae_type

@@ -117,6 +117,31 @@ class HipOps:
         hip.check(self.L.dcahip_colsum_chain(p(x), ldx, B, N, p(theta_w), p(out), hip.stream()),
                   'colsum_chain')
 
+    # ------------------------------------------------------------------ other optimizers, regularisers
+    def optimizer_step(self, kind, w, g, slot1, slot2, n, lr, it, clip):
+        p = hip.ptr
+        hip.check(self.L.dcahip_optimizer_step(hip.OPT_KINDS[kind], p(w), p(g), p(slot1), p(slot2), n, p(lr),
+                                               p(it), clip, hip.stream()), 'optimizer_step')
+
+    def counter_add(self, counter, v):
+        hip.check(self.L.dcahip_counter_add(hip.ptr(counter), v, hip.stream()), 'counter_add')
+
+    def reg_desc(self, segs):
+        """segs: list of (start, end, l1, l2) over the flat parameter buffer."""
+        d = hip.RegDesc()
+        d.nseg = len(segs)
+        for k, (a, b, l1, l2) in enumerate(segs):
+            d.start[k], d.end[k], d.l1[k], d.l2[k] = int(a), int(b), float(l1), float(l2)
+        return d
+
+    def l1l2_workspace_doubles(self):
+        return self.L.dcahip_l1l2_workspace_doubles()
+
+    def l1l2_apply(self, desc, w, g, loss_inout, ws):
+        p = hip.ptr
+        hip.check(self.L.dcahip_l1l2_apply(ctypes.byref(desc), p(w), p(g), p(loss_inout), p(ws),
+                                           hip.stream()), 'l1l2_apply')
+
     # ------------------------------------------------------------------ preprocessing
     def prep_chunks(self, n):
         return self.L.dcahip_prep_chunks(n)

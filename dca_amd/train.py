@@ -21,6 +21,10 @@ import torch
 from . import dist as ddist
 
 
+KERAS_DEFAULT_LR = {'sgd': 0.01, 'rmsprop': 0.001, 'adagrad': 0.001, 'adadelta': 0.001, 'adam': 0.001,
+                    'adamax': 0.001}
+
+
 class History:
     """Stand-in for keras.callbacks.History (api.py:205-206 reads ``.history``)."""
 
@@ -120,6 +124,8 @@ def fit_engine(eng, n_train_global, n_val_global, nt_local, nv_local, t0_global,
             runner.step(counts[t][comm.rank], sum(counts[t]), counts[t], b_local)
         if nv_local > 0:
             eng.eval_loss_sum(nt_local, nt_local + nv_local, val_scale)
+        if n_val_global > 0:
+            eng.add_val_penalty()
         if W > 1:
             comm.all_reduce_sum(eng.acc[1:])
         acc = eng.acc.cpu().numpy()                            # the one host sync per epoch
@@ -200,14 +206,16 @@ def train(adata, network, output_dir=None, optimizer='RMSprop', learning_rate=No
           validation_split=0.1, tensorboard=False, verbose=True, threads=None,
           **kwds):
     """Signature and defaults of dca/train.py:35-39.  ``threads`` (TF CPU pools) and
-    ``tensorboard`` have no meaning on the GPU path and are accepted and ignored; optimizers
-    other than RMSprop are not implemented yet and raise."""
-    if optimizer.lower() != 'rmsprop':
-        raise NotImplementedError("optimizer %r: only 'RMSprop' (the reference default, "
-                                  'train.py:35) is implemented on the MI355X path' % optimizer)
+    ``tensorboard`` have no meaning on the GPU path and are accepted and ignored; optimizers:
+    SGD, RMSprop, Adagrad, Adadelta, Adam, Adamax (Keras defaults); Nadam raises."""
     eng = network.engine
     if eng is None:
         raise RuntimeError('network.build() must be called before train()')
+    # train.py:54-57: opt.__dict__[optimizer](lr=learning_rate, clipvalue=clip_grad), the optimizer's
+    # own default learning rate when none is given
+    eng.set_optimizer(optimizer)
+    if learning_rate is None:
+        learning_rate = KERAS_DEFAULT_LR[optimizer.lower()]
     if output_dir is not None:
         os.makedirs(output_dir, exist_ok=True)
 

@@ -235,6 +235,39 @@ int dcahip_prep_scale(float* X, long ldx, int n, int G, const float* mean, const
 int dcahip_rmsprop_clip(float* w, const float* g, float* ms, long n, const float* lr,
                         float rho, float eps, float clip, void* stream);
 
+/*
+ * K-OPT: the other Keras optimizers selectable through dca/train.py:54-57 and the l1 / l2 kernel
+ * regularisers of dca/network.py:114-126,144-146,369-380, on the flat parameter buffer.
+ * dcahip_optimizer_step: g clipped to [-clip, clip] (clip <= 0: off), then the tf.keras update
+ * with default hyper-parameters (formulas in dcahip_opt.hip); slot1 / slot2 are the optimizer's
+ * state buffers ([n], may be NULL where the optimizer has none: SGD none, Adagrad slot1 (init 0.1),
+ * Adadelta / Adam / Adamax both).  *iter = completed steps (device memory; Adam / Adamax bias
+ * correction), advanced by dcahip_counter_add.  RMSprop is dcahip_rmsprop_clip.
+ * dcahip_l1l2_apply: for each segment [start, end) of the flat buffer: g += l1 sign(w) + 2 l2 w
+ * (g may be NULL: penalty only) and *loss_inout += sum l1 |w| + l2 w^2 (Keras adds the
+ * regularisation losses to the reported loss, training and validation).
+ */
+#define DCAHIP_OPT_SGD       0
+#define DCAHIP_OPT_RMSPROP   1
+#define DCAHIP_OPT_ADAGRAD   2
+#define DCAHIP_OPT_ADADELTA  3
+#define DCAHIP_OPT_ADAM      4
+#define DCAHIP_OPT_ADAMAX    5
+int dcahip_optimizer_step(int kind, float* w, const float* g, float* slot1, float* slot2, long n,
+                          const float* lr, const long long* iter, float clip, void* stream);
+int dcahip_counter_add(long long* counter, int v, void* stream);
+#define DCAHIP_REG_MAX_SEGS 16
+typedef struct {
+    int nseg;
+    long start[DCAHIP_REG_MAX_SEGS];
+    long end[DCAHIP_REG_MAX_SEGS];
+    float l1[DCAHIP_REG_MAX_SEGS];
+    float l2[DCAHIP_REG_MAX_SEGS];
+} dcahip_reg_desc;
+int dcahip_l1l2_workspace_doubles(void);
+int dcahip_l1l2_apply(const dcahip_reg_desc* d, const float* w, float* g, float* loss_inout,
+                      double* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

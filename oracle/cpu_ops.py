@@ -262,6 +262,46 @@ class CpuRefOps:
             s = s * np.where((e >= 1e-3) & (e <= 1e4), e, 0.0)
         _vec(out, N)[:] = s
 
+    # ------------------------------------------------------------------ other optimizers, regularisers
+    def optimizer_step(self, kind, w, g, slot1, slot2, n, lr, it, clip):
+        from . import net_np as N
+        wv = _vec(w, n)
+        gv = _vec(g, n).astype(np.float64)
+        a = _vec(slot1, n) if slot1 is not None else None
+        b = _vec(slot2, n) if slot2 is not None else None
+        t = (int(it[0].item()) if it is not None else 0) + 1
+        nw, na, nb = N.optimizer_update(kind, wv.astype(np.float64), gv,
+                                        None if a is None else a.astype(np.float64),
+                                        None if b is None else b.astype(np.float64),
+                                        float(lr[0].item()), t, clip)
+        wv[:] = nw
+        if a is not None:
+            a[:] = na
+        if b is not None:
+            b[:] = nb
+
+    def counter_add(self, counter, v):
+        counter[0] += v
+
+    def reg_desc(self, segs):
+        return [(int(a), int(b), float(l1), float(l2)) for a, b, l1, l2 in segs]
+
+    def l1l2_workspace_doubles(self):
+        return 16
+
+    def l1l2_apply(self, desc, w, g, loss_inout, ws):
+        pen = 0.0
+        for a, b, l1, l2 in desc:
+            if b <= a or (l1 == 0 and l2 == 0):
+                continue
+            x = torch.as_strided(w, (b - a,), (1,), w.storage_offset() + a).numpy().astype(np.float64)
+            if g is not None:
+                gv = torch.as_strided(g, (b - a,), (1,), g.storage_offset() + a).numpy()
+                gv[:] = gv + l1 * np.sign(x) + 2 * l2 * x
+            pen += l1 * np.abs(x).sum() + l2 * np.square(x).sum()
+        if loss_inout is not None and pen != 0.0:
+            loss_inout[0] = float(np.float32(float(loss_inout[0].item()) + pen))
+
     # ------------------------------------------------------------------ preprocessing
     def prep_chunks(self, n):
         return max(1, min(512, (n + 127) // 128))

@@ -72,8 +72,9 @@ def is_trainable(name):
 
 
 class OracleAE:
-    def __init__(self, ae_type, params, hidden_size, batchnorm=True, ridge=0.0):
+    def __init__(self, ae_type, params, hidden_size, batchnorm=True, ridge=0.0, reg=(0., 0., 0., 0.)):
         assert ae_type in AE_TYPES
+        self.reg = tuple(float(x) for x in reg)          # l1, l2, l1_enc, l2_enc (network.py:114-126)
         self.ae_type = ae_type
         self.p = params
         self.hidden_size = tuple(hidden_size)
@@ -137,6 +138,11 @@ class OracleAE:
         c = self.forward(X, sf, training=True)
         _, loss, d_mean, d_disp, d_pi = self._loss_grads(c, Y, n_total)
         g = {}
+        pen, greg = (0.0, {})
+        if any(self.reg):
+            pen, greg = reg_penalty_and_grads({k: v for k, v in p.items() if is_trainable(k)},
+                                              len(self.hidden_size), *self.reg)
+            loss = loss + pen
         HL = c['H'][-1]
         g['W_mean'] = HL.T @ d_mean
         g['b_mean'] = d_mean.sum(axis=0)
@@ -163,7 +169,15 @@ class OracleAE:
             g['b%d' % i] = dZ.sum(axis=0)
             if i > 0:
                 dH = dZ @ p['W%d' % i].T
+        for k, v in greg.items():
+            g[k] = g[k] + v
         return loss, g
+
+    def reg_penalty(self):
+        if not any(self.reg):
+            return 0.0
+        return reg_penalty_and_grads({k: v for k, v in self.p.items() if is_trainable(k)},
+                                     len(self.hidden_size), *self.reg)[0]
 
     def eval_loss_sum(self, X, Y, sf):
         """Inference-mode sum of element-wise NLL over the given rows."""
@@ -194,6 +208,62 @@ def rmsprop_step(params, grads, ms, lr, rho=0.9, eps=1e-7, clip=5.0):
             ms[k] = np.zeros_like(params[k])
         ms[k] = dt.type(rho) * ms[k] + dt.type(1 - rho) * np.square(g)
         params[k] = params[k] - dt.type(lr) * g / np.sqrt(ms[k] + dt.type(eps))
+
+
+KERAS_DEFAULT_LR = {'sgd': 0.01, 'rmsprop': 0.001, 'adagrad': 0.001, 'adadelta': 0.001, 'adam': 0.001,
+                    'adamax': 0.001}
+
+
+def optimizer_update(kind, w, g, a, b, lr, t, clip=5.0):
+    """One tf.keras optimizer update with default hyper-parameters (train.py:54-57 selects the
+    class by name); a, b = the optimizer's slots (None where absent); t = 1-based step."""
+    if clip is not None and clip > 0:
+        g = np.clip(g, -clip, clip)
+    if kind == 'sgd':
+        return w - lr * g, a, b
+    if kind == 'rmsprop':
+        a = 0.9 * a + 0.1 * g * g
+        return w - lr * g / np.sqrt(a + 1e-7), a, b
+    if kind == 'adagrad':
+        a = a + g * g
+        return w - lr * g / (np.sqrt(a) + 1e-7), a, b
+    if kind == 'adadelta':
+        a = 0.95 * a + 0.05 * g * g
+        u = g * np.sqrt(b + 1e-7) / np.sqrt(a + 1e-7)
+        b = 0.95 * b + 0.05 * u * u
+        return w - lr * u, a, b
+    if kind == 'adam':
+        a = 0.9 * a + 0.1 * g
+        b = 0.999 * b + 0.001 * g * g
+        return w - lr * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t) * a / (np.sqrt(b) + 1e-7), a, b
+    if kind == 'adamax':
+        a = 0.9 * a + 0.1 * g
+        b = np.maximum(0.999 * b, np.abs(g))
+        return w - lr / (1 - 0.9 ** t) * a / (b + 1e-7), a, b
+    raise ValueError(kind)
+
+
+def reg_coefs(name, n_hidden, l1, l2, l1_enc, l2_enc):
+    """(l1, l2) of parameter `name` (dca/network.py:101-126: encoder-specific coefficients for the
+    encoder and centre Dense kernels when non-zero; heads use l1/l2; biases / beta / theta: none)."""
+    if name.startswith('W_'):
+        return l1, l2
+    if name[0] == 'W' and name[1:].isdigit():
+        i = int(name[1:])
+        enc = i <= int(np.floor(n_hidden / 2.0))
+        return (l1_enc if (enc and l1_enc != 0.) else l1), (l2_enc if (enc and l2_enc != 0.) else l2)
+    return 0.0, 0.0
+
+
+def reg_penalty_and_grads(params, n_hidden, l1, l2, l1_enc, l2_enc):
+    pen, g = 0.0, {}
+    for k, v in params.items():
+        a, b = reg_coefs(k, n_hidden, l1, l2, l1_enc, l2_enc)
+        if a == 0. and b == 0.:
+            continue
+        pen += a * np.abs(v).sum() + b * np.square(v).sum()
+        g[k] = a * np.sign(v) + 2 * b * v
+    return pen, g
 
 
 # ------------------------------------------------------------------ callbacks
@@ -234,7 +304,7 @@ class EarlyStopping:
 
 def fit(net, X, Y, sf, epochs=300, batch_size=32, validation_split=0.1, learning_rate=None,
         clip_grad=5.0, reduce_lr=10, early_stop=15, shuffle_rng=np.random, val_batch_size=None,
-        on_batch=None):
+        on_batch=None, optimizer='rmsprop'):
     """Keras Model.fit as train.py:91-98 drives it. Returns history dict (loss, val_loss, lr).
 
     shuffle_rng: object with .shuffle (the numpy global RNG in the reference).
@@ -243,8 +313,10 @@ def fit(net, X, Y, sf, epochs=300, batch_size=32, validation_split=0.1, learning
     split_at = int(n * (1.0 - validation_split)) if validation_split else n
     Xt, Yt, sft = X[:split_at], Y[:split_at], sf[:split_at]
     Xv, Yv, sfv = X[split_at:], Y[split_at:], sf[split_at:]
-    lr = float(np.float32(0.001 if learning_rate is None else learning_rate))
+    optimizer = optimizer.lower()
+    lr = float(np.float32(KERAS_DEFAULT_LR[optimizer] if learning_rate is None else learning_rate))
     ms = {}
+    slots, step = {}, 0
     rl = ReduceLROnPlateau(reduce_lr) if reduce_lr else None
     es = EarlyStopping(early_stop) if early_stop else None
     hist = {'loss': [], 'val_loss': [], 'lr': []}
@@ -257,7 +329,17 @@ def fit(net, X, Y, sf, epochs=300, batch_size=32, validation_split=0.1, learning
         for s in range(0, split_at, batch_size):
             b = idx[s:s + batch_size]
             loss, g = net.loss_and_grads(Xt[b], Yt[b], sft[b])
-            rmsprop_step(net.p, g, ms, lr, clip=clip_grad)
+            if optimizer == 'rmsprop':
+                rmsprop_step(net.p, g, ms, lr, clip=clip_grad)
+            else:
+                step += 1
+                for k, gk in g.items():
+                    if k not in slots:
+                        slots[k] = (np.full_like(net.p[k], 0.1 if optimizer == 'adagrad' else 0.0),
+                                    np.zeros_like(net.p[k]))
+                    s1, s2 = slots[k]
+                    net.p[k], s1, s2 = optimizer_update(optimizer, net.p[k], gk, s1, s2, lr, step, clip_grad)
+                    slots[k] = (s1, s2)
             tot += float(loss) * len(b)
             if on_batch is not None:
                 on_batch(epoch, s // batch_size, float(loss))
@@ -269,7 +351,7 @@ def fit(net, X, Y, sf, epochs=300, batch_size=32, validation_split=0.1, learning
                 e = min(s + vb, len(Xv))
                 # Keras averages per-batch means weighted by batch size == sum / (nv*G)
                 vt += float(net.eval_loss_sum(Xv[s:e], Yv[s:e], sfv[s:e])) / G
-            val = vt / len(Xv)
+            val = vt / len(Xv) + net.reg_penalty()
             hist['val_loss'].append(val)
             if rl is not None:
                 lr = rl.on_epoch_end(val, lr)

@@ -70,3 +70,20 @@ def test_predict_matches_oracle():
                 np.testing.assert_allclose(out[k].numpy(), ref[k][s:s + b], rtol=2e-5, atol=1e-6, err_msg=k)
         if eng.lay.const_disp:
             np.testing.assert_allclose(eng.const_dispersion(), ref['dispersion'], rtol=1e-6)
+
+
+@pytest.mark.parametrize('optimizer', __import__('_opt_cases').OPTIMIZERS)
+def test_other_optimizers_fit_matches_oracle(optimizer):
+    """train.py:54-57 picks the Keras optimizer by name: host logic (slots, step counter, default
+    learning rate) against the oracle's restatement of the tf.keras updates."""
+    from _opt_cases import run_fit_parity
+    run_fit_parity(CpuRefOps(), optimizer=optimizer)
+
+
+@pytest.mark.parametrize('reg', __import__('_opt_cases').REG_CASES)
+def test_l1_l2_regularisers_fit_matches_oracle(reg):
+    """network.py:114-126: l1/l2 (encoder-specific when given) on the Dense kernels: penalty in the
+    reported loss and val_loss, sign/2w terms in the gradients before clipvalue."""
+    from _opt_cases import run_fit_parity
+    run_fit_parity(CpuRefOps(), reg=reg)
+    run_fit_parity(CpuRefOps(), optimizer='Adam', reg=reg, ae_type='nb')

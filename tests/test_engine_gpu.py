@@ -204,3 +204,16 @@ def test_full_size_step_fused_equals_separate(ops):
             assert scale < 1e-6 * gu.abs().max().item()         # Dense bias feeding BatchNorm: identically 0
             continue
         assert (a - b).abs().max().item() <= 5e-5 * scale, (name, (a - b).abs().max().item(), scale)
+
+
+@pytest.mark.parametrize('optimizer', __import__('_opt_cases').OPTIMIZERS)
+def test_other_optimizers_fit_matches_oracle(ops, optimizer):
+    from _opt_cases import run_fit_parity
+    run_fit_parity(ops, optimizer=optimizer, rtol=1e-4)
+
+
+@pytest.mark.parametrize('reg', __import__('_opt_cases').REG_CASES)
+def test_l1_l2_regularisers_fit_matches_oracle(ops, reg):
+    from _opt_cases import run_fit_parity
+    run_fit_parity(ops, reg=reg, rtol=1e-4)
+    run_fit_parity(ops, optimizer='Adam', reg=reg, ae_type='nb', rtol=1e-4)
