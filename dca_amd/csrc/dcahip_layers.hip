@@ -20,6 +20,40 @@ namespace {
 constexpr int kMaxChunks = 256;
 constexpr int kApplyRows = 16;   // rows per workgroup in the apply kernels (256 workgroups at B = 4096)
 
+// Activation codes (the `act` / `relu` arguments of the C ABI): keras.activations names accepted by
+// Activation(self.activation) and LeakyReLU (alpha 0.3), dca/network.py:132-135.
+//   0 linear  1 relu  2 tanh  3 sigmoid  4 elu  5 selu  6 softplus  7 softsign  8 LeakyReLU(0.3)
+constexpr float kSeluScale = 1.0507009873554805f, kSeluAlpha = 1.6732632423543772f;
+
+__device__ __forceinline__ float act_fwd(int a, float x) {
+    switch (a) {
+        case 0: return x;
+        case 1: return fmaxf(x, 0.f);
+        case 2: return tanhf(x);
+        case 3: { const float e = expf(-fabsf(x)); const float s = 1.f / (1.f + e); return x >= 0.f ? s : e * s; }
+        case 4: return x > 0.f ? x : expm1f(x);
+        case 5: return kSeluScale * (x > 0.f ? x : kSeluAlpha * expm1f(x));
+        case 6: return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x)));
+        case 7: return x / (1.f + fabsf(x));
+        default: return x > 0.f ? x : 0.3f * x;
+    }
+}
+
+// derivative expressed through the OUTPUT h = act(x) (what the backward pass has at hand)
+__device__ __forceinline__ float act_grad(int a, float h) {
+    switch (a) {
+        case 0: return 1.f;
+        case 1: return h > 0.f ? 1.f : 0.f;
+        case 2: return 1.f - h * h;
+        case 3: return h * (1.f - h);
+        case 4: return h > 0.f ? 1.f : h + 1.f;
+        case 5: return h > 0.f ? kSeluScale : h + kSeluScale * kSeluAlpha;
+        case 6: return -expm1f(-h);                          // sigmoid(x) = 1 - exp(-softplus(x))
+        case 7: { const float t = 1.f - fabsf(h); return t * t; }
+        default: return h > 0.f ? 1.f : 0.3f;
+    }
+}
+
 __host__ __device__ inline int n_chunks(int B) {
     int r = (B + 63) / 64;           // 64 chunks at B = 4096: every apply workgroup re-merges them
     return r < 1 ? 1 : (r > kMaxChunks ? kMaxChunks : r);
@@ -194,7 +228,7 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(BnApplyArgs a) {
             const float xh = (a.Z[(long)i * a.ldz + c] - mean) * inv;
             if (a.xhat) a.xhat[(long)i * a.ldx + c] = xh;
             float y = xh + beta;
-            if (a.relu) y = fmaxf(y, 0.f);
+            y = act_fwd(a.relu, y);
             a.Hout[(long)i * a.ldh + c] = y;
         }
     }
@@ -204,7 +238,7 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(BnApplyArgs a) {
 __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(const float* dH, long ldd,
                                                           const float* Hact, long ldh,
                                                           const float* xhat, long ldx, int B, int H,
-                                                          float* part) {
+                                                          float* part, int act) {
     __shared__ float sm[256];
     const int R = gridDim.x, r = blockIdx.x;
     const int cr = chunk_rows(B, R);
@@ -216,7 +250,7 @@ __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(const float* dH, long 
         if (c < H)
 #pragma unroll 8
         for (int i = r0 + ty; i < r1; i += 4) {
-            const float dy = Hact[(long)i * ldh + c] > 0.f ? dH[(long)i * ldd + c] : 0.f;
+            const float dy = dH[(long)i * ldd + c] * act_grad(act, Hact[(long)i * ldh + c]);
             s1 += dy; s2 += dy * xhat[(long)i * ldx + c];
         }
         const float t1 = wg_rowlane_sum(s1, sm);
@@ -231,7 +265,7 @@ __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(const float* dH, long 
 struct BnBwdArgs {
     const float* dH; long ldd; const float* Hact; long ldh; const float* xhat; long ldx;
     const float* inv_std; const float* sums; int E; float n_total; int B, H;
-    float* dZ; long ldz; float* dbeta;
+    float* dZ; long ldz; float* dbeta; int act;
 };
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
@@ -263,27 +297,27 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
         if (c >= a.H) continue;
         const float m1 = s1[c], m2 = s2[c], inv = a.inv_std[c];
         for (int i = r0 + ty; i < r1; i += 4) {
-            const float dy = a.Hact[(long)i * a.ldh + c] > 0.f ? a.dH[(long)i * a.ldd + c] : 0.f;
+            const float dy = a.dH[(long)i * a.ldd + c] * act_grad(a.act, a.Hact[(long)i * a.ldh + c]);
             a.dZ[(long)i * a.ldz + c] = inv * (dy - m1 - a.xhat[(long)i * a.ldx + c] * m2);
         }
     }
 }
 
 __global__ __launch_bounds__(256) void relu_bwd_kernel(const float* dH, long ldd, const float* Hact,
-                                                       long ldh, int B, int H, float* dZ, long ldz) {
+                                                       long ldh, int B, int H, float* dZ, long ldz, int act) {
     const long total = (long)B * H;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int r = (int)(i / H), c = (int)(i - (long)r * H);
-        dZ[(long)r * ldz + c] = Hact[(long)r * ldh + c] > 0.f ? dH[(long)r * ldd + c] : 0.f;
+        dZ[(long)r * ldz + c] = dH[(long)r * ldd + c] * act_grad(act, Hact[(long)r * ldh + c]);
     }
 }
 
 __global__ __launch_bounds__(256) void relu_fwd_kernel(const float* Z, long ldz, int B, int H,
-                                                       float* Hout, long ldh) {
+                                                       float* Hout, long ldh, int act) {
     const long total = (long)B * H;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int r = (int)(i / H), c = (int)(i - (long)r * H);
-        Hout[(long)r * ldh + c] = fmaxf(Z[(long)r * ldz + c], 0.f);
+        Hout[(long)r * ldh + c] = act_fwd(act, Z[(long)r * ldz + c]);
     }
 }
 
@@ -375,20 +409,20 @@ extern "C" int dcahip_bn_relu_apply(const float* Z, long ldz, int B, int H, cons
 
 extern "C" int dcahip_bn_bwd_sums(const float* dH, long ldd, const float* Hact, long ldh,
                                   const float* xhat, long ldx, int B, int H, float* part,
-                                  void* stream) {
+                                  int act, void* stream) {
     if (!dH || !Hact || !xhat || !part || B <= 0 || H <= 0) return DCAHIP_EINVAL;
     hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(n_chunks(B)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), dH, ldd, Hact, ldh, xhat, ldx, B, H, part);
+                       static_cast<hipStream_t>(stream), dH, ldd, Hact, ldh, xhat, ldx, B, H, part, act);
     return (int)hipGetLastError();
 }
 
 extern "C" int dcahip_bn_bwd_apply(const float* dH, long ldd, const float* Hact, long ldh,
                                    const float* xhat, long ldx, const float* inv_std,
                                    const float* sums, int E, float n_total, int B, int H, float* dZ,
-                                   long ldz, float* dbeta, void* stream) {
+                                   long ldz, float* dbeta, int act, void* stream) {
     if (!dH || !Hact || !xhat || !inv_std || !sums || !dZ || E <= 0 || B <= 0 || H <= 0)
         return DCAHIP_EINVAL;
-    BnBwdArgs a{dH, ldd, Hact, ldh, xhat, ldx, inv_std, sums, E, n_total, B, H, dZ, ldz, dbeta};
+    BnBwdArgs a{dH, ldd, Hact, ldh, xhat, ldx, inv_std, sums, E, n_total, B, H, dZ, ldz, dbeta, act};
     const int grid = (B + kApplyRows - 1) / kApplyRows;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 2 * H * sizeof(float),
                        static_cast<hipStream_t>(stream), a);
@@ -396,22 +430,22 @@ extern "C" int dcahip_bn_bwd_apply(const float* dH, long ldd, const float* Hact,
 }
 
 extern "C" int dcahip_relu_bwd(const float* dH, long ldd, const float* Hact, long ldh, int B, int H,
-                               float* dZ, long ldz, void* stream) {
+                               float* dZ, long ldz, int act, void* stream) {
     if (!dH || !Hact || !dZ || B <= 0 || H <= 0) return DCAHIP_EINVAL;
     long g = ((long)B * H + 255) / 256;
     if (g > 2048) g = 2048;
     hipLaunchKernelGGL(relu_bwd_kernel, dim3((int)g), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       dH, ldd, Hact, ldh, B, H, dZ, ldz);
+                       dH, ldd, Hact, ldh, B, H, dZ, ldz, act);
     return (int)hipGetLastError();
 }
 
 extern "C" int dcahip_relu_fwd(const float* Z, long ldz, int B, int H, float* Hout, long ldh,
-                               void* stream) {
+                               int act, void* stream) {
     if (!Z || !Hout || B <= 0 || H <= 0) return DCAHIP_EINVAL;
     long g = ((long)B * H + 255) / 256;
     if (g > 2048) g = 2048;
     hipLaunchKernelGGL(relu_fwd_kernel, dim3((int)g), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       Z, ldz, B, H, Hout, ldh);
+                       Z, ldz, B, H, Hout, ldh, act);
     return (int)hipGetLastError();
 }
 

@@ -35,6 +35,8 @@ AE_HEADS = {                      # ae_type -> (heads in the fused block, const 
     'poisson': (('mean',), False),                       # network.py:233-246 (poisson_loss)
     'normal': (('mean',), False),                        # network.py:143-156 (mse_loss, linear mean)
 }
+ACT_CODES = {'linear': 0, 'relu': 1, 'tanh': 2, 'sigmoid': 3, 'elu': 4, 'selu': 5, 'softplus': 6,
+             'softsign': 7, 'LeakyReLU': 8}
 AE_LOSS_FLAG = {'poisson': 4, 'normal': 8}              # DCAHIP_NLL_POISSON / DCAHIP_NLL_MSE
 
 
@@ -149,7 +151,7 @@ class ParamLayout:
 
 class Engine:
     def __init__(self, ae_type, input_size, output_size=None, hidden_size=(64, 32, 64),
-                 batchnorm=True, ridge=0.0, ops=None, comm=None, device=None):
+                 batchnorm=True, ridge=0.0, ops=None, comm=None, device=None, activation='relu'):
         if ae_type not in AE_HEADS:
             raise NotImplementedError('ae_type %r is not available on the MI355X path yet '
                                       '(supported: %s)' % (ae_type, ', '.join(AE_HEADS)))
@@ -164,6 +166,10 @@ class Engine:
         output_size = input_size if output_size is None else output_size
         self.lay = ParamLayout(ae_type, input_size, output_size, hidden_size, batchnorm)
         self.ridge = float(ridge)
+        if activation not in ACT_CODES:
+            raise NotImplementedError('activation %r is not available on the MI355X path (supported: %s)'
+                                      % (activation, ', '.join(ACT_CODES)))
+        self.act = ACT_CODES[activation]       # Activation(self.activation), network.py:132-135
         lay = self.lay
         self.has_pi = 'pi' in lay.heads
         self.flags = (1 if self.has_pi else 0) | (2 if lay.const_disp else 0) | AE_LOSS_FLAG.get(ae_type, 0)
@@ -438,14 +444,14 @@ class Engine:
                 if training:
                     entries, cnts, E = self._batch_moments(i, B, h, counts)
                     ops.bn_relu_apply(self.Z[i], self.ldh[i], B, h, entries, cnts, E, beta,
-                                      self.mm[i], self.mv[i], BN_MOMENTUM, BN_EPS, True, self.H[i],
+                                      self.mm[i], self.mv[i], BN_MOMENTUM, BN_EPS, self.act, self.H[i],
                                       self.ldh[i], self.XH[i], self.ldh[i], self.inv_std[i])
                 else:
                     ops.bn_relu_apply(self.Z[i], self.ldh[i], B, h, None, None, 0, beta, self.mm[i],
-                                      self.mv[i], BN_MOMENTUM, BN_EPS, True, self.H[i], self.ldh[i],
+                                      self.mv[i], BN_MOMENTUM, BN_EPS, self.act, self.H[i], self.ldh[i],
                                       None, 0, None)
             else:
-                ops.relu_fwd(self.Z[i], self.ldh[i], B, h, self.H[i], self.ldh[i])
+                ops.relu_fwd(self.Z[i], self.ldh[i], B, h, self.H[i], self.ldh[i], self.act)
             K = h
         return K
 
@@ -547,7 +553,7 @@ class Engine:
                 entries, cnts, E = self._batch_moments(i, 0, h, self.counts_world)
                 self.ops.bn_relu_apply(self.Z[i], self.ldh[i], 0, h, entries, cnts, E,
                                        lay.view(self.w, 'beta%d' % i), self.mm[i], self.mv[i],
-                                       BN_MOMENTUM, BN_EPS, True, self.H[i], self.ldh[i], None, 0, None)
+                                       BN_MOMENTUM, BN_EPS, self.act, self.H[i], self.ldh[i], None, 0, None)
         self._launch_heads_bucket()
         for i in reversed(range(len(lay.hidden))):
             if lay.batchnorm:
@@ -577,16 +583,16 @@ class Engine:
             h = lay.hidden[i]
             if lay.batchnorm:
                 ops.bn_bwd_sums(self.dH[i], self.ldh[i], self.H[i], self.ldh[i], self.XH[i],
-                                self.ldh[i], B, h, self.bpart[i])
+                                self.ldh[i], B, h, self.bpart[i], self.act)
                 E = ops.col_moments_chunks(B)
                 if comm.world > 1:
                     E = self._reduce_bwd_sums(i, E, h)
                 ops.bn_bwd_apply(self.dH[i], self.ldh[i], self.H[i], self.ldh[i], self.XH[i],
                                  self.ldh[i], self.inv_std[i], self.bpart[i], E, float(Bg), B, h,
-                                 self.dZ[i], self.ldh[i], lay.view(g, 'beta%d' % i))
+                                 self.dZ[i], self.ldh[i], lay.view(g, 'beta%d' % i), self.act)
             else:
                 ops.relu_bwd(self.dH[i], self.ldh[i], self.H[i], self.ldh[i], B, h, self.dZ[i],
-                             self.ldh[i])
+                             self.ldh[i], self.act)
             Kp = lay.G_in if i == 0 else lay.hidden[i - 1]
             gW = lay.view(g, 'W%d' % i)
             if i == 0:

@@ -28,6 +28,9 @@ class RegDesc(_c.Structure):
                 ('l1', _c.c_float * REG_MAX_SEGS), ('l2', _c.c_float * REG_MAX_SEGS)]
 
 
+ACT_CODES = {'linear': 0, 'relu': 1, 'tanh': 2, 'sigmoid': 3, 'elu': 4, 'selu': 5, 'softplus': 6,
+             'softsign': 7, 'LeakyReLU': 8}
+
 OPT_KINDS = {'sgd': 0, 'rmsprop': 1, 'adagrad': 2, 'adadelta': 3, 'adam': 4, 'adamax': 5}
 
 _SIGNATURES = {
@@ -58,13 +61,13 @@ _SIGNATURES = {
                                         _f32p, _f32p, _f32p, _c.c_float, _c.c_float, _c.c_int,
                                         _f32p, _c.c_long, _f32p, _c.c_long, _f32p, _vp]),
     'dcahip_bn_bwd_sums': (_c.c_int, [_f32p, _c.c_long, _f32p, _c.c_long, _f32p, _c.c_long, _c.c_int,
-                                      _c.c_int, _f32p, _vp]),
+                                      _c.c_int, _f32p, _c.c_int, _vp]),
     'dcahip_bn_bwd_apply': (_c.c_int, [_f32p, _c.c_long, _f32p, _c.c_long, _f32p, _c.c_long, _f32p,
                                        _f32p, _c.c_int, _c.c_float, _c.c_int, _c.c_int, _f32p,
-                                       _c.c_long, _f32p, _vp]),
+                                       _c.c_long, _f32p, _c.c_int, _vp]),
     'dcahip_relu_bwd': (_c.c_int, [_f32p, _c.c_long, _f32p, _c.c_long, _c.c_int, _c.c_int, _f32p,
-                                   _c.c_long, _vp]),
-    'dcahip_relu_fwd': (_c.c_int, [_f32p, _c.c_long, _c.c_int, _c.c_int, _f32p, _c.c_long, _vp]),
+                                   _c.c_long, _c.c_int, _vp]),
+    'dcahip_relu_fwd': (_c.c_int, [_f32p, _c.c_long, _c.c_int, _c.c_int, _f32p, _c.c_long, _c.c_int, _vp]),
     'dcahip_colsum_chain': (_c.c_int, [_f32p, _c.c_long, _c.c_int, _c.c_int, _f32p, _f32p, _vp]),
     'dcahip_optimizer_step': (_c.c_int, [_c.c_int, _f32p, _f32p, _f32p, _f32p, _c.c_long, _f32p, _i64p,
                                          _c.c_float, _vp]),

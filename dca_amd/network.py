@@ -105,7 +105,7 @@ class Autoencoder():
         unsupported = []
         if self.ae_type not in _engine.AE_HEADS:
             unsupported.append('ae_type=%r' % self.ae_type)
-        if self.activation != 'relu':
+        if self.activation not in _engine.ACT_CODES:
             unsupported.append('activation=%r' % self.activation)
         if self.init != 'glorot_uniform':
             unsupported.append('init=%r' % self.init)
@@ -121,7 +121,7 @@ class Autoencoder():
         ops = _test_ops_factory() if _test_ops_factory is not None else None
         self.engine = _engine.Engine(self.ae_type, self.input_size, self.output_size,
                                      self.hidden_size, self.batchnorm, self.ridge, ops=ops,
-                                     comm=self.comm)
+                                     comm=self.comm, activation=self.activation)
         self.engine.init_params(self.seed)
         self.engine.set_regularizers(self.l1_coef, self.l2_coef, self.l1_enc_coef, self.l2_enc_coef)
         self.model = self.engine             # what train() drives (reference: the Keras Model)

@@ -91,25 +91,25 @@ class HipOps:
                                               p(mm), p(mv), momentum, eps, int(relu), p(Hout), ldh,
                                               p(xhat), ldx, p(inv_std), hip.stream()), 'bn_relu_apply')
 
-    def bn_bwd_sums(self, dH, ldd, Hact, ldh, xhat, ldx, B, H, part):
+    def bn_bwd_sums(self, dH, ldd, Hact, ldh, xhat, ldx, B, H, part, act=1):
         p = hip.ptr
         hip.check(self.L.dcahip_bn_bwd_sums(p(dH), ldd, p(Hact), ldh, p(xhat), ldx, B, H, p(part),
-                                            hip.stream()), 'bn_bwd_sums')
+                                            act, hip.stream()), 'bn_bwd_sums')
 
     def bn_bwd_apply(self, dH, ldd, Hact, ldh, xhat, ldx, inv_std, sums, E, n_total, B, H, dZ, ldz,
-                     dbeta):
+                     dbeta, act=1):
         p = hip.ptr
         hip.check(self.L.dcahip_bn_bwd_apply(p(dH), ldd, p(Hact), ldh, p(xhat), ldx, p(inv_std),
                                              p(sums), E, float(n_total), B, H, p(dZ), ldz, p(dbeta),
-                                             hip.stream()), 'bn_bwd_apply')
+                                             act, hip.stream()), 'bn_bwd_apply')
 
-    def relu_bwd(self, dH, ldd, Hact, ldh, B, H, dZ, ldz):
+    def relu_bwd(self, dH, ldd, Hact, ldh, B, H, dZ, ldz, act=1):
         p = hip.ptr
-        hip.check(self.L.dcahip_relu_bwd(p(dH), ldd, p(Hact), ldh, B, H, p(dZ), ldz, hip.stream()),
+        hip.check(self.L.dcahip_relu_bwd(p(dH), ldd, p(Hact), ldh, B, H, p(dZ), ldz, act, hip.stream()),
                   'relu_bwd')
 
-    def relu_fwd(self, Z, ldz, B, H, Hout, ldh):
-        hip.check(self.L.dcahip_relu_fwd(hip.ptr(Z), ldz, B, H, hip.ptr(Hout), ldh, hip.stream()),
+    def relu_fwd(self, Z, ldz, B, H, Hout, ldh, act=1):
+        hip.check(self.L.dcahip_relu_fwd(hip.ptr(Z), ldz, B, H, hip.ptr(Hout), ldh, act, hip.stream()),
                   'relu_fwd')
 
     def colsum_chain(self, x, ldx, B, N, theta_w, out):

@@ -165,7 +165,10 @@ long dcahip_sgemm_workspace_bytes(int ta, int tb, int M, int N, int K, int colsu
  *     writes h, xhat (may be NULL), inv_std[H], and (training) updates
  *        moving = moving - (moving - batch) * (1 - momentum)   (biased variance).
  *     With entries == NULL it runs in INFERENCE mode on moving_mean / moving_var.
- *     relu == 0 skips the activation.  B == 0 is legal (only the moving statistics are
+ *     `relu` is the activation code: 0 linear, 1 relu, 2 tanh, 3 sigmoid, 4 elu, 5 selu, 6 softplus,
+ *     7 softsign, 8 LeakyReLU(0.3) (Activation(self.activation) / advanced activations,
+ *     dca/network.py:132-135); the backward entry points take the same code as `act` and derive
+ *     the slope from the forward OUTPUT h.  B == 0 is legal (only the moving statistics are
  *     updated): a data-parallel rank with an exhausted shard still joins the exchange.
  */
 int dcahip_col_moments_chunks(int B);
@@ -188,15 +191,15 @@ int dcahip_bn_relu_apply(const float* Z, long ldz, int B, int H,
  * Without batch norm use dcahip_relu_bwd (dz = dh*[h>0]).
  */
 int dcahip_bn_bwd_sums(const float* dH, long ldd, const float* Hact, long ldh,
-                       const float* xhat, long ldx, int B, int H, float* part, void* stream);
+                       const float* xhat, long ldx, int B, int H, float* part, int act, void* stream);
 int dcahip_bn_bwd_apply(const float* dH, long ldd, const float* Hact, long ldh,
                         const float* xhat, long ldx, const float* inv_std,
                         const float* sums, int E, float n_total, int B, int H,
-                        float* dZ, long ldz, float* dbeta, void* stream);
+                        float* dZ, long ldz, float* dbeta, int act, void* stream);
 int dcahip_relu_bwd(const float* dH, long ldd, const float* Hact, long ldh, int B, int H,
-                    float* dZ, long ldz, void* stream);
+                    float* dZ, long ldz, int act, void* stream);
 /* h = max(z, 0): Activation('relu') of a stack built with batchnorm=False (network.py:132-135). */
-int dcahip_relu_fwd(const float* Z, long ldz, int B, int H, float* Hout, long ldh, void* stream);
+int dcahip_relu_fwd(const float* Z, long ldz, int B, int H, float* Hout, long ldh, int act, void* stream);
 
 /* out[c] (+)= chain(c) * sum_r x[r, c]; chain = d clip(exp(w),1e-3,1e4)/dw if theta_w given
  * (ConstantDispersionLayer gradient, dca/layers.py:17-21), else 1. */

@@ -222,16 +222,17 @@ class CpuRefOps:
         if xhat is not None:
             _mat(xhat, B, H, ldx)[:] = xh
         y = xh + (_vec(beta, H) if beta is not None else 0.0)
-        if relu:
-            y = np.maximum(y, 0)
+        from . import net_np as N
+        y = N.act_fwd(int(relu), y)
         _mat(Hout, B, H, ldh)[:] = y
         if inv_std is not None:
             _vec(inv_std, H)[:] = inv
 
-    def bn_bwd_sums(self, dH, ldd, Hact, ldh, xhat, ldx, B, H, part):
+    def bn_bwd_sums(self, dH, ldd, Hact, ldh, xhat, ldx, B, H, part, act=1):
+        from . import net_np as N
         R = _chunks(B)
         cr = -(-B // R)
-        dy = _mat(dH, B, H, ldd).astype(np.float64) * (_mat(Hact, B, H, ldh) > 0)
+        dy = _mat(dH, B, H, ldd).astype(np.float64) * N.act_grad_from_out(act, _mat(Hact, B, H, ldh).astype(np.float64))
         xh = _mat(xhat, B, H, ldx).astype(np.float64)
         p = _vec(part, R * 2 * H).reshape(R, 2, H)
         for r in range(R):
@@ -240,20 +241,23 @@ class CpuRefOps:
             p[r, 1] = (dy[s] * xh[s]).sum(0)
 
     def bn_bwd_apply(self, dH, ldd, Hact, ldh, xhat, ldx, inv_std, sums, E, n_total, B, H, dZ, ldz,
-                     dbeta):
+                     dbeta, act=1):
+        from . import net_np as N
         s = _vec(sums, E * 2 * H).reshape(E, 2, H).astype(np.float64).sum(0)
-        dy = _mat(dH, B, H, ldd).astype(np.float64) * (_mat(Hact, B, H, ldh) > 0)
+        dy = _mat(dH, B, H, ldd).astype(np.float64) * N.act_grad_from_out(act, _mat(Hact, B, H, ldh).astype(np.float64))
         xh = _mat(xhat, B, H, ldx).astype(np.float64)
         inv = _vec(inv_std, H).astype(np.float64)
         _mat(dZ, B, H, ldz)[:] = inv * (dy - s[0] / n_total - xh * s[1] / n_total)
         if dbeta is not None:
             _vec(dbeta, H)[:] = s[0]
 
-    def relu_bwd(self, dH, ldd, Hact, ldh, B, H, dZ, ldz):
-        _mat(dZ, B, H, ldz)[:] = _mat(dH, B, H, ldd) * (_mat(Hact, B, H, ldh) > 0)
+    def relu_bwd(self, dH, ldd, Hact, ldh, B, H, dZ, ldz, act=1):
+        from . import net_np as N
+        _mat(dZ, B, H, ldz)[:] = _mat(dH, B, H, ldd).astype(np.float64) * N.act_grad_from_out(act, _mat(Hact, B, H, ldh).astype(np.float64))
 
-    def relu_fwd(self, Zt, ldz, B, H, Hout, ldh):
-        _mat(Hout, B, H, ldh)[:] = np.maximum(_mat(Zt, B, H, ldz), 0)
+    def relu_fwd(self, Zt, ldz, B, H, Hout, ldh, act=1):
+        from . import net_np as N
+        _mat(Hout, B, H, ldh)[:] = N.act_fwd(act, _mat(Zt, B, H, ldz).astype(np.float64))
 
     def colsum_chain(self, x, ldx, B, N, theta_w, out):
         s = _mat(x, B, N, ldx).astype(np.float64).sum(0)

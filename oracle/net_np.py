@@ -30,6 +30,53 @@ BN_EPS = 1e-3
 AE_TYPES = ('zinb-conddisp', 'zinb', 'nb-conddisp', 'nb', 'poisson', 'normal')
 
 
+ACT_CODES = {'linear': 0, 'relu': 1, 'tanh': 2, 'sigmoid': 3, 'elu': 4, 'selu': 5, 'softplus': 6,
+             'softsign': 7, 'LeakyReLU': 8}
+SELU_SCALE, SELU_ALPHA = 1.0507009873554805, 1.6732632423543772
+
+
+def act_fwd(code, x):
+    """keras.activations by name / LeakyReLU(alpha=0.3) (dca/network.py:132-135)."""
+    if code == 0: return x
+    if code == 1: return np.maximum(x, 0)
+    if code == 2: return np.tanh(x)
+    if code == 3: return Z.sigmoid(x)
+    if code == 4: return np.where(x > 0, x, np.expm1(np.minimum(x, 0)))
+    if code == 5: return SELU_SCALE * np.where(x > 0, x, SELU_ALPHA * np.expm1(np.minimum(x, 0)))
+    if code == 6: return Z.softplus(x)
+    if code == 7: return x / (1 + np.abs(x))
+    if code == 8: return np.where(x > 0, x, 0.3 * x)
+    raise ValueError(code)
+
+
+def act_grad(code, x):
+    """d act / dx as a function of the pre-activation x."""
+    if code == 0: return np.ones_like(x)
+    if code == 1: return (x > 0).astype(x.dtype)
+    if code == 2: return 1 - np.tanh(x) ** 2
+    if code == 3: s = Z.sigmoid(x); return s * (1 - s)
+    if code == 4: return np.where(x > 0, 1.0, np.exp(np.minimum(x, 0)))
+    if code == 5: return SELU_SCALE * np.where(x > 0, 1.0, SELU_ALPHA * np.exp(np.minimum(x, 0)))
+    if code == 6: return Z.sigmoid(x)
+    if code == 7: return 1 / (1 + np.abs(x)) ** 2
+    if code == 8: return np.where(x > 0, 1.0, 0.3)
+    raise ValueError(code)
+
+
+def act_grad_from_out(code, h):
+    """The same derivative expressed through the output h = act(x) (the C ABI's contract)."""
+    if code == 0: return np.ones_like(h)
+    if code == 1: return (h > 0).astype(h.dtype)
+    if code == 2: return 1 - h * h
+    if code == 3: return h * (1 - h)
+    if code == 4: return np.where(h > 0, 1.0, h + 1)
+    if code == 5: return np.where(h > 0, SELU_SCALE, h + SELU_SCALE * SELU_ALPHA)
+    if code == 6: return -np.expm1(-h)
+    if code == 7: return (1 - np.abs(h)) ** 2
+    if code == 8: return np.where(h > 0, 1.0, 0.3)
+    raise ValueError(code)
+
+
 def glorot_uniform(rng, fan_in, fan_out, dtype):
     lim = np.sqrt(6.0 / (fan_in + fan_out))
     return rng.uniform(-lim, lim, size=(fan_in, fan_out)).astype(dtype)
@@ -72,8 +119,10 @@ def is_trainable(name):
 
 
 class OracleAE:
-    def __init__(self, ae_type, params, hidden_size, batchnorm=True, ridge=0.0, reg=(0., 0., 0., 0.)):
+    def __init__(self, ae_type, params, hidden_size, batchnorm=True, ridge=0.0, reg=(0., 0., 0., 0.),
+                 activation='relu'):
         assert ae_type in AE_TYPES
+        self.act = ACT_CODES[activation]
         self.reg = tuple(float(x) for x in reg)          # l1, l2, l1_enc, l2_enc (network.py:114-126)
         self.ae_type = ae_type
         self.p = params
@@ -108,7 +157,7 @@ class OracleAE:
             else:
                 Yb = Zi
             cache['Yb'].append(Yb)
-            H = np.maximum(Yb, 0)
+            H = act_fwd(self.act, Yb)
             cache['H'].append(H)
         cache['a_mean'] = H @ p['W_mean'] + p['b_mean']
         cache['a_disp'] = H @ p['W_disp'] + p['b_disp'] if 'W_disp' in p else None
@@ -158,7 +207,7 @@ class OracleAE:
             g['b_pi'] = d_pi.sum(axis=0)
             dH = dH + d_pi @ p['W_pi'].T
         for i in reversed(range(len(self.hidden_size))):
-            dYb = dH * (c['Yb'][i] > 0)
+            dYb = dH * act_grad(self.act, c['Yb'][i])
             if self.batchnorm:
                 xh, inv = c['xh'][i], c['inv'][i]
                 g['beta%d' % i] = dYb.sum(axis=0)

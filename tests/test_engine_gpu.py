@@ -217,3 +217,24 @@ def test_l1_l2_regularisers_fit_matches_oracle(ops, reg):
     from _opt_cases import run_fit_parity
     run_fit_parity(ops, reg=reg, rtol=1e-4)
     run_fit_parity(ops, optimizer='Adam', reg=reg, ae_type='nb', rtol=1e-4)
+
+
+@pytest.mark.parametrize('batchnorm', [True, False])
+@pytest.mark.parametrize('activation', ['linear', 'tanh', 'sigmoid', 'elu', 'selu', 'softplus', 'softsign', 'LeakyReLU'])
+def test_activations_single_step_matches_oracle(ops, activation, batchnorm):
+    """Activation(self.activation) / LeakyReLU of dca/network.py:132-135: forward, the slope taken
+    from the forward output in the backward kernels, moving statistics."""
+    n, G, hs, B = 90, 33, (12, 5, 12), 40
+    X, Y, sf, p = make_problem(n, G, hs, 'zinb-conddisp', batchnorm, seed=6)
+    rows = np.random.RandomState(1).permutation(n)[:B]
+    ref = oracle_net('zinb-conddisp', p, hs, batchnorm, activation=activation)
+    rl, rg = ref.loss_and_grads(X[rows].astype(np.float64), Y[rows].astype(np.float64), sf[rows].astype(np.float64))
+    eng = make_engine(ops, 'zinb-conddisp', G, hs, batchnorm, 0.0, p, X, Y, sf, activation=activation)
+    loss, g, newp = run_single_step(eng, rows)
+    assert abs(loss - rl) < 1e-5 * abs(rl), (loss, rl)
+    assert_grads_close(g, rg)
+    N.rmsprop_step(ref.p, rg, {}, 1e-3)                       # the engine's step included the update
+    out_ref = ref.predict(X[:16].astype(np.float64), sf[:16].astype(np.float64))
+    out = eng.predict_chunk(0, 16, {'mean', 'latent'})
+    for k in ('mean', 'latent'):
+        np.testing.assert_allclose(out[k].cpu().numpy(), out_ref[k], rtol=2e-3, atol=2e-4, err_msg=k)
