@@ -585,11 +585,16 @@ class Engine:
                 ops.bn_bwd_sums(self.dH[i], self.ldh[i], self.H[i], self.ldh[i], self.XH[i],
                                 self.ldh[i], B, h, self.bpart[i], self.act)
                 E = ops.col_moments_chunks(B)
+                local_s1 = None
                 if comm.world > 1:
-                    E = self._reduce_bwd_sums(i, E, h)
+                    E, local_s1 = self._reduce_bwd_sums(i, E, h)
                 ops.bn_bwd_apply(self.dH[i], self.ldh[i], self.H[i], self.ldh[i], self.XH[i],
                                  self.ldh[i], self.inv_std[i], self.bpart[i], E, float(Bg), B, h,
                                  self.dZ[i], self.ldh[i], lay.view(g, 'beta%d' % i), self.act)
+                if local_s1 is not None:
+                    # bn_bwd_apply wrote d beta from the GLOBAL sums; the gradient bucket is summed
+                    # over ranks afterwards, so each rank must contribute its LOCAL share only
+                    lay.view(g, 'beta%d' % i).copy_(local_s1)
             else:
                 ops.relu_bwd(self.dH[i], self.ldh[i], self.H[i], self.ldh[i], B, h, self.dZ[i],
                              self.ldh[i], self.act)
@@ -627,9 +632,10 @@ class Engine:
     def _reduce_bwd_sums(self, i, E, h):
         """SyncBN backward: local chunk sums -> one [2h] vector -> all-reduce."""
         s = self.bpart[i][:E * 2 * h].view(E, 2 * h).sum(dim=0)
+        local_s1 = s[:h].clone()
         self.comm.all_reduce_sum(s)
         self.bpart[i][:2 * h].copy_(s)
-        return 1
+        return 1, local_s1
 
     # ------------------------------------------------------------------ evaluation / inference
     def eval_loss_sum(self, r0, r1, scale, chunk=None):

@@ -57,7 +57,8 @@ def _run(rank, world, port, cfg, q):
     try:
         from dca_amd.engine import Engine
         from dca_amd.train import fit_engine
-        n, G, hs, ae, bn, B, epochs, seed = cfg
+        n, G, hs, ae, bn, B, epochs, seed = cfg[:8]
+        optimizer = cfg[8] if len(cfg) > 8 else None
         X, Y, sf, p = make_problem(n, G, hs, ae, bn, seed=3)
         n_train = int(n * 0.9)
         n_val = n - n_train
@@ -67,6 +68,9 @@ def _run(rank, world, port, cfg, q):
         rows = np.r_[np.arange(t0, t0 + nt), n_train + np.arange(v0, v0 + nv)]
         eng = Engine(ae, G, G, hs, bn, 0.0, ops=CpuRefOps(), comm=comm)
         eng.set_params(p)
+        if optimizer:
+            eng.set_optimizer(optimizer)
+            eng.set_lr(0.01)
         eng.load_data(X[rows], Y[rows], sf[rows])
         h = fit_engine(eng, n_train, n_val, nt, nv, t0, epochs=epochs, batch_size=B,
                        shuffle_rng=np.random.RandomState(seed), reduce_lr=1, early_stop=0)
@@ -125,6 +129,45 @@ def test_two_rank_dp_equals_single_process_and_oracle(ae, bn, n, B):
                batch_size=B, shuffle_rng=FixedOrders(orders), reduce_lr=1, early_stop=0)
     np.testing.assert_allclose(hist_dp['loss'], rh['loss'], rtol=1e-4)
     np.testing.assert_allclose(hist_dp['val_loss'], rh['val_loss'], rtol=1e-4)
+
+
+def test_two_rank_dp_gradients_are_summed_once():
+    """SGD is linear in the gradient (RMSprop hides a rank-count factor on a parameter's gradient
+    behind its scale invariance): every parameter, batch-norm beta included, must follow the
+    single-process trajectory tightly."""
+    ae, bn, n, B = 'zinb-conddisp', True, 60, 16
+    G, hs, epochs, seed, W = 14, (6, 3, 6), 2, 17, 2
+    cfg = (n, G, hs, ae, bn, B, epochs, seed, 'sgd')
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_run, args=(r, W, port, cfg, q)) for r in range(W)]
+    for pr in procs:
+        pr.start()
+    hist_dp, p_dp = q.get(timeout=120)
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    from dca_amd.engine import Engine
+    from dca_amd.train import fit_engine
+    X, Y, sf, p = make_problem(n, G, hs, ae, bn, seed=3)
+    n_train = int(n * 0.9)
+    orders = dp_equivalent_orders(n_train, W, B // W, epochs, seed)
+    eng = Engine(ae, G, G, hs, bn, 0.0, ops=CpuRefOps())
+    eng.set_params(p)
+    eng.set_optimizer('sgd')
+    eng.set_lr(0.01)
+    eng.load_data(X, Y, sf)
+    h1 = fit_engine(eng, n_train, n - n_train, n_train, n - n_train, 0, epochs=epochs, batch_size=B,
+                    shuffle_rng=FixedOrders(orders), reduce_lr=1, early_stop=0)
+    np.testing.assert_allclose(hist_dp['loss'], h1.history['loss'], rtol=1e-5)
+    p1 = eng.get_params()
+    for k in p1:
+        if k[0] == 'b' and k[1:].isdigit():
+            continue                      # bias in front of batch-norm: gradient is rounding noise
+        np.testing.assert_allclose(p_dp[k], p1[k], rtol=1e-4, atol=1e-5, err_msg=k)
+        if k.startswith('beta'):
+            assert np.abs(p1[k] - p[k]).max() > 1e-4      # the check is not vacuous
 
 
 def test_shard_and_local_order():

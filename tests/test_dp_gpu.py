@@ -1,0 +1,81 @@
+"""Data-parallel path with the REAL kernels: 2 processes share the one GPU of the test box and
+exchange over gloo (RCCL needs one GPU per rank; the exchange pattern -- SyncBN statistics, the
+two gradient buckets with the asynchronous heads bucket on its own group, loss slot -- is the same
+code).  Must reproduce the single-process run on the same global batches."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import make_problem
+from test_dp_gloo import FixedOrders, dp_equivalent_orders, _free_port
+from dca_amd import dist as ddist
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(rank, world, port, cfg, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank), DCA_AMD_DIST_BACKEND='gloo')
+    try:
+        from dca_amd.engine import Engine
+        from dca_amd.train import fit_engine
+        comm = ddist.init_from_env()
+        n, G, hs, ae, bn, B, epochs, seed = cfg
+        X, Y, sf, p = make_problem(n, G, hs, ae, bn, seed=3)
+        n_train = int(n * 0.9)
+        n_val = n - n_train
+        t0, nt = ddist.shard(n_train, world, rank)
+        v0, nv = ddist.shard(n_val, world, rank)
+        rows = np.r_[np.arange(t0, t0 + nt), n_train + np.arange(v0, v0 + nv)]
+        eng = Engine(ae, G, G, hs, bn, 0.0, comm=comm)
+        eng.set_params(p)
+        eng.load_data(X[rows], Y[rows], sf[rows])
+        h = fit_engine(eng, n_train, n_val, nt, nv, t0, epochs=epochs, batch_size=B,
+                       shuffle_rng=np.random.RandomState(seed), reduce_lr=1, early_stop=0)
+        torch.cuda.synchronize()
+        if rank == 0:
+            q.put((h.history, eng.get_params()))
+        dist.barrier()
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('ae,n,B', [('zinb-conddisp', 300, 64), ('zinb', 203, 32)])
+def test_two_ranks_on_one_gpu_equal_single_process(ae, n, B):
+    G, hs, epochs, seed, W, bn = 150, (64, 32, 64), 2, 17, 2, True
+    cfg = (n, G, hs, ae, bn, B, epochs, seed)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_run, args=(r, W, port, cfg, q)) for r in range(W)]
+    for pr in procs:
+        pr.start()
+    hist_dp, p_dp = q.get(timeout=300)
+    for pr in procs:
+        pr.join(timeout=120)
+        assert pr.exitcode == 0
+
+    from dca_amd.engine import Engine
+    from dca_amd.train import fit_engine
+    X, Y, sf, p = make_problem(n, G, hs, ae, bn, seed=3)
+    n_train = int(n * 0.9)
+    orders = dp_equivalent_orders(n_train, W, B // W, epochs, seed)
+    eng = Engine(ae, G, G, hs, bn, 0.0)
+    eng.set_params(p)
+    eng.load_data(X, Y, sf)
+    h1 = fit_engine(eng, n_train, n - n_train, n_train, n - n_train, 0, epochs=epochs, batch_size=B,
+                    shuffle_rng=FixedOrders(orders), reduce_lr=1, early_stop=0)
+    # same kernels on both sides; the association order of the cross-rank sums differs
+    np.testing.assert_allclose(hist_dp['loss'], h1.history['loss'], rtol=3e-5)
+    np.testing.assert_allclose(hist_dp['val_loss'], h1.history['val_loss'], rtol=3e-5)
+    assert hist_dp['lr'] == h1.history['lr']
+    p1 = eng.get_params()
+    for k in p1:
+        if k[0] == 'b' and k[1:].isdigit():
+            continue
+        np.testing.assert_allclose(p_dp[k], p1[k], rtol=2e-3, atol=2e-3, err_msg=k)
