@@ -1,4 +1,5 @@
-"""Builds dca_amd/csrc/libdcahip.so for gfx950 with hipcc (cross-compiles without a GPU).
+"""Builds dca_amd/csrc/libdcahip.so for gfx950 with hipcc (cross-compiles without a GPU) and the
+host-only dca_amd/csrc/libdcahost.so (include/dcahost.h: result writers) with g++.
 
     python -m dca_amd.build            # rebuild if any source is newer than the library
     python -m dca_amd.build --force
@@ -18,6 +19,8 @@ LIB = os.path.join(CSRC, 'libdcahip.so')
 SOURCES = ['dcahip_zinb.hip', 'dcahip_gemm.hip', 'dcahip_layers.hip', 'dcahip_heads.hip', 'dcahip_prep.hip', 'dcahip_opt.hip']
 HEADERS = ['zinb_math.hpp']
 ARCH = 'gfx950'
+HOST_LIB = os.path.join(CSRC, 'libdcahost.so')
+HOST_SOURCES = ['dcahost_tsv.cpp']
 
 
 def _hipcc():
@@ -47,5 +50,28 @@ def build_hip(force=False, verbose=True):
     return LIB
 
 
+def host_needs_build():
+    if not os.path.exists(HOST_LIB):
+        return True
+    t = os.path.getmtime(HOST_LIB)
+    deps = [os.path.join(CSRC, s) for s in HOST_SOURCES] + [os.path.join(ROOT, 'include', 'dcahost.h')]
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build_host(force=False, verbose=True):
+    if not force and not host_needs_build():
+        return HOST_LIB
+    cxx = shutil.which('g++') or shutil.which('c++')
+    if not cxx:
+        raise RuntimeError('g++ not found: cannot build libdcahost.so')
+    cmd = [cxx, '-O3', '-std=c++17', '-fPIC', '-shared', '-pthread', '-I' + os.path.join(ROOT, 'include'),
+           '-o', HOST_LIB] + [os.path.join(CSRC, s) for s in HOST_SOURCES]
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return HOST_LIB
+
+
 if __name__ == '__main__':
     print(build_hip(force='--force' in sys.argv))
+    print(build_host(force='--force' in sys.argv))

@@ -1,0 +1,295 @@
+// Host-side TSV writer for the result matrices (include/dcahost.h; replaces dca/io.py:120-129 for
+// the CLI outputs of dca/network.py:223-231, 413-421).  g++ -O3 -pthread, no GPU, no torch.
+//
+// '%.6f' without floating-point arithmetic: a finite binary value is M * 2^E with an integer M;
+// 10^6 = 2^6 * 15625, so value * 10^6 = (M * 15625) * 2^(E+6) -- a left shift, or a right shift with
+// round-half-even on the shifted-out bits.  That is the correctly rounded decimal printf / Python
+// produce.  Values too large for 63 bits of micro-units fall back to snprintf.
+#include <cerrno>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <atomic>
+#include <string>
+#include <thread>
+#include <vector>
+#include <fcntl.h>
+#include <unistd.h>
+
+#include "dcahost.h"
+
+namespace {
+
+const char kDigits2[201] =
+    "00010203040506070809101112131415161718192021222324252627282930313233343536373839"
+    "40414243444546474849505152535455565758596061626364656667686970717273747576777879"
+    "8081828384858687888990919293949596979899";
+
+constexpr int kMaxField = 64;   // sign + 39 integer digits of FLT_MAX (or DBL via snprintf, capped below) + '.' + 6
+
+inline char* put_micro(char* p, bool neg, uint64_t n) {
+    // n = |value| in units of 1e-6
+    uint64_t ip = n / 1000000u;
+    uint32_t fr = (uint32_t)(n - ip * 1000000u);
+    if (neg) *p++ = '-';
+    if (ip < 10) {
+        *p++ = (char)('0' + ip);
+    } else {
+        char tmp[24];
+        int k = 0;
+        while (ip >= 100) {
+            const uint64_t q = ip / 100;
+            const uint32_t r = (uint32_t)(ip - q * 100);
+            tmp[k++] = kDigits2[2 * r + 1];
+            tmp[k++] = kDigits2[2 * r];
+            ip = q;
+        }
+        if (ip >= 10) {
+            tmp[k++] = kDigits2[2 * ip + 1];
+            tmp[k++] = kDigits2[2 * ip];
+        } else {
+            tmp[k++] = (char)('0' + ip);
+        }
+        while (k) *p++ = tmp[--k];
+    }
+    *p++ = '.';
+    const uint32_t a = fr / 10000u, b = (fr / 100u) % 100u, c = fr % 100u;
+    p[0] = kDigits2[2 * a];  p[1] = kDigits2[2 * a + 1];
+    p[2] = kDigits2[2 * b];  p[3] = kDigits2[2 * b + 1];
+    p[4] = kDigits2[2 * c];  p[5] = kDigits2[2 * c + 1];
+    return p + 6;
+}
+
+inline char* put_special(char* p, bool neg, bool is_nan) {
+    if (is_nan) return p;                       // pandas na_rep=''
+    if (neg) *p++ = '-';
+    p[0] = 'i'; p[1] = 'n'; p[2] = 'f';
+    return p + 3;
+}
+
+inline char* put_f32(char* p, float v) {
+    uint32_t u;
+    memcpy(&u, &v, 4);
+    const bool neg = (u >> 31) != 0;
+    const uint32_t ex = (u >> 23) & 0xffu;
+    uint32_t m = u & 0x7fffffu;
+    if (ex == 0xffu) return put_special(p, neg, m != 0);
+    int e;
+    if (ex) { m |= 0x800000u; e = (int)ex - 150; } else { e = -149; }
+    const uint64_t prod = (uint64_t)m * 15625u;            // < 2^38
+    const int sh = e + 6;
+    uint64_t n;
+    if (sh >= 0) {
+        if (sh > 25) {                                     // >= 2^63 micro-units: rare, let libc do it
+            return p + snprintf(p, kMaxField, "%.6f", (double)v);
+        }
+        n = prod << sh;
+    } else {
+        const int s = -sh;
+        if (s >= 40) {
+            n = 0;                                         // prod < 2^38 -> below half a micro-unit
+        } else {
+            n = prod >> s;
+            const uint64_t rem = prod & ((1ull << s) - 1), half = 1ull << (s - 1);
+            if (rem > half || (rem == half && (n & 1))) ++n;
+        }
+    }
+    return put_micro(p, neg, n);
+}
+
+inline char* put_f64(char* p, double v) {
+    uint64_t u;
+    memcpy(&u, &v, 8);
+    const bool neg = (u >> 63) != 0;
+    const uint32_t ex = (uint32_t)((u >> 52) & 0x7ffu);
+    uint64_t m = u & 0xfffffffffffffull;
+    if (ex == 0x7ffu) return put_special(p, neg, m != 0);
+    int e;
+    if (ex) { m |= 1ull << 52; e = (int)ex - 1075; } else { e = -1074; }
+    const unsigned __int128 prod = (unsigned __int128)m * 15625u;   // < 2^67
+    const int sh = e + 6;
+    unsigned __int128 n;
+    if (sh >= 0) {
+        if (sh > 50) return p + snprintf(p, kMaxField * 6, "%.6f", v);
+        n = prod << sh;
+    } else {
+        const int s = -sh;
+        if (s >= 69) {
+            n = 0;
+        } else {
+            n = prod >> s;
+            const unsigned __int128 one = 1;
+            const unsigned __int128 rem = prod & ((one << s) - 1), half = one << (s - 1);
+            if (rem > half || (rem == half && ((uint64_t)n & 1))) ++n;
+        }
+    }
+    if (n >> 63) return p + snprintf(p, kMaxField * 6, "%.6f", v);
+    return put_micro(p, neg, (uint64_t)n);
+}
+
+template <typename T> struct Fmt;
+template <> struct Fmt<float>  { static constexpr int kMax = kMaxField;     static char* put(char* p, float v)  { return put_f32(p, v); } };
+template <> struct Fmt<double> { static constexpr int kMax = kMaxField * 6; static char* put(char* p, double v) { return put_f64(p, v); } };
+
+template <typename T>
+long format_values(const T* v, long n, char* out, long cap) {
+    char* p = out;
+    for (long i = 0; i < n; ++i) {
+        if (cap - (p - out) < Fmt<T>::kMax + 1) return DCAHOST_EINVAL;
+        if (i) *p++ = '\t';
+        p = Fmt<T>::put(p, v[i]);
+    }
+    return (long)(p - out);
+}
+
+bool write_all(int fd, const char* b, size_t n) {
+    while (n) {
+        const ssize_t w = ::write(fd, b, n);
+        if (w < 0) {
+            if (errno == EINTR) continue;
+            return false;
+        }
+        b += w;
+        n -= (size_t)w;
+    }
+    return true;
+}
+
+// One block of output rows [r0, r1): gathered into a contiguous scratch through 32 x 32 tiles when
+// the output row is strided in memory (the transposed case), then formatted row by row.
+template <typename T>
+void format_block(const T* data, long r0, long r1, long ncols, long rs, long cs,
+                  const char* const* rownames, std::vector<T>& scratch, std::string& out) {
+    const long nr = r1 - r0;
+    const T* src = data + r0 * rs;
+    long srs = rs;
+    if (cs != 1) {
+        scratch.resize((size_t)nr * (size_t)ncols);
+        constexpr long TB = 32;
+        for (long c0 = 0; c0 < ncols; c0 += TB) {
+            const long c1 = c0 + TB < ncols ? c0 + TB : ncols;
+            for (long c = c0; c < c1; ++c) {
+                const T* col = data + c * cs + r0 * rs;       // walks the stored matrix along its fast axis when rs == 1
+                for (long r = 0; r < nr; ++r) scratch[(size_t)r * ncols + c] = col[r * rs];
+            }
+        }
+        src = scratch.data();
+        srs = ncols;
+    }
+    out.clear();
+    size_t pos = 0;
+    for (long r = 0; r < nr; ++r) {
+        const size_t nlen = rownames ? strlen(rownames[r0 + r]) : 0;
+        const size_t need = pos + nlen + 2 + (size_t)ncols * (Fmt<T>::kMax + 1);
+        if (out.size() < need) out.resize(need + need / 2);
+        char* p = &out[pos];
+        if (rownames) {
+            memcpy(p, rownames[r0 + r], nlen);
+            p += nlen;
+            *p++ = '\t';
+        }
+        const T* row = src + r * srs;
+        for (long c = 0; c < ncols; ++c) {
+            if (c) *p++ = '\t';
+            p = Fmt<T>::put(p, row[c]);
+        }
+        *p++ = '\n';
+        pos = (size_t)(p - &out[0]);
+    }
+    out.resize(pos);
+}
+
+template <typename T>
+int write_tsv(const char* path, const T* data, long nrows, long ncols, long rs, long cs,
+              const char* const* rownames, const char* const* colnames, int nthreads) {
+    if (!path || nrows < 0 || ncols < 0 || (nrows > 0 && ncols > 0 && !data)) return DCAHOST_EINVAL;
+    const int fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) return DCAHOST_EIO;
+    bool ok = true;
+    if (colnames) {
+        std::string h;
+        for (long c = 0; c < ncols; ++c) {
+            if (c || rownames) h.push_back('\t');             // empty index label in front
+            h.append(colnames[c]);
+        }
+        h.push_back('\n');
+        ok = write_all(fd, h.data(), h.size());
+    }
+    if (ok && nrows > 0) {
+        if (nthreads <= 0) {
+            nthreads = (int)std::thread::hardware_concurrency();
+            if (nthreads <= 0) nthreads = 1;
+            if (nthreads > 64) nthreads = 64;
+        }
+        long rows_per = ncols > 0 ? 400000 / ncols : nrows;    // ~4 MB of text per block
+        if (rows_per < 16) rows_per = 16;
+        if (rows_per > nrows) rows_per = nrows;
+        const long nblocks = (nrows + rows_per - 1) / rows_per;
+        if (nthreads > nblocks) nthreads = (int)nblocks;
+        // rounds of nthreads blocks: formatted in parallel, written in order while nothing else runs
+        // on this thread (the next round's formatting overlaps the page-cache copy of the previous
+        // one through the second buffer set)
+        std::vector<std::string> bufs[2];
+        bufs[0].resize(nthreads);
+        bufs[1].resize(nthreads);
+        std::vector<std::vector<T>> scratch(nthreads);
+        auto run_round = [&](long b0, int set) {
+            std::vector<std::thread> th;
+            const long nb = (nblocks - b0 < nthreads) ? nblocks - b0 : nthreads;
+            for (long k = 1; k < nb; ++k)
+                th.emplace_back([&, k] {
+                    const long r0 = (b0 + k) * rows_per, r1 = r0 + rows_per < nrows ? r0 + rows_per : nrows;
+                    format_block<T>(data, r0, r1, ncols, rs, cs, rownames, scratch[k], bufs[set][k]);
+                });
+            {
+                const long r0 = b0 * rows_per, r1 = r0 + rows_per < nrows ? r0 + rows_per : nrows;
+                format_block<T>(data, r0, r1, ncols, rs, cs, rownames, scratch[0], bufs[set][0]);
+            }
+            for (auto& t : th) t.join();
+            return nb;
+        };
+        long b0 = 0;
+        int set = 0;
+        long nb = run_round(b0, set);
+        while (ok && nb > 0) {
+            const long next0 = b0 + nb;
+            long nnext = 0;
+            std::thread producer;
+            const int nset = set ^ 1;
+            if (next0 < nblocks) producer = std::thread([&] { nnext = run_round(next0, nset); });
+            for (long k = 0; ok && k < nb; ++k) ok = write_all(fd, bufs[set][k].data(), bufs[set][k].size());
+            if (producer.joinable()) producer.join();
+            b0 = next0;
+            nb = nnext;
+            set = nset;
+        }
+    }
+    const int saved = errno;
+    if (::close(fd) != 0 && ok) return DCAHOST_EIO;
+    if (!ok) { errno = saved; return DCAHOST_EIO; }
+    return DCAHOST_OK;
+}
+
+}  // namespace
+
+extern "C" int dcahost_write_tsv_f32(const char* path, const float* data, long nrows, long ncols,
+                                     long row_stride, long col_stride, const char* const* rownames,
+                                     const char* const* colnames, int nthreads) {
+    return write_tsv<float>(path, data, nrows, ncols, row_stride, col_stride, rownames, colnames, nthreads);
+}
+
+extern "C" int dcahost_write_tsv_f64(const char* path, const double* data, long nrows, long ncols,
+                                     long row_stride, long col_stride, const char* const* rownames,
+                                     const char* const* colnames, int nthreads) {
+    return write_tsv<double>(path, data, nrows, ncols, row_stride, col_stride, rownames, colnames, nthreads);
+}
+
+extern "C" long dcahost_format_f32(const float* v, long n, char* out, long cap) {
+    if (!v || !out || n < 0) return DCAHOST_EINVAL;
+    return format_values<float>(v, n, out, cap);
+}
+
+extern "C" long dcahost_format_f64(const double* v, long n, char* out, long cap) {
+    if (!v || !out || n < 0) return DCAHOST_EINVAL;
+    return format_values<double>(v, n, out, cap);
+}

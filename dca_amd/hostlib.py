@@ -1,0 +1,84 @@
+"""ctypes binding of include/dcahost.h (dca_amd/csrc/libdcahost.so): host-side result writers.
+
+The library is host-only C++ (g++), so unlike libdcahip.so it is built on first use when missing."""
+import ctypes
+import os
+
+import numpy as np
+
+from . import build as _build
+
+_lib = None
+
+_cpp = ctypes.POINTER(ctypes.c_char_p)
+_SIGNATURES = {
+    'dcahost_write_tsv_f32': (ctypes.c_int, [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_long, ctypes.c_long,
+                                             ctypes.c_long, _cpp, _cpp, ctypes.c_int]),
+    'dcahost_write_tsv_f64': (ctypes.c_int, [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_long, ctypes.c_long,
+                                             ctypes.c_long, _cpp, _cpp, ctypes.c_int]),
+    'dcahost_format_f32': (ctypes.c_long, [ctypes.c_void_p, ctypes.c_long, ctypes.c_char_p, ctypes.c_long]),
+    'dcahost_format_f64': (ctypes.c_long, [ctypes.c_void_p, ctypes.c_long, ctypes.c_char_p, ctypes.c_long]),
+}
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = _build.build_host(verbose=False)
+        L = ctypes.CDLL(path, use_errno=True)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _names(names, n):
+    if names is None:
+        return None, None
+    enc = [str(x).encode('utf-8') for x in names]
+    if len(enc) != n:
+        raise ValueError('expected %d names, got %d' % (n, len(enc)))
+    return (ctypes.c_char_p * n)(*enc), enc
+
+
+def names_need_quoting(names):
+    """csv.QUOTE_MINIMAL (pandas' to_csv) would quote these; the native writer emits names verbatim."""
+    if names is None:
+        return False
+    return any(ch in s for s in map(str, names) for ch in ('\t', '"', '\n', '\r'))
+
+
+def write_tsv(path, matrix, rownames=None, colnames=None, threads=0):
+    """matrix: 2-D float32 / float64 ndarray with ANY strides (a transposed view costs nothing);
+    rownames / colnames: sequences or None."""
+    m = np.asarray(matrix)
+    if m.ndim != 2 or m.dtype not in (np.float32, np.float64):
+        raise TypeError('write_tsv needs a 2-D float32 / float64 array')
+    item = m.dtype.itemsize
+    if m.size and (m.strides[0] % item or m.strides[1] % item or m.strides[0] < 0 or m.strides[1] < 0):
+        m = np.ascontiguousarray(m)
+    nr, nc = m.shape
+    rs, cs = (m.strides[0] // item, m.strides[1] // item) if m.size else (nc, 1)
+    rn, _keep_r = _names(rownames, nr)
+    cn, _keep_c = _names(colnames, nc)
+    fn = lib().dcahost_write_tsv_f32 if m.dtype == np.float32 else lib().dcahost_write_tsv_f64
+    rc = fn(os.fsencode(path), m.ctypes.data, nr, nc, rs, cs, rn, cn, int(threads))
+    if rc == -2:
+        err = ctypes.get_errno()
+        raise OSError(err, os.strerror(err), str(path))
+    if rc != 0:
+        raise ValueError('dcahost_write_tsv: invalid arguments')
+
+
+def format_values(values):
+    """'%.6f' of each value, tab-joined (bytes) -- the formatting kernel, for tests."""
+    v = np.ascontiguousarray(values)
+    fn = lib().dcahost_format_f32 if v.dtype == np.float32 else lib().dcahost_format_f64
+    cap = 400 * max(1, v.size)
+    buf = ctypes.create_string_buffer(cap)
+    n = fn(v.ctypes.data, v.size, buf, cap)
+    if n < 0:
+        raise ValueError('dcahost_format failed')
+    return buf.raw[:n]

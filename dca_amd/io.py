@@ -17,6 +17,7 @@ import pandas as pd
 import scipy.sparse as sp_sparse
 
 from ._anndata import AnnData, MiniAnnData, is_anndata
+from . import hostlib
 
 
 def _dense(X):
@@ -216,10 +217,20 @@ def read_genelist(filename):
 
 
 def write_text_matrix(matrix, filename, rownames=None, colnames=None, transpose=False):
-    """dca/io.py:120-129: TSV with '%.6f' floats; transpose swaps the name vectors too."""
+    """dca/io.py:120-129: TSV with '%.6f' floats; transpose swaps the name vectors too.
+
+    float32 / float64 matrices go through the native multi-threaded writer (include/dcahost.h,
+    dca_amd/csrc/dcahost_tsv.cpp), which writes the bytes pandas' to_csv(float_format='%.6f') writes;
+    the transposed (gene x cell) files are read through strides, not copied.  Anything else (integer
+    matrices, names that need CSV quoting) takes the pandas call of the reference."""
     if transpose:
         matrix = matrix.T
         rownames, colnames = colnames, rownames
+    m = matrix if isinstance(matrix, np.ndarray) else None
+    if m is not None and m.ndim == 2 and m.dtype in (np.float32, np.float64) \
+            and not hostlib.names_need_quoting(rownames) and not hostlib.names_need_quoting(colnames):
+        hostlib.write_tsv(filename, m, rownames, colnames)
+        return
     pd.DataFrame(matrix, index=rownames, columns=colnames).to_csv(filename,
                                                                   sep='\t',
                                                                   index=(rownames is not None),

@@ -1,0 +1,53 @@
+/* dcahost.h -- host-side (no GPU) entry points of the MI355X DCA path: the output formats on the
+ * far side of the hot path.  Plain C ABI, built with g++ into dca_amd/csrc/libdcahost.so.
+ *
+ * Replaces, for the result matrices the CLI writes (dca/network.py:223-231, 413-421):
+ *   dca/io.py:120-129  write_text_matrix(matrix, filename, rownames, colnames, transpose)
+ *     = pandas.DataFrame(matrix, index=rownames, columns=colnames).to_csv(filename, sep='\t',
+ *       index=(rownames is not None), header=(colnames is not None), float_format='%.6f')
+ * The bytes written are those pandas writes (tests/test_tsv_cpu.py compares them): one header line
+ * (an empty first cell when there is an index column), then per row the optional name and the
+ * values as correctly rounded '%.6f' (round-half-even on the exact binary value, '-0.000000'
+ * keeps its sign, NaN -> empty field, +-inf -> 'inf' / '-inf'), '\n' line ends.  Names are written
+ * verbatim: the caller keeps names that would need CSV quoting (tab, quote, CR, LF) away from here.
+ *
+ * At BASELINE configs[2] one result matrix is 20 000 x 68 579 values = 12 GB of text; the reference
+ * formats it value by value in Python.  Here row blocks are formatted by a pool of threads (fp32
+ * values through an exact integer path: mantissa x 15625 shifted by the exponent, no floating-point
+ * rounding anywhere) and written in order by the calling thread.
+ */
+#ifndef DCAHOST_H
+#define DCAHOST_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DCAHOST_OK 0
+#define DCAHOST_EINVAL (-1)
+#define DCAHOST_EIO (-2)
+
+/* Matrix element (r, c) of the OUTPUT is data[r * row_stride + c * col_stride] (strides in
+ * elements), so transpose=True of the reference is row_stride = 1, col_stride = ld of the stored
+ * matrix -- no transposed copy is made by the caller; row blocks are gathered through cache-sized
+ * tiles.  rownames / colnames: arrays of nrows / ncols NUL-terminated UTF-8 strings, or NULL
+ * (no index column / no header line).  nthreads <= 0: one per hardware thread (at most 64).
+ * Returns DCAHOST_OK, DCAHOST_EINVAL (bad arguments) or DCAHOST_EIO (open / write failed; errno set). */
+int dcahost_write_tsv_f32(const char* path, const float* data, long nrows, long ncols,
+                          long row_stride, long col_stride,
+                          const char* const* rownames, const char* const* colnames, int nthreads);
+
+int dcahost_write_tsv_f64(const char* path, const double* data, long nrows, long ncols,
+                          long row_stride, long col_stride,
+                          const char* const* rownames, const char* const* colnames, int nthreads);
+
+/* Formats n values as '%.6f' separated by tabs into out (capacity cap bytes); returns the number of
+ * bytes written or DCAHOST_EINVAL when cap is too small (64 bytes per value always suffice).
+ * The formatting kernel of the writers, exported for the parity tests. */
+long dcahost_format_f32(const float* v, long n, char* out, long cap);
+long dcahost_format_f64(const double* v, long n, char* out, long cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
