@@ -37,6 +37,7 @@ AE_HEADS = {                      # ae_type -> (heads in the fused block, const 
 }
 ACT_CODES = {'linear': 0, 'relu': 1, 'tanh': 2, 'sigmoid': 3, 'elu': 4, 'selu': 5, 'softplus': 6,
              'softsign': 7, 'LeakyReLU': 8}
+INPUT_DROPOUT_LAYER = 255     # Philox counter word 3 of the input dropout (hidden layer i uses i)
 AE_LOSS_FLAG = {'poisson': 4, 'normal': 8}              # DCAHIP_NLL_POISSON / DCAHIP_NLL_MSE
 
 
@@ -151,7 +152,8 @@ class ParamLayout:
 
 class Engine:
     def __init__(self, ae_type, input_size, output_size=None, hidden_size=(64, 32, 64),
-                 batchnorm=True, ridge=0.0, ops=None, comm=None, device=None, activation='relu'):
+                 batchnorm=True, ridge=0.0, ops=None, comm=None, device=None, activation='relu',
+                 hidden_dropout=0., input_dropout=0., dropout_seed=0):
         if ae_type not in AE_HEADS:
             raise NotImplementedError('ae_type %r is not available on the MI355X path yet '
                                       '(supported: %s)' % (ae_type, ', '.join(AE_HEADS)))
@@ -202,6 +204,18 @@ class Engine:
         self.reg = None             # l1 / l2 kernel regularisers (network.py:114-126)
         self.reg_ws = None
         self._counts_local_key = self._counts_world_key = None
+        # Dropout (network.py:98-99, 137-138): rates per hidden layer + input; masks are a function of
+        # (seed, step counter in device memory, layer, global batch row, unit) -- K-DROP
+        hd = list(hidden_dropout) if isinstance(hidden_dropout, (list, tuple)) else [hidden_dropout] * len(lay.hidden)
+        assert len(hd) == len(lay.hidden)
+        self.drop = [float(r) for r in hd]
+        self.in_drop = float(input_dropout)
+        assert all(0.0 <= r < 1.0 for r in self.drop + [self.in_drop]), 'dropout rates must be in [0, 1)'
+        self.has_dropout = any(r > 0.0 for r in self.drop) or self.in_drop > 0.0
+        self.drop_seed = int(dropout_seed) & (2 ** 64 - 1)
+        self.drop_iter = torch.zeros(1, dtype=torch.int64, device=self.dev)
+        self.row0 = 0               # this rank's first row inside the global batch
+        self.Xb = None
 
     def _t(self, name):
         return self.prof.section(name) if self.prof is not None else _NULL
@@ -319,7 +333,8 @@ class Engine:
         and the fit loop's scalars (epoch, lr, callback counters, history)."""
         import json
         extra = {} if self.slot2 is None else {'slot2': self.slot2.cpu().numpy()}
-        np.savez(path, w=self.w.cpu().numpy(), ms=self.ms.cpu().numpy(), opt_iter=self.opt_iter.cpu().numpy(), **extra,
+        np.savez(path, w=self.w.cpu().numpy(), ms=self.ms.cpu().numpy(), opt_iter=self.opt_iter.cpu().numpy(),
+                 drop_iter=self.drop_iter.cpu().numpy(), **extra,
                  **{'mm%d' % i: t.cpu().numpy() for i, t in enumerate(self.mm)},
                  **{'mv%d' % i: t.cpu().numpy() for i, t in enumerate(self.mv)},
                  fit=np.frombuffer(json.dumps(fit_state).encode(), dtype=np.uint8))
@@ -332,6 +347,8 @@ class Engine:
             self.ms.copy_(torch.as_tensor(z['ms']))
             if 'opt_iter' in z.files:
                 self.opt_iter.copy_(torch.as_tensor(z['opt_iter']))
+            if 'drop_iter' in z.files:
+                self.drop_iter.copy_(torch.as_tensor(z['drop_iter']))
             if self.slot2 is not None and 'slot2' in z.files:
                 self.slot2.copy_(torch.as_tensor(z['slot2']))
             for i in range(len(self.mm)):
@@ -386,6 +403,10 @@ class Engine:
         self.Z = [torch.zeros(B, l, **f32) for l in self.ldh]
         self.XH = [torch.zeros(B, l, **f32) for l in self.ldh] if lay.batchnorm else []
         self.H = [torch.zeros(B, l, **f32) for l in self.ldh]
+        # outputs after dropout (the next layer's input); layers without dropout alias H
+        self.HD = [torch.zeros(B, l, **f32) if r > 0.0 else None for l, r in zip(self.ldh, self.drop)]
+        self.Hcur = list(self.H)
+        self.Xb = None                                  # input-dropout batch, allocated on first use
         self.dH = [torch.zeros(B, l, **f32) for l in self.ldh]
         self.dZ = [torch.zeros(B, l, **f32) for l in self.ldh]
         self.A = torch.zeros(B, lay.NH, **f32)
@@ -429,7 +450,17 @@ class Engine:
         for i, h in enumerate(lay.hidden):
             Wi = lay.view(w, 'W%d' % i); bi = lay.view(w, 'b%d' % i)
             if i == 0:
-                if rows_from[0] == 'perm':
+                if training and self.in_drop > 0.0:
+                    assert rows_from[0] == 'perm'
+                    if self.Xb is None or self.Xb.shape[0] < self.Bmax:
+                        self.Xb = torch.zeros(self.Bmax, self.ldx, dtype=torch.float32, device=self.dev)
+                    ops.dropout_apply(self.X, self.ldx, self.perm, self.cursor, B, K, self.in_drop,
+                                      self.drop_seed, self.drop_iter, INPUT_DROPOUT_LAYER, self.row0,
+                                      self.Xb, self.ldx)
+                    with self._t('gemm_enc0_fwd'):
+                        ops.sgemm(0, 0, B, h, K, self.Xb, self.ldx, Wi, h, self.Z[0], self.ldh[0],
+                                  bias=bi, ws=self.ws)
+                elif rows_from[0] == 'perm':
                     with self._t('gemm_enc0_fwd'):
                         ops.sgemm(0, 0, B, h, K, self.X, self.ldx, Wi, h, self.Z[0], self.ldh[0],
                                   bias=bi, perm=self.perm, cursor=self.cursor, ws=self.ws)
@@ -437,7 +468,7 @@ class Engine:
                     ops.sgemm(0, 0, B, h, K, self.X[rows_from[1]:], self.ldx, Wi, h, self.Z[0],
                               self.ldh[0], bias=bi, ws=self.ws)
             else:
-                ops.sgemm(0, 0, B, h, K, self.H[i - 1], self.ldh[i - 1], Wi, h, self.Z[i],
+                ops.sgemm(0, 0, B, h, K, self.Hcur[i - 1], self.ldh[i - 1], Wi, h, self.Z[i],
                           self.ldh[i], bias=bi, ws=self.ws)
             if lay.batchnorm:
                 beta = lay.view(w, 'beta%d' % i)
@@ -452,6 +483,12 @@ class Engine:
                                       None, 0, None)
             else:
                 ops.relu_fwd(self.Z[i], self.ldh[i], B, h, self.H[i], self.ldh[i], self.act)
+            if training and self.drop[i] > 0.0:
+                ops.dropout_apply(self.H[i], self.ldh[i], None, None, B, h, self.drop[i], self.drop_seed,
+                                  self.drop_iter, i, self.row0, self.HD[i], self.ldh[i])
+                self.Hcur[i] = self.HD[i]
+            else:
+                self.Hcur[i] = self.H[i]
             K = h
         return K
 
@@ -481,7 +518,7 @@ class Engine:
     def _heads_forward(self, B, K):
         lay, ops = self.lay, self.ops
         with self._t('gemm_heads_fwd'):
-            ops.sgemm(0, 0, B, lay.NH, K, self.H[-1], self.ldh[-1], lay.view(self.w, 'Wh'), lay.NH,
+            ops.sgemm(0, 0, B, lay.NH, K, self.Hcur[-1], self.ldh[-1], lay.view(self.w, 'Wh'), lay.NH,
                       self.A, lay.NH, bias=lay.view(self.w, 'bh'), ws=self.ws)
 
     def _plane(self, buf, head):
@@ -515,6 +552,7 @@ class Engine:
             if self._counts_world_key != key:
                 self.counts_world.copy_(torch.as_tensor(world_counts, dtype=torch.float32))
                 self._counts_world_key = key
+            self.row0 = int(sum(world_counts[:comm.rank]))
         if B > 0:
             self._forward_backward(B, Bg, inv_n)
         else:
@@ -535,6 +573,8 @@ class Engine:
             ops.optimizer_step(self.opt_kind, w, g, None if self.opt_kind == 'sgd' else self.ms,
                                self.slot2, lay.P, self.lr, self.opt_iter, self.clip)
             ops.counter_add(self.opt_iter, 1)
+        if self.has_dropout:
+            ops.counter_add(self.drop_iter, 1)
         ops.step_end(g[lay.P:], float(Bg), self.hist, rows_per_slot or max(self.Bmax, 1), self.acc,
                      self.cursor, B)
 
@@ -566,7 +606,7 @@ class Engine:
         KL = self._hidden_forward(B, ('perm',), True, self.counts_world)
         if self.ws_heads is not None:
             with self._t('heads_fused'):
-                n = ops.heads_fused(self.H[-1], self.ldh[-1], lay.view(w, 'Wh'), lay.NH,
+                n = ops.heads_fused(self.Hcur[-1], self.ldh[-1], lay.view(w, 'Wh'), lay.NH,
                                     lay.view(w, 'bh'), lay.Gp,
                                     lay.view(w, 'theta_w') if lay.const_disp else None, self.Y,
                                     self.ldy, self.sf, self.perm, self.cursor, B, KL, lay.G_out,
@@ -581,6 +621,9 @@ class Engine:
         L = len(lay.hidden)
         for i in reversed(range(L)):
             h = lay.hidden[i]
+            if self.drop[i] > 0.0:      # gradient through the dropout of this layer's output: same mask
+                ops.dropout_apply(self.dH[i], self.ldh[i], None, None, B, h, self.drop[i], self.drop_seed,
+                                  self.drop_iter, i, self.row0, self.dH[i], self.ldh[i])
             if lay.batchnorm:
                 ops.bn_bwd_sums(self.dH[i], self.ldh[i], self.H[i], self.ldh[i], self.XH[i],
                                 self.ldh[i], B, h, self.bpart[i], self.act)
@@ -602,10 +645,14 @@ class Engine:
             gW = lay.view(g, 'W%d' % i)
             if i == 0:
                 with self._t('gemm_enc0_dW'):
-                    ops.sgemm(1, 0, Kp, h, B, self.X, self.ldx, self.dZ[0], self.ldh[0], gW, h,
-                              perm=self.perm, cursor=self.cursor, colsum_row=True, ws=self.ws)
+                    if self.in_drop > 0.0:
+                        ops.sgemm(1, 0, Kp, h, B, self.Xb, self.ldx, self.dZ[0], self.ldh[0], gW, h,
+                                  colsum_row=True, ws=self.ws)
+                    else:
+                        ops.sgemm(1, 0, Kp, h, B, self.X, self.ldx, self.dZ[0], self.ldh[0], gW, h,
+                                  perm=self.perm, cursor=self.cursor, colsum_row=True, ws=self.ws)
             else:
-                ops.sgemm(1, 0, Kp, h, B, self.H[i - 1], self.ldh[i - 1], self.dZ[i], self.ldh[i], gW,
+                ops.sgemm(1, 0, Kp, h, B, self.Hcur[i - 1], self.ldh[i - 1], self.dZ[i], self.ldh[i], gW,
                           h, colsum_row=True, ws=self.ws)
                 ops.sgemm(0, 1, B, Kp, h, self.dZ[i], self.ldh[i], lay.view(w, 'W%d' % i), h,
                           self.dH[i - 1], self.ldh[i - 1], ws=self.ws)
@@ -620,7 +667,7 @@ class Engine:
             n = self._nll(B, self.perm, self.cursor, self.Y, self.sf, inv_n, True)
         ops.loss_finalize(self.partials, n, inv_n, g[lay.P:])
         with self._t('gemm_heads_dW'):
-            ops.sgemm(1, 0, KL, lay.NH, B, self.H[-1], self.ldh[-1], self.D, self.ldD,
+            ops.sgemm(1, 0, KL, lay.NH, B, self.Hcur[-1], self.ldh[-1], self.D, self.ldD,
                       lay.view(g, 'Wh'), lay.NH, colsum_row=True, ws=self.ws)
         if lay.const_disp:
             ops.colsum_chain(self.Dth, self.ldD, B, lay.G_out, lay.view(w, 'theta_w'),

@@ -109,8 +109,6 @@ class Autoencoder():
             unsupported.append('activation=%r' % self.activation)
         if self.init != 'glorot_uniform':
             unsupported.append('init=%r' % self.init)
-        if any(d > 0.0 for d in self.hidden_dropout) or self.input_dropout > 0.0:
-            unsupported.append('dropout')
         if unsupported:
             raise NotImplementedError('not implemented on the MI355X path yet: ' + ', '.join(unsupported))
 
@@ -121,7 +119,9 @@ class Autoencoder():
         ops = _test_ops_factory() if _test_ops_factory is not None else None
         self.engine = _engine.Engine(self.ae_type, self.input_size, self.output_size,
                                      self.hidden_size, self.batchnorm, self.ridge, ops=ops,
-                                     comm=self.comm, activation=self.activation)
+                                     comm=self.comm, activation=self.activation,
+                                     hidden_dropout=self.hidden_dropout, input_dropout=self.input_dropout,
+                                     dropout_seed=self.seed)
         self.engine.init_params(self.seed)
         self.engine.set_regularizers(self.l1_coef, self.l2_coef, self.l1_enc_coef, self.l2_enc_coef)
         self.model = self.engine             # what train() drives (reference: the Keras Model)

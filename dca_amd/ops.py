@@ -123,6 +123,12 @@ class HipOps:
         hip.check(self.L.dcahip_optimizer_step(hip.OPT_KINDS[kind], p(w), p(g), p(slot1), p(slot2), n, p(lr),
                                                p(it), clip, hip.stream()), 'optimizer_step')
 
+    def dropout_apply(self, x, ldx, perm, cursor, B, h, rate, seed, step, layer, row0, out, ldo):
+        p = hip.ptr
+        hip.check(self.L.dcahip_dropout_apply(p(x), ldx, p(perm), p(cursor), B, h, float(rate), int(seed),
+                                              p(step), int(layer), int(row0), p(out), ldo, hip.stream()),
+                  'dropout_apply')
+
     def counter_add(self, counter, v):
         hip.check(self.L.dcahip_counter_add(hip.ptr(counter), v, hip.stream()), 'counter_add')
 

@@ -271,6 +271,26 @@ int dcahip_l1l2_workspace_doubles(void);
 int dcahip_l1l2_apply(const dcahip_reg_desc* d, const float* w, float* g, float* loss_inout,
                       double* workspace, void* stream);
 
+/*
+ * K-DROP: Keras Dropout of dca/network.py:98-99 (input_dropout) and :137-138 (hidden_dropout),
+ * training mode only: out[r, c] = x[src(r), c] * keep(r, c) / (1 - rate).
+ * src(r) = perm[*cursor + r] when perm != NULL (the minibatch gather of the input layer), else r;
+ * in place (out == x) is allowed when perm == NULL.  The same call applied to the incoming
+ * gradient is the backward pass (the mask is recomputed, never stored).
+ * keep(r, c): Philox4x32-10 (Salmon et al., SC'11) with key = seed, counter =
+ * (group lo, group hi, (uint32)*step, layer), group = (row0 + r) * ceil(h / 4) + c / 4, word c % 4
+ * of the output block; u = (word >> 8) * 2^-24 and the unit is kept when u >= rate (TF:
+ * random_uniform >= rate).  row0 = index of this rank's first row inside the global batch, so a
+ * data-parallel run draws the masks of the single-process run.  *step is device memory (captured
+ * step graphs stay valid); the host advances it with dcahip_counter_add.  The reference's masks
+ * come from TF's stateful RNG and are not reproducible across TF builds: parity here is statistical
+ * (keep frequency, scaling) and exact against oracle/net_np.py's restatement of this generator,
+ * which is pinned on the published Random123 known-answer vectors.
+ */
+int dcahip_dropout_apply(const float* x, long ldx, const int* perm, const long long* cursor, int B, int h,
+                         float rate, unsigned long long seed, const long long* step, int layer, long row0,
+                         float* out, long ldo, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -284,6 +284,19 @@ class CpuRefOps:
         if b is not None:
             b[:] = nb
 
+    def dropout_apply(self, x, ldx, perm, cursor, B, h, rate, seed, step, layer, row0, out, ldo):
+        from . import net_np as N
+        if B == 0:
+            return
+        if perm is not None:
+            c = int(cursor.item()) if cursor is not None else 0
+            rows = perm[c:c + B].numpy().astype(np.int64)
+            src = _mat(x, int(rows.max()) + 1, h, ldx)[rows]
+        else:
+            src = _mat(x, B, h, ldx)
+        keep = N.dropout_keep(seed, int(step[0].item()) if step is not None else 0, layer, row0, B, h, rate)
+        _mat(out, B, h, ldo)[:] = np.where(keep, src * N.dropout_scale(rate), np.float32(0))
+
     def counter_add(self, counter, v):
         counter[0] += v
 

@@ -77,6 +77,52 @@ def act_grad_from_out(code, h):
     raise ValueError(code)
 
 
+# ------------------------------------------------------------------ dropout generator
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Philox4x32-10 of Salmon, Moraes, Dror, Shaw, "Parallel random numbers: as easy as 1, 2, 3"
+    (SC'11) on uint32 arrays (broadcasting); returns the 4 output words.  Pinned on the Random123
+    known-answer vectors in tests/test_dropout_cpu.py.  This is the generator of K-DROP
+    (include/dcahip.h dcahip_dropout_apply); the reference's own masks come from TF's stateful RNG
+    (keras Dropout, dca/network.py:98-99, 137-138) and are not reproducible."""
+    c0, c1, c2, c3 = [np.asarray(c, dtype=np.uint64) & np.uint64(0xffffffff) for c in (c0, c1, c2, c3)]
+    c0, c1, c2, c3 = np.broadcast_arrays(c0, c1, c2, c3)
+    k0 = np.uint64(int(k0) & 0xffffffff)
+    k1 = np.uint64(int(k1) & 0xffffffff)
+    m32 = np.uint64(0xffffffff)
+    sh = np.uint64(32)
+    for _ in range(10):
+        p0 = np.uint64(0xD2511F53) * c0
+        p1 = np.uint64(0xCD9E8D57) * c2
+        n0 = (p1 >> sh) ^ c1 ^ k0
+        n1 = p1 & m32
+        n2 = (p0 >> sh) ^ c3 ^ k1
+        n3 = p0 & m32
+        c0, c1, c2, c3 = n0, n1, n2, n3
+        k0 = (k0 + np.uint64(0x9E3779B9)) & m32
+        k1 = (k1 + np.uint64(0xBB67AE85)) & m32
+    return c0.astype(np.uint32), c1.astype(np.uint32), c2.astype(np.uint32), c3.astype(np.uint32)
+
+
+def dropout_keep(seed, step, layer, row0, B, h, rate):
+    """[B, h] boolean keep mask of K-DROP: unit (r, c) uses word c % 4 of the Philox block with
+    counter (group lo, group hi, step, layer), group = (row0 + r) * ceil(h/4) + c // 4, key = seed;
+    kept when (word >> 8) * 2^-24 >= rate (TF: random_uniform >= rate)."""
+    hq = (h + 3) // 4
+    grp = (np.uint64(row0) + np.arange(B, dtype=np.uint64))[:, None] * np.uint64(hq) + np.arange(hq, dtype=np.uint64)[None, :]
+    words = philox4x32_10(grp & np.uint64(0xffffffff), grp >> np.uint64(32), np.uint64(int(step) & 0xffffffff),
+                          np.uint64(layer), int(seed) & 0xffffffff, (int(seed) >> 32) & 0xffffffff)
+    w = np.stack(words, axis=-1).reshape(B, hq * 4)[:, :h]
+    u = (w >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)
+    return u >= np.float32(rate)
+
+
+def dropout_scale(rate):
+    return np.float32(1.0) / (np.float32(1.0) - np.float32(rate))
+
+
+INPUT_DROPOUT_LAYER = 255          # Philox counter word 3 of the input dropout; hidden layer i uses i
+
+
 def glorot_uniform(rng, fan_in, fan_out, dtype):
     lim = np.sqrt(6.0 / (fan_in + fan_out))
     return rng.uniform(-lim, lim, size=(fan_in, fan_out)).astype(dtype)
@@ -120,8 +166,15 @@ def is_trainable(name):
 
 class OracleAE:
     def __init__(self, ae_type, params, hidden_size, batchnorm=True, ridge=0.0, reg=(0., 0., 0., 0.),
-                 activation='relu'):
+                 activation='relu', hidden_dropout=0., input_dropout=0., dropout_seed=0):
         assert ae_type in AE_TYPES
+        hd = hidden_dropout if isinstance(hidden_dropout, (list, tuple)) else [hidden_dropout] * len(hidden_size)
+        assert len(hd) == len(hidden_size)                  # network.py:87-90
+        self.hidden_dropout = [float(x) for x in hd]
+        self.input_dropout = float(input_dropout)
+        self.dropout_seed = int(dropout_seed)
+        self.step = 0                                       # completed training steps (dropout counter)
+        self.row0 = 0
         self.act = ACT_CODES[activation]
         self.reg = tuple(float(x) for x in reg)          # l1, l2, l1_enc, l2_enc (network.py:114-126)
         self.ae_type = ae_type
@@ -136,7 +189,12 @@ class OracleAE:
     def forward(self, X, sf, training):
         p, dt = self.p, self.dtype
         H = X.astype(dt)
-        cache = {'H': [H], 'xh': [], 'inv': [], 'Yb': [], 'Z': []}
+        cache = {'H': [H], 'xh': [], 'inv': [], 'Yb': [], 'Z': [], 'keep': {}}
+        if training and self.input_dropout > 0.0:            # network.py:98-99
+            keep = dropout_keep(self.dropout_seed, self.step, INPUT_DROPOUT_LAYER, self.row0, H.shape[0],
+                                H.shape[1], self.input_dropout)
+            H = np.where(keep, H * dt.type(dropout_scale(self.input_dropout)), dt.type(0))
+            cache['H'][0] = H
         for i in range(len(self.hidden_size)):
             Zi = H @ p['W%d' % i] + p['b%d' % i]
             cache['Z'].append(Zi)
@@ -158,6 +216,11 @@ class OracleAE:
                 Yb = Zi
             cache['Yb'].append(Yb)
             H = act_fwd(self.act, Yb)
+            if training and self.hidden_dropout[i] > 0.0:    # network.py:137-138
+                keep = dropout_keep(self.dropout_seed, self.step, i, self.row0, H.shape[0], H.shape[1],
+                                    self.hidden_dropout[i])
+                cache['keep'][i] = keep
+                H = np.where(keep, H * dt.type(dropout_scale(self.hidden_dropout[i])), dt.type(0))
             cache['H'].append(H)
         cache['a_mean'] = H @ p['W_mean'] + p['b_mean']
         cache['a_disp'] = H @ p['W_disp'] + p['b_disp'] if 'W_disp' in p else None
@@ -207,6 +270,9 @@ class OracleAE:
             g['b_pi'] = d_pi.sum(axis=0)
             dH = dH + d_pi @ p['W_pi'].T
         for i in reversed(range(len(self.hidden_size))):
+            if i in c['keep']:
+                dH = np.where(c['keep'][i], dH * self.dtype.type(dropout_scale(self.hidden_dropout[i])),
+                              self.dtype.type(0))
             dYb = dH * act_grad(self.act, c['Yb'][i])
             if self.batchnorm:
                 xh, inv = c['xh'][i], c['inv'][i]
@@ -220,6 +286,7 @@ class OracleAE:
                 dH = dZ @ p['W%d' % i].T
         for k, v in greg.items():
             g[k] = g[k] + v
+        self.step += 1
         return loss, g
 
     def reg_penalty(self):

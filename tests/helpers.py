@@ -25,14 +25,14 @@ def make_problem(n, G, hs, ae_type, batchnorm=True, seed=0, dtype=np.float64):
     return X, Y, sf, p
 
 
-def oracle_net(ae_type, p, hs, batchnorm, ridge=0.0, dtype=np.float64, activation='relu'):
+def oracle_net(ae_type, p, hs, batchnorm, ridge=0.0, dtype=np.float64, activation='relu', **dropout):
     return N.OracleAE(ae_type, {k: np.asarray(v, dtype).copy() for k, v in p.items()}, hs, batchnorm, ridge,
-                      activation=activation)
+                      activation=activation, **dropout)
 
 
-def make_engine(ops, ae_type, G, hs, batchnorm, ridge, p, X, Y, sf, comm=None, activation='relu'):
+def make_engine(ops, ae_type, G, hs, batchnorm, ridge, p, X, Y, sf, comm=None, activation='relu', **dropout):
     from dca_amd.engine import Engine
-    eng = Engine(ae_type, G, G, hs, batchnorm, ridge, ops=ops, comm=comm, activation=activation)
+    eng = Engine(ae_type, G, G, hs, batchnorm, ridge, ops=ops, comm=comm, activation=activation, **dropout)
     eng.set_params(p)
     eng.load_data(X, Y, sf)
     return eng

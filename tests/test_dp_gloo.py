@@ -59,6 +59,7 @@ def _run(rank, world, port, cfg, q):
         from dca_amd.train import fit_engine
         n, G, hs, ae, bn, B, epochs, seed = cfg[:8]
         optimizer = cfg[8] if len(cfg) > 8 else None
+        drop = cfg[9] if len(cfg) > 9 else {}
         X, Y, sf, p = make_problem(n, G, hs, ae, bn, seed=3)
         n_train = int(n * 0.9)
         n_val = n - n_train
@@ -66,7 +67,7 @@ def _run(rank, world, port, cfg, q):
         t0, nt = ddist.shard(n_train, world, rank)
         v0, nv = ddist.shard(n_val, world, rank)
         rows = np.r_[np.arange(t0, t0 + nt), n_train + np.arange(v0, v0 + nv)]
-        eng = Engine(ae, G, G, hs, bn, 0.0, ops=CpuRefOps(), comm=comm)
+        eng = Engine(ae, G, G, hs, bn, 0.0, ops=CpuRefOps(), comm=comm, **drop)
         eng.set_params(p)
         if optimizer:
             eng.set_optimizer(optimizer)
@@ -168,6 +169,33 @@ def test_two_rank_dp_gradients_are_summed_once():
         np.testing.assert_allclose(p_dp[k], p1[k], rtol=1e-4, atol=1e-5, err_msg=k)
         if k.startswith('beta'):
             assert np.abs(p1[k] - p[k]).max() > 1e-4      # the check is not vacuous
+
+
+def test_two_rank_dp_with_dropout_draws_the_single_process_masks():
+    """K-DROP indexes its generator by the row's position in the GLOBAL batch: two ranks reproduce the
+    single-process run (and the oracle) with dropout on."""
+    ae, bn, n, B = 'zinb-conddisp', True, 60, 16
+    G, hs, epochs, seed, W = 14, (6, 3, 6), 2, 17, 2
+    drop = dict(hidden_dropout=[0.3, 0.0, 0.2], input_dropout=0.2, dropout_seed=11)
+    cfg = (n, G, hs, ae, bn, B, epochs, seed, None, drop)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_run, args=(r, W, port, cfg, q)) for r in range(W)]
+    for pr in procs:
+        pr.start()
+    hist_dp, p_dp = q.get(timeout=120)
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    X, Y, sf, p = make_problem(n, G, hs, ae, bn, seed=3)
+    n_train = int(n * 0.9)
+    orders = dp_equivalent_orders(n_train, W, B // W, epochs, seed)
+    ref = N.OracleAE(ae, {k: np.asarray(v, np.float64).copy() for k, v in p.items()}, hs, bn, **drop)
+    rh = N.fit(ref, X.astype(np.float64), Y.astype(np.float64), sf.astype(np.float64), epochs=epochs,
+               batch_size=B, shuffle_rng=FixedOrders(orders), reduce_lr=1, early_stop=0)
+    np.testing.assert_allclose(hist_dp['loss'], rh['loss'], rtol=1e-4)
+    np.testing.assert_allclose(hist_dp['val_loss'], rh['val_loss'], rtol=1e-4)
 
 
 def test_shard_and_local_order():
