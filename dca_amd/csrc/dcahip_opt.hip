@@ -9,6 +9,7 @@
 //   Adadelta  a = .95 a + .05 g^2 ; u = g sqrt(d + 1e-7) / sqrt(a + 1e-7) ; d = .95 d + .05 u^2 ; w -= lr u
 //   Adam      m = .9 m + .1 g ; v = .999 v + .001 g^2 ; w -= lr sqrt(1-.999^t)/(1-.9^t) m / (sqrt(v) + 1e-7)
 //   Adamax    m = .9 m + .1 g ; u = max(.999 u, |g|) ; w -= lr/(1-.9^t) m / (u + 1e-7)
+//   Nadam     dcahip_nadam_step below (momentum schedule with a running product kept in device memory)
 // g is clipped to [-clip, clip] first (Keras clipvalue).  t = *iter + 1 is read from device memory
 // (captured step graphs stay valid); dcahip_counter_add advances it after the step.
 #include <hip/hip_runtime.h>
@@ -101,6 +102,37 @@ __global__ __launch_bounds__(256) void l1l2_finish_kernel(const double* partial,
     }
 }
 
+// tf.keras Nadam (optimizer_v2/nadam.py): momentum schedule mu_t = b1 (1 - 0.5 * 0.96^(0.004 t)), its running
+// product m_schedule (a float32 variable there, device memory here), then
+//   g' = g / (1 - P_t) ; m = b1 m + (1-b1) g ; m' = m / (1 - P_t mu_{t+1}) ; v = b2 v + (1-b2) g^2 ; v' = v / (1 - b2^t)
+//   w -= lr ((1 - mu_t) g' + mu_{t+1} m') / (sqrt(v') + eps),   P_t = prod_{i<=t} mu_i
+__device__ __forceinline__ float nadam_mu(double t) { return (float)(0.9 * (1.0 - 0.5 * pow(0.96, 0.004 * t))); }
+
+__global__ __launch_bounds__(256) void nadam_kernel(float* w, const float* g, float* m, float* v, long n, const float* lr_p,
+                                                    const long long* iter, const float* m_schedule, float clip) {
+    const float lr = *lr_p;
+    const double t = (double)(*iter + 1);
+    const float mu_t = nadam_mu(t), mu_t1 = nadam_mu(t + 1.0);
+    const float p_new = *m_schedule * mu_t, p_next = p_new * mu_t1;
+    const float vden = (float)(1.0 - pow(0.999, t));
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        float gi = g[i];
+        if (clip > 0.f) gi = fminf(fmaxf(gi, -clip), clip);
+        const float gp = gi / (1.f - p_new);
+        const float mi = 0.9f * m[i] + 0.1f * gi;
+        const float vi = 0.999f * v[i] + 0.001f * gi * gi;
+        const float mbar = (1.f - mu_t) * gp + mu_t1 * (mi / (1.f - p_next));
+        w[i] -= lr * mbar / (sqrtf(vi / vden) + 1e-7f);
+        m[i] = mi;
+        v[i] = vi;
+    }
+}
+
+__global__ void nadam_schedule_kernel(float* m_schedule, const long long* iter) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *m_schedule *= nadam_mu((double)(*iter + 1));
+}
+
 constexpr int kRegBlocks = 64;
 
 }  // namespace
@@ -117,6 +149,17 @@ extern "C" int dcahip_optimizer_step(int kind, float* w, const float* g, float* 
     if (grid > 4096) grid = 4096;
     OptArgs a{w, g, slot1, slot2, n, lr, iter, kind, clip};
     hipLaunchKernelGGL(optimizer_kernel, dim3((int)grid), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dcahip_nadam_step(float* w, const float* g, float* m, float* v, long n, const float* lr,
+                                 const long long* iter, float* m_schedule, float clip, void* stream) {
+    if (!w || !g || !m || !v || !lr || !iter || !m_schedule || n <= 0) return DCAHIP_EINVAL;
+    long grid = (n + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(nadam_kernel, dim3((int)grid), dim3(256), 0, s, w, g, m, v, n, lr, iter, m_schedule, clip);
+    hipLaunchKernelGGL(nadam_schedule_kernel, dim3(1), dim3(64), 0, s, m_schedule, iter);   // after every read of the old product
     return (int)hipGetLastError();
 }
 

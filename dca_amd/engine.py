@@ -106,6 +106,58 @@ class SingleProcess:
         return None
 
 
+def _truncated_normal(rng, stddev, shape):
+    """TF truncated_normal: values beyond two standard deviations are redrawn."""
+    out = rng.normal(0.0, 1.0, size=shape)
+    bad = np.abs(out) > 2.0
+    while bad.any():
+        out[bad] = rng.normal(0.0, 1.0, size=int(bad.sum()))
+        bad = np.abs(out) > 2.0
+    return out * stddev
+
+
+KERAS_INITIALIZERS = ('glorot_uniform', 'glorot_normal', 'he_uniform', 'he_normal', 'lecun_uniform', 'lecun_normal',
+                      'random_uniform', 'random_normal', 'truncated_normal', 'orthogonal', 'zeros', 'ones')
+
+
+def keras_initializer(name, rng, fan_in, fan_out):
+    """[fan_in, fan_out] float32 kernel from a Keras initialiser name (tf.keras 2.x defaults:
+    VarianceScaling(scale, mode, distribution) with the 0.8796 truncation correction for the *_normal
+    family; RandomUniform +-0.05; RandomNormal / TruncatedNormal stddev 0.05; Orthogonal gain 1)."""
+    key = name.lower() if isinstance(name, str) else name
+    vs = {'glorot_uniform': (1.0, 'avg', 'u'), 'glorot_normal': (1.0, 'avg', 'n'),
+          'he_uniform': (2.0, 'in', 'u'), 'he_normal': (2.0, 'in', 'n'),
+          'lecun_uniform': (1.0, 'in', 'u'), 'lecun_normal': (1.0, 'in', 'n')}
+    shape = (fan_in, fan_out)
+    if key in vs:
+        scale, mode, distr = vs[key]
+        n = (fan_in + fan_out) / 2.0 if mode == 'avg' else float(fan_in)
+        if distr == 'u':
+            lim = math.sqrt(3.0 * scale / n)
+            w = rng.uniform(-lim, lim, size=shape)
+        else:
+            w = _truncated_normal(rng, math.sqrt(scale / n) / .87962566103423978, shape)
+    elif key == 'random_uniform':
+        w = rng.uniform(-0.05, 0.05, size=shape)
+    elif key == 'random_normal':
+        w = rng.normal(0.0, 0.05, size=shape)
+    elif key == 'truncated_normal':
+        w = _truncated_normal(rng, 0.05, shape)
+    elif key == 'orthogonal':
+        a = rng.normal(0.0, 1.0, size=(max(shape), min(shape)))
+        q, r = np.linalg.qr(a)
+        q = q * np.sign(np.diag(r))
+        w = q if fan_in >= fan_out else q.T
+    elif key == 'zeros':
+        w = np.zeros(shape)
+    elif key == 'ones':
+        w = np.ones(shape)
+    else:
+        raise NotImplementedError('init=%r is not implemented on the MI355X path (available: %s)'
+                                  % (name, ', '.join(KERAS_INITIALIZERS)))
+    return np.ascontiguousarray(w, dtype=np.float32)
+
+
 class ParamLayout:
     """Offsets of every tensor in the flat parameter / gradient / RMSprop buffers."""
 
@@ -200,6 +252,7 @@ class Engine:
         self._pending = None        # in-flight all-reduce of the heads bucket (data parallel)
         self.opt_kind = 'rmsprop'   # train.py:54-57 picks the Keras optimizer by name
         self.slot2 = None
+        self.m_sched = None         # Nadam: running product of the momentum schedule
         self.opt_iter = torch.zeros(1, dtype=torch.int64, device=self.dev)
         self.reg = None             # l1 / l2 kernel regularisers (network.py:114-126)
         self.reg_ws = None
@@ -221,21 +274,20 @@ class Engine:
         return self.prof.section(name) if self.prof is not None else _NULL
 
     # ------------------------------------------------------------------ parameters
-    def init_params(self, seed=0):
-        """glorot_uniform kernels (keras default, network.py:57), zero biases / beta /
-        log-dispersion.  The stream is numpy RandomState(seed) (TensorFlow's initialiser stream
-        is not reproducible outside TensorFlow)."""
+    def init_params(self, seed=0, init='glorot_uniform'):
+        """Dense kernels from the named Keras initialiser (network.py:57 default glorot_uniform; every
+        Dense of network.py:124-126, 369-380 gets kernel_initializer=self.init), zero biases / beta /
+        log-dispersion.  The stream is numpy RandomState(seed): TensorFlow's initialiser stream is not
+        reproducible outside TensorFlow, the distributions are (tf.keras 2.x VarianceScaling et al.)."""
         rng = np.random.RandomState(seed)
         lay = self.lay
         p = {}
         fan_in = lay.G_in
         for i, h in enumerate(lay.hidden):
-            lim = math.sqrt(6.0 / (fan_in + h))
-            p['W%d' % i] = rng.uniform(-lim, lim, size=(fan_in, h)).astype(np.float32)
+            p['W%d' % i] = keras_initializer(init, rng, fan_in, h)
             fan_in = h
         for hd in lay.heads:
-            lim = math.sqrt(6.0 / (fan_in + lay.G_out))
-            p['W_' + hd] = rng.uniform(-lim, lim, size=(fan_in, lay.G_out)).astype(np.float32)
+            p['W_' + hd] = keras_initializer(init, rng, fan_in, lay.G_out)
         self.set_params(p)
 
     def set_params(self, p):
@@ -295,12 +347,13 @@ class Engine:
     def set_optimizer(self, name):
         """Keras optimizer by name with its default hyper-parameters; resets the slots."""
         name = name.lower()
-        if name not in ('sgd', 'rmsprop', 'adagrad', 'adadelta', 'adam', 'adamax'):
+        if name not in ('sgd', 'rmsprop', 'adagrad', 'adadelta', 'adam', 'adamax', 'nadam'):
             raise NotImplementedError('optimizer %r is not implemented on the MI355X path (available: SGD, '
-                                      'RMSprop, Adagrad, Adadelta, Adam, Adamax)' % name)
+                                      'RMSprop, Adagrad, Adadelta, Adam, Adamax, Nadam)' % name)
         self.opt_kind = name
         self.ms.fill_(0.1 if name == 'adagrad' else 0.0)       # tf.keras initial_accumulator_value
-        self.slot2 = torch.zeros_like(self.ms) if name in ('adadelta', 'adam', 'adamax') else None
+        self.slot2 = torch.zeros_like(self.ms) if name in ('adadelta', 'adam', 'adamax', 'nadam') else None
+        self.m_sched = torch.ones(1, dtype=torch.float32, device=self.dev) if name == 'nadam' else None
         self.opt_iter.zero_()
 
     def set_regularizers(self, l1=0., l2=0., l1_enc=0., l2_enc=0.):
@@ -333,6 +386,8 @@ class Engine:
         and the fit loop's scalars (epoch, lr, callback counters, history)."""
         import json
         extra = {} if self.slot2 is None else {'slot2': self.slot2.cpu().numpy()}
+        if self.m_sched is not None:
+            extra['m_sched'] = self.m_sched.cpu().numpy()
         np.savez(path, w=self.w.cpu().numpy(), ms=self.ms.cpu().numpy(), opt_iter=self.opt_iter.cpu().numpy(),
                  drop_iter=self.drop_iter.cpu().numpy(), **extra,
                  **{'mm%d' % i: t.cpu().numpy() for i, t in enumerate(self.mm)},
@@ -347,6 +402,8 @@ class Engine:
             self.ms.copy_(torch.as_tensor(z['ms']))
             if 'opt_iter' in z.files:
                 self.opt_iter.copy_(torch.as_tensor(z['opt_iter']))
+            if self.m_sched is not None and 'm_sched' in z.files:
+                self.m_sched.copy_(torch.as_tensor(z['m_sched']))
             if 'drop_iter' in z.files:
                 self.drop_iter.copy_(torch.as_tensor(z['drop_iter']))
             if self.slot2 is not None and 'slot2' in z.files:
@@ -569,6 +626,9 @@ class Engine:
         if self.opt_kind == 'rmsprop':
             with self._t('rmsprop_clip'):
                 ops.rmsprop_clip(w, g, self.ms, lay.P, self.lr, RMS_RHO, RMS_EPS, self.clip)
+        elif self.opt_kind == 'nadam':
+            ops.nadam_step(w, g, self.ms, self.slot2, lay.P, self.lr, self.opt_iter, self.m_sched, self.clip)
+            ops.counter_add(self.opt_iter, 1)
         else:
             ops.optimizer_step(self.opt_kind, w, g, None if self.opt_kind == 'sgd' else self.ms,
                                self.slot2, lay.P, self.lr, self.opt_iter, self.clip)

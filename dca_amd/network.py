@@ -107,8 +107,8 @@ class Autoencoder():
             unsupported.append('ae_type=%r' % self.ae_type)
         if self.activation not in _engine.ACT_CODES:
             unsupported.append('activation=%r' % self.activation)
-        if self.init != 'glorot_uniform':
-            unsupported.append('init=%r' % self.init)
+        if not isinstance(self.init, str) or self.init.lower() not in _engine.KERAS_INITIALIZERS:
+            unsupported.append('init=%r' % (self.init,))
         if unsupported:
             raise NotImplementedError('not implemented on the MI355X path yet: ' + ', '.join(unsupported))
 
@@ -122,7 +122,7 @@ class Autoencoder():
                                      comm=self.comm, activation=self.activation,
                                      hidden_dropout=self.hidden_dropout, input_dropout=self.input_dropout,
                                      dropout_seed=self.seed)
-        self.engine.init_params(self.seed)
+        self.engine.init_params(self.seed, self.init)
         self.engine.set_regularizers(self.l1_coef, self.l2_coef, self.l1_enc_coef, self.l2_enc_coef)
         self.model = self.engine             # what train() drives (reference: the Keras Model)
         self.encoder = self.engine

@@ -123,6 +123,11 @@ class HipOps:
         hip.check(self.L.dcahip_optimizer_step(hip.OPT_KINDS[kind], p(w), p(g), p(slot1), p(slot2), n, p(lr),
                                                p(it), clip, hip.stream()), 'optimizer_step')
 
+    def nadam_step(self, w, g, m, v, n, lr, it, m_schedule, clip):
+        p = hip.ptr
+        hip.check(self.L.dcahip_nadam_step(p(w), p(g), p(m), p(v), n, p(lr), p(it), p(m_schedule), clip, hip.stream()),
+                  'nadam_step')
+
     def dropout_apply(self, x, ldx, perm, cursor, B, h, rate, seed, step, layer, row0, out, ldo):
         p = hip.ptr
         hip.check(self.L.dcahip_dropout_apply(p(x), ldx, p(perm), p(cursor), B, h, float(rate), int(seed),

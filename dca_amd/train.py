@@ -22,7 +22,7 @@ from . import dist as ddist
 
 
 KERAS_DEFAULT_LR = {'sgd': 0.01, 'rmsprop': 0.001, 'adagrad': 0.001, 'adadelta': 0.001, 'adam': 0.001,
-                    'adamax': 0.001}
+                    'adamax': 0.001, 'nadam': 0.001}
 
 
 class History:

@@ -259,6 +259,11 @@ int dcahip_rmsprop_clip(float* w, const float* g, float* ms, long n, const float
 int dcahip_optimizer_step(int kind, float* w, const float* g, float* slot1, float* slot2, long n,
                           const float* lr, const long long* iter, float clip, void* stream);
 int dcahip_counter_add(long long* counter, int v, void* stream);
+/* tf.keras Nadam (beta_1 .9, beta_2 .999, epsilon 1e-7, schedule decay .004): m, v = the two slots ([n], zero
+ * initialised), *m_schedule = running product of the momentum schedule (device float, initialised to 1 by the
+ * host; the call multiplies it by mu_t after the update has read it), *iter = completed steps as above. */
+int dcahip_nadam_step(float* w, const float* g, float* m, float* v, long n, const float* lr,
+                      const long long* iter, float* m_schedule, float clip, void* stream);
 #define DCAHIP_REG_MAX_SEGS 16
 typedef struct {
     int nseg;

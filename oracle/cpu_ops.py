@@ -284,6 +284,17 @@ class CpuRefOps:
         if b is not None:
             b[:] = nb
 
+    def nadam_step(self, w, g, m, v, n, lr, it, m_schedule, clip):
+        from . import net_np as N
+        t = int(it[0].item()) + 1
+        wv, mv, vv = _vec(w, n), _vec(m, n), _vec(v, n)
+        nw, na, nb = N.optimizer_update('nadam', wv.astype(np.float64), _vec(g, n).astype(np.float64),
+                                        mv.astype(np.float64), vv.astype(np.float64), float(lr[0].item()), t, clip)
+        wv[:] = nw
+        mv[:] = na
+        vv[:] = nb
+        m_schedule[0] = float(m_schedule[0].item()) * N.nadam_mu(t)
+
     def dropout_apply(self, x, ldx, perm, cursor, B, h, rate, seed, step, layer, row0, out, ldo):
         from . import net_np as N
         if B == 0:

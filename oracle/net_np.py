@@ -327,7 +327,11 @@ def rmsprop_step(params, grads, ms, lr, rho=0.9, eps=1e-7, clip=5.0):
 
 
 KERAS_DEFAULT_LR = {'sgd': 0.01, 'rmsprop': 0.001, 'adagrad': 0.001, 'adadelta': 0.001, 'adam': 0.001,
-                    'adamax': 0.001}
+                    'adamax': 0.001, 'nadam': 0.001}
+
+
+def nadam_mu(t):
+    return 0.9 * (1.0 - 0.5 * 0.96 ** (0.004 * t))
 
 
 def optimizer_update(kind, w, g, a, b, lr, t, clip=5.0):
@@ -356,6 +360,17 @@ def optimizer_update(kind, w, g, a, b, lr, t, clip=5.0):
         a = 0.9 * a + 0.1 * g
         b = np.maximum(0.999 * b, np.abs(g))
         return w - lr / (1 - 0.9 ** t) * a / (b + 1e-7), a, b
+    if kind == 'nadam':
+        # tf.keras optimizer_v2/nadam.py: _prepare_local (momentum schedule, cached running product)
+        # and _resource_apply_dense
+        mu_t, mu_t1 = nadam_mu(t), nadam_mu(t + 1)
+        p_new = float(np.prod([nadam_mu(i) for i in range(1, t + 1)]))
+        p_next = p_new * mu_t1
+        gp = g / (1.0 - p_new)
+        a = 0.9 * a + 0.1 * g
+        b = 0.999 * b + 0.001 * g * g
+        mbar = (1.0 - mu_t) * gp + mu_t1 * a / (1.0 - p_next)
+        return w - lr * mbar / (np.sqrt(b / (1.0 - 0.999 ** t)) + 1e-7), a, b
     raise ValueError(kind)
 
 

@@ -5,7 +5,7 @@ import numpy as np
 from helpers import make_problem, make_engine
 from oracle import net_np as N
 
-OPTIMIZERS = ['SGD', 'Adagrad', 'Adadelta', 'Adam', 'Adamax']
+OPTIMIZERS = ['SGD', 'Adagrad', 'Adadelta', 'Adam', 'Adamax', 'Nadam']
 REG_CASES = [(1e-4, 2e-4, 0., 0.), (1e-4, 0., 3e-4, 2e-4)]
 
 

@@ -108,3 +108,38 @@ def test_activations_single_step_matches_oracle(activation, batchnorm):
     out = eng.predict_chunk(0, 16, {'mean', 'latent'})
     for k in ('mean', 'latent'):
         np.testing.assert_allclose(out[k].cpu().numpy(), out_ref[k], rtol=2e-3, atol=2e-4, err_msg=k)
+
+
+def test_keras_initializers_have_the_keras_distributions():
+    """kernel_initializer=self.init (network.py:57,124-126): limits / variances of tf.keras 2.x."""
+    from dca_amd.engine import keras_initializer, KERAS_INITIALIZERS
+    fi, fo = 400, 300
+    rng = np.random.RandomState(0)
+    lim = {'glorot_uniform': np.sqrt(6.0 / (fi + fo)), 'he_uniform': np.sqrt(6.0 / fi), 'lecun_uniform': np.sqrt(3.0 / fi),
+           'random_uniform': 0.05}
+    std = {'glorot_normal': np.sqrt(2.0 / (fi + fo)), 'he_normal': np.sqrt(2.0 / fi), 'lecun_normal': np.sqrt(1.0 / fi),
+           'random_normal': 0.05}
+    for name in KERAS_INITIALIZERS:
+        w = keras_initializer(name, rng, fi, fo)
+        assert w.shape == (fi, fo) and w.dtype == np.float32
+        if name in lim:
+            assert np.abs(w).max() <= lim[name] and np.abs(w).max() > 0.99 * lim[name]
+            assert abs(w.std() - lim[name] / np.sqrt(3)) < 0.01 * lim[name]
+        if name in std:
+            assert abs(w.std() - std[name]) < 0.02 * std[name], name
+            if name != 'random_normal':                        # truncated at 2 sigma of the untruncated normal
+                assert np.abs(w).max() <= 2.0 * std[name] / .87962566103423978 + 1e-6
+    w = keras_initializer('truncated_normal', rng, fi, fo)
+    assert np.abs(w).max() <= 0.1 + 1e-7 and abs(w.std() - 0.05 * .87962566103423978) < 1e-3
+    q = keras_initializer('orthogonal', rng, fi, fo)
+    np.testing.assert_allclose(q.T @ q, np.eye(fo), atol=1e-5)
+    q = keras_initializer('orthogonal', rng, fo, fi)
+    np.testing.assert_allclose(q @ q.T, np.eye(fo), atol=1e-5)
+    assert (keras_initializer('zeros', rng, 3, 4) == 0).all() and (keras_initializer('ones', rng, 3, 4) == 1).all()
+    with pytest.raises(NotImplementedError):
+        keras_initializer('no_such_init', rng, 3, 4)
+    from dca_amd.engine import Engine
+    eng = Engine('zinb', 20, hidden_size=(8, 4, 8), ops=CpuRefOps())
+    eng.init_params(1, 'he_normal')
+    p = eng.get_params()
+    assert abs(p['W0'].std() - np.sqrt(2.0 / 20)) < 0.08 and (p['b0'] == 0).all() and (p['theta_w'] == 0).all()
