@@ -449,6 +449,42 @@ extern "C" int dcahip_relu_fwd(const float* Z, long ldz, int B, int H, float* Ho
     return (int)hipGetLastError();
 }
 
+// Shared (per-cell scalar) heads of the *-shared networks: Dense(1) output -> [B, G] plane and back.
+__global__ __launch_bounds__(256) void bcast_cols_kernel(const float* __restrict__ s, long lds, int B, int G,
+                                                         float* __restrict__ out, long ldo) {
+    const int r = blockIdx.y;
+    const float v = s[(long)r * lds];
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < G; c += gridDim.x * 256) out[(long)r * ldo + c] = v;
+}
+
+__global__ __launch_bounds__(256) void row_sums_strided_kernel(const float* __restrict__ x, long ldx, int B, int G,
+                                                               float* __restrict__ out, long ldo) {
+    // one wave per row; fp64 lane partials over a fixed column assignment, butterfly in a fixed order: deterministic
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= B) return;
+    const int lane = threadIdx.x & 63;
+    double acc = 0.0;
+    for (int c = lane; c < G; c += 64) acc += (double)x[(long)r * ldx + c];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (lane == 0) out[(long)r * ldo] = (float)acc;
+}
+
+extern "C" int dcahip_bcast_cols(const float* s, long lds, int B, int G, float* out, long ldo, void* stream) {
+    if (!s || !out || B <= 0 || G <= 0 || ldo < G || lds < 1) return DCAHIP_EINVAL;
+    int gx = (G + 255) / 256;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(bcast_cols_kernel, dim3(gx, B), dim3(256), 0, static_cast<hipStream_t>(stream), s, lds, B, G, out, ldo);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dcahip_row_sums_strided(const float* x, long ldx, int B, int G, float* out, long ldo, void* stream) {
+    if (!x || !out || B <= 0 || G <= 0 || ldx < G || ldo < 1) return DCAHIP_EINVAL;
+    hipLaunchKernelGGL(row_sums_strided_kernel, dim3((B + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       x, ldx, B, G, out, ldo);
+    return (int)hipGetLastError();
+}
+
 extern "C" int dcahip_colsum_chain(const float* x, long ldx, int B, int N, const float* theta_w,
                                    float* out, void* stream) {
     if (!x || !out || B <= 0 || N <= 0) return DCAHIP_EINVAL;

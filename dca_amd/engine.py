@@ -34,6 +34,9 @@ AE_HEADS = {                      # ae_type -> (heads in the fused block, const 
     'nb': (('mean',), True),                             # network.py:249-270
     'poisson': (('mean',), False),                       # network.py:233-246 (poisson_loss)
     'normal': (('mean',), False),                        # network.py:143-156 (mse_loss, linear mean)
+    # Dense(1) dispersion (and dropout) broadcast over the genes: network.py:343-362, 464-491
+    'nb-shared': (('mean', 'disp'), False, ('disp',)),
+    'zinb-shared': (('mean', 'disp', 'pi'), False, ('disp', 'pi')),
 }
 ACT_CODES = {'linear': 0, 'relu': 1, 'tanh': 2, 'sigmoid': 3, 'elu': 4, 'selu': 5, 'softplus': 6,
              'softsign': 7, 'LeakyReLU': 8}
@@ -163,10 +166,15 @@ class ParamLayout:
 
     def __init__(self, ae_type, input_size, output_size, hidden_size, batchnorm):
         self.ae_type = ae_type
-        self.heads, self.const_disp = AE_HEADS[ae_type]
+        self.heads, self.const_disp = AE_HEADS[ae_type][:2]
+        self.shared = AE_HEADS[ae_type][2] if len(AE_HEADS[ae_type]) > 2 else ()
+        self.planes = tuple(h for h in self.heads if h not in self.shared)     # heads with one unit per gene
         self.G_in, self.G_out = input_size, output_size
         self.Gp = _r4(output_size)
-        self.NH = len(self.heads) * self.Gp
+        # columns of the heads' Dense block: the full-width heads, then 4 columns holding the Dense(1)
+        # heads; A / D rows additionally carry one broadcast plane per shared head behind them
+        self.NH = len(self.planes) * self.Gp + (4 if self.shared else 0)
+        self.ldA = self.NH + len(self.shared) * self.Gp
         self.hidden = tuple(int(h) for h in hidden_size)
         self.batchnorm = batchnorm
         self.seg = {}
@@ -198,8 +206,17 @@ class ParamLayout:
         return flat[off:off + int(np.prod(shape))].view(*shape)
 
     def head_cols(self, head):
-        k = self.heads.index(head)
+        if head in self.shared:
+            c = len(self.planes) * self.Gp + self.shared.index(head)
+            return c, c + 1
+        k = self.planes.index(head)
         return k * self.Gp, k * self.Gp + self.G_out
+
+    def plane_offset(self, head):
+        """Column of the head's [B, G] plane inside a row of A / D."""
+        if head in self.shared:
+            return self.NH + self.shared.index(head) * self.Gp
+        return self.planes.index(head) * self.Gp
 
 
 class Engine:
@@ -240,14 +257,14 @@ class Engine:
         self.partials = torch.zeros(ops.max_partials, dtype=torch.float64, device=self.dev)
         self.val_loss_tmp = torch.zeros(1, **f32)
         self.clip = 5.0                                   # train.py:37 clip_grad
-        self.ldD = lay.NH + (lay.Gp if lay.const_disp else 0)
+        self.ldD = lay.ldA + (lay.Gp if lay.const_disp else 0)
         self.Bmax = 0
         self.X = self.Y = self.sf = self.perm = None
         self.hist = None
         self.prof = None            # EventProfiler or None
         # K-HEADS (heads forward + NLL + both backward products in one kernel) whenever the
         # library supports the shape; DCA_AMD_FUSED_HEADS=0 forces the separate kernels
-        self.use_fused = os.environ.get('DCA_AMD_FUSED_HEADS', '1') != '0'
+        self.use_fused = os.environ.get('DCA_AMD_FUSED_HEADS', '1') != '0' and not lay.shared
         self.ws_heads = None
         self._pending = None        # in-flight all-reduce of the heads bucket (data parallel)
         self.opt_kind = 'rmsprop'   # train.py:54-57 picks the Keras optimizer by name
@@ -287,7 +304,7 @@ class Engine:
             p['W%d' % i] = keras_initializer(init, rng, fan_in, h)
             fan_in = h
         for hd in lay.heads:
-            p['W_' + hd] = keras_initializer(init, rng, fan_in, lay.G_out)
+            p['W_' + hd] = keras_initializer(init, rng, fan_in, 1 if hd in lay.shared else lay.G_out)
         self.set_params(p)
 
     def set_params(self, p):
@@ -466,10 +483,10 @@ class Engine:
         self.Xb = None                                  # input-dropout batch, allocated on first use
         self.dH = [torch.zeros(B, l, **f32) for l in self.ldh]
         self.dZ = [torch.zeros(B, l, **f32) for l in self.ldh]
-        self.A = torch.zeros(B, lay.NH, **f32)
+        self.A = torch.zeros(B, lay.ldA, **f32)
         # gradient planes of the heads (+ one d nll/d theta plane behind them for const-disp)
         self.D = torch.zeros(B, self.ldD, **f32)
-        self.Dth = self.D[:, lay.NH:] if lay.const_disp else None
+        self.Dth = self.D[:, lay.ldA:] if lay.const_disp else None
         R = ops.col_moments_chunks(B)
         self.inv_std = [torch.zeros(h, **f32) for h in lay.hidden]
         self.part = [torch.zeros(max(R, self.comm.world) * 2 * h, **f32) for h in lay.hidden]
@@ -576,24 +593,32 @@ class Engine:
         lay, ops = self.lay, self.ops
         with self._t('gemm_heads_fwd'):
             ops.sgemm(0, 0, B, lay.NH, K, self.Hcur[-1], self.ldh[-1], lay.view(self.w, 'Wh'), lay.NH,
-                      self.A, lay.NH, bias=lay.view(self.w, 'bh'), ws=self.ws)
+                      self.A, lay.ldA, bias=lay.view(self.w, 'bh'), ws=self.ws)
+        for hd in lay.shared:        # Dense(1) pre-activation -> the plane the loss / inference kernels read
+            c0, _ = lay.head_cols(hd)
+            ops.bcast_cols(self.A[:, c0:], lay.ldA, B, lay.G_out, self._plane(self.A, hd), lay.ldA)
 
     def _plane(self, buf, head):
         lay = self.lay
         if head not in lay.heads:
             return None
-        return buf[:, lay.heads.index(head) * lay.Gp:]
+        return buf[:, lay.plane_offset(head):]
 
     def _nll(self, B, perm, cursor, Y, sf, inv_n, grad):
         lay, ops = self.lay, self.ops
         A, D = self.A, self.D
         tw = lay.view(self.w, 'theta_w') if lay.const_disp else None
         d_disp = (self.Dth if lay.const_disp else self._plane(D, 'disp')) if grad else None
-        return ops.zinb_nll(self._plane(A, 'mean'), self._plane(A, 'disp'), self._plane(A, 'pi'),
-                            lay.NH, tw, Y, self.ldy, sf, perm, cursor, B, lay.G_out, self.ridge,
-                            inv_n, self.flags, self._plane(D, 'mean') if grad else None, d_disp,
-                            self._plane(D, 'pi') if grad else None, self.ldD if grad else 0,
-                            self.partials)
+        n = ops.zinb_nll(self._plane(A, 'mean'), self._plane(A, 'disp'), self._plane(A, 'pi'),
+                         lay.ldA, tw, Y, self.ldy, sf, perm, cursor, B, lay.G_out, self.ridge,
+                         inv_n, self.flags, self._plane(D, 'mean') if grad else None, d_disp,
+                         self._plane(D, 'pi') if grad else None, self.ldD if grad else 0,
+                         self.partials)
+        if grad:
+            for hd in lay.shared:    # gradient of the Dense(1) unit = its plane summed over the genes
+                c0, _ = lay.head_cols(hd)
+                ops.row_sums_strided(self._plane(D, hd), self.ldD, B, lay.G_out, D[:, c0:], self.ldD)
+        return n
 
     # ------------------------------------------------------------------ one training step
     def train_step(self, B, B_global=None, world_counts=None, rows_per_slot=None):
@@ -772,14 +797,14 @@ class Engine:
             m = self._plane(A, 'mean')
             d = self._plane(A, 'disp') if 'dispersion' in want else None
             p = self._plane(A, 'pi') if 'dropout' in want else None
-            ops.heads_infer(m, d, p, lay.NH, self.sf[r0:], b, lay.G_out,
-                            m if 'mean' in want else None, d, p, lay.NH, self.flags & 8)
+            ops.heads_infer(m, d, p, lay.ldA, self.sf[r0:], b, lay.G_out,
+                            m if 'mean' in want else None, d, p, lay.ldA, self.flags & 8)
             if 'mean' in want:
                 out['mean'] = m[:b, :lay.G_out]
-            if d is not None:
-                out['dispersion'] = d[:b, :lay.G_out]
+            if d is not None:        # shared heads: one value per cell ([n, 1], what the Dense(1) sub-model predicts)
+                out['dispersion'] = d[:b, :1 if 'disp' in lay.shared else lay.G_out]
             if p is not None:
-                out['dropout'] = p[:b, :lay.G_out]
+                out['dropout'] = p[:b, :1 if 'pi' in lay.shared else lay.G_out]
         return out
 
     def const_dispersion(self):

@@ -175,6 +175,8 @@ class Autoencoder():
         outs = {}
         for k in want:
             cols = lay.hidden[eng.center] if k == 'latent' else lay.G_out
+            if (k == 'dispersion' and 'disp' in lay.shared) or (k == 'dropout' and 'pi' in lay.shared):
+                cols = 1                                  # Dense(1) heads of the *-shared networks
             outs[k] = np.empty((n, cols), dtype=np.float32)
         # results leave through two pinned staging buffers per output: the device -> host copy of
         # chunk i runs asynchronously while the host moves chunk i-1 into the result arrays
@@ -291,8 +293,21 @@ class NBAutoencoder(Autoencoder):
                               colnames=colnames, transpose=True)
 
 
+def _write_shared(adata, file_path):
+    """The Dense(1) outputs are [n, 1]: one row of n values per file.  (The reference passes the gene
+    names as row names here, network.py:336-339 / 413-421 inherited, which pandas rejects.)"""
+    for key, fn in (('X_dca_dispersion', 'dispersion.tsv'), ('X_dca_dropout', 'dropout.tsv')):
+        if key in adata.obsm_keys():
+            write_text_matrix(adata.obsm[key], os.path.join(file_path, fn), transpose=True)
+
+
 class NBSharedAutoencoder(NBAutoencoder):
+    """network.py:343-362: dispersion = Dense(1), one value per cell, broadcast over the genes in the loss."""
     ae_type = 'nb-shared'
+
+    def write(self, adata, file_path, mode='denoise', colnames=None):
+        Autoencoder.write(self, adata, file_path, mode, colnames=colnames)
+        _write_shared(adata, file_path)
 
 
 class ZINBAutoencoder(Autoencoder):
@@ -330,7 +345,12 @@ class ZINBAutoencoderElemPi(ZINBAutoencoder):
 
 
 class ZINBSharedAutoencoder(ZINBAutoencoder):
+    """network.py:464-491: dropout and dispersion = Dense(1), one value per cell each."""
     ae_type = 'zinb-shared'
+
+    def write(self, adata, file_path, mode='denoise', colnames=None):
+        Autoencoder.write(self, adata, file_path, mode, colnames=colnames)
+        _write_shared(adata, file_path)
 
 
 class ZINBConstantDispAutoencoder(Autoencoder):

@@ -123,6 +123,13 @@ class HipOps:
         hip.check(self.L.dcahip_optimizer_step(hip.OPT_KINDS[kind], p(w), p(g), p(slot1), p(slot2), n, p(lr),
                                                p(it), clip, hip.stream()), 'optimizer_step')
 
+    def bcast_cols(self, s, lds, B, G, out, ldo):
+        hip.check(self.L.dcahip_bcast_cols(hip.ptr(s), lds, B, G, hip.ptr(out), ldo, hip.stream()), 'bcast_cols')
+
+    def row_sums_strided(self, x, ldx, B, G, out, ldo):
+        hip.check(self.L.dcahip_row_sums_strided(hip.ptr(x), ldx, B, G, hip.ptr(out), ldo, hip.stream()),
+                  'row_sums_strided')
+
     def nadam_step(self, w, g, m, v, n, lr, it, m_schedule, clip):
         p = hip.ptr
         hip.check(self.L.dcahip_nadam_step(p(w), p(g), p(m), p(v), n, p(lr), p(it), p(m_schedule), clip, hip.stream()),

@@ -200,6 +200,13 @@ int dcahip_relu_bwd(const float* dH, long ldd, const float* Hact, long ldh, int 
                     float* dZ, long ldz, int act, void* stream);
 /* h = max(z, 0): Activation('relu') of a stack built with batchnorm=False (network.py:132-135). */
 int dcahip_relu_fwd(const float* Z, long ldz, int B, int H, float* Hout, long ldh, int act, void* stream);
+/* Shared heads (NBSharedAutoencoder / ZINBSharedAutoencoder, network.py:343-362, 464-491): dispersion and
+ * dropout come from Dense(1) layers and broadcast over the genes inside the loss (loss.py:85-88,130-137).
+ * dcahip_bcast_cols: out[r, c] = s[r * lds] for c < G (the scalar pre-activation spread into the plane
+ * the loss kernel reads).  dcahip_row_sums_strided: out[r * ldo] = sum_c x[r, c] (the plane of
+ * pre-activation gradients folded back into the gradient of the scalar); fp64 accumulation, fixed order. */
+int dcahip_bcast_cols(const float* s, long lds, int B, int G, float* out, long ldo, void* stream);
+int dcahip_row_sums_strided(const float* x, long ldx, int B, int G, float* out, long ldo, void* stream);
 
 /* out[c] (+)= chain(c) * sum_r x[r, c]; chain = d clip(exp(w),1e-3,1e4)/dw if theta_w given
  * (ConstantDispersionLayer gradient, dca/layers.py:17-21), else 1. */

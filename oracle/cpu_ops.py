@@ -284,6 +284,12 @@ class CpuRefOps:
         if b is not None:
             b[:] = nb
 
+    def bcast_cols(self, s, lds, B, G, out, ldo):
+        _mat(out, B, G, ldo)[:] = _mat(s, B, 1, lds)
+
+    def row_sums_strided(self, x, ldx, B, G, out, ldo):
+        _mat(out, B, 1, ldo)[:, 0] = _mat(x, B, G, ldx).astype(np.float64).sum(axis=1)
+
     def nadam_step(self, w, g, m, v, n, lr, it, m_schedule, clip):
         from . import net_np as N
         t = int(it[0].item()) + 1

@@ -27,7 +27,8 @@ from . import zinb_np as Z
 
 BN_MOMENTUM = 0.99
 BN_EPS = 1e-3
-AE_TYPES = ('zinb-conddisp', 'zinb', 'nb-conddisp', 'nb', 'poisson', 'normal')
+AE_TYPES = ('zinb-conddisp', 'zinb', 'nb-conddisp', 'nb', 'poisson', 'normal', 'nb-shared', 'zinb-shared')
+SHARED_HEADS = {'nb-shared': ('disp',), 'zinb-shared': ('disp', 'pi')}     # Dense(1): network.py:343-362, 464-491
 
 
 ACT_CODES = {'linear': 0, 'relu': 1, 'tanh': 2, 'sigmoid': 3, 'elu': 4, 'selu': 5, 'softplus': 6,
@@ -145,13 +146,14 @@ def init_params(ae_type, input_size, hidden_size, output_size=None, batchnorm=Tr
             p['mv%d' % i] = np.ones(h, dtype)
         fan_in = h
     heads = ['mean']
-    if ae_type in ('zinb-conddisp', 'nb-conddisp'):
+    if ae_type in ('zinb-conddisp', 'nb-conddisp', 'nb-shared', 'zinb-shared'):
         heads.append('disp')
     if ae_type.startswith('zinb'):
         heads.append('pi')
     for hd in heads:
-        p['W_' + hd] = glorot_uniform(rng, fan_in, output_size, dtype)
-        p['b_' + hd] = np.zeros(output_size, dtype)
+        width = 1 if hd in SHARED_HEADS.get(ae_type, ()) else output_size
+        p['W_' + hd] = glorot_uniform(rng, fan_in, width, dtype)
+        p['b_' + hd] = np.zeros(width, dtype)
     if ae_type in ('zinb', 'nb'):
         p['theta_w'] = np.zeros(output_size, dtype)
     return p
@@ -236,12 +238,21 @@ class OracleAE:
         if self.ae_type == 'normal':
             ls, lm, dm = Z.mse_loss_and_grads(c['a_mean'], Y, c['sf'], n_total)
             return ls, lm, dm, None, None
+        # shared heads: the [B, 1] Dense(1) outputs broadcast against [B, G] inside the loss
+        # (loss.py:85-88, 130-140; the ridge term too); their gradient is the sum over the genes
+        shape = c['a_mean'].shape
+        a_disp = np.broadcast_to(c['a_disp'], shape) if c['a_disp'] is not None else None
+        a_pi = np.broadcast_to(c['a_pi'], shape) if c['a_pi'] is not None else None
         if self.ae_type.startswith('zinb'):
-            ls, lm, dm, dd, dpi = Z.zinb_loss_and_grads(c['a_mean'], c['a_disp'], c['a_pi'], Y,
+            ls, lm, dm, dd, dpi = Z.zinb_loss_and_grads(c['a_mean'], a_disp, a_pi, Y,
                                                         c['sf'], self.ridge, n_total, tw)
         else:
-            ls, lm, dm, dd = Z.nb_loss_and_grads(c['a_mean'], c['a_disp'], Y, c['sf'], n_total, tw)
+            ls, lm, dm, dd = Z.nb_loss_and_grads(c['a_mean'], a_disp, Y, c['sf'], n_total, tw)
             dpi = None
+        if c['a_disp'] is not None and c['a_disp'].shape[1] == 1 and shape[1] != 1:
+            dd = dd.sum(axis=1, keepdims=True)
+        if c['a_pi'] is not None and c['a_pi'].shape[1] == 1 and shape[1] != 1:
+            dpi = dpi.sum(axis=1, keepdims=True)
         return ls, lm, dm, dd, dpi
 
     def loss_and_grads(self, X, Y, sf, n_total=None):

@@ -143,3 +143,49 @@ def test_keras_initializers_have_the_keras_distributions():
     eng.init_params(1, 'he_normal')
     p = eng.get_params()
     assert abs(p['W0'].std() - np.sqrt(2.0 / 20)) < 0.08 and (p['b0'] == 0).all() and (p['theta_w'] == 0).all()
+
+
+@pytest.mark.parametrize('ae_type', ['nb-shared', 'zinb-shared'])
+def test_shared_heads_oracle_gradient_matches_finite_differences(ae_type):
+    """Dense(1) dispersion / dropout broadcast over genes (network.py:343-362, 464-491): the oracle's
+    analytic gradient of the scalar units against central differences of its own loss (ridge on)."""
+    n, G, hs = 10, 7, (5, 3, 5)
+    X, Y, sf, p = make_problem(n, G, hs, ae_type, False, seed=3)
+    assert p['W_disp'].shape == (5, 1) and p['b_disp'].shape == (1,)
+    net = oracle_net(ae_type, p, hs, False, ridge=0.05)
+    loss, g = net.loss_and_grads(X, Y, sf)
+    names = ['W_disp', 'b_disp', 'W_mean', 'W2'] + (['W_pi', 'b_pi'] if ae_type == 'zinb-shared' else [])
+    for name in names:
+        for idx in np.ndindex(*net.p[name].shape):
+            if idx[0] > 2 or (len(idx) > 1 and idx[1] > 2):
+                continue
+            old, eps, vals = net.p[name][idx], 1e-6, []
+            for d in (eps, -eps):
+                net.p[name][idx] = old + d
+                vals.append(net.loss_and_grads(X, Y, sf)[0])
+            net.p[name][idx] = old
+            fd = (vals[0] - vals[1]) / (2 * eps)
+            assert abs(fd - g[name][idx]) < 1e-6 * max(1.0, abs(fd)) + 1e-9, (name, idx, fd, g[name][idx])
+
+
+def test_shared_heads_api_and_outputs(tmp_path):
+    import pandas as pd
+    from conftest import synth_counts
+    from dca_amd.api import dca
+    from dca_amd._anndata import AnnData
+    from dca_amd.network import override_ops
+    n, G = 60, 25
+    ad = AnnData(synth_counts(n, G, 5).astype(np.float32), obs=pd.DataFrame(index=['c%d' % i for i in range(n)]),
+                 var=pd.DataFrame(index=['g%d' % i for i in range(G)]))
+    with override_ops(CpuRefOps):
+        for ae in ('nb-shared', 'zinb-shared'):
+            out, net = dca(ad, ae_type=ae, hidden_size=(8, 4, 8), epochs=2, batch_size=16, return_info=True,
+                           return_model=True, copy=True, verbose=False)
+            assert out.obsm['X_dca_dispersion'].shape == (n, 1)
+            assert (out.obsm['X_dca_dispersion'] > 0).all() and np.isfinite(out.X).all()
+            if ae == 'zinb-shared':
+                d = out.obsm['X_dca_dropout']
+                assert d.shape == (n, 1) and ((d > 0) & (d < 1)).all()
+            net.write(out, str(tmp_path / ae), mode='denoise')
+            row = open(str(tmp_path / ae / 'dispersion.tsv')).read().strip().split('\t')
+            assert len(row) == n

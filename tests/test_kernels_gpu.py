@@ -368,3 +368,29 @@ def test_rmsprop_clip(ops):
     w_ref = w - 1e-3 * gc / np.sqrt(ms_ref + 1e-7)
     np.testing.assert_allclose(dms.cpu().numpy(), ms_ref, rtol=1e-6)
     np.testing.assert_allclose(dw.cpu().numpy(), w_ref, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize('B,G,ld', [(1, 1, 4), (37, 203, 208), (300, 20000, 20004)])
+def test_shared_head_plumbing_kernels(B, G, ld):
+    """dcahip_bcast_cols / dcahip_row_sums_strided (Dense(1) heads of the *-shared networks)."""
+    from dca_amd.ops import HipOps
+    ops = HipOps()
+    dev = torch.device('cuda')
+    rng = np.random.RandomState(B)
+    s = torch.as_tensor(rng.normal(size=(B, 4)).astype(np.float32)).to(dev)
+    out = torch.full((B, ld), -3.0, device=dev)
+    ops.bcast_cols(s[:, 1:], 4, B, G, out, ld)
+    got = out.cpu().numpy()
+    np.testing.assert_array_equal(got[:, :G], np.repeat(s.cpu().numpy()[:, 1:2], G, axis=1))
+    assert (got[:, G:] == -3.0).all()
+    x = rng.normal(size=(B, ld)).astype(np.float32) * 1e-3
+    xd = torch.as_tensor(x).to(dev)
+    r = torch.full((B, 4), 9.0, device=dev)
+    ops.row_sums_strided(xd, ld, B, G, r[:, 2:], 4)
+    got = r.cpu().numpy()
+    want = x[:, :G].astype(np.float64).sum(axis=1)
+    np.testing.assert_allclose(got[:, 2], want, rtol=2e-7, atol=1e-9)
+    assert (got[:, [0, 1, 3]] == 9.0).all()
+    r2 = torch.zeros(B, 4, device=dev)
+    ops.row_sums_strided(xd, ld, B, G, r2[:, 2:], 4)
+    assert torch.equal(r2[:, 2], r[:, 2])                       # deterministic
