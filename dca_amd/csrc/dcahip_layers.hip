@@ -470,6 +470,79 @@ __global__ __launch_bounds__(256) void row_sums_strided_kernel(const float* __re
     if (lane == 0) out[(long)r * ldo] = (float)acc;
 }
 
+// zinb-elempi (ZINBAutoencoderElemPi, network.py:424-461): m = -(Dense output) feeds MeanAct, and the dropout
+// logit is an element-wise affine map of m (ElementwiseDense, layers.py:50-82): a_pi = k_g m + c_g.
+__global__ __launch_bounds__(256) void elempi_fwd_kernel(float* __restrict__ a_mean, long lda, const float* __restrict__ k,
+                                                         const float* __restrict__ c, int B, int G,
+                                                         float* __restrict__ a_pi, long ldp) {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= G) return;
+    const float kg = k[g], cg = c[g];
+    for (int r = blockIdx.y; r < B; r += gridDim.y) {
+        const float m = -a_mean[(long)r * lda + g];
+        a_mean[(long)r * lda + g] = m;
+        a_pi[(long)r * ldp + g] = kg * m + cg;
+    }
+}
+
+// d_mean: in = dL/dm, out = dL/d(Dense output) = -(dL/dm + k_g dL/da_pi); partial[y][0][g] = sum_r dL/da_pi m,
+// partial[y][1][g] = sum_r dL/da_pi over the rows of slice y (fixed assignment: deterministic)
+__global__ __launch_bounds__(256) void elempi_bwd_kernel(const float* __restrict__ m, long lda, float* __restrict__ d_mean,
+                                                         const float* __restrict__ d_pi, long ldd,
+                                                         const float* __restrict__ k, int B, int G,
+                                                         double* __restrict__ partial) {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= G) return;
+    const float kg = k[g];
+    double sk = 0.0, sc = 0.0;
+    for (int r = blockIdx.y; r < B; r += gridDim.y) {
+        const float dp = d_pi[(long)r * ldd + g];
+        sk += (double)(dp * m[(long)r * lda + g]);
+        sc += (double)dp;
+        d_mean[(long)r * ldd + g] = -(d_mean[(long)r * ldd + g] + kg * dp);
+    }
+    partial[((long)blockIdx.y * 2 + 0) * G + g] = sk;
+    partial[((long)blockIdx.y * 2 + 1) * G + g] = sc;
+}
+
+__global__ __launch_bounds__(256) void elempi_finish_kernel(const double* __restrict__ partial, int R, int G,
+                                                            float* __restrict__ gk, float* __restrict__ gc) {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= G) return;
+    double sk = 0.0, sc = 0.0;
+    for (int y = 0; y < R; ++y) {
+        sk += partial[((long)y * 2 + 0) * G + g];
+        sc += partial[((long)y * 2 + 1) * G + g];
+    }
+    gk[g] = (float)sk;
+    gc[g] = (float)sc;
+}
+
+constexpr int kElemPiSlices = 32;
+
+extern "C" int dcahip_elempi_workspace_doubles(int G) { return G > 0 ? kElemPiSlices * 2 * G : 0; }
+
+extern "C" int dcahip_elempi_fwd(float* a_mean, long lda, const float* k, const float* c, int B, int G,
+                                 float* a_pi, long ldp, void* stream) {
+    if (!a_mean || !k || !c || !a_pi || B <= 0 || G <= 0 || lda < G || ldp < G) return DCAHIP_EINVAL;
+    const int gy = B < 64 ? B : 64;
+    hipLaunchKernelGGL(elempi_fwd_kernel, dim3((G + 255) / 256, gy), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       a_mean, lda, k, c, B, G, a_pi, ldp);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dcahip_elempi_bwd(const float* m, long lda, float* d_mean, const float* d_pi, long ldd, const float* k,
+                                 int B, int G, float* gk, float* gc, double* workspace, void* stream) {
+    if (!m || !d_mean || !d_pi || !k || !gk || !gc || !workspace || B <= 0 || G <= 0 || lda < G || ldd < G)
+        return DCAHIP_EINVAL;
+    const int R = B < kElemPiSlices ? B : kElemPiSlices;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(elempi_bwd_kernel, dim3((G + 255) / 256, R), dim3(256), 0, s, m, lda, d_mean, d_pi, ldd, k, B, G,
+                       workspace);
+    hipLaunchKernelGGL(elempi_finish_kernel, dim3((G + 255) / 256), dim3(256), 0, s, workspace, R, G, gk, gc);
+    return (int)hipGetLastError();
+}
+
 extern "C" int dcahip_bcast_cols(const float* s, long lds, int B, int G, float* out, long ldo, void* stream) {
     if (!s || !out || B <= 0 || G <= 0 || ldo < G || lds < 1) return DCAHIP_EINVAL;
     int gx = (G + 255) / 256;

@@ -37,7 +37,14 @@ AE_HEADS = {                      # ae_type -> (heads in the fused block, const 
     # Dense(1) dispersion (and dropout) broadcast over the genes: network.py:343-362, 464-491
     'nb-shared': (('mean', 'disp'), False, ('disp',)),
     'zinb-shared': (('mean', 'disp', 'pi'), False, ('disp', 'pi')),
+    # one private last decoder layer per head: network.py:553-661 (zinb-fork), 664-760 (nb-fork)
+    'nb-fork': (('mean', 'disp'), False, ()),
+    'zinb-fork': (('mean', 'disp', 'pi'), False, ()),
 }
+AE_FORK = ('nb-fork', 'zinb-fork')
+# network.py:424-461: mean head negated, dropout logit = ElementwiseDense of it (per-gene scale k and offset c)
+AE_HEADS['zinb-elempi'] = (('mean', 'disp', 'pi'), False, ())
+AE_ELEMPI = ('zinb-elempi',)
 ACT_CODES = {'linear': 0, 'relu': 1, 'tanh': 2, 'sigmoid': 3, 'elu': 4, 'selu': 5, 'softplus': 6,
              'softsign': 7, 'LeakyReLU': 8}
 INPUT_DROPOUT_LAYER = 255     # Philox counter word 3 of the input dropout (hidden layer i uses i)
@@ -123,7 +130,7 @@ KERAS_INITIALIZERS = ('glorot_uniform', 'glorot_normal', 'he_uniform', 'he_norma
                       'random_uniform', 'random_normal', 'truncated_normal', 'orthogonal', 'zeros', 'ones')
 
 
-def keras_initializer(name, rng, fan_in, fan_out):
+def keras_initializer(name, rng, fan_in, fan_out, shape=None):
     """[fan_in, fan_out] float32 kernel from a Keras initialiser name (tf.keras 2.x defaults:
     VarianceScaling(scale, mode, distribution) with the 0.8796 truncation correction for the *_normal
     family; RandomUniform +-0.05; RandomNormal / TruncatedNormal stddev 0.05; Orthogonal gain 1)."""
@@ -131,7 +138,7 @@ def keras_initializer(name, rng, fan_in, fan_out):
     vs = {'glorot_uniform': (1.0, 'avg', 'u'), 'glorot_normal': (1.0, 'avg', 'n'),
           'he_uniform': (2.0, 'in', 'u'), 'he_normal': (2.0, 'in', 'n'),
           'lecun_uniform': (1.0, 'in', 'u'), 'lecun_normal': (1.0, 'in', 'n')}
-    shape = (fan_in, fan_out)
+    shape = (fan_in, fan_out) if shape is None else shape
     if key in vs:
         scale, mode, distr = vs[key]
         n = (fan_in + fan_out) / 2.0 if mode == 'avg' else float(fan_in)
@@ -146,7 +153,7 @@ def keras_initializer(name, rng, fan_in, fan_out):
         w = rng.normal(0.0, 0.05, size=shape)
     elif key == 'truncated_normal':
         w = _truncated_normal(rng, 0.05, shape)
-    elif key == 'orthogonal':
+    elif key == 'orthogonal' and len(shape) == 2:
         a = rng.normal(0.0, 1.0, size=(max(shape), min(shape)))
         q, r = np.linalg.qr(a)
         q = q * np.sign(np.diag(r))
@@ -168,14 +175,30 @@ class ParamLayout:
         self.ae_type = ae_type
         self.heads, self.const_disp = AE_HEADS[ae_type][:2]
         self.shared = AE_HEADS[ae_type][2] if len(AE_HEADS[ae_type]) > 2 else ()
-        self.planes = tuple(h for h in self.heads if h not in self.shared)     # heads with one unit per gene
+        self.elempi = ae_type in AE_ELEMPI
+        # heads that are Dense layers off the decoder output / heads with one Dense unit per gene
+        self.dense_heads = tuple(h for h in self.heads if not (self.elempi and h == 'pi'))
+        self.planes = tuple(h for h in self.dense_heads if h not in self.shared)
         self.G_in, self.G_out = input_size, output_size
         self.Gp = _r4(output_size)
         # columns of the heads' Dense block: the full-width heads, then 4 columns holding the Dense(1)
         # heads; A / D rows additionally carry one broadcast plane per shared head behind them
         self.NH = len(self.planes) * self.Gp + (4 if self.shared else 0)
-        self.ldA = self.NH + len(self.shared) * self.Gp
+        self.ldA = self.NH + (len(self.shared) + (1 if self.elempi else 0)) * self.Gp
         self.hidden = tuple(int(h) for h in hidden_size)
+        self.center = int(np.floor(len(self.hidden) / 2.0))         # network.py:102
+        # *-fork: every layer behind the centre is built once per head FROM THE CENTRE OUTPUT
+        # (network.py:587-612 never advances last_hidden there), so only the last decoder layer reaches the
+        # heads.  The per-head Dense(h) layers side by side are one Dense(nheads * h) (batch-norm,
+        # activation and dropout act per unit); head j reads columns [j h, (j+1) h) of its output.
+        self.fork = len(self.heads) if ae_type in AE_FORK else 0
+        self.hfork = 0
+        if self.fork:
+            if len(self.hidden) - 1 <= self.center:
+                raise ValueError('%s needs at least one hidden layer behind the centre (the reference fails with '
+                                 'AttributeError: last_hidden_mean)' % ae_type)
+            self.hfork = self.hidden[-1]
+            self.hidden = self.hidden[:self.center + 1] + (self.fork * self.hfork,)
         self.batchnorm = batchnorm
         self.seg = {}
         off = 0
@@ -194,10 +217,14 @@ class ParamLayout:
             if batchnorm:
                 add('beta%d' % i, (h,))
             fan_in = h
-        add('Wh', (fan_in, self.NH), align=True)
+        self.hL = self.hfork if self.fork else fan_in   # rows of the heads' Dense block (inputs per head)
+        add('Wh', (self.hL, self.NH), align=True)
         add('bh', (self.NH,))
         if self.const_disp:
             add('theta_w', (self.Gp,), align=True)
+        if self.elempi:
+            add('pi_k', (self.Gp,), align=True)         # ElementwiseDense kernel / bias (layers.py:58-68)
+            add('pi_c', (self.Gp,), align=True)
         self.P = _r4(off)
         self.total = self.P + 4                         # [P] carries the batch loss
 
@@ -216,13 +243,15 @@ class ParamLayout:
         """Column of the head's [B, G] plane inside a row of A / D."""
         if head in self.shared:
             return self.NH + self.shared.index(head) * self.Gp
+        if head not in self.planes:                     # the element-wise dropout logit of zinb-elempi
+            return self.NH
         return self.planes.index(head) * self.Gp
 
 
 class Engine:
     def __init__(self, ae_type, input_size, output_size=None, hidden_size=(64, 32, 64),
                  batchnorm=True, ridge=0.0, ops=None, comm=None, device=None, activation='relu',
-                 hidden_dropout=0., input_dropout=0., dropout_seed=0):
+                 hidden_dropout=0., input_dropout=0., dropout_seed=0, sharedpi=False):
         if ae_type not in AE_HEADS:
             raise NotImplementedError('ae_type %r is not available on the MI355X path yet '
                                       '(supported: %s)' % (ae_type, ', '.join(AE_HEADS)))
@@ -244,7 +273,7 @@ class Engine:
         lay = self.lay
         self.has_pi = 'pi' in lay.heads
         self.flags = (1 if self.has_pi else 0) | (2 if lay.const_disp else 0) | AE_LOSS_FLAG.get(ae_type, 0)
-        self.center = int(np.floor(len(lay.hidden) / 2.0))          # network.py:102
+        self.center = lay.center
         f32 = dict(dtype=torch.float32, device=self.dev)
         self.w = torch.zeros(lay.total, **f32)
         self.g = torch.zeros(lay.total, **f32)
@@ -264,7 +293,10 @@ class Engine:
         self.prof = None            # EventProfiler or None
         # K-HEADS (heads forward + NLL + both backward products in one kernel) whenever the
         # library supports the shape; DCA_AMD_FUSED_HEADS=0 forces the separate kernels
-        self.use_fused = os.environ.get('DCA_AMD_FUSED_HEADS', '1') != '0' and not lay.shared
+        self.use_fused = os.environ.get('DCA_AMD_FUSED_HEADS', '1') != '0' and not (lay.shared or lay.fork or lay.elempi)
+        self.sharedpi = bool(sharedpi) and lay.elempi       # ElementwiseDense(1): one scale / offset for all genes
+        self.ws_elempi = torch.zeros(ops.elempi_workspace_doubles(lay.G_out), dtype=torch.float64, device=self.dev) \
+            if lay.elempi else None
         self.ws_heads = None
         self._pending = None        # in-flight all-reduce of the heads bucket (data parallel)
         self.opt_kind = 'rmsprop'   # train.py:54-57 picks the Keras optimizer by name
@@ -276,8 +308,11 @@ class Engine:
         self._counts_local_key = self._counts_world_key = None
         # Dropout (network.py:98-99, 137-138): rates per hidden layer + input; masks are a function of
         # (seed, step counter in device memory, layer, global batch row, unit) -- K-DROP
-        hd = list(hidden_dropout) if isinstance(hidden_dropout, (list, tuple)) else [hidden_dropout] * len(lay.hidden)
-        assert len(hd) == len(lay.hidden)
+        n_conf = len(tuple(hidden_size))                    # rates come per configured layer (network.py:87-90)
+        hd = list(hidden_dropout) if isinstance(hidden_dropout, (list, tuple)) else [hidden_dropout] * n_conf
+        assert len(hd) == n_conf
+        if lay.fork:                                        # the last layer's rate applies to every branch
+            hd = hd[:lay.center + 1] + [hd[-1]]
         self.drop = [float(r) for r in hd]
         self.in_drop = float(input_dropout)
         assert all(0.0 <= r < 1.0 for r in self.drop + [self.in_drop]), 'dropout rates must be in [0, 1)'
@@ -301,10 +336,18 @@ class Engine:
         p = {}
         fan_in = lay.G_in
         for i, h in enumerate(lay.hidden):
-            p['W%d' % i] = keras_initializer(init, rng, fan_in, h)
+            if lay.fork and i == len(lay.hidden) - 1:       # one Dense(hfork) per head, side by side
+                p['W%d' % i] = np.concatenate([keras_initializer(init, rng, fan_in, lay.hfork)
+                                               for _ in range(lay.fork)], axis=1)
+            else:
+                p['W%d' % i] = keras_initializer(init, rng, fan_in, h)
             fan_in = h
-        for hd in lay.heads:
-            p['W_' + hd] = keras_initializer(init, rng, fan_in, 1 if hd in lay.shared else lay.G_out)
+        for hd in lay.dense_heads:
+            p['W_' + hd] = keras_initializer(init, rng, lay.hL, 1 if hd in lay.shared else lay.G_out)
+        if lay.elempi:      # 1-D kernel of shape (units,): Keras takes fan_in = fan_out = units
+            units = 1 if self.sharedpi else lay.G_out
+            k = keras_initializer(init, rng, units, units, shape=(units,))
+            p['pi_k'] = np.full(lay.G_out, k[0], np.float32) if self.sharedpi else k
         self.set_params(p)
 
     def set_params(self, p):
@@ -313,20 +356,21 @@ class Engine:
         lay = self.lay
         w = self.w.cpu()
         for name, (off, shape) in lay.seg.items():
-            if name in ('Wh', 'bh', 'theta_w'):
+            if name in ('Wh', 'bh', 'theta_w', 'pi_k', 'pi_c'):
                 continue
             if name in p:
                 w[off:off + int(np.prod(shape))] = torch.as_tensor(
                     np.asarray(p[name], dtype=np.float32).reshape(-1))
         Wh = lay.view(w, 'Wh'); bh = lay.view(w, 'bh')
-        for hd in lay.heads:
+        for hd in lay.dense_heads:
             c0, c1 = lay.head_cols(hd)
             if 'W_' + hd in p:
                 Wh[:, c0:c1] = torch.as_tensor(np.asarray(p['W_' + hd], dtype=np.float32))
             if 'b_' + hd in p:
                 bh[c0:c1] = torch.as_tensor(np.asarray(p['b_' + hd], dtype=np.float32))
-        if lay.const_disp and 'theta_w' in p:
-            lay.view(w, 'theta_w')[:lay.G_out] = torch.as_tensor(np.asarray(p['theta_w'], np.float32))
+        for name in ('theta_w', 'pi_k', 'pi_c'):         # per-gene vectors, padded to Gp
+            if name in lay.seg and name in p:
+                lay.view(w, name)[:lay.G_out] = torch.as_tensor(np.asarray(p[name], np.float32))
         self.w.copy_(w)
         for i in range(len(self.mm)):
             if 'mm%d' % i in p:
@@ -339,16 +383,17 @@ class Engine:
         f = flat.detach().cpu()
         out = {}
         for name in lay.seg:
-            if name in ('Wh', 'bh', 'theta_w'):
+            if name in ('Wh', 'bh', 'theta_w', 'pi_k', 'pi_c'):
                 continue
             out[name] = lay.view(f, name).numpy().copy()
         Wh = lay.view(f, 'Wh'); bh = lay.view(f, 'bh')
-        for hd in lay.heads:
+        for hd in lay.dense_heads:
             c0, c1 = lay.head_cols(hd)
             out['W_' + hd] = Wh[:, c0:c1].numpy().copy()
             out['b_' + hd] = bh[c0:c1].numpy().copy()
-        if lay.const_disp:
-            out['theta_w'] = lay.view(f, 'theta_w')[:lay.G_out].numpy().copy()
+        for name in ('theta_w', 'pi_k', 'pi_c'):
+            if name in lay.seg:
+                out[name] = lay.view(f, name)[:lay.G_out].numpy().copy()
         return out
 
     def get_params(self):
@@ -377,7 +422,7 @@ class Engine:
         """kernel_regularizer=l1_l2(..) of every Dense kernel (network.py:114-126, 144-146, 369-380):
         encoder / centre layers take the *_enc coefficients when those are non-zero."""
         lay = self.lay
-        center = int(np.floor(len(lay.hidden) / 2.0))
+        center = lay.center
         segs = []
         for i in range(len(lay.hidden)):
             a = l1_enc if (i <= center and l1_enc != 0.) else l1
@@ -386,6 +431,11 @@ class Engine:
             segs.append((off, off + int(np.prod(shape)), a, b))
         off, shape = lay.seg['Wh']
         segs.append((off, off + int(np.prod(shape)), l1, l2))
+        if lay.elempi:               # ElementwiseDense kernel_regularizer (network.py:443-445)
+            if self.sharedpi and (l1 != 0. or l2 != 0.):
+                raise NotImplementedError('l1 / l2 on the shared ElementwiseDense kernel (sharedpi=True)')
+            off, _ = lay.seg['pi_k']
+            segs.append((off, off + lay.G_out, l1, l2))
         segs = [sg for sg in segs if sg[2] != 0. or sg[3] != 0.]
         self.reg = self.ops.reg_desc(segs) if segs else None
         self.reg_ws = torch.zeros(self.ops.l1l2_workspace_doubles(), dtype=torch.float64, device=self.dev) \
@@ -507,9 +557,10 @@ class Engine:
                 if i > 0:
                     need = max(need, ops.sgemm_workspace_bytes(0, 1, b, K, h))
                 K = h
-            need = max(need, ops.sgemm_workspace_bytes(0, 0, b, lay.NH, K))
-            need = max(need, ops.sgemm_workspace_bytes(1, 0, K, lay.NH, b, True))
-            need = max(need, ops.sgemm_workspace_bytes(0, 1, b, K, lay.NH))
+            for _c0, nc, _h0 in self._head_blocks():
+                need = max(need, ops.sgemm_workspace_bytes(0, 0, b, nc, lay.hL))
+                need = max(need, ops.sgemm_workspace_bytes(1, 0, lay.hL, nc, b, True))
+                need = max(need, ops.sgemm_workspace_bytes(0, 1, b, lay.hL, nc))
         self.ws = torch.zeros(max(need // 4, 4), **f32)
         nb = ops.heads_fused_workspace_bytes(B, K, lay.G_out, lay.Gp, self.flags) if self.use_fused else 0
         self.ws_heads = torch.zeros(nb // 4, **f32) if nb > 0 else None
@@ -591,12 +642,25 @@ class Engine:
 
     def _heads_forward(self, B, K):
         lay, ops = self.lay, self.ops
+        Wh, bh = lay.view(self.w, 'Wh'), lay.view(self.w, 'bh')
         with self._t('gemm_heads_fwd'):
-            ops.sgemm(0, 0, B, lay.NH, K, self.Hcur[-1], self.ldh[-1], lay.view(self.w, 'Wh'), lay.NH,
-                      self.A, lay.ldA, bias=lay.view(self.w, 'bh'), ws=self.ws)
+            for c0, nc, h0 in self._head_blocks():
+                ops.sgemm(0, 0, B, nc, lay.hL, self.Hcur[-1][:, h0:], self.ldh[-1], Wh[:, c0:], lay.NH,
+                          self.A[:, c0:], lay.ldA, bias=bh[c0:], ws=self.ws)
+        if lay.elempi:               # m = -(Dense output) in place; dropout logit = k m + c
+            ops.elempi_fwd(self._plane(self.A, 'mean'), lay.ldA, lay.view(self.w, 'pi_k'), lay.view(self.w, 'pi_c'),
+                           B, lay.G_out, self._plane(self.A, 'pi'), lay.ldA)
         for hd in lay.shared:        # Dense(1) pre-activation -> the plane the loss / inference kernels read
             c0, _ = lay.head_cols(hd)
             ops.bcast_cols(self.A[:, c0:], lay.ldA, B, lay.G_out, self._plane(self.A, hd), lay.ldA)
+
+    def _head_blocks(self):
+        """(first column, columns, first input unit) of each GEMM of the heads' Dense block: one for the
+        whole block, or one per head when every head has its private decoder layer (*-fork)."""
+        lay = self.lay
+        if not lay.fork:
+            return [(0, lay.NH, 0)]
+        return [(j * lay.Gp, lay.Gp, j * lay.hfork) for j in range(lay.fork)]
 
     def _plane(self, buf, head):
         lay = self.lay
@@ -614,6 +678,13 @@ class Engine:
                          inv_n, self.flags, self._plane(D, 'mean') if grad else None, d_disp,
                          self._plane(D, 'pi') if grad else None, self.ldD if grad else 0,
                          self.partials)
+        if grad and lay.elempi:
+            gk, gc = lay.view(self.g, 'pi_k'), lay.view(self.g, 'pi_c')
+            ops.elempi_bwd(self._plane(A, 'mean'), lay.ldA, self._plane(D, 'mean'), self._plane(D, 'pi'), self.ldD,
+                           lay.view(self.w, 'pi_k'), B, lay.G_out, gk, gc, self.ws_elempi)
+            if self.sharedpi:        # one scalar pair: every (identical) entry receives the total gradient
+                gk[:lay.G_out] = gk[:lay.G_out].sum()
+                gc[:lay.G_out] = gc[:lay.G_out].sum()
         if grad:
             for hd in lay.shared:    # gradient of the Dense(1) unit = its plane summed over the genes
                 c0, _ = lay.head_cols(hd)
@@ -751,15 +822,18 @@ class Engine:
         with self._t('zinb_nll'):
             n = self._nll(B, self.perm, self.cursor, self.Y, self.sf, inv_n, True)
         ops.loss_finalize(self.partials, n, inv_n, g[lay.P:])
+        gWh, Wh = lay.view(g, 'Wh'), lay.view(w, 'Wh')
         with self._t('gemm_heads_dW'):
-            ops.sgemm(1, 0, KL, lay.NH, B, self.Hcur[-1], self.ldh[-1], self.D, self.ldD,
-                      lay.view(g, 'Wh'), lay.NH, colsum_row=True, ws=self.ws)
+            for c0, nc, h0 in self._head_blocks():      # colsum_row: the bias gradient lands in row hL = 'bh'
+                ops.sgemm(1, 0, lay.hL, nc, B, self.Hcur[-1][:, h0:], self.ldh[-1], self.D[:, c0:], self.ldD,
+                          gWh[:, c0:], lay.NH, colsum_row=True, ws=self.ws)
         if lay.const_disp:
             ops.colsum_chain(self.Dth, self.ldD, B, lay.G_out, lay.view(w, 'theta_w'),
                              lay.view(g, 'theta_w'))
         with self._t('gemm_heads_dH'):
-            ops.sgemm(0, 1, B, KL, lay.NH, self.D, self.ldD, lay.view(w, 'Wh'), lay.NH, self.dH[-1],
-                      self.ldh[-1], ws=self.ws)
+            for c0, nc, h0 in self._head_blocks():
+                ops.sgemm(0, 1, B, lay.hL, nc, self.D[:, c0:], self.ldD, Wh[:, c0:], lay.NH,
+                          self.dH[-1][:, h0:], self.ldh[-1], ws=self.ws)
 
     def _reduce_bwd_sums(self, i, E, h):
         """SyncBN backward: local chunk sums -> one [2h] vector -> all-reduce."""

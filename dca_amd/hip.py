@@ -72,6 +72,10 @@ _SIGNATURES = {
     'dcahip_optimizer_step': (_c.c_int, [_c.c_int, _f32p, _f32p, _f32p, _f32p, _c.c_long, _f32p, _i64p,
                                          _c.c_float, _vp]),
     'dcahip_counter_add': (_c.c_int, [_i64p, _c.c_int, _vp]),
+    'dcahip_elempi_workspace_doubles': (_c.c_int, [_c.c_int]),
+    'dcahip_elempi_fwd': (_c.c_int, [_f32p, _c.c_long, _f32p, _f32p, _c.c_int, _c.c_int, _f32p, _c.c_long, _vp]),
+    'dcahip_elempi_bwd': (_c.c_int, [_f32p, _c.c_long, _f32p, _f32p, _c.c_long, _f32p, _c.c_int, _c.c_int, _f32p, _f32p,
+                                     _f64p, _vp]),
     'dcahip_bcast_cols': (_c.c_int, [_f32p, _c.c_long, _c.c_int, _c.c_int, _f32p, _c.c_long, _vp]),
     'dcahip_row_sums_strided': (_c.c_int, [_f32p, _c.c_long, _c.c_int, _c.c_int, _f32p, _c.c_long, _vp]),
     'dcahip_nadam_step': (_c.c_int, [_f32p, _f32p, _f32p, _f32p, _c.c_long, _f32p, _i64p, _f32p, _c.c_float, _vp]),

@@ -121,7 +121,7 @@ class Autoencoder():
                                      self.hidden_size, self.batchnorm, self.ridge, ops=ops,
                                      comm=self.comm, activation=self.activation,
                                      hidden_dropout=self.hidden_dropout, input_dropout=self.input_dropout,
-                                     dropout_seed=self.seed)
+                                     dropout_seed=self.seed, sharedpi=getattr(self, 'sharedpi', False))
         self.engine.init_params(self.seed, self.init)
         self.engine.set_regularizers(self.l1_coef, self.l2_coef, self.l1_enc_coef, self.l2_enc_coef)
         self.model = self.engine             # what train() drives (reference: the Keras Model)

@@ -123,6 +123,18 @@ class HipOps:
         hip.check(self.L.dcahip_optimizer_step(hip.OPT_KINDS[kind], p(w), p(g), p(slot1), p(slot2), n, p(lr),
                                                p(it), clip, hip.stream()), 'optimizer_step')
 
+    def elempi_workspace_doubles(self, G):
+        return int(self.L.dcahip_elempi_workspace_doubles(G))
+
+    def elempi_fwd(self, a_mean, lda, k, c, B, G, a_pi, ldp):
+        p = hip.ptr
+        hip.check(self.L.dcahip_elempi_fwd(p(a_mean), lda, p(k), p(c), B, G, p(a_pi), ldp, hip.stream()), 'elempi_fwd')
+
+    def elempi_bwd(self, m, lda, d_mean, d_pi, ldd, k, B, G, gk, gc, ws):
+        p = hip.ptr
+        hip.check(self.L.dcahip_elempi_bwd(p(m), lda, p(d_mean), p(d_pi), ldd, p(k), B, G, p(gk), p(gc), p(ws),
+                                           hip.stream()), 'elempi_bwd')
+
     def bcast_cols(self, s, lds, B, G, out, ldo):
         hip.check(self.L.dcahip_bcast_cols(hip.ptr(s), lds, B, G, hip.ptr(out), ldo, hip.stream()), 'bcast_cols')
 

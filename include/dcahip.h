@@ -205,6 +205,16 @@ int dcahip_relu_fwd(const float* Z, long ldz, int B, int H, float* Hout, long ld
  * dcahip_bcast_cols: out[r, c] = s[r * lds] for c < G (the scalar pre-activation spread into the plane
  * the loss kernel reads).  dcahip_row_sums_strided: out[r * ldo] = sum_c x[r, c] (the plane of
  * pre-activation gradients folded back into the gradient of the scalar); fp64 accumulation, fixed order. */
+/* zinb-elempi (ZINBAutoencoderElemPi network.py:424-461, ElementwiseDense layers.py:50-82): the mean head's Dense
+ * output is negated (m = -a feeds MeanAct) and the dropout logit is a_pi[r, g] = k[g] m[r, g] + c[g].
+ * dcahip_elempi_fwd: a_mean <- m in place, a_pi plane written.  dcahip_elempi_bwd: d_mean holds dL/dm on entry and
+ * dL/d(Dense output) = -(dL/dm + k dL/da_pi) on return; gk[g] = sum_r dL/da_pi m, gc[g] = sum_r dL/da_pi (fp64
+ * partials over a fixed row assignment: deterministic); workspace: dcahip_elempi_workspace_doubles(G) doubles. */
+int dcahip_elempi_workspace_doubles(int G);
+int dcahip_elempi_fwd(float* a_mean, long lda, const float* k, const float* c, int B, int G,
+                      float* a_pi, long ldp, void* stream);
+int dcahip_elempi_bwd(const float* m, long lda, float* d_mean, const float* d_pi, long ldd, const float* k,
+                      int B, int G, float* gk, float* gc, double* workspace, void* stream);
 int dcahip_bcast_cols(const float* s, long lds, int B, int G, float* out, long ldo, void* stream);
 int dcahip_row_sums_strided(const float* x, long ldx, int B, int G, float* out, long ldo, void* stream);
 

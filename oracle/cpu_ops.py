@@ -284,6 +284,22 @@ class CpuRefOps:
         if b is not None:
             b[:] = nb
 
+    def elempi_workspace_doubles(self, G):
+        return 4
+
+    def elempi_fwd(self, a_mean, lda, k, c, B, G, a_pi, ldp):
+        a = _mat(a_mean, B, G, lda)
+        a[:] = -a
+        _mat(a_pi, B, G, ldp)[:] = a * _vec(k, G) + _vec(c, G)
+
+    def elempi_bwd(self, m, lda, d_mean, d_pi, ldd, k, B, G, gk, gc, ws):
+        mm = _mat(m, B, G, lda).astype(np.float64)
+        dp = _mat(d_pi, B, G, ldd).astype(np.float64)
+        dm = _mat(d_mean, B, G, ldd)
+        _vec(gk, G)[:] = (dp * mm).sum(axis=0)
+        _vec(gc, G)[:] = dp.sum(axis=0)
+        dm[:] = -(dm.astype(np.float64) + dp * _vec(k, G).astype(np.float64))
+
     def bcast_cols(self, s, lds, B, G, out, ldo):
         _mat(out, B, G, ldo)[:] = _mat(s, B, 1, lds)
 

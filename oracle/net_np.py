@@ -27,7 +27,21 @@ from . import zinb_np as Z
 
 BN_MOMENTUM = 0.99
 BN_EPS = 1e-3
-AE_TYPES = ('zinb-conddisp', 'zinb', 'nb-conddisp', 'nb', 'poisson', 'normal', 'nb-shared', 'zinb-shared')
+AE_TYPES = ('zinb-conddisp', 'zinb', 'nb-conddisp', 'nb', 'poisson', 'normal', 'nb-shared', 'zinb-shared',
+            'nb-fork', 'zinb-fork', 'zinb-elempi')
+# network.py:553-760: behind the centre every head gets its own Dense(h) -> BN -> act -> dropout, all fed by the
+# CENTRE output (last_hidden is not advanced there, so only the last decoder layer reaches the heads)
+FORK_HEADS = {'nb-fork': ('mean', 'disp'), 'zinb-fork': ('mean', 'disp', 'pi')}
+
+
+def effective_hidden(ae_type, hidden_size):
+    """Layer widths as computed: *-fork = encoder .. centre, then the per-head last layers side by side."""
+    hs = tuple(int(h) for h in hidden_size)
+    if ae_type not in FORK_HEADS:
+        return hs
+    center = int(np.floor(len(hs) / 2.0))
+    assert len(hs) - 1 > center, 'fork networks need a hidden layer behind the centre'
+    return hs[:center + 1] + (len(FORK_HEADS[ae_type]) * hs[-1],)
 SHARED_HEADS = {'nb-shared': ('disp',), 'zinb-shared': ('disp', 'pi')}     # Dense(1): network.py:343-362, 464-491
 
 
@@ -137,8 +151,13 @@ def init_params(ae_type, input_size, hidden_size, output_size=None, batchnorm=Tr
     rng = np.random.RandomState(seed)
     p = {}
     fan_in = input_size
-    for i, h in enumerate(hidden_size):
-        p['W%d' % i] = glorot_uniform(rng, fan_in, h, dtype)
+    eff = effective_hidden(ae_type, hidden_size)
+    nfork = len(FORK_HEADS.get(ae_type, ()))
+    for i, h in enumerate(eff):
+        if nfork and i == len(eff) - 1:
+            p['W%d' % i] = np.concatenate([glorot_uniform(rng, fan_in, h // nfork, dtype) for _ in range(nfork)], axis=1)
+        else:
+            p['W%d' % i] = glorot_uniform(rng, fan_in, h, dtype)
         p['b%d' % i] = np.zeros(h, dtype)
         if batchnorm:
             p['beta%d' % i] = np.zeros(h, dtype)
@@ -146,10 +165,18 @@ def init_params(ae_type, input_size, hidden_size, output_size=None, batchnorm=Tr
             p['mv%d' % i] = np.ones(h, dtype)
         fan_in = h
     heads = ['mean']
-    if ae_type in ('zinb-conddisp', 'nb-conddisp', 'nb-shared', 'zinb-shared'):
+    if nfork:
+        fan_in = fan_in // nfork                       # every head reads its own branch
+    if ae_type in ('zinb-conddisp', 'nb-conddisp', 'nb-shared', 'zinb-shared', 'nb-fork', 'zinb-fork'):
         heads.append('disp')
     if ae_type.startswith('zinb'):
         heads.append('pi')
+    if ae_type == 'zinb-elempi':
+        heads = ['mean', 'disp']
+        # ElementwiseDense (layers.py:50-82): kernel and bias of shape (units,); glorot on a 1-D shape takes
+        # fan_in = fan_out = units
+        p['pi_k'] = rng.uniform(-np.sqrt(3.0 / output_size), np.sqrt(3.0 / output_size), size=output_size).astype(dtype)
+        p['pi_c'] = np.zeros(output_size, dtype)
     for hd in heads:
         width = 1 if hd in SHARED_HEADS.get(ae_type, ()) else output_size
         p['W_' + hd] = glorot_uniform(rng, fan_in, width, dtype)
@@ -181,10 +208,15 @@ class OracleAE:
         self.reg = tuple(float(x) for x in reg)          # l1, l2, l1_enc, l2_enc (network.py:114-126)
         self.ae_type = ae_type
         self.p = params
-        self.hidden_size = tuple(hidden_size)
+        self.n_hidden = len(tuple(hidden_size))                    # as configured (regulariser stages, centre)
+        self.center = int(np.floor(self.n_hidden / 2.0))           # network.py:102
+        self.hidden_size = effective_hidden(ae_type, hidden_size)
+        self.fork = FORK_HEADS.get(ae_type, ())
+        self.hfork = int(tuple(hidden_size)[-1]) if self.fork else 0
+        if self.fork:                                              # the last layer's rate applies to every branch
+            self.hidden_dropout = self.hidden_dropout[:self.center + 1] + [self.hidden_dropout[-1]]
         self.batchnorm = batchnorm
         self.ridge = ridge
-        self.center = int(np.floor(len(self.hidden_size) / 2.0))   # network.py:102
         self.dtype = params['W0'].dtype
 
     # ---------------------------------------------------------------- forward
@@ -224,11 +256,21 @@ class OracleAE:
                 cache['keep'][i] = keep
                 H = np.where(keep, H * dt.type(dropout_scale(self.hidden_dropout[i])), dt.type(0))
             cache['H'].append(H)
-        cache['a_mean'] = H @ p['W_mean'] + p['b_mean']
-        cache['a_disp'] = H @ p['W_disp'] + p['b_disp'] if 'W_disp' in p else None
-        cache['a_pi'] = H @ p['W_pi'] + p['b_pi'] if 'W_pi' in p else None
+        cache['a_mean'] = self._head_in(H, 'mean') @ p['W_mean'] + p['b_mean']
+        if self.ae_type == 'zinb-elempi':        # network.py:438-447: minus, then ElementwiseDense -> sigmoid
+            cache['a_mean'] = -cache['a_mean']
+            cache['a_pi_elem'] = cache['a_mean'] * p['pi_k'] + p['pi_c']
+        cache['a_disp'] = self._head_in(H, 'disp') @ p['W_disp'] + p['b_disp'] if 'W_disp' in p else None
+        cache['a_pi'] = self._head_in(H, 'pi') @ p['W_pi'] + p['b_pi'] if 'W_pi' in p else cache.get('a_pi_elem')
         cache['sf'] = sf.astype(dt)
         return cache
+
+    def _head_in(self, H, head):
+        """Input of a head's Dense: the decoder output, or the head's own branch of a fork network."""
+        if not self.fork:
+            return H
+        j = self.fork.index(head)
+        return H[:, j * self.hfork:(j + 1) * self.hfork]
 
     def _loss_grads(self, c, Y, n_total):
         tw = self.p.get('theta_w')
@@ -264,22 +306,28 @@ class OracleAE:
         pen, greg = (0.0, {})
         if any(self.reg):
             pen, greg = reg_penalty_and_grads({k: v for k, v in p.items() if is_trainable(k)},
-                                              len(self.hidden_size), *self.reg)
+                                              self.n_hidden, *self.reg)
             loss = loss + pen
         HL = c['H'][-1]
-        g['W_mean'] = HL.T @ d_mean
+        if self.ae_type == 'zinb-elempi':
+            g['pi_k'] = (d_pi * c['a_mean']).sum(axis=0)
+            g['pi_c'] = d_pi.sum(axis=0)
+            d_mean = -(d_mean + d_pi * p['pi_k'])           # back through the affine map and the minus
+        g['W_mean'] = self._head_in(HL, 'mean').T @ d_mean
         g['b_mean'] = d_mean.sum(axis=0)
-        dH = d_mean @ p['W_mean'].T
+        parts = {'mean': d_mean @ p['W_mean'].T}
         if 'W_disp' in p:
-            g['W_disp'] = HL.T @ d_disp
+            g['W_disp'] = self._head_in(HL, 'disp').T @ d_disp
             g['b_disp'] = d_disp.sum(axis=0)
-            dH = dH + d_disp @ p['W_disp'].T
+            parts['disp'] = d_disp @ p['W_disp'].T
         elif 'theta_w' in p:
             g['theta_w'] = d_disp
         if 'W_pi' in p:
-            g['W_pi'] = HL.T @ d_pi
+            g['W_pi'] = self._head_in(HL, 'pi').T @ d_pi
             g['b_pi'] = d_pi.sum(axis=0)
-            dH = dH + d_pi @ p['W_pi'].T
+            parts['pi'] = d_pi @ p['W_pi'].T
+        # shared decoder output: the heads' input gradients add up; fork: each lands in its own branch
+        dH = np.concatenate([parts[h] for h in self.fork], axis=1) if self.fork else sum(parts.values())
         for i in reversed(range(len(self.hidden_size))):
             if i in c['keep']:
                 dH = np.where(c['keep'][i], dH * self.dtype.type(dropout_scale(self.hidden_dropout[i])),
@@ -304,7 +352,7 @@ class OracleAE:
         if not any(self.reg):
             return 0.0
         return reg_penalty_and_grads({k: v for k, v in self.p.items() if is_trainable(k)},
-                                     len(self.hidden_size), *self.reg)[0]
+                                     self.n_hidden, *self.reg)[0]
 
     def eval_loss_sum(self, X, Y, sf):
         """Inference-mode sum of element-wise NLL over the given rows."""
@@ -388,7 +436,7 @@ def optimizer_update(kind, w, g, a, b, lr, t, clip=5.0):
 def reg_coefs(name, n_hidden, l1, l2, l1_enc, l2_enc):
     """(l1, l2) of parameter `name` (dca/network.py:101-126: encoder-specific coefficients for the
     encoder and centre Dense kernels when non-zero; heads use l1/l2; biases / beta / theta: none)."""
-    if name.startswith('W_'):
+    if name.startswith('W_') or name == 'pi_k':          # head kernels, ElementwiseDense kernel (network.py:443-445)
         return l1, l2
     if name[0] == 'W' and name[1:].isdigit():
         i = int(name[1:])

@@ -12,7 +12,7 @@ Two jobs:
 import numpy as np
 import torch
 
-from .net_np import BN_EPS, BN_MOMENTUM
+from .net_np import BN_EPS, BN_MOMENTUM, FORK_HEADS, effective_hidden
 
 EPS = 1e-10
 
@@ -50,7 +50,9 @@ class TorchAE:
     def __init__(self, ae_type, params, hidden_size, batchnorm=True, ridge=0.0,
                  dtype=torch.float32):
         self.ae_type = ae_type
-        self.hidden_size = tuple(hidden_size)
+        self.hidden_size = effective_hidden(ae_type, hidden_size)      # *-fork: W{last} holds the branches side by side
+        self.fork = FORK_HEADS.get(ae_type, ())
+        self.hfork = int(tuple(hidden_size)[-1]) if self.fork else 0
         self.batchnorm = batchnorm
         self.ridge = ridge
         self.p = {}
@@ -77,6 +79,27 @@ class TorchAE:
                     mu, var = p['mm%d' % i], p['mv%d' % i]
                 Zi = (Zi - mu) * torch.rsqrt(var + BN_EPS) + p['beta%d' % i]
             H = torch.relu(Zi)
+        if self.fork:
+            # network.py:587-612, 633-645: every head has its own last layer (a column block of the wide layer,
+            # batch-norm and activation are per unit) and its Dense reads only that block
+            hf = self.hfork
+            br = {h: H[:, j * hf:(j + 1) * hf] for j, h in enumerate(self.fork)}
+            mean = mean_act(br['mean'] @ p['W_mean'] + p['b_mean']) * sf.reshape(-1, 1)
+            theta = disp_act(br['disp'] @ p['W_disp'] + p['b_disp'])
+            if 'pi' in br:
+                el = zinb_nll(Y, mean, theta, torch.sigmoid(br['pi'] @ p['W_pi'] + p['b_pi']), self.ridge)
+            else:
+                el = nb_nll(Y, mean, theta)
+            return el.mean() if n_total is None else el.sum() / n_total
+        if self.ae_type == 'zinb-elempi':
+            # network.py:431-447: mean_no_act = -Dense(decoder); pi = sigmoid(ElementwiseDense(mean_no_act));
+            # mean = MeanAct(mean_no_act)
+            mean_no_act = -(H @ p['W_mean'] + p['b_mean'])
+            pi = torch.sigmoid(mean_no_act * p['pi_k'] + p['pi_c'])
+            mean = mean_act(mean_no_act) * sf.reshape(-1, 1)
+            theta = disp_act(H @ p['W_disp'] + p['b_disp'])
+            el = zinb_nll(Y, mean, theta, pi, self.ridge)
+            return el.mean() if n_total is None else el.sum() / n_total
         if self.ae_type == 'normal':         # dca/network.py:146-149 + dca/loss.py:24-27
             el = torch.square((H @ p['W_mean'] + p['b_mean']) * sf.reshape(-1, 1) - Y)
             return el.mean() if n_total is None else el.sum() / n_total

@@ -81,7 +81,11 @@ def test_api_errors():
                              'zinb-conddisp', 'zinb-shared', 'zinb-fork', 'zinb-elempi'}
     with override_ops(CpuRefOps):
         with pytest.raises(NotImplementedError):
-            dca(_adata(), ae_type='zinb-elempi', epochs=1)
+            dca(_adata(), activation='PReLU', epochs=1)
+        with pytest.raises(NotImplementedError):
+            dca(_adata(), init='no_such_init', epochs=1)
+        with pytest.raises(NotImplementedError):
+            dca(_adata(), optimizer='Ftrl', epochs=1)
 
 
 def test_product_build_refuses_to_run_without_gpu():

@@ -12,6 +12,8 @@ from helpers import make_problem, oracle_net, make_engine, assert_grads_close, r
 @pytest.mark.parametrize('batchnorm', [True, False])
 @pytest.mark.parametrize('n,G,hs', [(40, 30, (8, 4, 8)), (20, 6, (1,)), (70, 45, (16, 5))])
 def test_single_step_matches_oracle(ae_type, batchnorm, n, G, hs):
+    if ae_type in N.FORK_HEADS and len(hs) - 1 <= len(hs) // 2:
+        pytest.skip('fork networks need a hidden layer behind the centre')
     ridge = 0.03 if ae_type.startswith('zinb') else 0.0
     X, Y, sf, p = make_problem(n, G, hs, ae_type, batchnorm, seed=n)
     rows = np.random.RandomState(1).permutation(n)[:min(n - 3, 33)]
@@ -189,3 +191,137 @@ def test_shared_heads_api_and_outputs(tmp_path):
             net.write(out, str(tmp_path / ae), mode='denoise')
             row = open(str(tmp_path / ae / 'dispersion.tsv')).read().strip().split('\t')
             assert len(row) == n
+
+
+@pytest.mark.parametrize('ae_type', ['nb-fork', 'zinb-fork'])
+def test_fork_oracle_gradient_matches_finite_differences(ae_type):
+    """network.py:553-760 restated with explicit branches: each head reads only its own slice of the last layer."""
+    n, G, hs = 10, 7, (6, 4, 3, 4, 5)
+    X, Y, sf, p = make_problem(n, G, hs, ae_type, True, seed=3)
+    nh = len(N.FORK_HEADS[ae_type])
+    assert p['W3'].shape == (3, nh * 5) and p['W_mean'].shape == (5, G) and 'W4' not in p     # centre -> branches directly
+    net = oracle_net(ae_type, p, hs, True, ridge=0.02)
+    loss, g = net.loss_and_grads(X, Y, sf)
+    rng = np.random.RandomState(0)
+    for name in ('W3', 'beta3', 'W2', 'W_mean', 'W_disp', 'b_disp', 'W0'):
+        for _ in range(4):
+            idx = tuple(rng.randint(0, s) for s in net.p[name].shape)
+            old, eps, vals = net.p[name][idx], 1e-6, []
+            for d in (eps, -eps):
+                net.p[name][idx] = old + d
+                saved = {k: net.p[k].copy() for k in net.p if k.startswith(('mm', 'mv'))}
+                vals.append(net.loss_and_grads(X, Y, sf)[0])
+                net.p.update(saved)
+            net.p[name][idx] = old
+            fd = (vals[0] - vals[1]) / (2 * eps)
+            assert abs(fd - g[name][idx]) < 2e-6 * max(1.0, abs(fd)) + 1e-9, (name, idx, fd, g[name][idx])
+    # a head's weights see nothing of the other branches
+    h = net.forward(X, sf, training=False)
+    net.p['W3'][:, 5:10] += 1.0                       # disturb the dispersion branch only
+    h2 = net.forward(X, sf, training=False)
+    np.testing.assert_array_equal(h['a_mean'], h2['a_mean'])
+    assert not np.allclose(h['a_disp'], h2['a_disp'])
+
+
+def test_fork_deep_network_with_dropout_and_regularisers_matches_oracle():
+    ae, n, G, hs, B = 'zinb-fork', 64, 40, (16, 8, 4, 8, 12), 32
+    drop = dict(hidden_dropout=[0.1, 0.0, 0.2, 0.5, 0.3], input_dropout=0.1, dropout_seed=5)
+    reg = (1e-4, 2e-4, 3e-4, 0.)
+    X, Y, sf, p = make_problem(n, G, hs, ae, True, seed=6)
+    ref = N.OracleAE(ae, {k: np.asarray(v, np.float64).copy() for k, v in p.items()}, hs, True, 0.01, reg, **drop)
+    assert ref.hidden_size == (16, 8, 4, 36) and ref.hidden_dropout == [0.1, 0.0, 0.2, 0.3]
+    eng = make_engine(CpuRefOps(), ae, G, hs, True, 0.01, p, X, Y, sf, **drop)
+    eng.set_regularizers(*reg)
+    assert eng.lay.hidden == (16, 8, 4, 36) and eng.drop == [0.1, 0.0, 0.2, 0.3] and eng.center == 2
+    rows = np.random.RandomState(1).permutation(n)[:B]
+    rl, rg = ref.loss_and_grads(X[rows], Y[rows], sf[rows])
+    loss, g, _ = run_single_step(eng, rows)
+    assert abs(loss - rl) < 1e-5 * abs(rl)
+    assert_grads_close(g, rg)
+    out = eng.predict_chunk(0, 8, {'latent'})
+    assert out['latent'].shape == (8, 4)
+
+
+def test_fork_needs_a_decoder_layer_and_api_runs():
+    import pandas as pd
+    from conftest import synth_counts
+    from dca_amd.engine import Engine
+    from dca_amd.api import dca
+    from dca_amd._anndata import AnnData
+    from dca_amd.network import override_ops
+    with pytest.raises(ValueError):
+        Engine('zinb-fork', 10, hidden_size=(4,), ops=CpuRefOps())
+    with pytest.raises(ValueError):
+        Engine('nb-fork', 10, hidden_size=(4, 2), ops=CpuRefOps())
+    n, G = 60, 25
+    ad = AnnData(synth_counts(n, G, 5).astype(np.float32), obs=pd.DataFrame(index=['c%d' % i for i in range(n)]),
+                 var=pd.DataFrame(index=['g%d' % i for i in range(G)]))
+    with override_ops(CpuRefOps):
+        for ae in ('nb-fork', 'zinb-fork'):
+            out = dca(ad, ae_type=ae, hidden_size=(8, 4, 8), epochs=2, batch_size=16, return_info=True, copy=True,
+                      verbose=False)
+            assert out.obsm['X_dca_dispersion'].shape == (n, G) and np.isfinite(out.X).all()
+
+
+def test_elempi_oracle_gradient_matches_finite_differences():
+    """ZINBAutoencoderElemPi (network.py:424-461): mean = MeanAct(-Dense), pi = sigmoid(k * (-Dense) + c)."""
+    ae, n, G, hs = 'zinb-elempi', 10, 7, (5, 3, 5)
+    X, Y, sf, p = make_problem(n, G, hs, ae, False, seed=3)
+    assert p['pi_k'].shape == (G,) and p['pi_c'].shape == (G,) and 'W_pi' not in p
+    net = oracle_net(ae, p, hs, False, ridge=0.05)
+    c = net.forward(X, sf, training=False)
+    np.testing.assert_allclose(c['a_mean'], -(c['H'][-1] @ net.p['W_mean'] + net.p['b_mean']))
+    np.testing.assert_allclose(c['a_pi'], c['a_mean'] * net.p['pi_k'] + net.p['pi_c'])
+    loss, g = net.loss_and_grads(X, Y, sf)
+    for name in ('pi_k', 'pi_c', 'W_mean', 'b_mean', 'W_disp', 'W1'):
+        for idx in list(np.ndindex(*net.p[name].shape))[:6]:
+            old, eps, vals = net.p[name][idx], 1e-6, []
+            for d in (eps, -eps):
+                net.p[name][idx] = old + d
+                vals.append(net.loss_and_grads(X, Y, sf)[0])
+            net.p[name][idx] = old
+            fd = (vals[0] - vals[1]) / (2 * eps)
+            assert abs(fd - g[name][idx]) < 1e-6 * max(1.0, abs(fd)) + 1e-9, (name, idx, fd, g[name][idx])
+
+
+def test_elempi_regularised_fit_and_sharedpi():
+    from _opt_cases import run_fit_parity
+    run_fit_parity(CpuRefOps(), optimizer='RMSprop', reg=(1e-4, 2e-4, 0., 0.), ae_type='zinb-elempi')
+    # sharedpi: ElementwiseDense(1) -> one (k, c) pair for all genes: entries stay equal, gradient = the total
+    from dca_amd.engine import Engine
+    n, G, hs = 40, 12, (6, 3, 6)
+    X, Y, sf, p = make_problem(n, G, hs, 'zinb-elempi', True, seed=2)
+    p['pi_k'] = np.full(G, 0.3); p['pi_c'] = np.full(G, -0.1)
+    ref = oracle_net('zinb-elempi', p, hs, True)
+    _, rg = ref.loss_and_grads(X[:16], Y[:16], sf[:16])
+    eng = Engine('zinb-elempi', G, G, hs, True, 0.0, ops=CpuRefOps(), sharedpi=True)
+    eng.set_params(p)
+    eng.load_data(X, Y, sf)
+    _, g, newp = run_single_step(eng, np.arange(16))
+    np.testing.assert_allclose(g['pi_k'], np.full(G, rg['pi_k'].sum()), rtol=1e-4)
+    np.testing.assert_allclose(g['pi_c'], np.full(G, rg['pi_c'].sum()), rtol=1e-4)
+    assert np.ptp(newp['pi_k']) == 0 and np.ptp(newp['pi_c']) == 0
+    eng.init_params(3)
+    assert np.ptp(eng.get_params()['pi_k']) == 0
+    with pytest.raises(NotImplementedError):
+        eng.set_regularizers(1e-3, 0., 0., 0.)
+
+
+def test_every_ae_type_of_the_reference_builds_and_trains():
+    """AE_types (network.py:763-768): all 11 keys resolve, train and predict through dca()."""
+    import pandas as pd
+    from conftest import synth_counts
+    from dca_amd.api import dca
+    from dca_amd._anndata import AnnData
+    from dca_amd.network import override_ops, AE_types
+    assert set(AE_types) == {'normal', 'poisson', 'nb', 'nb-conddisp', 'nb-shared', 'nb-fork', 'zinb', 'zinb-conddisp',
+                             'zinb-shared', 'zinb-fork', 'zinb-elempi'}
+    n, G = 48, 20
+    ad = AnnData(synth_counts(n, G, 9).astype(np.float32), obs=pd.DataFrame(index=['c%d' % i for i in range(n)]),
+                 var=pd.DataFrame(index=['g%d' % i for i in range(G)]))
+    with override_ops(CpuRefOps):
+        for ae in AE_types:
+            out = dca(ad, ae_type=ae, hidden_size=(8, 4, 8), epochs=1, batch_size=16, return_info=True, copy=True,
+                      verbose=False)
+            assert np.isfinite(out.X).all(), ae
+            assert len(out.uns['dca_loss_history']['loss']) == 1

@@ -26,6 +26,8 @@ def ops():
 @pytest.mark.parametrize('n,G,hs,B', [(300, 203, (64, 32, 64), 32), (40, 6, (1,), 25),
                                       (600, 1000, (64, 32, 64), 300), (200, 130, (16, 5), 130)])
 def test_single_step_matches_oracle(ops, ae_type, batchnorm, n, G, hs, B):
+    if ae_type in N.FORK_HEADS and len(hs) - 1 <= len(hs) // 2:
+        pytest.skip('fork networks need a hidden layer behind the centre')
     ridge = 0.03 if ae_type.startswith('zinb') else 0.0
     X, Y, sf, p = make_problem(n, G, hs, ae_type, batchnorm, seed=n)
     rows = np.random.RandomState(1).permutation(n)[:B]

@@ -394,3 +394,35 @@ def test_shared_head_plumbing_kernels(B, G, ld):
     r2 = torch.zeros(B, 4, device=dev)
     ops.row_sums_strided(xd, ld, B, G, r2[:, 2:], 4)
     assert torch.equal(r2[:, 2], r[:, 2])                       # deterministic
+
+
+@pytest.mark.parametrize('B,G,ld', [(1, 1, 4), (37, 203, 208), (4096, 2000, 2000)])
+def test_elempi_kernels(B, G, ld):
+    """dcahip_elempi_fwd / _bwd (zinb-elempi) against numpy fp64."""
+    from dca_amd.ops import HipOps
+    ops = HipOps()
+    dev = torch.device('cuda')
+    rng = np.random.RandomState(B + G)
+    a = rng.normal(size=(B, ld)).astype(np.float32)
+    k = rng.normal(size=G).astype(np.float32)
+    c = rng.normal(size=G).astype(np.float32)
+    ad, kd, cd = (torch.as_tensor(x).to(dev) for x in (a, k, c))
+    pi = torch.full((B, ld), 5.0, device=dev)
+    ops.elempi_fwd(ad, ld, kd, cd, B, G, pi, ld)
+    m = -a[:, :G]
+    np.testing.assert_array_equal(ad.cpu().numpy()[:, :G], m)
+    np.testing.assert_allclose(pi.cpu().numpy()[:, :G], k * m + c, rtol=1e-6, atol=1e-6)
+    assert (pi.cpu().numpy()[:, G:] == 5.0).all() and (ad.cpu().numpy()[:, G:] == a[:, G:]).all()
+    dm = rng.normal(size=(B, ld)).astype(np.float32) * 1e-3
+    dp = rng.normal(size=(B, ld)).astype(np.float32) * 1e-3
+    dmd, dpd = torch.as_tensor(dm).to(dev), torch.as_tensor(dp).to(dev)
+    gk = torch.zeros(G + 3, device=dev); gc = torch.zeros(G + 3, device=dev)
+    ws = torch.zeros(ops.elempi_workspace_doubles(G), dtype=torch.float64, device=dev)
+    ops.elempi_bwd(ad, ld, dmd, dpd, ld, kd, B, G, gk, gc, ws)
+    np.testing.assert_allclose(dmd.cpu().numpy()[:, :G], -(dm[:, :G] + k * dp[:, :G]), rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(gk.cpu().numpy()[:G], (dp[:, :G].astype(np.float64) * m).sum(0), rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(gc.cpu().numpy()[:G], dp[:, :G].astype(np.float64).sum(0), rtol=1e-5, atol=1e-8)
+    gk2 = torch.zeros_like(gk); gc2 = torch.zeros_like(gc)
+    dmd.copy_(torch.as_tensor(dm).to(dev))
+    ops.elempi_bwd(ad, ld, dmd, dpd, ld, kd, B, G, gk2, gc2, ws)
+    assert torch.equal(gk, gk2) and torch.equal(gc, gc2)
