@@ -1,7 +1,8 @@
 """Command line of the reference (``dca input outputdir [flags]``, dca/__main__.py:18-154) on the
 MI355X path: same positionals, flag names, defaults and output files.  The option table below
-restates the reference's flag set; ``--hyper*`` (hyperopt/kopt search, dca/hyper.py) and
-``--tensorboard`` are accepted for command-line compatibility but not implemented.
+restates the reference's flag set; ``--hyper*`` runs dca_amd/hyper.py (the search space and outputs of
+dca/hyper.py with random proposals instead of hyperopt's TPE); ``--tensorboard`` is accepted for
+command-line compatibility and ignored.
 """
 import argparse
 import sys

@@ -1,0 +1,98 @@
+"""Hyper-parameter search of dca/hyper.py:14-112 (`dca --hyper`) without kopt / hyperopt.
+
+Same search space (hyper.py:19-43), same objective construction (data_fn: normalize with the sampled
+flags, hyper.py:45-57; model_fn: AE_types[aetype] with the sampled architecture / regularisation,
+RMSprop(lr, clipvalue=5), hyper.py:59-83; 20 % of the cells held out, the loss on them is minimised,
+hyper.py:85-95), same outputs (`<outputdir>/hyperopt_results/best.json`, `trials.pickle`).  The
+proposal distribution is plain random search over that space (numpy RandomState(42)); hyperopt's
+TPE sampler is a third-party algorithm that is not part of this path.  A trial that fails (for
+instance an activation this path does not implement: PReLU) is recorded as failed and skipped, as
+fmin(catch_eval_exceptions=True) does (hyper.py:99-104).  best.json holds the chosen VALUES (the
+reference writes hyperopt's choice indices and carries a TODO about it, hyper.py:109).  As in the
+reference the input is read with transpose=args.transpose (hyper.py:15-17: NOT the `not args.transpose`
+of the training pipeline, train.py:124-127), i.e. `--hyper` expects cell x gene unless -t is given.
+"""
+import json
+import os
+import pickle
+
+import numpy as np
+
+from . import io
+from .network import AE_types
+from .train import train
+
+HIDDEN_SIZES = ((64, 32, 64), (32, 16, 32), (64, 64), (32, 32), (16, 16), (16,), (32,), (64,), (128,))
+ACTIVATIONS = ('relu', 'selu', 'elu', 'PReLU', 'linear', 'LeakyReLU')
+AE_CHOICES = ('zinb', 'zinb-conddisp')
+KOPT_PATIENCE = 10          # kopt.CompileFN's default early-stopping patience
+VALID_SPLIT = 0.2           # hyper.py:90
+
+
+def _loguniform(rng, lo, hi):
+    return float(np.exp(rng.uniform(np.log(lo), np.log(hi))))
+
+
+def sample(rng):
+    """One draw from the space of hyper.py:19-43."""
+    return {
+        'data': {'norm_input_log': bool(rng.randint(2)),
+                 'norm_input_zeromean': bool(rng.randint(2)),
+                 'norm_input_sf': bool(rng.randint(2))},
+        'model': {'lr': _loguniform(rng, 1e-3, 1e-2),
+                  'ridge': _loguniform(rng, 1e-7, 1e-1),
+                  'l1_enc_coef': _loguniform(rng, 1e-7, 1e-1),
+                  'hidden_size': HIDDEN_SIZES[rng.randint(len(HIDDEN_SIZES))],
+                  'activation': ACTIVATIONS[rng.randint(len(ACTIVATIONS))],
+                  'aetype': AE_CHOICES[rng.randint(len(AE_CHOICES))],
+                  'batchnorm': bool(rng.randint(2)),
+                  'dropout': float(rng.uniform(0, 0.7)),
+                  'input_dropout': float(rng.uniform(0, 0.8))},
+    }
+
+
+def evaluate(adata, params, epochs, debug=False, seed=0):
+    """Trains one configuration; returns the best held-out loss and the history."""
+    d, m = params['data'], params['model']
+    ad = io.normalize(adata.copy(), size_factors=d['norm_input_sf'], logtrans_input=d['norm_input_log'],
+                      normalize_input=d['norm_input_zeromean'])
+    net = AE_types[m['aetype']](input_size=ad.n_vars, hidden_size=m['hidden_size'], l2_coef=0.0, l1_coef=0.0,
+                                l2_enc_coef=0.0, l1_enc_coef=m['l1_enc_coef'], ridge=m['ridge'],
+                                hidden_dropout=m['dropout'], input_dropout=m['input_dropout'],
+                                batchnorm=m['batchnorm'], activation=m['activation'], init='glorot_uniform',
+                                debug=debug)
+    net.seed = seed
+    net.build()
+    hist = train(ad, net, optimizer='RMSprop', learning_rate=m['lr'], epochs=epochs, reduce_lr=None,
+                 early_stop=KOPT_PATIENCE, batch_size=32, clip_grad=5.0, validation_split=VALID_SPLIT, verbose=False)
+    val = [v for v in hist.history.get('val_loss', []) if np.isfinite(v)]
+    if not val:
+        raise FloatingPointError('no finite validation loss')
+    return float(np.min(val)), hist.history
+
+
+def hyper(args):
+    adata = io.read_dataset(args.input, transpose=args.transpose, test_split=False)
+    output_dir = os.path.join(args.outputdir, 'hyperopt_results')
+    os.makedirs(output_dir, exist_ok=True)
+    rng = np.random.RandomState(42)
+    trials, best = [], None
+    for t in range(int(args.hypern)):
+        params = sample(rng)
+        rec = {'tid': t, 'params': params, 'status': 'ok'}
+        try:
+            rec['loss'], rec['history'] = evaluate(adata, params, int(args.hyperepoch), getattr(args, 'debug', False), seed=t)
+        except Exception as e:          # fmin(catch_eval_exceptions=True)
+            rec['status'], rec['error'] = 'fail', '%s: %s' % (type(e).__name__, e)
+        trials.append(rec)
+        if rec['status'] == 'ok' and (best is None or rec['loss'] < best['loss']):
+            best = rec
+        print('dca: hyper trial %d/%d: %s' % (t + 1, args.hypern, ('loss %.6f' % rec['loss']) if rec['status'] == 'ok'
+                                              else rec['error']))
+    with open(os.path.join(output_dir, 'trials.pickle'), 'wb') as f:
+        pickle.dump(trials, f)
+    best_out = {} if best is None else dict(loss=best['loss'], tid=best['tid'], **best['params'])
+    with open(os.path.join(output_dir, 'best.json'), 'wt') as f:
+        json.dump(best_out, f, sort_keys=True, indent=4)
+    print(best_out)
+    return best_out

@@ -207,7 +207,7 @@ def train(adata, network, output_dir=None, optimizer='RMSprop', learning_rate=No
           **kwds):
     """Signature and defaults of dca/train.py:35-39.  ``threads`` (TF CPU pools) and
     ``tensorboard`` have no meaning on the GPU path and are accepted and ignored; optimizers:
-    SGD, RMSprop, Adagrad, Adadelta, Adam, Adamax (Keras defaults); Nadam raises."""
+    SGD, RMSprop, Adagrad, Adadelta, Adam, Adamax, Nadam (Keras defaults)."""
     eng = network.engine
     if eng is None:
         raise RuntimeError('network.build() must be called before train()')
@@ -286,8 +286,10 @@ def train_with_args(args):
     np.random.seed(42)
     os.environ['PYTHONHASHSEED'] = '0'
 
-    if args.hyper:
-        raise NotImplementedError('--hyper needs kopt/hyperopt (dca/hyper.py); not available on this path')
+    if args.hyper:                              # train.py:119-122: do hyperpar optimization and exit
+        from .hyper import hyper
+        hyper(args)
+        return
 
     adata = io.read_dataset(args.input,
                             transpose=(not args.transpose),  # assume gene x cell by default

@@ -46,3 +46,34 @@ def test_cli_end_to_end(tmp_path):
     # no rownames, so after the transpose there are no column names)
     drop = pd.read_csv(os.path.join(out, 'dropout.tsv'), sep='\t', index_col=0, header=None)
     assert drop.shape == (G, n) and list(drop.index) == genes and ((drop.values >= 0) & (drop.values <= 1)).all()
+
+
+def test_cli_hyper_search(tmp_path):
+    """dca --hyper (dca/hyper.py): the reference's space, random proposals, best.json + trials.pickle."""
+    import json
+    import pickle
+    from dca_amd import hyper as H
+    rng = np.random.RandomState(0)
+    draws = [H.sample(rng) for _ in range(200)]
+    assert all(1e-3 <= d['model']['lr'] <= 1e-2 and 1e-7 <= d['model']['ridge'] <= 1e-1 for d in draws)
+    assert all(0 <= d['model']['dropout'] <= 0.7 and 0 <= d['model']['input_dropout'] <= 0.8 for d in draws)
+    assert {d['model']['hidden_size'] for d in draws} == set(H.HIDDEN_SIZES)
+    assert {d['model']['activation'] for d in draws} == set(H.ACTIVATIONS)
+    assert {d['model']['aetype'] for d in draws} == {'zinb', 'zinb-conddisp'}
+    n, G = 60, 16
+    y = synth_counts(n, G, 7)
+    f = str(tmp_path / 'counts.tsv')
+    pd.DataFrame(y.T.astype(int), index=['g%d' % i for i in range(G)], columns=['c%d' % i for i in range(n)]).to_csv(f, sep='\t')
+    out = str(tmp_path / 'res')
+    with override_ops(CpuRefOps):
+        main([f, out, '--hyper', '--hypern', '6', '--hyperepoch', '2'])
+    res = os.path.join(out, 'hyperopt_results')
+    best = json.load(open(os.path.join(res, 'best.json')))
+    trials = pickle.load(open(os.path.join(res, 'trials.pickle'), 'rb'))
+    assert len(trials) == 6 and {'loss', 'tid', 'data', 'model'} <= set(best)
+    ok = [t for t in trials if t['status'] == 'ok']
+    assert ok and best['loss'] == min(t['loss'] for t in ok)
+    for t in trials:       # PReLU is the one thing of the space this path does not implement: recorded, skipped
+        if t['status'] == 'fail':
+            assert t['params']['model']['activation'] == 'PReLU', t['error']
+    assert not os.path.exists(os.path.join(out, 'mean.tsv'))        # hyper() runs and exits (train.py:119-122)
