@@ -470,6 +470,69 @@ __global__ __launch_bounds__(256) void row_sums_strided_kernel(const float* __re
     if (lane == 0) out[(long)r * ldo] = (float)acc;
 }
 
+// keras.layers.PReLU (network.py:132-133, advanced_activations): f(x) = max(x, 0) + alpha_c min(x, 0) with one
+// trainable slope per unit (alpha_initializer zeros).  Runs as its own element-wise layer behind the batch-norm /
+// bias kernels (which then apply the linear activation).
+__global__ __launch_bounds__(256) void prelu_fwd_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ alpha,
+                                                        int B, int h, float* __restrict__ out, long ldo) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= h) return;
+    const float a = alpha[c];
+    for (int r = blockIdx.y; r < B; r += gridDim.y) {
+        const float v = x[(long)r * ldx + c];
+        out[(long)r * ldo + c] = v > 0.f ? v : a * v;
+    }
+}
+
+__global__ __launch_bounds__(256) void prelu_bwd_kernel(float* __restrict__ d, long ldd, const float* __restrict__ x, long ldx,
+                                                        const float* __restrict__ alpha, int B, int h,
+                                                        double* __restrict__ partial) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= h) return;
+    const float a = alpha[c];
+    double sa = 0.0;
+    for (int r = blockIdx.y; r < B; r += gridDim.y) {
+        const float v = x[(long)r * ldx + c];
+        const float g = d[(long)r * ldd + c];
+        if (v > 0.f) continue;                    // slope 1, no alpha term
+        sa += (double)(g * v);
+        d[(long)r * ldd + c] = a * g;
+    }
+    partial[(long)blockIdx.y * h + c] = sa;
+}
+
+__global__ __launch_bounds__(256) void prelu_finish_kernel(const double* __restrict__ partial, int R, int h,
+                                                           float* __restrict__ galpha) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= h) return;
+    double s = 0.0;
+    for (int y = 0; y < R; ++y) s += partial[(long)y * h + c];
+    galpha[c] = (float)s;
+}
+
+constexpr int kPreluSlices = 32;
+
+extern "C" int dcahip_prelu_workspace_doubles(int h) { return h > 0 ? kPreluSlices * h : 0; }
+
+extern "C" int dcahip_prelu_fwd(const float* x, long ldx, const float* alpha, int B, int h, float* out, long ldo,
+                                void* stream) {
+    if (!x || !alpha || !out || B <= 0 || h <= 0 || ldx < h || ldo < h) return DCAHIP_EINVAL;
+    const int gy = B < 64 ? B : 64;
+    hipLaunchKernelGGL(prelu_fwd_kernel, dim3((h + 255) / 256, gy), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       x, ldx, alpha, B, h, out, ldo);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dcahip_prelu_bwd(float* d, long ldd, const float* x, long ldx, const float* alpha, int B, int h,
+                                float* galpha, double* workspace, void* stream) {
+    if (!d || !x || !alpha || !galpha || !workspace || B <= 0 || h <= 0 || ldx < h || ldd < h) return DCAHIP_EINVAL;
+    const int R = B < kPreluSlices ? B : kPreluSlices;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(prelu_bwd_kernel, dim3((h + 255) / 256, R), dim3(256), 0, s, d, ldd, x, ldx, alpha, B, h, workspace);
+    hipLaunchKernelGGL(prelu_finish_kernel, dim3((h + 255) / 256), dim3(256), 0, s, workspace, R, h, galpha);
+    return (int)hipGetLastError();
+}
+
 // zinb-elempi (ZINBAutoencoderElemPi, network.py:424-461): m = -(Dense output) feeds MeanAct, and the dropout
 // logit is an element-wise affine map of m (ElementwiseDense, layers.py:50-82): a_pi = k_g m + c_g.
 __global__ __launch_bounds__(256) void elempi_fwd_kernel(float* __restrict__ a_mean, long lda, const float* __restrict__ k,

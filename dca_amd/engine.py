@@ -46,7 +46,7 @@ AE_FORK = ('nb-fork', 'zinb-fork')
 AE_HEADS['zinb-elempi'] = (('mean', 'disp', 'pi'), False, ())
 AE_ELEMPI = ('zinb-elempi',)
 ACT_CODES = {'linear': 0, 'relu': 1, 'tanh': 2, 'sigmoid': 3, 'elu': 4, 'selu': 5, 'softplus': 6,
-             'softsign': 7, 'LeakyReLU': 8}
+             'softsign': 7, 'LeakyReLU': 8, 'PReLU': 9}      # 9: own element-wise layer with trainable slopes
 INPUT_DROPOUT_LAYER = 255     # Philox counter word 3 of the input dropout (hidden layer i uses i)
 AE_LOSS_FLAG = {'poisson': 4, 'normal': 8}              # DCAHIP_NLL_POISSON / DCAHIP_NLL_MSE
 
@@ -171,8 +171,9 @@ def keras_initializer(name, rng, fan_in, fan_out, shape=None):
 class ParamLayout:
     """Offsets of every tensor in the flat parameter / gradient / RMSprop buffers."""
 
-    def __init__(self, ae_type, input_size, output_size, hidden_size, batchnorm):
+    def __init__(self, ae_type, input_size, output_size, hidden_size, batchnorm, prelu=False):
         self.ae_type = ae_type
+        self.prelu = bool(prelu)
         self.heads, self.const_disp = AE_HEADS[ae_type][:2]
         self.shared = AE_HEADS[ae_type][2] if len(AE_HEADS[ae_type]) > 2 else ()
         self.elempi = ae_type in AE_ELEMPI
@@ -216,6 +217,8 @@ class ParamLayout:
             add('b%d' % i, (h,))                        # bias right behind it: [in+1, out] block
             if batchnorm:
                 add('beta%d' % i, (h,))
+            if self.prelu:
+                add('alpha%d' % i, (h,))                # keras.layers.PReLU slopes (zeros)
             fan_in = h
         self.hL = self.hfork if self.fork else fan_in   # rows of the heads' Dense block (inputs per head)
         add('Wh', (self.hL, self.NH), align=True)
@@ -264,12 +267,15 @@ class Engine:
             torch.device('cuda', torch.cuda.current_device()) if ops.device_type == 'cuda'
             else torch.device('cpu'))
         output_size = input_size if output_size is None else output_size
-        self.lay = ParamLayout(ae_type, input_size, output_size, hidden_size, batchnorm)
+        self.lay = ParamLayout(ae_type, input_size, output_size, hidden_size, batchnorm, prelu=(activation == 'PReLU'))
         self.ridge = float(ridge)
         if activation not in ACT_CODES:
             raise NotImplementedError('activation %r is not available on the MI355X path (supported: %s)'
                                       % (activation, ', '.join(ACT_CODES)))
         self.act = ACT_CODES[activation]       # Activation(self.activation), network.py:132-135
+        self.prelu = activation == 'PReLU'
+        if self.prelu:                         # the BN / bias kernels stay linear, PReLU is its own layer behind them
+            self.act = 0
         lay = self.lay
         self.has_pi = 'pi' in lay.heads
         self.flags = (1 if self.has_pi else 0) | (2 if lay.const_disp else 0) | AE_LOSS_FLAG.get(ae_type, 0)
@@ -529,6 +535,9 @@ class Engine:
         self.H = [torch.zeros(B, l, **f32) for l in self.ldh]
         # outputs after dropout (the next layer's input); layers without dropout alias H
         self.HD = [torch.zeros(B, l, **f32) if r > 0.0 else None for l, r in zip(self.ldh, self.drop)]
+        self.HP = [torch.zeros(B, l, **f32) for l in self.ldh] if self.prelu else None    # PReLU outputs
+        self.ws_prelu = torch.zeros(ops.prelu_workspace_doubles(max(lay.hidden)), dtype=torch.float64, device=self.dev) \
+            if self.prelu else None
         self.Hcur = list(self.H)
         self.Xb = None                                  # input-dropout batch, allocated on first use
         self.dH = [torch.zeros(B, l, **f32) for l in self.ldh]
@@ -608,12 +617,15 @@ class Engine:
                                       None, 0, None)
             else:
                 ops.relu_fwd(self.Z[i], self.ldh[i], B, h, self.H[i], self.ldh[i], self.act)
+            cur = self.H[i]
+            if self.prelu:
+                ops.prelu_fwd(self.H[i], self.ldh[i], lay.view(w, 'alpha%d' % i), B, h, self.HP[i], self.ldh[i])
+                cur = self.HP[i]
             if training and self.drop[i] > 0.0:
-                ops.dropout_apply(self.H[i], self.ldh[i], None, None, B, h, self.drop[i], self.drop_seed,
+                ops.dropout_apply(cur, self.ldh[i], None, None, B, h, self.drop[i], self.drop_seed,
                                   self.drop_iter, i, self.row0, self.HD[i], self.ldh[i])
-                self.Hcur[i] = self.HD[i]
-            else:
-                self.Hcur[i] = self.H[i]
+                cur = self.HD[i]
+            self.Hcur[i] = cur
             K = h
         return K
 
@@ -780,6 +792,9 @@ class Engine:
             if self.drop[i] > 0.0:      # gradient through the dropout of this layer's output: same mask
                 ops.dropout_apply(self.dH[i], self.ldh[i], None, None, B, h, self.drop[i], self.drop_seed,
                                   self.drop_iter, i, self.row0, self.dH[i], self.ldh[i])
+            if self.prelu:              # dL/d(PReLU out) -> dL/d(its input) in place, slope gradients
+                ops.prelu_bwd(self.dH[i], self.ldh[i], self.H[i], self.ldh[i], lay.view(w, 'alpha%d' % i), B, h,
+                              lay.view(g, 'alpha%d' % i), self.ws_prelu)
             if lay.batchnorm:
                 ops.bn_bwd_sums(self.dH[i], self.ldh[i], self.H[i], self.ldh[i], self.XH[i],
                                 self.ldh[i], B, h, self.bpart[i], self.act)

@@ -72,6 +72,9 @@ _SIGNATURES = {
     'dcahip_optimizer_step': (_c.c_int, [_c.c_int, _f32p, _f32p, _f32p, _f32p, _c.c_long, _f32p, _i64p,
                                          _c.c_float, _vp]),
     'dcahip_counter_add': (_c.c_int, [_i64p, _c.c_int, _vp]),
+    'dcahip_prelu_workspace_doubles': (_c.c_int, [_c.c_int]),
+    'dcahip_prelu_fwd': (_c.c_int, [_f32p, _c.c_long, _f32p, _c.c_int, _c.c_int, _f32p, _c.c_long, _vp]),
+    'dcahip_prelu_bwd': (_c.c_int, [_f32p, _c.c_long, _f32p, _c.c_long, _f32p, _c.c_int, _c.c_int, _f32p, _f64p, _vp]),
     'dcahip_elempi_workspace_doubles': (_c.c_int, [_c.c_int]),
     'dcahip_elempi_fwd': (_c.c_int, [_f32p, _c.c_long, _f32p, _f32p, _c.c_int, _c.c_int, _f32p, _c.c_long, _vp]),
     'dcahip_elempi_bwd': (_c.c_int, [_f32p, _c.c_long, _f32p, _f32p, _c.c_long, _f32p, _c.c_int, _c.c_int, _f32p, _f32p,

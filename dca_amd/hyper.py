@@ -5,9 +5,9 @@ flags, hyper.py:45-57; model_fn: AE_types[aetype] with the sampled architecture 
 RMSprop(lr, clipvalue=5), hyper.py:59-83; 20 % of the cells held out, the loss on them is minimised,
 hyper.py:85-95), same outputs (`<outputdir>/hyperopt_results/best.json`, `trials.pickle`).  The
 proposal distribution is plain random search over that space (numpy RandomState(42)); hyperopt's
-TPE sampler is a third-party algorithm that is not part of this path.  A trial that fails (for
-instance an activation this path does not implement: PReLU) is recorded as failed and skipped, as
-fmin(catch_eval_exceptions=True) does (hyper.py:99-104).  best.json holds the chosen VALUES (the
+TPE sampler is a third-party algorithm that is not part of this path.  A trial that fails (a
+diverged loss, say) is recorded as failed and skipped, as fmin(catch_eval_exceptions=True) does
+(hyper.py:99-104).  best.json holds the chosen VALUES (the
 reference writes hyperopt's choice indices and carries a TODO about it, hyper.py:109).  As in the
 reference the input is read with transpose=args.transpose (hyper.py:15-17: NOT the `not args.transpose`
 of the training pipeline, train.py:124-127), i.e. `--hyper` expects cell x gene unless -t is given.

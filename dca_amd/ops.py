@@ -123,6 +123,18 @@ class HipOps:
         hip.check(self.L.dcahip_optimizer_step(hip.OPT_KINDS[kind], p(w), p(g), p(slot1), p(slot2), n, p(lr),
                                                p(it), clip, hip.stream()), 'optimizer_step')
 
+    def prelu_workspace_doubles(self, h):
+        return int(self.L.dcahip_prelu_workspace_doubles(h))
+
+    def prelu_fwd(self, x, ldx, alpha, B, h, out, ldo):
+        p = hip.ptr
+        hip.check(self.L.dcahip_prelu_fwd(p(x), ldx, p(alpha), B, h, p(out), ldo, hip.stream()), 'prelu_fwd')
+
+    def prelu_bwd(self, d, ldd, x, ldx, alpha, B, h, galpha, ws):
+        p = hip.ptr
+        hip.check(self.L.dcahip_prelu_bwd(p(d), ldd, p(x), ldx, p(alpha), B, h, p(galpha), p(ws), hip.stream()),
+                  'prelu_bwd')
+
     def elempi_workspace_doubles(self, G):
         return int(self.L.dcahip_elempi_workspace_doubles(G))
 

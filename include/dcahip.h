@@ -205,6 +205,14 @@ int dcahip_relu_fwd(const float* Z, long ldz, int B, int H, float* Hout, long ld
  * dcahip_bcast_cols: out[r, c] = s[r * lds] for c < G (the scalar pre-activation spread into the plane
  * the loss kernel reads).  dcahip_row_sums_strided: out[r * ldo] = sum_c x[r, c] (the plane of
  * pre-activation gradients folded back into the gradient of the scalar); fp64 accumulation, fixed order. */
+/* keras.layers.PReLU (activation='PReLU', network.py:132-133): out = max(x, 0) + alpha[c] min(x, 0), one trainable
+ * slope per unit.  x = the batch-norm (or bias) output with the LINEAR activation code.  dcahip_prelu_bwd: d holds
+ * dL/dout on entry and dL/dx on return; galpha[c] = sum_r dL/dout min(x, 0) (fp64 partials, fixed order);
+ * workspace: dcahip_prelu_workspace_doubles(h) doubles. */
+int dcahip_prelu_workspace_doubles(int h);
+int dcahip_prelu_fwd(const float* x, long ldx, const float* alpha, int B, int h, float* out, long ldo, void* stream);
+int dcahip_prelu_bwd(float* d, long ldd, const float* x, long ldx, const float* alpha, int B, int h,
+                     float* galpha, double* workspace, void* stream);
 /* zinb-elempi (ZINBAutoencoderElemPi network.py:424-461, ElementwiseDense layers.py:50-82): the mean head's Dense
  * output is negated (m = -a feeds MeanAct) and the dropout logit is a_pi[r, g] = k[g] m[r, g] + c[g].
  * dcahip_elempi_fwd: a_mean <- m in place, a_pi plane written.  dcahip_elempi_bwd: d_mean holds dL/dm on entry and

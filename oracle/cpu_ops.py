@@ -284,6 +284,20 @@ class CpuRefOps:
         if b is not None:
             b[:] = nb
 
+    def prelu_workspace_doubles(self, h):
+        return 4
+
+    def prelu_fwd(self, x, ldx, alpha, B, h, out, ldo):
+        xv = _mat(x, B, h, ldx)
+        _mat(out, B, h, ldo)[:] = np.where(xv > 0, xv, xv * _vec(alpha, h))
+
+    def prelu_bwd(self, d, ldd, x, ldx, alpha, B, h, galpha, ws):
+        xv = _mat(x, B, h, ldx).astype(np.float64)
+        dv = _mat(d, B, h, ldd)
+        d64 = dv.astype(np.float64)
+        _vec(galpha, h)[:] = (d64 * np.minimum(xv, 0)).sum(axis=0)
+        dv[:] = np.where(xv > 0, d64, d64 * _vec(alpha, h).astype(np.float64))
+
     def elempi_workspace_doubles(self, G):
         return 4
 

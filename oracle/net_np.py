@@ -42,11 +42,13 @@ def effective_hidden(ae_type, hidden_size):
     center = int(np.floor(len(hs) / 2.0))
     assert len(hs) - 1 > center, 'fork networks need a hidden layer behind the centre'
     return hs[:center + 1] + (len(FORK_HEADS[ae_type]) * hs[-1],)
+
+
 SHARED_HEADS = {'nb-shared': ('disp',), 'zinb-shared': ('disp', 'pi')}     # Dense(1): network.py:343-362, 464-491
 
 
 ACT_CODES = {'linear': 0, 'relu': 1, 'tanh': 2, 'sigmoid': 3, 'elu': 4, 'selu': 5, 'softplus': 6,
-             'softsign': 7, 'LeakyReLU': 8}
+             'softsign': 7, 'LeakyReLU': 8, 'PReLU': 9}    # 9: keras.layers.PReLU, slopes are parameters alpha{i}
 SELU_SCALE, SELU_ALPHA = 1.0507009873554805, 1.6732632423543772
 
 
@@ -141,6 +143,13 @@ INPUT_DROPOUT_LAYER = 255          # Philox counter word 3 of the input dropout;
 def glorot_uniform(rng, fan_in, fan_out, dtype):
     lim = np.sqrt(6.0 / (fan_in + fan_out))
     return rng.uniform(-lim, lim, size=(fan_in, fan_out)).astype(dtype)
+
+
+def add_prelu_params(p, ae_type, hidden_size, dtype=np.float64):
+    """keras.layers.PReLU behind every hidden layer: alpha of shape (units,), zeros (alpha_initializer)."""
+    for i, h in enumerate(effective_hidden(ae_type, hidden_size)):
+        p['alpha%d' % i] = np.zeros(h, dtype)
+    return p
 
 
 def init_params(ae_type, input_size, hidden_size, output_size=None, batchnorm=True,
@@ -249,7 +258,10 @@ class OracleAE:
             else:
                 Yb = Zi
             cache['Yb'].append(Yb)
-            H = act_fwd(self.act, Yb)
+            if self.act == 9:
+                H = np.maximum(Yb, 0) + p['alpha%d' % i] * np.minimum(Yb, 0)
+            else:
+                H = act_fwd(self.act, Yb)
             if training and self.hidden_dropout[i] > 0.0:    # network.py:137-138
                 keep = dropout_keep(self.dropout_seed, self.step, i, self.row0, H.shape[0], H.shape[1],
                                     self.hidden_dropout[i])
@@ -332,7 +344,11 @@ class OracleAE:
             if i in c['keep']:
                 dH = np.where(c['keep'][i], dH * self.dtype.type(dropout_scale(self.hidden_dropout[i])),
                               self.dtype.type(0))
-            dYb = dH * act_grad(self.act, c['Yb'][i])
+            if self.act == 9:
+                g['alpha%d' % i] = (dH * np.minimum(c['Yb'][i], 0)).sum(axis=0)
+                dYb = dH * np.where(c['Yb'][i] > 0, 1.0, p['alpha%d' % i])
+            else:
+                dYb = dH * act_grad(self.act, c['Yb'][i])
             if self.batchnorm:
                 xh, inv = c['xh'][i], c['inv'][i]
                 g['beta%d' % i] = dYb.sum(axis=0)

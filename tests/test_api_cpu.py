@@ -81,7 +81,7 @@ def test_api_errors():
                              'zinb-conddisp', 'zinb-shared', 'zinb-fork', 'zinb-elempi'}
     with override_ops(CpuRefOps):
         with pytest.raises(NotImplementedError):
-            dca(_adata(), activation='PReLU', epochs=1)
+            dca(_adata(), activation='no_such_activation', epochs=1)
         with pytest.raises(NotImplementedError):
             dca(_adata(), init='no_such_init', epochs=1)
         with pytest.raises(NotImplementedError):

@@ -325,3 +325,43 @@ def test_every_ae_type_of_the_reference_builds_and_trains():
                       verbose=False)
             assert np.isfinite(out.X).all(), ae
             assert len(out.uns['dca_loss_history']['loss']) == 1
+
+
+@pytest.mark.parametrize('batchnorm', [True, False])
+def test_prelu_oracle_finite_differences_and_engine_parity(batchnorm):
+    """activation='PReLU' (network.py:132-133): trainable slope per unit behind every hidden layer."""
+    ae, n, G, hs = 'zinb-conddisp', 24, 15, (8, 4, 8)
+    X, Y, sf, p = make_problem(n, G, hs, ae, batchnorm, seed=4)
+    N.add_prelu_params(p, ae, hs)
+    rng = np.random.RandomState(2)
+    for i in range(3):
+        p['alpha%d' % i] = rng.normal(0.1, 0.3, p['alpha%d' % i].shape)       # both signs
+    net = oracle_net(ae, p, hs, batchnorm, activation='PReLU')
+    loss, g = net.loss_and_grads(X, Y, sf)
+    for name in ('alpha0', 'alpha1', 'alpha2', 'W0', 'W2', 'W_pi'):
+        for idx in list(np.ndindex(*net.p[name].shape))[:5]:
+            old, eps, vals = net.p[name][idx], 1e-6, []
+            for d in (eps, -eps):
+                net.p[name][idx] = old + d
+                saved = {k: net.p[k].copy() for k in net.p if k.startswith(('mm', 'mv'))}
+                vals.append(net.loss_and_grads(X, Y, sf)[0])
+                net.p.update(saved)
+            net.p[name][idx] = old
+            fd = (vals[0] - vals[1]) / (2 * eps)
+            assert abs(fd - g[name][idx]) < 2e-6 * max(1.0, abs(fd)) + 1e-9, (name, idx, fd, g[name][idx])
+    from _dropout_cases import DROP
+    ref = oracle_net(ae, p, hs, batchnorm, activation='PReLU', **DROP)
+    eng = make_engine(CpuRefOps(), ae, G, hs, batchnorm, 0.0, p, X, Y, sf, activation='PReLU', **DROP)
+    rows = np.arange(16)
+    rl, rg = ref.loss_and_grads(X[rows], Y[rows], sf[rows])
+    loss, g, _ = run_single_step(eng, rows)
+    assert abs(loss - rl) < 1e-5 * abs(rl)
+    assert_grads_close(g, rg)
+    assert (make_engine(CpuRefOps(), ae, G, hs, batchnorm, 0.0, {}, X, Y, sf, activation='PReLU').get_params()['alpha1'] == 0).all()
+    # inference (fresh copies: the step above moved the engine's weights)
+    eng2 = make_engine(CpuRefOps(), ae, G, hs, batchnorm, 0.0, p, X, Y, sf, activation='PReLU')
+    eng2.reserve(8)
+    out = eng2.predict_chunk(0, 8, {'mean', 'latent'})
+    want = oracle_net(ae, p, hs, batchnorm, activation='PReLU').predict(X[:8], sf[:8])
+    np.testing.assert_allclose(out['mean'].numpy()[:, :G], want['mean'], rtol=2e-4)
+    np.testing.assert_allclose(out['latent'].numpy(), want['latent'], rtol=2e-4, atol=1e-5)

@@ -240,3 +240,27 @@ def test_activations_single_step_matches_oracle(ops, activation, batchnorm):
     out = eng.predict_chunk(0, 16, {'mean', 'latent'})
     for k in ('mean', 'latent'):
         np.testing.assert_allclose(out[k].cpu().numpy(), out_ref[k], rtol=2e-3, atol=2e-4, err_msg=k)
+
+
+@pytest.mark.parametrize('batchnorm', [True, False])
+def test_prelu_step_matches_oracle(ops, batchnorm):
+    from _dropout_cases import DROP
+    ae, n, G, hs = 'zinb-conddisp', 200, 150, (64, 32, 64)
+    X, Y, sf, p = make_problem(n, G, hs, ae, batchnorm, seed=4)
+    N.add_prelu_params(p, ae, hs)
+    rng = np.random.RandomState(2)
+    for i in range(3):
+        p['alpha%d' % i] = rng.normal(0.1, 0.3, p['alpha%d' % i].shape)
+    ref = oracle_net(ae, p, hs, batchnorm, activation='PReLU', **DROP)
+    eng = make_engine(ops, ae, G, hs, batchnorm, 0.0, p, X, Y, sf, activation='PReLU', **DROP)
+    rows = np.random.RandomState(1).permutation(n)[:96]
+    rl, rg = ref.loss_and_grads(X[rows], Y[rows], sf[rows])
+    loss, g, _ = run_single_step(eng, rows)
+    assert abs(loss - rl) < 1e-5 * abs(rl)
+    assert_grads_close(g, rg)
+    eng2 = make_engine(ops, ae, G, hs, batchnorm, 0.0, p, X, Y, sf, activation='PReLU')
+    eng2.reserve(32)
+    out = eng2.predict_chunk(0, 32, {'mean', 'latent'})
+    want = oracle_net(ae, p, hs, batchnorm, activation='PReLU').predict(X[:32], sf[:32])
+    np.testing.assert_allclose(out['mean'].cpu().numpy()[:, :G], want['mean'], rtol=3e-4)
+    np.testing.assert_allclose(out['latent'].cpu().numpy(), want['latent'], rtol=3e-4, atol=1e-5)

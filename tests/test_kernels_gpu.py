@@ -426,3 +426,28 @@ def test_elempi_kernels(B, G, ld):
     dmd.copy_(torch.as_tensor(dm).to(dev))
     ops.elempi_bwd(ad, ld, dmd, dpd, ld, kd, B, G, gk2, gc2, ws)
     assert torch.equal(gk, gk2) and torch.equal(gc, gc2)
+
+
+@pytest.mark.parametrize('B,h,ld', [(1, 1, 4), (37, 64, 64), (4096, 513, 516)])
+def test_prelu_kernels(B, h, ld):
+    from dca_amd.ops import HipOps
+    ops = HipOps()
+    dev = torch.device('cuda')
+    rng = np.random.RandomState(B + h)
+    x = rng.normal(size=(B, ld)).astype(np.float32)
+    x[0, 0] = 0.0
+    al = rng.normal(0, 0.5, size=h).astype(np.float32)
+    xd, ad = torch.as_tensor(x).to(dev), torch.as_tensor(al).to(dev)
+    out = torch.full((B, ld), 5.0, device=dev)
+    ops.prelu_fwd(xd, ld, ad, B, h, out, ld)
+    xv = x[:, :h]
+    np.testing.assert_array_equal(out.cpu().numpy()[:, :h], np.where(xv > 0, xv, al * xv).astype(np.float32))
+    assert (out.cpu().numpy()[:, h:] == 5.0).all()
+    d = rng.normal(size=(B, ld)).astype(np.float32) * 1e-2
+    dd = torch.as_tensor(d).to(dev)
+    ga = torch.zeros(h + 3, device=dev)
+    ws = torch.zeros(ops.prelu_workspace_doubles(h), dtype=torch.float64, device=dev)
+    ops.prelu_bwd(dd, ld, xd, ld, ad, B, h, ga, ws)
+    np.testing.assert_array_equal(dd.cpu().numpy()[:, :h], np.where(xv > 0, d[:, :h], al * d[:, :h]).astype(np.float32))
+    np.testing.assert_allclose(ga.cpu().numpy()[:h], (d[:, :h].astype(np.float64) * np.minimum(xv, 0)).sum(0),
+                               rtol=1e-5, atol=1e-8)
