@@ -64,7 +64,8 @@ struct HeadsArgs {
     const int* perm;
     const long long* cursor;
     float* ws_dw;  long dw_stride;   // [S][(hL + 2)][ldws]
-    float* ws_dh;                     // [ntg][NT*32][KT]
+    float* ws_dh;                     // [NT][ntg][32][KT]: the partials of one row tile are contiguous
+    int ntg;
     double* partials;
     long plane, ldws;
     int B, hL, G;
@@ -164,6 +165,8 @@ __global__ __launch_bounds__(64 * kWG * WR) void heads_fused_kernel(HeadsArgs p)
         // first count groups of tile t+1 are requested while tile t is in its Z / Bk phases.
         const int tstep = p.S * WR;
         int t = s * WR + r;
+        const long dh_tstride = (long)p.ntg * (kTR * KT);
+        float* const dh_base = p.ws_dh + (long)gt * (kTR * KT) + l31;
         int srow_l = 0;
         float sf_l = 1.f;
         float4 hv[KH / 4];
@@ -401,7 +404,7 @@ __global__ __launch_bounds__(64 * kWG * WR) void heads_fused_kernel(HeadsArgs p)
                             dHa[jb] = MFMA(a, b, dHa[jb]);
                         }
                     }
-                float* dst = p.ws_dh + ((long)gt * p.NT * kTR + row0) * KT + l31;   // rows padded to tiles
+                float* dst = dh_base + (long)t * dh_tstride;
 #pragma unroll
                 for (int jb = 0; jb < HLB; ++jb)
 #pragma unroll
@@ -419,6 +422,8 @@ __global__ __launch_bounds__(64 * kWG * WR) void heads_fused_kernel(HeadsArgs p)
                     bsum[h] += b;                    // bias gradient = column sum of D
 #pragma unroll
                     for (int ib = 0; ib < HLB; ++ib) {
+                        // rows beyond B: their staged D is exactly 0 and Hd was read from a clamped (finite)
+                        // row, so only the hidden-unit guard of the ragged-width variant is needed
                         const bool ok = (row0 + rowmap(e, hi) < p.B) && (FULLK || ib * 32 + l31 < p.hL);
                         dW[h][ib] = MFMA(ok ? Hd[ib][e] : 0.f, b, dW[h][ib]);
                     }
@@ -530,8 +535,8 @@ __global__ __launch_bounds__(256) void heads_reduce_dw_kernel(const float* ws, i
     }
 }
 
-// dH[row, i] = sum over gene tiles of ws[gt][row][i]; GL threads split the gene tiles of one
-// output quad, combined in fixed order through LDS.
+// dH[row, i] = sum over gene tiles of ws[row tile][gt][row % 32][i]; GL threads split the gene tiles of
+// one output quad, combined in fixed order through LDS.
 template <int GL>
 __global__ __launch_bounds__(256) void heads_reduce_dh_kernel(const float* ws, int ntg, int B, int Bpad,
                                                               int KT, int hL, float* dH, long lddh) {
@@ -543,10 +548,12 @@ __global__ __launch_bounds__(256) void heads_reduce_dh_kernel(const float* ws, i
     const long quad = (long)blockIdx.x * OUT + o;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (quad < nq) {
-        const float4* src = reinterpret_cast<const float4*>(ws) + quad;
+        const long tq = (long)kTR * q4;                      // quads of one (row tile, gene tile) partial
+        const long t = quad / tq, within = quad - t * tq;
+        const float4* src = reinterpret_cast<const float4*>(ws) + t * ntg * tq + within;
 #pragma unroll 4
         for (int gt = gl; gt < ntg; gt += GL) {
-            const float4 x = src[(long)gt * Bpad * q4];
+            const float4 x = src[(long)gt * tq];
             v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
         }
     }
@@ -653,7 +660,7 @@ extern "C" int dcahip_heads_fused(const float* H, long ldh, const float* Wh, lon
     if (ldw < (long)NH * plane || ldg < (long)NH * plane) return DCAHIP_EINVAL;
     float* ws_dh = static_cast<float*>(workspace);
     float* ws_dw = ws_dh + pl.dh_bytes / sizeof(float);
-    HeadsArgs a{g_timing, H, ldh, Wh, ldw, bh, theta_w, y, ldy, sf, perm, cursor, ws_dw, pl.dw_stride, ws_dh,
+    HeadsArgs a{g_timing, H, ldh, Wh, ldw, bh, theta_w, y, ldy, sf, perm, cursor, ws_dw, pl.dw_stride, ws_dh, pl.ntg,
                 loss_partials, plane, pl.ldws, B, hL, G, pl.S, pl.NT, ridge, inv_n};
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (has_pi && cdisp) launch_fused<true, true>(pl, a, s);
