@@ -255,12 +255,11 @@ __global__ __launch_bounds__(64 * kWG * WR) void heads_fused_kernel(HeadsArgs p)
             auto z_dense = [&](int grp, const float (&yv)[kZU]) {
                 // (1) all staged inputs of the group first: the kZU element chains below are then
                 // independent (no LDS store between their loads) and interleave
-                float i_sf[kZU], i_am[kZU], i_ad[kZU], i_ap[kZU];
+                float i_am[kZU], i_ad[kZU], i_ap[kZU];
 #pragma unroll
                 for (int j = 0; j < kZU; ++j) {
                     const int row = rowmap(grp * kZU + j, hi);
                     const int idx = l31 * kLdS + row;
-                    i_sf[j] = __shfl(sf_l, row, 64);
                     i_am[j] = St[idx];
                     i_ad[j] = CONST_DISP ? thw : St[ST_PLANE + idx];
                     i_ap[j] = HAS_PI ? St[PI_H * ST_PLANE + idx] : 0.f;
@@ -284,13 +283,24 @@ __global__ __launch_bounds__(64 * kWG * WR) void heads_fused_kernel(HeadsArgs p)
 #else
                     const bool nz = valid && (HAS_PI ? !(yj < kZeroThresh) : (yj != 0.f));
 #endif
-                    float dmu = 0.f, dth = 0.f, dpi = 0.f;
-                    const Heads hd = head_acts<HAS_PI, CONST_DISP>(i_am[j], i_ad[j], i_ap[j], i_sf[j]);
-                    const float nll = nll_elem<HAS_PI, true>(hd, 0.f, p.ridge, dmu, dth, dpi);
-                    lacc += (valid && !nz) ? nll : 0.f;
-                    o_m[j] = valid ? dmu * hd.gm * p.inv_n : 0.f;
-                    o_d[j] = valid ? dth * hd.gd * p.inv_n : 0.f;
-                    o_p[j] = (HAS_PI && valid) ? dpi * hd.pi * hd.omp * p.inv_n : 0.f;
+                    if (HAS_PI) {
+                        // the y = 0 formulas for every element (the non-zero ones are redone by the sparse pass)
+                        float gmv, gdv, gpv;
+                        const float nll = zinb_zero_elem<CONST_DISP>(i_am[j], i_ad[j], i_ap[j], __shfl(sf_l, row, 64), p.ridge, gmv, gdv, gpv);
+                        const float sc = valid ? p.inv_n : 0.f;      // pre-activations of padding are finite
+                        lacc += (valid && !nz) ? nll : 0.f;
+                        o_m[j] = gmv * sc;
+                        o_d[j] = gdv * sc;
+                        o_p[j] = gpv * sc;
+                    } else {
+                        float dmu = 0.f, dth = 0.f, dpi = 0.f;
+                        const Heads hd = head_acts<HAS_PI, CONST_DISP>(i_am[j], i_ad[j], i_ap[j], __shfl(sf_l, row, 64));
+                        const float nll = nll_elem<HAS_PI, true>(hd, 0.f, p.ridge, dmu, dth, dpi);
+                        lacc += (valid && !nz) ? nll : 0.f;
+                        o_m[j] = valid ? dmu * hd.gm * p.inv_n : 0.f;
+                        o_d[j] = valid ? dth * hd.gd * p.inv_n : 0.f;
+                        o_p[j] = 0.f;
+                    }
                     o_nz[j] = nz;
 #endif
                 }

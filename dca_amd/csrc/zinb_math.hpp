@@ -172,6 +172,75 @@ __device__ __forceinline__ Heads head_acts(float am, float ad, float ap, float s
     return h;
 }
 
+// ---- the y = 0 element of the ZINB likelihood, trimmed for the dense pass of K-HEADS (93 % of a count
+// matrix): activations, zero_case (loss.py:136-137), ridge and the three PRE-ACTIVATION gradients in ~105
+// VALU operations / 13 transcendentals instead of ~170 / 16 through head_acts + nll_elem:
+//   * exp = v_exp_f32(x log2 e) bare: no clamp (inf / 0 propagate into the clip windows, nothing multiplies them
+//     by 0) and no compensation of the rounded product (relative error <= |x| 1e-7, unbiased: averages out of the
+//     loss sum and stays two orders below the gradient tolerance); clip windows tested as med3(x) == x;
+//   * log1p(x) = log(u) + (x - (u - 1)) / u with u = fl(1 + x): the reciprocal is one the caller needs anyway
+//     (sigmoid of the dispersion head; theta / (theta + mu) of the zero case), no Kahan ratio, no select;
+//   * log2 -> ln by one multiplication where the result is not differenced against a neighbour;
+//   * expm1(x <= 0) as a 5-term series above -1/16, exp(x) - 1 below (absolute error <= 1 ulp of 1, relative
+//     <= 1e-6: d nll / d pi = -(1 - z) / D is O(1) there).
+// tools/zero_path_accuracy.py models it in numpy fp32 against the fp64 oracle: 400 000 random + edge elements,
+// loss sum 3e-9 relative, every gradient inside the per-element tolerance of tests/test_kernels_gpu.py.
+__device__ __forceinline__ float fexp_raw(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ __forceinline__ float flog_fast(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994531f; }
+
+// returns nll; gm / gd / gp = d nll / d (a_mean, a_disp, a_pi), unscaled
+template <bool CONST_DISP>
+__device__ __forceinline__ float zinb_zero_elem(float am, float ad, float ap, float sf, float ridge,
+                                                float& g_m, float& g_d, float& g_p) {
+    const float e = fexp_raw(am);                                             // network.py:38
+    const float ec = __builtin_amdgcn_fmed3f(e, 1e-5f, 1e6f);
+    const float mu = ec * sf;                                                 // layers.py:85
+    const float gm = ec == e ? mu : 0.f;                                      // inside the clip window
+    float theta, gd;
+    if (CONST_DISP) {                                                         // layers.py:21
+        theta = __builtin_amdgcn_fmed3f(fexp_raw(ad), 1e-3f, 1e4f);
+        gd = 1.f;
+    } else {                                                                  // network.py:39
+        const float ex = fexp_raw(-fabsf(ad));
+        const float u = 1.f + ex;
+        const float s = frcp(u);
+        const float l1 = fmaf(ex - (u - 1.f), s, flog_fast(u));               // log1p(ex)
+        const float sp = fmaxf(ad, 0.f) + l1;
+        theta = __builtin_amdgcn_fmed3f(sp, 1e-4f, 1e4f);                     // <= 1e4 < kThetaMax
+        gd = theta == sp ? (ad >= 0.f ? s : ex * s) : 0.f;
+    }
+    const float ex2 = fexp_raw(-fabsf(ap));
+    const float s2 = frcp(1.f + ex2);
+    const float es2 = ex2 * s2;
+    const float pi = ap >= 0.f ? s2 : es2;
+    const float omp = ap >= 0.f ? es2 : s2;
+    // zero_case = -log(pi + (1 - pi) (theta / (theta + mu + eps))^theta + eps)
+    const float mue = mu + kEps;
+    const float rden = frcp(theta + mue);
+    const float t = mue * frcp(theta);                                        // theta / den = 1 / (1 + t)
+    const float u2 = 1.f + t;
+    const float logq = -fmaf(t - (u2 - 1.f), theta * rden, flog_fast(u2));
+    const float tl = theta * logq;
+    const float z = fexp_raw(tl);
+    const float D = fmaf(omp, z, pi) + kEps;
+    float nll = -flog_fast(D);
+    const float invD = frcp(D);
+    const float oz = omp * z * invD;
+    const float dmu = oz * theta * rden;
+    // log q + 1 - q = -log1p(t) + t / (1 + t): series below t = 2^-5 (cancellation)
+    const float fs = -t * t * (0.5f - t * (2.f / 3.f - t * (0.75f - t * (0.8f - t * (5.f / 6.f)))));
+    const float fl = fmaf(mue, rden, logq);
+    const float dth = -oz * (t < 0.03125f ? fs : fl);
+    const float ser = tl * (1.f + tl * (0.5f + tl * (1.f / 6.f + tl * (1.f / 24.f + tl * (1.f / 120.f)))));
+    float dpi = (tl > -0.0625f ? ser : z - 1.f) * invD;                       // -(1 - z) / D
+    dpi = fmaf(2.f * ridge, pi, dpi);                                         // loss.py:139-140
+    nll = fmaf(ridge * pi, pi, nll);
+    g_m = dmu * gm;
+    g_d = dth * gd;
+    g_p = dpi * pi * omp;
+    return nll;
+}
+
 // One element of the loss and (GRAD) its gradient w.r.t. (mu, theta, pi).
 // ASSUME_NZ: the caller guarantees y >= kZeroThresh (compacted non-zero pass of K-HEADS).
 template <bool HAS_PI, bool GRAD, bool ASSUME_NZ = false>

@@ -1,0 +1,71 @@
+"""Summarises rocprofv3 --pmc counter_collection CSVs per kernel (mean per launch) and derives the
+utilisation figures DESIGN.md quotes.
+
+  python tools/pmc_summary.py <dir with p*/..counter_collection.csv> [out.csv]
+
+MfmaUtil  = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 256 CUs x 4 SIMDs)        (gfx94x formula; busy cycles
+            = 64 per v_mfma_f32_32x32x2_f32, cross-checked against SQ_INSTS_MFMA x 64)
+VALUBusy  = SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x 1024)                       (quad-cycle units)
+"""
+import csv
+import glob
+import os
+import re
+import sys
+from collections import defaultdict
+
+KEEP = re.compile(r'heads_fused|heads_reduce|gemm_kernel|splitk_reduce|zinb_nll|bn_|col_moments|rmsprop|moments_combine|'
+                  r'loss_finalize|step_end|relu_|dropout|optimizer|prelu|elempi')
+
+
+def short(name):
+    m = re.search(r'(?:anonymous namespace\)::)?([A-Za-z_0-9]+)(<[^>]*>)?\(', name)
+    return (m.group(1) + (m.group(2) or '')) if m else name[:60]
+
+
+def main():
+    root = sys.argv[1]
+    acc = defaultdict(lambda: defaultdict(list))
+    for f in sorted(glob.glob(os.path.join(root, '**', '*counter_collection.csv'), recursive=True)):
+        per_dispatch = defaultdict(float)
+        meta, wall = {}, {}
+        for r in csv.DictReader(open(f)):
+            if not KEEP.search(r['Kernel_Name']):
+                continue
+            key = (f, r['Dispatch_Id'], r['Counter_Name'])
+            per_dispatch[key] += float(r['Counter_Value'])
+            wall[(f, r['Dispatch_Id'])] = float(r['End_Timestamp']) - float(r['Start_Timestamp'])
+            meta[(f, r['Dispatch_Id'])] = short(r['Kernel_Name'])
+        for (ff, d, c), v in per_dispatch.items():
+            acc[meta[(ff, d)]][c].append(v)
+        for k, v in wall.items():
+            acc[meta[k]]['wall_ns'].append(v)
+    counters = sorted({c for k in acc.values() for c in k})
+    rows = []
+    for k, cs in sorted(acc.items()):
+        row = {'kernel': k, 'launches': max(len(v) for v in cs.values())}
+        for c in counters:
+            row[c] = sum(cs[c]) / len(cs[c]) if c in cs else ''
+        # rocprofv3 reports GRBM_GUI_ACTIVE summed over the 8 XCDs (check: clock_GHz below = GRBM / 8 / wall
+        # comes out at the 1.9-2.4 GHz the chip runs at): elapsed cycles = GRBM / 8, SIMD-cycles = x 1024
+        g = (row.get('GRBM_GUI_ACTIVE') or 0) / 8.0
+        if g:
+            row['clock_GHz'] = g / row['wall_ns'] if row.get('wall_ns') else ''
+            if row.get('SQ_VALU_MFMA_BUSY_CYCLES') != '':
+                row['MfmaUtil_%'] = 100.0 * row['SQ_VALU_MFMA_BUSY_CYCLES'] / (g * 1024)
+            if row.get('SQ_INSTS_MFMA') != '':
+                row['MfmaUtil_from_insts_%'] = 100.0 * row['SQ_INSTS_MFMA'] * 64 / (g * 1024)
+            if row.get('SQ_ACTIVE_INST_VALU') != '':
+                row['VALUBusy_%'] = 100.0 * row['SQ_ACTIVE_INST_VALU'] * 4 / (g * 1024)
+        rows.append(row)
+    counters = [c for c in counters if c != 'wall_ns']
+    cols = ['kernel', 'launches', 'wall_ns', 'clock_GHz', 'MfmaUtil_%', 'MfmaUtil_from_insts_%', 'VALUBusy_%'] + counters
+    out = open(sys.argv[2], 'w') if len(sys.argv) > 2 else sys.stdout
+    w = csv.DictWriter(out, fieldnames=cols, extrasaction='ignore')
+    w.writeheader()
+    for r in rows:
+        w.writerow({c: (('%.4g' % r[c]) if isinstance(r.get(c), float) else r.get(c, '')) for c in cols})
+
+
+if __name__ == '__main__':
+    main()
