@@ -81,8 +81,9 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// FULLK: hL == 32 * HLB exactly (the default 64-wide decoder): no k / hidden-unit guards at all,
-// which also keeps a dozen loop-invariant clamped offsets and predicates out of the register file.
+// FULLK: hL == 32 * HLB exactly and H rows densely packed (ldh == hL; the default 64-wide decoder): no k /
+// hidden-unit guards at all and a compile-time row stride (H loads are one base + immediate offsets), which
+// also keeps dozens of loop-invariant clamped offsets, address pairs and predicates out of the register file.
 template <bool HAS_PI, bool CONST_DISP, int HLB, int WR, bool FULLK>
 __global__ __launch_bounds__(64 * kWG * WR) void heads_fused_kernel(HeadsArgs p) {
     constexpr int NH = 1 + (CONST_DISP ? 0 : 1) + (HAS_PI ? 1 : 0);
@@ -102,7 +103,8 @@ __global__ __launch_bounds__(64 * kWG * WR) void heads_fused_kernel(HeadsArgs p)
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     __shared__ double lred[kWG * WR];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: tile indices live in SGPRs
     const int l31 = lane & 31, hi = lane >> 5;
     const int g = wave / WR, r = wave % WR;
     const int s = blockIdx.x % p.S, gb = blockIdx.x / p.S;
@@ -160,6 +162,7 @@ __global__ __launch_bounds__(64 * kWG * WR) void heads_fused_kernel(HeadsArgs p)
         const float thw = (CONST_DISP && gvalid) ? p.theta_w[gene] : 0.f;
 
         const int hl4 = (p.hL + 3) & ~3;
+        const long LDH = FULLK ? (long)KT : p.ldh;
         const int gene_c = gvalid ? gene : p.G - 1;         // clamped: loads stay unconditional
         // Software pipeline across tiles: the row indices (perm), size factors, H rows and the
         // first count groups of tile t+1 are requested while tile t is in its Z / Bk phases.
@@ -173,8 +176,25 @@ __global__ __launch_bounds__(64 * kWG * WR) void heads_fused_kernel(HeadsArgs p)
         float yA[kZU], yB[kZU];
         auto row_clamped = [&](int tt) { const int rl = tt * kTR + l31; return rl < p.B ? rl : p.B - 1; };
         auto load_srow = [&](int tt) { const int rlc = row_clamped(tt); return p.perm ? p.perm[cur + rlc] : (int)(cur + rlc); };
+        // FULLK: H through a buffer resource ([B x KT] floats): every load is (per-lane offset fixed for the whole
+        // kernel) + (wave-uniform tile offset in an SGPR) + immediate, and rows beyond B read as 0 in hardware --
+        // no clamps, no selects, no 64-bit address pairs in the register file
+        const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.H), 0, FULLK ? p.B * KT * 4 : 0, 0x00020000);
+        const int hv_lane = (l31 * KT + hi * KH) * 4;            // bytes: row l31 of a tile, this lane half's k range
+        const int hd_lane = (4 * hi * KT + l31) * 4;             // bytes: row 4 hi of a tile, hidden unit l31
         auto load_hv = [&](int tt) {
-            const float* hp = p.H + (long)row_clamped(tt) * p.ldh;
+            if (FULLK) {
+                const int so = tt * (kTR * KT * 4);
+#pragma unroll
+                for (int c = 0; c < KH / 4; ++c) {
+                    const auto w = __builtin_amdgcn_raw_buffer_load_b128(hrs, hv_lane + 16 * c, so, 0);
+                    static_assert(sizeof(w) == 16, "128-bit buffer load");
+                    hv[c] = __builtin_bit_cast(float4, w);
+                }
+                return;
+            }
+            const float* hp = p.H + (long)row_clamped(tt) * LDH;
 #pragma unroll
             for (int c = 0; c < KH / 4; ++c) {
                 const int k = hi * KH + 4 * c;
@@ -207,10 +227,10 @@ __global__ __launch_bounds__(64 * kWG * WR) void heads_fused_kernel(HeadsArgs p)
             for (int c = 0; c < KH / 4; ++c) {
                 const int k = hi * KH + 4 * c;
                 float* d = St + l31 * kLdH + k;
-                d[0] = (rv && (FULLK || k + 0 < p.hL)) ? hv[c].x : 0.f;
-                d[1] = (rv && (FULLK || k + 1 < p.hL)) ? hv[c].y : 0.f;
-                d[2] = (rv && (FULLK || k + 2 < p.hL)) ? hv[c].z : 0.f;
-                d[3] = (rv && (FULLK || k + 3 < p.hL)) ? hv[c].w : 0.f;
+                d[0] = (FULLK || (rv && k + 0 < p.hL)) ? hv[c].x : 0.f;      // FULLK: rows beyond B were loaded as 0
+                d[1] = (FULLK || (rv && k + 1 < p.hL)) ? hv[c].y : 0.f;
+                d[2] = (FULLK || (rv && k + 2 < p.hL)) ? hv[c].z : 0.f;
+                d[3] = (FULLK || (rv && k + 3 < p.hL)) ? hv[c].w : 0.f;
             }
             wave_sync();
             TSTAMP(1)
@@ -381,16 +401,26 @@ __global__ __launch_bounds__(64 * kWG * WR) void heads_fused_kernel(HeadsArgs p)
             // product (H rows, lanes along the hidden units) -- all in flight during the dH MFMAs
             const float sf_n = p.sf[srow_n];
             float Hd[HLB][16];
+            if (FULLK) {
+                const int so = row0 * (KT * 4);
 #pragma unroll
-            for (int ib = 0; ib < HLB; ++ib)
+                for (int ib = 0; ib < HLB; ++ib)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int row = row0 + rowmap(e, hi);
-                    const int i = ib * 32 + l31;
-                    const int rc = row < p.B ? row : p.B - 1;
-                    const int ic = (FULLK || i < hl4) ? i : hl4 - 1;
-                    Hd[ib][e] = p.H[(long)rc * p.ldh + ic];
-                }
+                    for (int e = 0; e < 16; ++e)
+                        Hd[ib][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                            hrs, hd_lane + (rowmap(e, 0) * KT + ib * 32) * 4, so, 0));
+            } else {
+#pragma unroll
+                for (int ib = 0; ib < HLB; ++ib)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int row = row0 + rowmap(e, hi);
+                        const int i = ib * 32 + l31;
+                        const int rc = row < p.B ? row : p.B - 1;
+                        const int ic = i < hl4 ? i : hl4 - 1;
+                        Hd[ib][e] = p.H[(long)rc * LDH + ic];
+                    }
+            }
             wave_sync();
             TSTAMP(4)
 
@@ -628,7 +658,7 @@ long long* g_timing = nullptr;
 
 template <bool P, bool C>
 void launch_fused(const HeadsPlan& pl, const HeadsArgs& a, hipStream_t s) {
-    const bool full = a.hL == 32 * pl.HLB;
+    const bool full = a.hL == 32 * pl.HLB && a.ldh == 32 * pl.HLB;
 #define DCA_LF(WRV, FK) hipLaunchKernelGGL((heads_fused_kernel<P, C, 2, WRV, FK>), dim3(pl.grid), dim3(64 * kWG * WRV), 0, s, a)
     if (pl.WR == 4) { if (full) DCA_LF(4, true); else DCA_LF(4, false); }
     else            { if (full) DCA_LF(1, true); else DCA_LF(1, false); }

@@ -99,8 +99,8 @@ def zero_elem(am, ad, ap, sf, ridge):
     fl = fma(mue, rden, logq)
     dth = (-oz * np.where(t < f32(0.03125), fs.astype(f32), fl)).astype(f32)
     x = tl
-    ser = (x * (one + x * (f32(0.5) + x * (f32(1 / 6) + x * (f32(1 / 24) + x * f32(1 / 120)))))).astype(f32)
-    em1 = np.where(x > f32(-0.0625), ser, (z - one).astype(f32))
+    ser = (x * fma(x, fma(x, np.full_like(x, f32(1 / 6)), np.full_like(x, f32(0.5))), np.ones_like(x))).astype(f32)
+    em1 = np.where(x > f32(-0.015625), ser, (z - one).astype(f32))
     dpi = (em1 * invD).astype(f32)
     dpi = fma(np.full_like(pi, f32(2 * ridge)), pi, dpi)
     nll = fma((pi * f32(ridge)).astype(f32), pi, nll)
