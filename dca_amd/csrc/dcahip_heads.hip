@@ -462,9 +462,9 @@ __global__ __launch_bounds__(64 * kWG * WR) void heads_fused_kernel(HeadsArgs p)
                     bsum[h] += b;                    // bias gradient = column sum of D
 #pragma unroll
                     for (int ib = 0; ib < HLB; ++ib) {
-                        // rows beyond B: their staged D is exactly 0 and Hd was read from a clamped (finite)
-                        // row, so only the hidden-unit guard of the ragged-width variant is needed
-                        const bool ok = (row0 + rowmap(e, hi) < p.B) && (FULLK || ib * 32 + l31 < p.hL);
+                        // FULLK: no select -- rows beyond B were loaded as 0 (buffer bounds) and their staged D
+                        // is exactly 0 as well
+                        const bool ok = FULLK || ((row0 + rowmap(e, hi) < p.B) && (ib * 32 + l31 < p.hL));
                         dW[h][ib] = MFMA(ok ? Hd[ib][e] : 0.f, b, dW[h][ib]);
                     }
                 }
