@@ -359,15 +359,21 @@ __global__ __launch_bounds__(64 * kWG * WR) void heads_fused_kernel(HeadsArgs p)
                 const float ap = HAS_PI ? St[PI_H * ST_PLANE + idx] : 0.f;
                 float yq = (float)(e >> 16);
                 if ((e >> 16) == 0xFFFFu) yq = p.y[(long)sr * p.ldy + g0 + gq];
-                float dmu = 0.f, dth = 0.f, dpi = 0.f;
-                const Heads hd = head_acts<HAS_PI, CONST_DISP>(am, ad, ap, sfr);
-                const float nll = nll_elem<HAS_PI, true, true>(hd, yq, p.ridge, dmu, dth, dpi);
+                float o1, o2, o3 = 0.f, nll;
+                if (HAS_PI) {
+                    nll = zinb_nz_elem<CONST_DISP>(am, ad, ap, sfr, yq, p.ridge, o1, o2, o3);
+                } else {
+                    float dmu = 0.f, dth = 0.f, dpi = 0.f;
+                    const Heads hd = head_acts<HAS_PI, CONST_DISP>(am, ad, ap, sfr);
+                    nll = nll_elem<HAS_PI, true, true>(hd, yq, p.ridge, dmu, dth, dpi);
+                    o1 = dmu * hd.gm; o2 = dth * hd.gd;
+                }
                 lacc += act ? nll : 0.f;
                 if (act) {
-                    St[idx] = dmu * hd.gm * p.inv_n;
-                    const float od = dth * hd.gd * p.inv_n;
+                    St[idx] = o1 * p.inv_n;
+                    const float od = o2 * p.inv_n;
                     if (CONST_DISP) St[TH_P * ST_PLANE + idx] = od; else St[ST_PLANE + idx] = od;
-                    if (HAS_PI) St[PI_H * ST_PLANE + idx] = dpi * hd.pi * hd.omp * p.inv_n;
+                    if (HAS_PI) St[PI_H * ST_PLANE + idx] = o3 * p.inv_n;
                 }
             };
             auto z_flush = [&](bool last) {

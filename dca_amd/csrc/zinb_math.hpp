@@ -188,32 +188,41 @@ __device__ __forceinline__ Heads head_acts(float am, float ad, float ap, float s
 __device__ __forceinline__ float fexp_raw(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 __device__ __forceinline__ float flog_fast(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994531f; }
 
-// returns nll; gm / gd / gp = d nll / d (a_mean, a_disp, a_pi), unscaled
+struct ZAct { float mu, gm, theta, gd, pi, omp; };
+
 template <bool CONST_DISP>
-__device__ __forceinline__ float zinb_zero_elem(float am, float ad, float ap, float sf, float ridge,
-                                                float& g_m, float& g_d, float& g_p) {
+__device__ __forceinline__ ZAct zinb_acts(float am, float ad, float ap, float sf) {
+    ZAct a;
     const float e = fexp_raw(am);                                             // network.py:38
     const float ec = __builtin_amdgcn_fmed3f(e, 1e-5f, 1e6f);
-    const float mu = ec * sf;                                                 // layers.py:85
-    const float gm = ec == e ? mu : 0.f;                                      // inside the clip window
-    float theta, gd;
+    a.mu = ec * sf;                                                           // layers.py:85
+    a.gm = ec == e ? a.mu : 0.f;                                              // inside the clip window
     if (CONST_DISP) {                                                         // layers.py:21
-        theta = __builtin_amdgcn_fmed3f(fexp_raw(ad), 1e-3f, 1e4f);
-        gd = 1.f;
+        a.theta = __builtin_amdgcn_fmed3f(fexp_raw(ad), 1e-3f, 1e4f);
+        a.gd = 1.f;
     } else {                                                                  // network.py:39
         const float ex = fexp_raw(-fabsf(ad));
         const float u = 1.f + ex;
         const float s = frcp(u);
         const float l1 = fmaf(ex - (u - 1.f), s, flog_fast(u));               // log1p(ex)
         const float sp = fmaxf(ad, 0.f) + l1;
-        theta = __builtin_amdgcn_fmed3f(sp, 1e-4f, 1e4f);                     // <= 1e4 < kThetaMax
-        gd = theta == sp ? (ad >= 0.f ? s : ex * s) : 0.f;
+        a.theta = __builtin_amdgcn_fmed3f(sp, 1e-4f, 1e4f);                   // <= 1e4 < kThetaMax
+        a.gd = a.theta == sp ? (ad >= 0.f ? s : ex * s) : 0.f;
     }
     const float ex2 = fexp_raw(-fabsf(ap));
     const float s2 = frcp(1.f + ex2);
     const float es2 = ex2 * s2;
-    const float pi = ap >= 0.f ? s2 : es2;
-    const float omp = ap >= 0.f ? es2 : s2;
+    a.pi = ap >= 0.f ? s2 : es2;
+    a.omp = ap >= 0.f ? es2 : s2;
+    return a;
+}
+
+// returns nll; gm / gd / gp = d nll / d (a_mean, a_disp, a_pi), unscaled
+template <bool CONST_DISP>
+__device__ __forceinline__ float zinb_zero_elem(float am, float ad, float ap, float sf, float ridge,
+                                                float& g_m, float& g_d, float& g_p) {
+    const ZAct a = zinb_acts<CONST_DISP>(am, ad, ap, sf);
+    const float mu = a.mu, gm = a.gm, theta = a.theta, gd = a.gd, pi = a.pi, omp = a.omp;
     // zero_case = -log(pi + (1 - pi) (theta / (theta + mu + eps))^theta + eps)
     const float mue = mu + kEps;
     const float rden = frcp(theta + mue);
@@ -238,6 +247,45 @@ __device__ __forceinline__ float zinb_zero_elem(float am, float ad, float ap, fl
     nll = fmaf(ridge * pi, pi, nll);
     g_m = dmu * gm;
     g_d = dth * gd;
+    g_p = dpi * pi * omp;
+    return nll;
+}
+
+// The y > 0 element (nb_case, loss.py:87-88,130) with the same activations: compacted non-zero pass of K-HEADS.
+// log(tp) - log(mu + eps) is taken as one log of the ratio (both reciprocals are needed by the gradient anyway),
+// log1p(mu / tp) through the 1 / u = tp / (tp + mu) identity.
+template <bool CONST_DISP>
+__device__ __forceinline__ float zinb_nz_elem(float am, float ad, float ap, float sf, float y, float ridge,
+                                              float& g_m, float& g_d, float& g_p) {
+    const ZAct a = zinb_acts<CONST_DISP>(am, ad, ap, sf);
+    const float mu = a.mu, theta = a.theta, pi = a.pi, omp = a.omp;
+    const float tp = theta + kEps, mue = mu + kEps;
+    const float rtp = frcp(tp), rtm = frcp(tp + mu), rmue = frcp(mue);
+    const float x = mu * rtp, u = 1.f + x;
+    const float l1p = fmaf(x - (u - 1.f), tp * rtm, flog_fast(u));
+    float t1, dpsi = 0.f;
+    if (y > (float)kSmallY) {
+        nb_t1_large<true>(tp, y, t1, dpsi);
+    } else if (y == floorf(y)) {
+        const int n = (int)y;
+        float p1 = 1.f, p2 = 1.f;
+        for (int i = 0; i < n; ++i) {
+            const float xx = tp + (float)i;
+            if (i < 8) p1 *= xx; else p2 *= xx;
+            dpsi += frcp(xx);
+        }
+        t1 = kLogFact[n] - (flog(p1) + (n > 8 ? flog(p2) : 0.f));
+    } else {
+        t1 = nb_t1_generic<true>(tp, y, &dpsi);
+    }
+    const float ompe = omp + kEps;
+    float nll = t1 + fmaf(theta + y, l1p, y * flog(tp * rmue)) - flog_fast(ompe);
+    nll = fmaf(ridge * pi, pi, nll);
+    const float dmu = theta * (mue - y) * rtm * rmue;
+    const float dth = -dpsi + l1p + (y * tp - theta * mu) * rtp * rtm;
+    const float dpi = fmaf(2.f * ridge, pi, frcp(ompe));
+    g_m = dmu * a.gm;
+    g_d = dth * a.gd;
     g_p = dpi * pi * omp;
     return nll;
 }
