@@ -632,6 +632,7 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 bool make_heads_plan(int B, int hL, int G, long plane, int flags, HeadsPlan* out) {
     if (flags & (DCAHIP_NLL_POISSON | DCAHIP_NLL_MSE)) return false;     // NB / ZINB family only
     if (B <= 0 || G <= 0 || hL <= 0 || hL > 64 || plane < G || (plane & 3) || plane > ((G + 31) & ~31)) return false;
+    if (B > (1 << 22)) return false;                 // H is addressed through a 32-bit buffer resource (B x 64 floats)
     const bool has_pi = flags & DCAHIP_NLL_HAS_PI, cdisp = flags & DCAHIP_NLL_CONST_DISP;
     const int NH = 1 + (cdisp ? 0 : 1) + (has_pi ? 1 : 0);
     HeadsPlan p;
