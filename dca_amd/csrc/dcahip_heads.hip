@@ -24,6 +24,7 @@
 //   * deterministic: fixed summation orders everywhere (no atomics).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "dcahip.h"
 #include "zinb_math.hpp"
 
@@ -164,6 +165,10 @@ __global__ __launch_bounds__(64 * kWG * WR) void heads_fused_kernel(HeadsArgs p)
         const int hl4 = (p.hL + 3) & ~3;
         const long LDH = FULLK ? (long)KT : p.ldh;
         const int gene_c = gvalid ? gene : p.G - 1;         // clamped: loads stay unconditional
+        // count loads: storage row (non-negative) x row stride as ONE 32 x 32 -> 64-bit multiply-add instead of
+        // the sign-extended 64 x 64 product (three quarter-rate multiplies per load); the plan checks ldy < 2^32
+        const float* const ycol = p.y + gene_c;
+        const unsigned ldy_u = (unsigned)p.ldy;
         // Software pipeline across tiles: the row indices (perm), size factors, H rows and the
         // first count groups of tile t+1 are requested while tile t is in its Z / Bk phases.
         const int tstep = p.S * WR;
@@ -209,7 +214,7 @@ __global__ __launch_bounds__(64 * kWG * WR) void heads_fused_kernel(HeadsArgs p)
 #pragma unroll
             for (int j = 0; j < kZU; ++j) {
                 const int sr = __shfl(srow_l, rowmap(j, hi), 64);
-                yA[j] = p.y[(long)sr * p.ldy + gene_c];
+                yA[j] = ycol[(unsigned long long)(unsigned)sr * ldy_u];
             }
         }
 #ifdef DCA_HEADS_TIMING
@@ -272,7 +277,8 @@ __global__ __launch_bounds__(64 * kWG * WR) void heads_fused_kernel(HeadsArgs p)
             // runs ~2x per tile instead of 16x with 5 % of its lanes alive.
             float lacc = 0.f;
             int qn = 0;
-            auto z_dense = [&](int grp, const float (&yv)[kZU]) {
+            auto z_dense = [&](auto fullv, int grp, const float (&yv)[kZU]) {
+                constexpr bool FULLV = decltype(fullv)::value;      // interior tile: every row and gene of it exists
                 // (1) all staged inputs of the group first: the kZU element chains below are then
                 // independent (no LDS store between their loads) and interleave
                 float i_am[kZU], i_ad[kZU], i_ap[kZU];
@@ -290,7 +296,7 @@ __global__ __launch_bounds__(64 * kWG * WR) void heads_fused_kernel(HeadsArgs p)
 #pragma unroll
                 for (int j = 0; j < kZU; ++j) {
                     const int row = rowmap(grp * kZU + j, hi);
-                    const bool valid = (row0 + row < p.B) && gvalid;
+                    const bool valid = FULLV || ((row0 + row < p.B) && gvalid);
                     const float yj = yv[j];
 #if defined(DCA_EXP_NOZ)
                     const bool nz = false;
@@ -388,45 +394,28 @@ __global__ __launch_bounds__(64 * kWG * WR) void heads_fused_kernel(HeadsArgs p)
 #pragma unroll
                 for (int j = 0; j < kZU; ++j) {
                     const int sr = __shfl(srow_src, rowmap(grp * kZU + j, hi), 64);
-                    yv[j] = p.y[(long)sr * p.ldy + gene_c];
+                    yv[j] = ycol[(unsigned long long)(unsigned)sr * ldy_u];
                 }
             };
+            auto z_loop = [&](auto fullv) {
 #pragma unroll 1
-            for (int it = 0; it < 16 / (2 * kZU); ++it) {
-                const bool last = it + 1 == 16 / (2 * kZU);
-                load_y(srow_l, 2 * it + 1, yB);
-                z_dense(2 * it, yA);
-                z_flush(false);
-                if (!last) load_y(srow_l, 2 * it + 2, yA);
-                else load_y(srow_n, 0, yA);              // next tile's first group
-                z_dense(2 * it + 1, yB);
-                z_flush(last);
-            }
+                for (int it = 0; it < 16 / (2 * kZU); ++it) {
+                    const bool last = it + 1 == 16 / (2 * kZU);
+                    load_y(srow_l, 2 * it + 1, yB);
+                    z_dense(fullv, 2 * it, yA);
+                    z_flush(false);
+                    if (!last) load_y(srow_l, 2 * it + 2, yA);
+                    else load_y(srow_n, 0, yA);              // next tile's first group
+                    z_dense(fullv, 2 * it + 1, yB);
+                    z_flush(last);
+                }
+            };
+            // wave-uniform: all but the last row tile / gene tile take the path without validity selects
+            if (row0 + kTR <= p.B && g0 + kTG <= p.G) z_loop(std::true_type{}); else z_loop(std::false_type{});
             dacc += (double)lacc;
             // next tile: size factors; this tile: A operands of the weight-gradient
             // product (H rows, lanes along the hidden units) -- all in flight during the dH MFMAs
             const float sf_n = p.sf[srow_n];
-            float Hd[HLB][16];
-            if (FULLK) {
-                const int so = row0 * (KT * 4);
-#pragma unroll
-                for (int ib = 0; ib < HLB; ++ib)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e)
-                        Hd[ib][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                            hrs, hd_lane + (rowmap(e, 0) * KT + ib * 32) * 4, so, 0));
-            } else {
-#pragma unroll
-                for (int ib = 0; ib < HLB; ++ib)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int row = row0 + rowmap(e, hi);
-                        const int i = ib * 32 + l31;
-                        const int rc = row < p.B ? row : p.B - 1;
-                        const int ic = i < hl4 ? i : hl4 - 1;
-                        Hd[ib][e] = p.H[(long)rc * LDH + ic];
-                    }
-            }
             wave_sync();
             TSTAMP(4)
 
@@ -455,6 +444,27 @@ __global__ __launch_bounds__(64 * kWG * WR) void heads_fused_kernel(HeadsArgs p)
                 for (int jb = 0; jb < HLB; ++jb)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) dst[rowmap(e, hi) * KT + jb * 32] = dHa[jb][e];
+            }
+            float Hd[HLB][16];
+            if (FULLK) {
+                const int so = row0 * (KT * 4);
+#pragma unroll
+                for (int ib = 0; ib < HLB; ++ib)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        Hd[ib][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                            hrs, hd_lane + (rowmap(e, 0) * KT + ib * 32) * 4, so, 0));
+            } else {
+#pragma unroll
+                for (int ib = 0; ib < HLB; ++ib)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int row = row0 + rowmap(e, hi);
+                        const int i = ib * 32 + l31;
+                        const int rc = row < p.B ? row : p.B - 1;
+                        const int ic = i < hl4 ? i : hl4 - 1;
+                        Hd[ib][e] = p.H[(long)rc * LDH + ic];
+                    }
             }
             load_hv(tn);                           // next tile's H rows: in flight during the dW MFMAs
             TSTAMP(5)
@@ -705,6 +715,7 @@ extern "C" int dcahip_heads_fused(const float* H, long ldh, const float* Wh, lon
         return DCAHIP_EINVAL;
     const int NH = 1 + (cdisp ? 0 : 1) + (has_pi ? 1 : 0);
     if (ldw < (long)NH * plane || ldg < (long)NH * plane) return DCAHIP_EINVAL;
+    if (ldy < G || ldy > 0xffffffffL) return DCAHIP_EINVAL;
     float* ws_dh = static_cast<float*>(workspace);
     float* ws_dw = ws_dh + pl.dh_bytes / sizeof(float);
     HeadsArgs a{g_timing, H, ldh, Wh, ldw, bh, theta_w, y, ldy, sf, perm, cursor, ws_dw, pl.dw_stride, ws_dh, pl.ntg,

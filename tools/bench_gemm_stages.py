@@ -3,6 +3,10 @@ import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+if os.environ.get('DCA_AMD_LIB'):
+    from dca_amd import build as _b
+    _b.LIB = os.environ['DCA_AMD_LIB']
+    _b.needs_build = lambda: False
 from dca_amd.ops import HipOps
 ops = HipOps()
 dev = torch.device('cuda')
@@ -27,6 +31,6 @@ def timeit(fn, it=30):
 
 print('stages', os.environ.get('DCA_GEMM_STAGES', 'default'))
 print('fwd ', ' '.join('S=%d: %.3f' % (sk, timeit(lambda: ops.sgemm(0, 0, B, h, G, X, G, W0, h, Z, h, bias=W0[G], perm=perm, cursor=cur, split_k=sk, ws=ws)))
-                       for sk in (0, 16, 20, 24, 32, 40, 48)))
+                       for sk in (32, 24, 32, 48, 64, 96, 128)))
 print('dW  ', ' '.join('S=%d: %.3f' % (sk, timeit(lambda: ops.sgemm(1, 0, G, h, B, X, G, dZ, h, gW, h, perm=perm, cursor=cur, colsum_row=True, split_k=sk, ws=ws)))
-                       for sk in (0, 3, 4, 5, 6, 8)))
+                       for sk in (6, 4, 6, 8, 12, 13, 16)))
