@@ -319,12 +319,12 @@ __global__ __launch_bounds__(64 * kWG * WR) void heads_fused_kernel(HeadsArgs p)
                         o_d[j] = gdv * sc;
                         o_p[j] = gpv * sc;
                     } else {
-                        float dmu = 0.f, dth = 0.f, dpi = 0.f;
-                        const Heads hd = head_acts<HAS_PI, CONST_DISP>(i_am[j], i_ad[j], i_ap[j], __shfl(sf_l, row, 64));
-                        const float nll = nll_elem<HAS_PI, true>(hd, 0.f, p.ridge, dmu, dth, dpi);
+                        float gmv, gdv;
+                        const float nll = nb_zero_elem<CONST_DISP>(i_am[j], i_ad[j], __shfl(sf_l, row, 64), gmv, gdv);
+                        const float sc = valid ? p.inv_n : 0.f;
                         lacc += (valid && !nz) ? nll : 0.f;
-                        o_m[j] = valid ? dmu * hd.gm * p.inv_n : 0.f;
-                        o_d[j] = valid ? dth * hd.gd * p.inv_n : 0.f;
+                        o_m[j] = gmv * sc;
+                        o_d[j] = gdv * sc;
                         o_p[j] = 0.f;
                     }
                     o_nz[j] = nz;

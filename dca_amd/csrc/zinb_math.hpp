@@ -251,6 +251,34 @@ __device__ __forceinline__ float zinb_zero_elem(float am, float ad, float ap, fl
     return nll;
 }
 
+// The y = 0 element of the plain NB likelihood (loss.py:87-88 with y = 0: t1 = 0, t2 = theta log1p(mu / tp)).
+template <bool CONST_DISP>
+__device__ __forceinline__ float nb_zero_elem(float am, float ad, float sf, float& g_m, float& g_d) {
+    const float e = fexp_raw(am);
+    const float ec = __builtin_amdgcn_fmed3f(e, 1e-5f, 1e6f);
+    const float mu = ec * sf;
+    const float gm = ec == e ? mu : 0.f;
+    float theta, gd;
+    if (CONST_DISP) {
+        theta = __builtin_amdgcn_fmed3f(fexp_raw(ad), 1e-3f, 1e4f);
+        gd = 1.f;
+    } else {
+        const float ex = fexp_raw(-fabsf(ad));
+        const float u = 1.f + ex;
+        const float s = frcp(u);
+        const float sp = fmaxf(ad, 0.f) + fmaf(ex - (u - 1.f), s, flog_fast(u));
+        theta = __builtin_amdgcn_fmed3f(sp, 1e-4f, 1e4f);
+        gd = theta == sp ? (ad >= 0.f ? s : ex * s) : 0.f;
+    }
+    const float tp = theta + kEps;
+    const float rtm = frcp(tp + mu);
+    const float x = mu * frcp(tp), u2 = 1.f + x;
+    const float l1p = fmaf(x - (u2 - 1.f), tp * rtm, flog_fast(u2));        // log1p(mu / tp); 1 / u = tp / (tp + mu)
+    g_m = theta * rtm * gm;                                                 // theta (mu + eps) / ((tp + mu)(mu + eps))
+    g_d = (l1p - theta * x * rtm) * gd;
+    return theta * l1p;
+}
+
 // The y > 0 element (nb_case, loss.py:87-88,130) with the same activations: compacted non-zero pass of K-HEADS.
 // log(tp) - log(mu + eps) is taken as one log of the ratio (both reciprocals are needed by the gradient anyway),
 // log1p(mu / tp) through the 1 / u = tp / (tp + mu) identity.
