@@ -8,7 +8,7 @@ so = os.path.join(ROOT, 'tools', '_dbg', 'libdcahip_timing.so')
 if not os.path.exists(so):
     subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-DDCA_HEADS_TIMING',
                            '-I' + os.path.join(ROOT, 'include'), '-o', so] + [os.path.join(src, f) for f in
-                           ('dcahip_zinb.hip', 'dcahip_gemm.hip', 'dcahip_layers.hip', 'dcahip_heads.hip')])
+                           __import__('dca_amd.build', fromlist=['SOURCES']).SOURCES])
 from dca_amd import build as b
 b.LIB = so
 b.needs_build = lambda: False
@@ -23,7 +23,7 @@ sys.argv = [sys.argv[0]] + sys.argv[1:]
 exec(open(os.path.join(ROOT, 'tools', 'bench_heads.py')).read())
 t = tim.cpu().numpy().reshape(-1, 8)
 t = t[t.sum(1) > 0]
-names = ['loop-top', 'H->LDS', 'F (mfma issue)', 'dump+Hd issue', 'Z', 'dW', 'dH+store', 'rest']
+names = ['loop-top', 'H->LDS', 'F (96 mfma)', 'staging stores', 'Z dense+sparse', 'dH (96 mfma) + partial store', 'Hd loads + dW (96 mfma)', 'rest']
 tot = t.sum(1).mean()
 print('waves', len(t), 'mean cycles per wave (s_memtime @100MHz ticks?)', tot)
 for i, nme in enumerate(names):
