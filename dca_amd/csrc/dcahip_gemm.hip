@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, int
 }
 
 struct Plan {
-    int cfg;       // 0: 128x64, 1: 64x128, 2: 128x128
+    int cfg;       // 0: 128x64, 1: 64x128, 2: 128x128, 3: 64x64
     int BM, BN;
     int mtiles, ntiles, split, kslab;
 };
@@ -290,7 +290,12 @@ constexpr int kBK = 32;
 
 Plan make_plan(int M, int N, int K, int split_k) {
     Plan p;
-    if (N <= 64) { p.cfg = 0; p.BM = 128; p.BN = 64; }
+    // skinny outputs with many rows (the first layer at throughput batches: 4096 x 64 x 20000 and 20000 x 64 x 4096):
+    // 64 x 64 tiles, 16 KB of LDS -> up to 9 workgroups per CU interleave their load / barrier / MFMA phases
+    // (tools/bench_gemm_stages.py: 0.140 ms against 0.159 for the weight gradient, 0.144 against 0.148 forward;
+    // 256 x 64 tiles: 0.21-0.29 ms)
+    if (N <= 64 && M >= 2048) { p.cfg = 3; p.BM = 64; p.BN = 64; }
+    else if (N <= 64) { p.cfg = 0; p.BM = 128; p.BN = 64; }
     else if (M <= 64) { p.cfg = 1; p.BM = 64; p.BN = 128; }
     else { p.cfg = 2; p.BM = 128; p.BN = 128; }
     p.mtiles = (M + p.BM - 1) / p.BM;
@@ -303,8 +308,9 @@ Plan make_plan(int M, int N, int K, int split_k) {
         // B = 4096 (tools/bench_gemm.py): 4096x64x20000 best at 32 tiles x 32 splits = 1024
         // workgroups (0.147 ms vs 0.239 at 384), 20000x64x4096 at 157 x 6 = 942 (0.160 vs 0.214)
         S = 1;
-        if (tiles < 1024) {
-            S = (int)(1024 / tiles);
+        const long target = p.cfg == 3 ? 1536 : 1024;
+        if (tiles < target) {
+            S = (int)(target / tiles);
             if (S > nchunks / 2) S = nchunks / 2;
             if (S > 128) S = 128;
             if (S < 1) S = 1;
@@ -361,6 +367,7 @@ extern "C" int dcahip_sgemm(int ta, int tb, int M, int N, int K, const float* A,
     int rc;
     if (p.cfg == 0) rc = launch_cfg<128, 64, 4, 1>(a, ta, tb, vec, grid, s);
     else if (p.cfg == 1) rc = launch_cfg<64, 128, 1, 4>(a, ta, tb, vec, grid, s);
+    else if (p.cfg == 3) rc = launch_cfg<64, 64, 2, 2>(a, ta, tb, vec, grid, s);
     else rc = launch_cfg<128, 128, 2, 2>(a, ta, tb, vec, grid, s);
     if (rc != 0) return rc;
     if (p.split > 1) {

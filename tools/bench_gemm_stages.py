@@ -29,8 +29,8 @@ def timeit(fn, it=30):
     return s.elapsed_time(e) / it
 
 
-print('stages', os.environ.get('DCA_GEMM_STAGES', 'default'))
+print('big', os.environ.get('DCA_GEMM_BIG', '0'))
 print('fwd ', ' '.join('S=%d: %.3f' % (sk, timeit(lambda: ops.sgemm(0, 0, B, h, G, X, G, W0, h, Z, h, bias=W0[G], perm=perm, cursor=cur, split_k=sk, ws=ws)))
-                       for sk in (32, 24, 32, 48, 64, 96, 128)))
+                       for sk in (0, 0, 16, 24, 32, 48, 64)))
 print('dW  ', ' '.join('S=%d: %.3f' % (sk, timeit(lambda: ops.sgemm(1, 0, G, h, B, X, G, dZ, h, gW, h, perm=perm, cursor=cur, colsum_row=True, split_k=sk, ws=ws)))
-                       for sk in (6, 4, 6, 8, 12, 13, 16)))
+                       for sk in (0, 0, 3, 4, 6, 8, 12)))
