@@ -148,7 +148,14 @@ def ptr(t):
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def stream():
+    """Raw handle of torch's current stream on the current device (every kernel is launched on it).  The
+    private fast getter saves ~8 us per launch over torch.cuda.current_stream() (two dozen launches per step)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
