@@ -106,6 +106,10 @@ __global__ __launch_bounds__(64 * kWG * WR) void heads_fused_kernel(HeadsArgs p)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: tile indices live in SGPRs
+#ifdef DCA_HEADS_TIMING
+    const long long t_entry = __builtin_readcyclecounter();
+    long long t_loop0 = t_entry, t_loop1 = t_entry;
+#endif
     const int l31 = lane & 31, hi = lane >> 5;
     const int g = wave / WR, r = wave % WR;
     const int s = blockIdx.x % p.S, gb = blockIdx.x / p.S;
@@ -220,6 +224,7 @@ __global__ __launch_bounds__(64 * kWG * WR) void heads_fused_kernel(HeadsArgs p)
 #ifdef DCA_HEADS_TIMING
         long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         long long tlast = __builtin_readcyclecounter();
+        t_loop0 = tlast;
 #endif
         for (; t < p.NT; t += tstep) {
             TSTAMP(0)
@@ -494,8 +499,9 @@ __global__ __launch_bounds__(64 * kWG * WR) void heads_fused_kernel(HeadsArgs p)
             TSTAMP(6)
         }
 #ifdef DCA_HEADS_TIMING
+        t_loop1 = __builtin_readcyclecounter();
         if (p.timing && lane == 0)
-            for (int i = 0; i < 8; ++i) p.timing[((long)blockIdx.x * (kWG * WR) + wave) * 8 + i] = tacc[i];
+            for (int i = 0; i < 8; ++i) p.timing[((long)blockIdx.x * (kWG * WR) + wave) * 10 + i] = tacc[i];
 #endif
     }
 
@@ -565,6 +571,13 @@ __global__ __launch_bounds__(64 * kWG * WR) void heads_fused_kernel(HeadsArgs p)
             if (cw && hi == 0) out[(long)(p.hL + 1) * p.ldws + gene] = tv;
         }
     }
+#ifdef DCA_HEADS_TIMING
+    if (p.timing && lane == 0) {
+        long long* tp = p.timing + ((long)blockIdx.x * (kWG * WR) + wave) * 10;
+        tp[8] = t_loop0 - t_entry;                                   // prologue: weights -> LDS, first requests
+        tp[9] = (long long)__builtin_readcyclecounter() - t_loop1;   // epilogue: loss, dW tree, partial stores issued
+    }
+#endif
 }
 
 // gW[i, col] = sum_s ws[s][i][col], i = 0..hL (row hL = bias gradient), then the

@@ -17,13 +17,13 @@ from dca_amd.ops import HipOps
 ops = HipOps()
 L = hip.lib()
 L.dcahip_heads_set_timing.argtypes = [ctypes.c_void_p]
-tim = torch.zeros(2048 * 8 * 8, dtype=torch.int64, device='cuda')
+tim = torch.zeros(2048 * 8 * 10, dtype=torch.int64, device='cuda')
 L.dcahip_heads_set_timing(tim.data_ptr())
 sys.argv = [sys.argv[0]] + sys.argv[1:]
 exec(open(os.path.join(ROOT, 'tools', 'bench_heads.py')).read())
-t = tim.cpu().numpy().reshape(-1, 8)
+t = tim.cpu().numpy().reshape(-1, 10)
 t = t[t.sum(1) > 0]
-names = ['loop-top', 'H->LDS', 'F (96 mfma)', 'staging stores', 'Z dense+sparse', 'dH (96 mfma) + partial store', 'Hd loads + dW (96 mfma)', 'rest']
+names = ['loop-top', 'H->LDS', 'F (96 mfma)', 'staging stores', 'Z dense+sparse', 'dH (96 mfma) + partial store', 'Hd loads + dW (96 mfma)', 'rest', 'PROLOGUE (W -> LDS)', 'EPILOGUE (dW tree + stores)']
 tot = t.sum(1).mean()
 print('waves', len(t), 'mean cycles per wave (s_memtime @100MHz ticks?)', tot)
 for i, nme in enumerate(names):
