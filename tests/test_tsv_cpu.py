@@ -132,6 +132,7 @@ def test_errors(tmp_path):
 
 
 def test_exports():
+    hostlib.lib()                                   # builds the library on first use
     L = ctypes.CDLL(hostlib._build.HOST_LIB)
     hdr = open(os.path.join(os.path.dirname(hostlib._build.HERE), 'include', 'dcahost.h')).read()
     import re
