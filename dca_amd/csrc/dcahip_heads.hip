@@ -67,6 +67,7 @@ struct HeadsArgs {
     float* ws_dw;  long dw_stride;   // [S][(hL + 2)][ldws]
     float* ws_dh;                     // [NT][ntg][32][KT]: the partials of one row tile are contiguous
     int ntg;
+    const int* tile_order;            // gene tiles in the order workgroups take them (kWG consecutive entries each), or NULL
     double* partials;
     long plane, ldws;
     int B, hL, G;
@@ -113,7 +114,9 @@ __global__ __launch_bounds__(64 * kWG * WR) void heads_fused_kernel(HeadsArgs p)
     const int l31 = lane & 31, hi = lane >> 5;
     const int g = wave / WR, r = wave % WR;
     const int s = blockIdx.x % p.S, gb = blockIdx.x / p.S;
-    const int gt = gb * kWG + g;
+    // which gene tiles share a workgroup is free (every result is per gene tile): the caller can pair tiles of
+    // similar non-zero load, a workgroup lasts as long as its slower tile
+    const int gt = p.tile_order ? p.tile_order[gb * kWG + g] : gb * kWG + g;
     const int g0 = gt * kTG;
     const int gene = g0 + l31;
     const bool tile_ok = g0 < p.G;
@@ -134,7 +137,8 @@ __global__ __launch_bounds__(64 * kWG * WR) void heads_fused_kernel(HeadsArgs p)
             const int k = rest % KT; rest /= KT;
             const int h = rest % NH;
             const int gg = rest / NH;
-            const int gcol = (gb * kWG + gg) * kTG + c4 * 4;
+            const int gtile = p.tile_order ? p.tile_order[gb * kWG + gg] : gb * kWG + gg;
+            const int gcol = gtile * kTG + c4 * 4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (k < p.hL && gcol < p.plane)
                 v = *reinterpret_cast<const float4*>(p.Wh + (long)k * p.ldw + (long)h * p.plane + gcol);
@@ -226,7 +230,12 @@ __global__ __launch_bounds__(64 * kWG * WR) void heads_fused_kernel(HeadsArgs p)
         long long tlast = __builtin_readcyclecounter();
         t_loop0 = tlast;
 #endif
+        // Two waves share a SIMD (wave w and w + 4 of the workgroup) and one of them runs ~15 % ahead of the other
+        // (issue arbitration by priority, then age); the workgroup then waits for the slower half at the end.
+        // Alternating the priority per tile, in anti-phase between the halves, treats them alike.
+        int tile_no = wave >> 2;
         for (; t < p.NT; t += tstep) {
+            if (kWG * WR == 8) { if ((tile_no++) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
             TSTAMP(0)
             const int row0 = t * kTR;
             const bool rv = row0 + l31 < p.B;
@@ -711,6 +720,17 @@ extern "C" long dcahip_heads_fused_workspace_bytes(int B, int hL, int G, long pl
 extern "C" void dcahip_heads_set_timing(long long* buf) { g_timing = buf; }
 #endif
 
+extern "C" int dcahip_heads_tile_order_len(int G) { return G > 0 ? (((G + kTG - 1) / kTG + kWG - 1) / kWG) * kWG : 0; }
+
+extern "C" int dcahip_heads_fused_ordered(const float* H, long ldh, const float* Wh, long ldw,
+                                          const float* bh, long plane, const float* theta_w,
+                                          const float* y, long ldy, const float* sf, const int* perm,
+                                          const long long* cursor, int B, int hL, int G, float ridge,
+                                          float inv_n, int flags, float* gW, long ldg, float* g_theta,
+                                          float* dH, long lddh, double* loss_partials, int* n_partials_out,
+                                          void* workspace, long workspace_bytes, const int* tile_order,
+                                          void* stream);
+
 extern "C" int dcahip_heads_fused(const float* H, long ldh, const float* Wh, long ldw,
                                   const float* bh, long plane, const float* theta_w,
                                   const float* y, long ldy, const float* sf, const int* perm,
@@ -718,6 +738,19 @@ extern "C" int dcahip_heads_fused(const float* H, long ldh, const float* Wh, lon
                                   float inv_n, int flags, float* gW, long ldg, float* g_theta,
                                   float* dH, long lddh, double* loss_partials, int* n_partials_out,
                                   void* workspace, long workspace_bytes, void* stream) {
+    return dcahip_heads_fused_ordered(H, ldh, Wh, ldw, bh, plane, theta_w, y, ldy, sf, perm, cursor, B, hL, G, ridge,
+                                      inv_n, flags, gW, ldg, g_theta, dH, lddh, loss_partials, n_partials_out,
+                                      workspace, workspace_bytes, nullptr, stream);
+}
+
+extern "C" int dcahip_heads_fused_ordered(const float* H, long ldh, const float* Wh, long ldw,
+                                          const float* bh, long plane, const float* theta_w,
+                                          const float* y, long ldy, const float* sf, const int* perm,
+                                          const long long* cursor, int B, int hL, int G, float ridge,
+                                          float inv_n, int flags, float* gW, long ldg, float* g_theta,
+                                          float* dH, long lddh, double* loss_partials, int* n_partials_out,
+                                          void* workspace, long workspace_bytes, const int* tile_order,
+                                          void* stream) {
     const bool has_pi = flags & DCAHIP_NLL_HAS_PI, cdisp = flags & DCAHIP_NLL_CONST_DISP;
     HeadsPlan pl;
     if (!make_heads_plan(B, hL, G, plane, flags, &pl)) return DCAHIP_EINVAL;
@@ -732,7 +765,7 @@ extern "C" int dcahip_heads_fused(const float* H, long ldh, const float* Wh, lon
     float* ws_dh = static_cast<float*>(workspace);
     float* ws_dw = ws_dh + pl.dh_bytes / sizeof(float);
     HeadsArgs a{g_timing, H, ldh, Wh, ldw, bh, theta_w, y, ldy, sf, perm, cursor, ws_dw, pl.dw_stride, ws_dh, pl.ntg,
-                loss_partials, plane, pl.ldws, B, hL, G, pl.S, pl.NT, ridge, inv_n};
+                tile_order, loss_partials, plane, pl.ldws, B, hL, G, pl.S, pl.NT, ridge, inv_n};
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (has_pi && cdisp) launch_fused<true, true>(pl, a, s);
     else if (has_pi) launch_fused<true, false>(pl, a, s);

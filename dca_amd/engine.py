@@ -295,6 +295,7 @@ class Engine:
         self.ldD = lay.ldA + (lay.Gp if lay.const_disp else 0)
         self.Bmax = 0
         self.X = self.Y = self.sf = self.perm = None
+        self.tile_order = None
         self.hist = None
         self.prof = None            # EventProfiler or None
         # K-HEADS (heads forward + NLL + both backward products in one kernel) whenever the
@@ -513,6 +514,7 @@ class Engine:
                 self.Y[s:e, :lay.G_out] = torch.as_tensor(np.ascontiguousarray(ys, dtype=np.float32)).to(self.dev)
         sfv = np.ones(n, np.float32) if sf is None else np.asarray(sf, dtype=np.float32).reshape(-1)
         self.sf = torch.as_tensor(sfv).to(self.dev)
+        self._set_tile_order()
 
     def attach_device_data(self, X, Y, sf):
         """Uses tensors that already live on the device (synthetic generators, bench)."""
@@ -520,6 +522,25 @@ class Engine:
         assert X.shape[1] == _r4(lay.G_in) and (Y is None or Y.shape[1] == lay.Gp)
         self.n, self.ldx, self.ldy = X.shape[0], X.shape[1], lay.Gp
         self.X, self.Y, self.sf = X, Y, sf
+        self._set_tile_order()
+
+    def _set_tile_order(self):
+        """K-HEADS: which 32-gene tiles share a workgroup.  A workgroup lasts as long as its slower tile and the
+        tiles' cost follows their non-zero counts (the compacted NB pass), so tiles are sorted by the non-zero count
+        of their columns (heaviest first) and taken pairwise: one pass over the resident counts per dataset."""
+        self.tile_order = None
+        if self.Y is None or not self.use_fused or self.ops.device_type != 'cuda':
+            return
+        lay = self.lay
+        n_ord = self.ops.heads_tile_order_len(lay.G_out)
+        ntg = (lay.G_out + 31) // 32
+        rows = min(self.Y.shape[0], 65536)                       # a sample is enough to rank the tiles
+        nz = torch.zeros(ntg * 32, dtype=torch.float32, device=self.dev)
+        for s in range(0, rows, 8192):
+            nz[:lay.G_out] += (self.Y[s:min(rows, s + 8192), :lay.G_out] != 0).sum(dim=0)
+        order = torch.argsort(nz.view(ntg, 32).sum(dim=1), descending=True).to(torch.int32)
+        pad = torch.arange(ntg, n_ord, dtype=torch.int32, device=self.dev)
+        self.tile_order = torch.cat([order, pad]).contiguous()
 
     # ------------------------------------------------------------------ work buffers
     def reserve(self, B):
@@ -780,7 +801,8 @@ class Engine:
                                     self.ldy, self.sf, self.perm, self.cursor, B, KL, lay.G_out,
                                     self.ridge, inv_n, self.flags, lay.view(g, 'Wh'), lay.NH,
                                     lay.view(g, 'theta_w') if lay.const_disp else None,
-                                    self.dH[-1], self.ldh[-1], self.partials, self.ws_heads)
+                                    self.dH[-1], self.ldh[-1], self.partials, self.ws_heads,
+                                    tile_order=self.tile_order)
             ops.loss_finalize(self.partials, n, inv_n, g[lay.P:])
         else:
             self._heads_backward_unfused(B, KL, inv_n)

@@ -49,15 +49,18 @@ class HipOps:
     def heads_fused_workspace_bytes(self, B, hL, G, plane, flags):
         return self.L.dcahip_heads_fused_workspace_bytes(B, hL, G, plane, flags)
 
+    def heads_tile_order_len(self, G):
+        return int(self.L.dcahip_heads_tile_order_len(G))
+
     def heads_fused(self, H, ldh, Wh, ldw, bh, plane, theta_w, Y, ldy, sf, perm, cursor, B, hL, G,
-                    ridge, inv_n, flags, gW, ldg, g_theta, dH, lddh, partials, ws):
+                    ridge, inv_n, flags, gW, ldg, g_theta, dH, lddh, partials, ws, tile_order=None):
         n = ctypes.c_int(0)
         p = hip.ptr
-        hip.check(self.L.dcahip_heads_fused(p(H), ldh, p(Wh), ldw, p(bh), plane, p(theta_w), p(Y), ldy,
-                                            p(sf), p(perm), p(cursor), B, hL, G, ridge, inv_n, flags,
-                                            p(gW), ldg, p(g_theta), p(dH), lddh, p(partials),
-                                            ctypes.byref(n), p(ws), ws.numel() * ws.element_size(),
-                                            hip.stream()), 'heads_fused')
+        hip.check(self.L.dcahip_heads_fused_ordered(p(H), ldh, p(Wh), ldw, p(bh), plane, p(theta_w), p(Y), ldy,
+                                                    p(sf), p(perm), p(cursor), B, hL, G, ridge, inv_n, flags,
+                                                    p(gW), ldg, p(g_theta), p(dH), lddh, p(partials),
+                                                    ctypes.byref(n), p(ws), ws.numel() * ws.element_size(),
+                                                    p(tile_order), hip.stream()), 'heads_fused')
         return n.value
 
     # ------------------------------------------------------------------ gemm

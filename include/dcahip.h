@@ -133,6 +133,21 @@ int dcahip_heads_fused(const float* H, long ldh, const float* Wh, long ldw, cons
                        float* gW, long ldg, float* g_theta, float* dH, long lddh,
                        double* loss_partials, int* n_partials_out,
                        void* workspace, long workspace_bytes, void* stream);
+/* Same, with the order in which workgroups take the 32-gene tiles: tile_order = device array of
+ * dcahip_heads_tile_order_len(G) ints, a permutation of 0 .. ceil(G/32)-1 (padded with values >= ceil(G/32));
+ * every 2 consecutive entries share a workgroup.  Results do not depend on it (each is per gene tile); a workgroup
+ * lasts as long as its slower tile, so pairing tiles of similar non-zero load (sort by the non-zero count of the
+ * tile's 32 count columns) removes the imbalance: measured 15 % between the two tiles of a workgroup in file order,
+ * 8 % of the kernel.  NULL = identity (what dcahip_heads_fused passes). */
+int dcahip_heads_tile_order_len(int G);
+int dcahip_heads_fused_ordered(const float* H, long ldh, const float* Wh, long ldw, const float* bh,
+                               long plane, const float* theta_w,
+                               const float* y, long ldy, const float* sf,
+                               const int* perm, const long long* cursor,
+                               int B, int hL, int G, float ridge, float inv_n, int flags,
+                               float* gW, long ldg, float* g_theta, float* dH, long lddh,
+                               double* loss_partials, int* n_partials_out,
+                               void* workspace, long workspace_bytes, const int* tile_order, void* stream);
 
 /*
  * C[M,N] = op(A) * op(B) (+ bias) on the fp32 MFMA pipe (v_mfma_f32_32x32x2_f32), LDS-tiled,

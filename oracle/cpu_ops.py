@@ -117,9 +117,13 @@ class CpuRefOps:
     def heads_fused_workspace_bytes(self, B, hL, G, plane, flags):
         return 16 if (1 <= hL <= 64 and not flags & 12) else 0
 
+    def heads_tile_order_len(self, G):
+        return ((G + 31) // 32 + 1) // 2 * 2
+
     def heads_fused(self, H, ldh, Wh, ldw, bh, plane, theta_w, Y, ldy, sf, perm, cursor, B, hL, G,
-                    ridge, inv_n, flags, gW, ldg, g_theta, dH, lddh, partials, ws):
-        """Contract of dcahip_heads_fused = the composition of the separate entry points."""
+                    ridge, inv_n, flags, gW, ldg, g_theta, dH, lddh, partials, ws, tile_order=None):
+        """Contract of dcahip_heads_fused = the composition of the separate entry points (tile_order only
+        changes which workgroup computes what)."""
         has_pi, cdisp = bool(flags & 1), bool(flags & 2)
         nh = 1 + (0 if cdisp else 1) + (1 if has_pi else 0)
         NH = nh * plane

@@ -45,7 +45,7 @@ def reference(Hm, W, b, tw, y, sf, flags, ridge, n_total):
     return heads, ls / n_total, gW, gb, dH, (dd if cdisp else None)
 
 
-def run_case(ops, flags, B, G, hL, seed, ridge=0.0, use_perm=True, odd_counts=False):
+def run_case(ops, flags, B, G, hL, seed, ridge=0.0, use_perm=True, odd_counts=False, tile_order=None):
     has_pi, cdisp = bool(flags & 1), bool(flags & 2)
     rng = np.random.RandomState(seed)
     f = lambda a: a.astype(np.float32).astype(np.float64)
@@ -95,7 +95,8 @@ def run_case(ops, flags, B, G, hL, seed, ridge=0.0, use_perm=True, odd_counts=Fa
     ws = torch.full((nb // 4,), float('nan'), device='cuda')      # every slot read must be written
     n = ops.heads_fused(dHp, ldh, dWh, NH, dWh[hL], Gp, dtw if cdisp else None, dY, Gp, dsf, dperm,
                         dcur, B, hL, G, ridge, 1.0 / n_total, flags, gWd, NH,
-                        gth if cdisp else None, dHd, ldh, part, ws)
+                        gth if cdisp else None, dHd, ldh, part, ws,
+                        tile_order=None if tile_order is None else torch.as_tensor(tile_order, dtype=torch.int32).cuda())
     loss = torch.zeros(1, device='cuda')
     ops.loss_finalize(part, n, 1.0 / n_total, loss)
     torch.cuda.synchronize()
@@ -156,3 +157,23 @@ def test_heads_fused_ragged_shapes(ops):
     """Batch and gene counts that end inside a tile (192 = 6 row tiles, 777 genes = 24.3 gene tiles)."""
     out = run_case(ops, 1, 192, 777, 64, seed=9)
     check(out)
+
+
+@pytest.mark.parametrize('flags,B,G', [(1, 200, 777), (3, 96, 333), (0, 260, 1000)])
+def test_heads_fused_tile_order_changes_nothing(ops, flags, B, G):
+    """dcahip_heads_fused_ordered: any pairing of the 32-gene tiles gives the results of the identity order --
+    bitwise for every gradient (each is per gene tile, the dH partial sums run over gene-tile ids), the loss to
+    fp64 re-association of the per-workgroup partials."""
+    ntg = (G + 31) // 32
+    n_ord = ops.heads_tile_order_len(G)
+    assert n_ord == (ntg + 1) // 2 * 2
+    a = run_case(ops, flags, B, G, 64, seed=11)
+    check(a)
+    rng = np.random.RandomState(4)
+    for order in (np.r_[np.arange(ntg)[::-1], np.arange(ntg, n_ord)], np.r_[rng.permutation(ntg), np.arange(ntg, n_ord)]):
+        b = run_case(ops, flags, B, G, 64, seed=11, tile_order=order)
+        for k in a:
+            if k == 'loss':
+                assert abs(a[k][0] - b[k][0]) <= 1e-6 * abs(a[k][0])
+            else:
+                assert np.array_equal(np.asarray(a[k][0]), np.asarray(b[k][0])), k

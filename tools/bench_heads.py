@@ -41,9 +41,18 @@ part = torch.zeros(ops.max_partials, dtype=torch.float64, device=dev)
 ws = torch.zeros(ops.heads_fused_workspace_bytes(B, hL, G, Gp, flags) // 4, device=dev)
 inv_n = 1.0 / (B * G)
 
+order = None
+if os.environ.get('TILE_ORDER', '1') != '0':          # pair gene tiles of similar non-zero load (engine._set_tile_order)
+    ntg = (G + 31) // 32
+    nz = torch.zeros(ntg * 32, device=dev)
+    nz[:G] = (Y[:, :G] != 0).sum(dim=0)
+    o = torch.argsort(nz.view(ntg, 32).sum(dim=1), descending=True).to(torch.int32)
+    order = torch.cat([o, torch.arange(ntg, ops.heads_tile_order_len(G), dtype=torch.int32, device=dev)]).contiguous()
+
+
 def fused():
     return ops.heads_fused(H, hL, Wh, NH, Wh[hL], Gp, tw if flags & 2 else None, Y, Gp, sf, perm, cur, B, hL, G,
-                           0.0, inv_n, flags, gW, NH, gth if flags & 2 else None, dH, hL, part, ws)
+                           0.0, inv_n, flags, gW, NH, gth if flags & 2 else None, dH, hL, part, ws, tile_order=order)
 
 def timeit(fn, n):
     fn(); torch.cuda.synchronize()

@@ -28,3 +28,16 @@ tot = t.sum(1).mean()
 print('waves', len(t), 'mean cycles per wave (s_memtime @100MHz ticks?)', tot)
 for i, nme in enumerate(names):
     print('  %-16s %12.0f  %5.1f%%' % (nme, t[:, i].mean(), 100 * t[:, i].mean() / tot))
+# spread of the main-loop time inside a workgroup (8 waves): what the barrier in front of the dW tree waits for
+full = tim.cpu().numpy().reshape(-1, 10)
+nw = 8
+g = full[:(len(full) // nw) * nw].reshape(-1, nw, 10)
+g = g[g[:, :, :8].sum(axis=(1, 2)) > 0]
+loop = g[:, :, :8].sum(axis=2)                      # [workgroup, wave]
+print('workgroups', len(g), ' loop cycles per wave: mean %.0f  within-workgroup max-mean %.0f  max-min %.0f' % (
+    loop.mean(), (loop.max(axis=1) - loop.mean(axis=1)).mean(), (loop.max(axis=1) - loop.min(axis=1)).mean()))
+print('epilogue per wave: mean %.0f  min over the workgroup (= the last arriver) %.0f' % (g[:, :, 9].mean(), g[:, :, 9].min(axis=1).mean()))
+# wave = g * WR + r (g = gene tile of the pair, r = row slot): where does the spread come from?
+lg = loop.reshape(len(loop), 2, 4)
+print('spread between the two gene tiles of a workgroup |mean_g0 - mean_g1|: %.0f   spread over row slots within a gene tile (max-min): %.0f'
+      % (np.abs(lg[:, 0].mean(axis=1) - lg[:, 1].mean(axis=1)).mean(), (lg.max(axis=2) - lg.min(axis=2)).mean()))
