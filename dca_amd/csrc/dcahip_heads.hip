@@ -453,6 +453,7 @@ __global__ __launch_bounds__(64 * kWG * WR) void heads_fused_kernel(HeadsArgs p)
                             dHa[jb] = MFMA(a, b, dHa[jb]);
                         }
                     }
+                TSTAMP(7)                              // timing build: MFMA part of the dH phase ends here
                 float* dst = dh_base + (long)t * dh_tstride;
 #pragma unroll
                 for (int jb = 0; jb < HLB; ++jb)

@@ -23,7 +23,7 @@ sys.argv = [sys.argv[0]] + sys.argv[1:]
 exec(open(os.path.join(ROOT, 'tools', 'bench_heads.py')).read())
 t = tim.cpu().numpy().reshape(-1, 10)
 t = t[t.sum(1) > 0]
-names = ['loop-top', 'H->LDS', 'F (96 mfma)', 'staging stores', 'Z dense+sparse', 'dH (96 mfma) + partial store', 'Hd loads + dW (96 mfma)', 'rest', 'PROLOGUE (W -> LDS)', 'EPILOGUE (dW tree + stores)']
+names = ['loop-top', 'H->LDS', 'F (96 mfma)', 'staging stores', 'Z dense+sparse', 'dH: partial stores + Hd / hv load issue', 'dW (96 mfma)', 'dH: 96 mfma', 'PROLOGUE (W -> LDS)', 'EPILOGUE (dW tree + stores)']
 tot = t.sum(1).mean()
 print('waves', len(t), 'mean cycles per wave (s_memtime @100MHz ticks?)', tot)
 for i, nme in enumerate(names):
