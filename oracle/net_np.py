@@ -227,6 +227,7 @@ class OracleAE:
         self.batchnorm = batchnorm
         self.ridge = ridge
         self.dtype = params['W0'].dtype
+        self.row_threads = 0                                # > 1: likelihood of large batches on a thread pool
 
     # ---------------------------------------------------------------- forward
     def forward(self, X, sf, training):
@@ -297,7 +298,17 @@ class OracleAE:
         shape = c['a_mean'].shape
         a_disp = np.broadcast_to(c['a_disp'], shape) if c['a_disp'] is not None else None
         a_pi = np.broadcast_to(c['a_pi'], shape) if c['a_pi'] is not None else None
-        if self.ae_type.startswith('zinb'):
+        if self.row_threads > 1 and shape[0] * shape[1] >= 1 << 20:
+            # benchmark-size batches: the element-wise likelihood over row chunks on a thread pool
+            nt = float(shape[0] * shape[1]) if n_total is None else n_total
+            if self.ae_type.startswith('zinb'):
+                ls, lm, dm, dd, dpi = Z.rows_in_parallel(Z.zinb_loss_and_grads, (c['a_mean'], a_disp, a_pi, Y, c['sf']),
+                                                         self.row_threads, ridge=self.ridge, n_total=nt, theta_w=tw)
+            else:
+                ls, lm, dm, dd = Z.rows_in_parallel(Z.nb_loss_and_grads, (c['a_mean'], a_disp, Y, c['sf']),
+                                                    self.row_threads, n_total=nt, theta_w=tw)
+                dpi = None
+        elif self.ae_type.startswith('zinb'):
             ls, lm, dm, dd, dpi = Z.zinb_loss_and_grads(c['a_mean'], a_disp, a_pi, Y,
                                                         c['sf'], self.ridge, n_total, tw)
         else:

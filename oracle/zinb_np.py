@@ -221,6 +221,41 @@ def nb_loss_and_grads(a_mean, a_disp, y, sf, n_total=None, theta_w=None):
     return loss_sum, loss_sum / dt.type(n), d_mean, d_disp
 
 
+def rows_in_parallel(fn, row_args, threads, **kw):
+    """Evaluates a *_loss_and_grads function over row chunks on a thread pool (numpy / scipy ufuncs
+    release the GIL).  The likelihood is element-wise and its reductions are plain sums, so the result
+    is the single-call result up to the order of the loss / per-gene sums.  Used only to make
+    benchmark-size comparisons (4 096 x 20 000 and larger) finish in seconds.
+
+    row_args: positional arguments of fn that are [B, ...] arrays or None (split along axis 0);
+    kw: the remaining keyword arguments; n_total must be given (the chunks must not normalise by
+    their own size)."""
+    from concurrent.futures import ThreadPoolExecutor
+    assert kw.get('n_total') is not None
+    B = next(a for a in row_args if a is not None).shape[0]
+    nch = max(1, min(int(threads), B // 8 if B >= 8 else 1))
+    bounds = np.linspace(0, B, nch + 1).astype(int)
+    def piece(i):
+        s, e = bounds[i], bounds[i + 1]
+        return fn(*[None if a is None else a[s:e] for a in row_args], **kw)
+    if nch == 1:
+        return piece(0)
+    with ThreadPoolExecutor(nch) as ex:
+        parts = list(ex.map(piece, range(nch)))
+    ls = sum(p[0] for p in parts)
+    n = kw['n_total']
+    out = [ls, ls / parts[0][0].dtype.type(n)]
+    for k in range(2, len(parts[0])):
+        vals = [p[k] for p in parts]
+        if vals[0] is None:
+            out.append(None)
+        elif vals[0].ndim == 1:                    # per-gene sums (constant dispersion): add
+            out.append(sum(vals))
+        else:
+            out.append(np.concatenate(vals, axis=0))
+    return tuple(out)
+
+
 # ------------------------------------------------------------------ Poisson / squared error
 def poisson_nll(y, mu):
     """dca/loss.py:36-55: y_pred - y*log(y_pred + 1e-10) + lgamma(y + 1)."""

@@ -1,9 +1,15 @@
 """End-to-end parity on the MI355X: the engine driving the HIP kernels through the C ABI against
 the fp64 oracle (oracle/net_np.py) with identical injected weights and batch order.
 
-Tolerances (fp32 kernels vs fp64 oracle):  batch / epoch loss 1e-4 relative (BASELINE.md
-target), gradients 2e-3 relative + 2e-5 of the tensor's max, outputs mean/dispersion/dropout
-1e-4 relative after training steps.
+Tolerances asserted here (fp32 kernels vs fp64 oracle; the same numbers are in DESIGN.md section 2):
+  * one training step: batch loss 1e-5 relative; every gradient 2e-3 relative + 2e-5 of its tensor's
+    max (helpers.assert_grads_close); BN moving statistics 1e-4 -- at test sizes AND at the benchmark
+    shape (68 579 x 20 000 resident, batch 4 096 and 32: test_full_size_step_matches_oracle);
+  * a fit (2 epochs of BASELINE configs[1]): per-epoch loss / val_loss against the fp64 oracle over a
+    SET of problem seeds (no picked seed): every seed within 5e-3, the seeds that stay on the fp64
+    trajectory within 1e-5 (typical 2e-7), and no more seeds leaving it than the fp32 oracle's own count
+    on the same seeds + max(1, n/5) -- fit_acceptance() states this in full;
+  * outputs mean / dispersion / dropout / latent after training: 2e-3 relative + 2e-4 absolute.
 """
 import numpy as np
 import pytest
@@ -46,40 +52,74 @@ def test_single_step_matches_oracle(ops, ae_type, batchnorm, n, G, hs, B):
             np.testing.assert_allclose(newp['mv%d' % i], ref.p['mv%d' % i], rtol=1e-4, atol=1e-6)
 
 
+def _golden_fit():
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'fit_c2_oracle.npz'))
+    return {k: g[k] for k in g.files}
+
+
+FIT_TIGHT, FIT_LOOSE = 1e-5, 5e-3
+
+
+def fit_distance(hist, gold, key, ref='f64'):
+    """max over epochs and {loss, val_loss} of |x / oracle_fp64 - 1|."""
+    return max(abs(a / b - 1) for q in ('loss', 'val_loss') for a, b in zip(hist[q], gold[key + '/' + ref + '/' + q]))
+
+
+def fit_acceptance(dist, dist_fp32_oracle):
+    """The acceptance statement for a set of seeds (dist: per-seed distance of a fit to the fp64 oracle's):
+      (1) every seed within 5e-3 -- a trajectory whose ReLU mask flipped once is still the same optimisation;
+      (2) the number of seeds beyond 1e-5 (left the fp64 trajectory) exceeds the fp32 ORACLE's number on the same
+          seeds by at most max(1, n_seeds // 5) -- leaving is a property of fp32 arithmetic on the problem (the fp32
+          oracle leaves at 1 of 10 zinb-conddisp seeds, 3 of 10 nb seeds, 2 of 4 zinb seeds), and a different fp32
+          summation order leaves at different seeds;
+      (3) the seeds that stay agree to 1e-6 at best (typical 2e-7): the loop computes the same numbers."""
+    dist, dist_fp32_oracle = np.asarray(dist), np.asarray(dist_fp32_oracle)
+    assert (dist <= FIT_LOOSE).all(), dist
+    assert (dist > FIT_TIGHT).sum() <= (dist_fp32_oracle > FIT_TIGHT).sum() + max(1, len(dist) // 5), (dist, dist_fp32_oracle)
+    assert dist.min() <= 1e-6, dist
+
+
 @pytest.mark.parametrize('ae_type,use_graph', [('zinb-conddisp', True), ('zinb-conddisp', False),
                                                ('zinb', True), ('nb-conddisp', True), ('nb', True),
                                                ('poisson', True), ('normal', True)])
 def test_fit_epoch_losses_match_oracle(ops, ae_type, use_graph):
-    """BASELINE config 2 shape (2 000 x 1 000, 64-32-64, B=32): per-epoch loss / val_loss."""
+    """BASELINE configs[1] shape (2 000 x 1 000, 64-32-64, B = 32, 2 epochs): per-epoch loss / val_loss of the
+    device fit loop against the fp64 oracle's Keras-fit restatement, over every problem seed of the golden
+    fixture (tests/golden/fit_c2_oracle.npz, generator committed beside it; 10 seeds for the flagship
+    types, 4 for the others) -- no seed is picked.
+
+    Acceptance: fit_acceptance() above, with the fp32 oracle's distances on the same seeds (from the same fixture)
+    as the yardstick -- BASELINE's 1e-4 per-epoch target holds for every seed that stays on the fp64 trajectory
+    (typical agreement 2e-7), and no fp32 implementation, the oracle's included, stays on it for every seed."""
     from dca_amd.train import fit_engine
-    n, G, hs = 2000, 1000, (64, 32, 64)
-    epochs = 2
-    # seed 23: multi-epoch trajectories are chaotic at ReLU boundaries -- a hidden pre-activation
-    # within ~1e-7 of zero flips its mask under any fp32 re-association (seen once in 114 steps
-    # with seed 21: identical per-step gradients to 1e-8, see
-    # test_fused_and_separate_heads_agree_stepwise, yet val_loss 1e-3 apart).  The per-step
-    # parity tests above are the strict ones; this one checks the fit loop end to end.  Typical agreement
-    # (tools/fit_parity_sweep.py, seeds 23-27 on the MI355X): zinb-conddisp 2e-7 / 6e-7 on the two epoch losses,
-    # nb 4e-8 / 1e-7 -- except nb at seed 23, where one mask flips late in epoch 1 (val_loss 3e-4 apart): seed 24.
-    X, Y, sf, p = make_problem(n, G, hs, ae_type, True, seed=24 if ae_type == 'nb' else 23)
-    ref = oracle_net(ae_type, p, hs, True)
-    rh = N.fit(ref, X.astype(np.float64), Y.astype(np.float64), sf.astype(np.float64), epochs=epochs,
-               batch_size=32, shuffle_rng=np.random.RandomState(5))
-    eng = make_engine(ops, ae_type, G, hs, True, 0.0, p, X, Y, sf)
-    n_train = int(n * 0.9)
-    h = fit_engine(eng, n_train, n - n_train, n_train, n - n_train, 0, epochs=epochs, batch_size=32,
-                   shuffle_rng=np.random.RandomState(5), use_graph=use_graph)
-    np.testing.assert_allclose(h.history['loss'], rh['loss'], rtol=1e-4)
-    np.testing.assert_allclose(h.history['val_loss'], rh['val_loss'], rtol=1e-4)
-    # outputs after training: mean / dispersion / dropout / latent
-    out_ref = ref.predict(X[:64].astype(np.float64), sf[:64].astype(np.float64))
-    eng.reserve(64)
-    want = {'mean', 'latent'} | ({'dispersion'} if 'disp' in eng.lay.heads else set()) \
-        | ({'dropout'} if 'pi' in eng.lay.heads else set())
-    out = eng.predict_chunk(0, 64, want)
-    torch.cuda.synchronize()
-    for k in want:
-        np.testing.assert_allclose(out[k].cpu().numpy(), out_ref[k], rtol=2e-3, atol=2e-4, err_msg=k)
+    from golden.make_fit_c2_golden import SEEDS, N_CELLS as n, N_GENES as G, HIDDEN as hs, EPOCHS, BATCH, SHUFFLE_SEED, N_PREDICT
+    gold = _golden_fit()
+    seeds = SEEDS[ae_type] if use_graph else SEEDS[ae_type][:3]
+    dist = []
+    for seed in seeds:
+        X, Y, sf, p = make_problem(n, G, hs, ae_type, True, seed=seed)
+        eng = make_engine(ops, ae_type, G, hs, True, 0.0, p, X, Y, sf)
+        n_train = int(n * 0.9)
+        h = fit_engine(eng, n_train, n - n_train, n_train, n - n_train, 0, epochs=EPOCHS, batch_size=BATCH,
+                       shuffle_rng=np.random.RandomState(SHUFFLE_SEED), use_graph=use_graph)
+        key = '%s/%d' % (ae_type, seed)
+        dist.append(fit_distance(h.history, gold, key))
+        if seed == seeds[0] and dist[-1] <= FIT_TIGHT:
+            # outputs after training: mean / dispersion / dropout / latent (first N_PREDICT cells)
+            eng.reserve(64)
+            want = {'mean', 'latent'} | ({'dispersion'} if 'disp' in eng.lay.heads else set()) \
+                | ({'dropout'} if 'pi' in eng.lay.heads else set())
+            out = eng.predict_chunk(0, N_PREDICT, want)
+            torch.cuda.synchronize()
+            for k in want:
+                np.testing.assert_allclose(out[k].cpu().numpy(), gold[key + '/f64/out_' + k], rtol=2e-3, atol=2e-4,
+                                           err_msg=k)
+    d32 = [fit_distance({q: gold['%s/%d/f32/%s' % (ae_type, sd, q)] for q in ('loss', 'val_loss')}, gold, '%s/%d' % (ae_type, sd))
+           for sd in seeds]
+    print('fit parity %s: per-seed max rel distance to the fp64 oracle: engine %s, fp32 oracle %s'
+          % (ae_type, ['%.1e' % d for d in dist], ['%.1e' % d for d in d32]))
+    fit_acceptance(dist, d32)
 
 
 @pytest.mark.parametrize('ae_type', ['zinb-conddisp', 'zinb', 'nb-conddisp', 'nb'])
@@ -164,20 +204,76 @@ def test_large_batch_step(ops):
     assert_grads_close(g, rg)
 
 
-def test_full_size_step_fused_equals_separate(ops):
-    """BASELINE configs[2] at FULL size (68 579 x 20 000 resident, batch 4096): the oracle cannot
-    run here in seconds, so parity is carried by a size-independent property -- the fused K-HEADS
-    step and the separate-kernel step (both checked against the oracle at small sizes above) must
-    agree on the loss and on every gradient from the same state -- plus finiteness and the
-    NLL's known scale on this generator."""
+@pytest.fixture(scope='module')
+def c3(ops):
+    """BASELINE configs[2] at FULL size, resident in HBM exactly as bench.py builds it: 68 579 x 20 000 synthetic
+    counts (dca_amd/synth.py), size factors and z-scored log counts by K-PREP."""
     from dca_amd import synth, prep
-    from dca_amd.engine import Engine
-    n, G, hs, B = 68579, 20000, (64, 32, 64), 4096
+    n, G = 68579, 20000
     dev = torch.device('cuda')
     Y = synth.generate_counts(n, G, device=dev)
     counts = prep.cell_counts(ops, Y, n, G)
     sf = counts / counts.median()
     X = prep.transform(ops, Y, n, G, sf, True, True)
+    yield dict(n=n, G=G, X=X, Y=Y, sf=sf, hs=(64, 32, 64))
+    del X, Y, sf
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize('B', [4096, 32])
+def test_full_size_step_matches_oracle(ops, c3, B):
+    """The shape bench.py publishes (BASELINE configs[2]: 68 579 x 20 000 resident, zinb-conddisp 64-32-64), at the
+    bench's batch 4 096 and at the reference-default batch 32 (dca/train.py:37): ONE full training step -- forward,
+    ZINB loss (dca/loss.py:122-156), backward, clipvalue + RMSprop, BN moving statistics -- against the fp64 oracle
+    on the same gathered rows, then the outputs of the updated network on 256 cells.  Same tolerances as the
+    small-shape test above.  (The oracle's element-wise likelihood runs over row chunks on host threads.)"""
+    import os
+    from dca_amd.engine import Engine
+    n, G, hs = c3['n'], c3['G'], c3['hs']
+    p = N.init_params('zinb-conddisp', G, hs, batchnorm=True, seed=2, dtype=np.float64)
+    rng = np.random.RandomState(B)
+    for k in p:
+        if k[0] in 'bt':                       # biases / beta: zero-initialised, perturbed so their gradients count
+            p[k] = rng.normal(0, .1, p[k].shape)
+    p = {k: np.asarray(v, np.float32) for k, v in p.items()}
+    eng = Engine('zinb-conddisp', G, G, hs, True, 0.0, ops=ops)
+    assert eng.use_fused
+    eng.set_params(p)
+    eng.attach_device_data(c3['X'], c3['Y'], c3['sf'])
+    rows = np.random.RandomState(1).permutation(n)[:B]
+    rt = torch.as_tensor(rows).cuda()
+    Xr = c3['X'][rt][:, :G].cpu().numpy().astype(np.float64)
+    Yr = c3['Y'][rt][:, :G].cpu().numpy().astype(np.float64)
+    sfr = c3['sf'][rt].cpu().numpy().astype(np.float64)
+    assert 0.90 < (Yr == 0).mean() < 0.96                    # the 68k-PBMC sparsity regime of SURVEY 8d
+    ref = oracle_net('zinb-conddisp', p, hs, True)
+    ref.row_threads = max(1, min(64, os.cpu_count() or 1))
+    rl, rg = ref.loss_and_grads(Xr, Yr, sfr)
+    N.rmsprop_step(ref.p, rg, {}, 1e-3)
+    loss, g, newp = run_single_step(eng, rows)
+    assert eng.ws_heads is not None                          # K-HEADS ran
+    assert abs(loss - rl) < 1e-5 * abs(rl), (loss, rl)
+    assert_grads_close(g, rg)
+    for i in range(len(hs)):
+        np.testing.assert_allclose(newp['mm%d' % i], ref.p['mm%d' % i], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(newp['mv%d' % i], ref.p['mv%d' % i], rtol=1e-4, atol=1e-6)
+    # outputs of the updated network (inference mode) on the first 256 cells
+    eng.reserve(max(B, 256))
+    out = eng.predict_chunk(0, 256, {'mean', 'dispersion', 'dropout', 'latent'})
+    torch.cuda.synchronize()
+    want = ref.predict(c3['X'][:256, :G].cpu().numpy().astype(np.float64), c3['sf'][:256].cpu().numpy().astype(np.float64))
+    for k in ('mean', 'dispersion', 'dropout', 'latent'):
+        np.testing.assert_allclose(out[k].cpu().numpy(), want[k], rtol=2e-3, atol=2e-4, err_msg=k)
+
+
+def test_full_size_step_fused_equals_separate(ops, c3):
+    """Full-size companion of test_full_size_step_matches_oracle: the fused K-HEADS step and the separate-kernel
+    step (GEMM + K-ZINB + 2 GEMMs: the path of decoders wider than 64) agree on the loss and on every gradient
+    from the same state at 68 579 x 20 000, batch 4096."""
+    from dca_amd.engine import Engine
+    n, G, hs, B = c3['n'], c3['G'], c3['hs'], 4096
+    dev = torch.device('cuda')
+    X, Y, sf = c3['X'], c3['Y'], c3['sf']
     engs = []
     for fused in (True, False):
         e = Engine('zinb-conddisp', G, G, hs, True, 0.0, ops=ops)

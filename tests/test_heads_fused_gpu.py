@@ -22,12 +22,21 @@ def dev(a, dtype=torch.float32):
     return torch.as_tensor(np.ascontiguousarray(a)).to(dtype).cuda()
 
 
-def reference(Hm, W, b, tw, y, sf, flags, ridge, n_total):
-    """fp64: A = H W + b per head -> loss / grads -> gW, gb, dH, (g_theta)."""
+def reference(Hm, W, b, tw, y, sf, flags, ridge, n_total, threads=1):
+    """fp64: A = H W + b per head -> loss / grads -> gW, gb, dH, (g_theta).  threads > 1: the element-wise
+    likelihood over row chunks on host threads (benchmark-size cases)."""
     has_pi, cdisp = bool(flags & 1), bool(flags & 2)
     heads = ['mean'] + ([] if cdisp else ['disp']) + (['pi'] if has_pi else [])
     A = {h: Hm @ W[h] + b[h] for h in heads}
-    if has_pi:
+    if threads > 1:
+        if has_pi:
+            ls, lm, dm, dd, dp = Z.rows_in_parallel(Z.zinb_loss_and_grads, (A['mean'], A.get('disp'), A['pi'], y, sf),
+                                                    threads, ridge=ridge, n_total=n_total, theta_w=tw if cdisp else None)
+        else:
+            ls, lm, dm, dd = Z.rows_in_parallel(Z.nb_loss_and_grads, (A['mean'], A.get('disp'), y, sf), threads,
+                                                n_total=n_total, theta_w=tw if cdisp else None)
+            dp = None
+    elif has_pi:
         ls, lm, dm, dd, dp = Z.zinb_loss_and_grads(A['mean'], A.get('disp'), A['pi'], y, sf, ridge,
                                                    n_total, tw if cdisp else None)
     else:
@@ -45,7 +54,8 @@ def reference(Hm, W, b, tw, y, sf, flags, ridge, n_total):
     return heads, ls / n_total, gW, gb, dH, (dd if cdisp else None)
 
 
-def run_case(ops, flags, B, G, hL, seed, ridge=0.0, use_perm=True, odd_counts=False, tile_order=None):
+def run_case(ops, flags, B, G, hL, seed, ridge=0.0, use_perm=True, odd_counts=False, tile_order=None, counts=None,
+             threads=1):
     has_pi, cdisp = bool(flags & 1), bool(flags & 2)
     rng = np.random.RandomState(seed)
     f = lambda a: a.astype(np.float32).astype(np.float64)
@@ -55,13 +65,13 @@ def run_case(ops, flags, B, G, hL, seed, ridge=0.0, use_perm=True, odd_counts=Fa
     W = {h: f(rng.normal(0, 0.25, (hL, G))) for h in heads}
     b = {h: f(rng.normal(0, 0.3, G)) for h in heads}
     tw = f(rng.normal(0, 1.5, G))
-    y = f(synth_counts(B, G, seed))
+    y = f(synth_counts(B, G, seed)) if counts is None else f(counts)
     if odd_counts:        # non-integer 'counts' (check_counts=False), large and > 65535 counts
         y[0, :6] = [2.52, 0.5, 17.0, 70000.0, 200.0, 5000.0]
         y[1, 1:4] = [16.0, 16.5, 65535.0]
     sf = f(rng.lognormal(0, 0.3, B))
     n_total = float(B * G)
-    _, lm, gW, gb, dH, dth = reference(Hm, W, b, tw, y, sf, flags, ridge, n_total)
+    _, lm, gW, gb, dH, dth = reference(Hm, W, b, tw, y, sf, flags, ridge, n_total, threads)
 
     Gp = (G + 3) // 4 * 4
     NH = nh * Gp
@@ -134,6 +144,21 @@ def check(out, edge=False):
 @pytest.mark.parametrize('B,G,hL', [(8, 40, 64), (33, 1000, 64), (5, 6, 16), (150, 203, 50), (260, 333, 64)])
 def test_heads_fused_vs_oracle(ops, flags, B, G, hL):
     out = run_case(ops, flags, B, G, hL, seed=B + G, ridge=0.05 if flags & 1 else 0.0)
+    check(out)
+
+
+@pytest.mark.parametrize('flags', [1, 3])
+def test_heads_fused_benchmark_shape_vs_oracle(ops, flags):
+    """The launch bench.py's roofline line is quoted on (BASELINE configs[2] at the bench batch): B = 4 096 cells x
+    G = 20 000 genes, hL = 64, ZINB with conditional (flags 1) / constant (flags 3) dispersion, counts from the
+    bench's own generator (dca_amd/synth.py: ~93 % zeros) -- against the fp64 oracle (numpy matmuls around
+    oracle.zinb_np, dca/loss.py:122-156), same tolerances as every other case here."""
+    import os
+    from dca_amd import synth
+    B, G = 4096, 20000
+    y = synth.generate_counts(B, G, device='cuda', seed=11 + flags)[:, :G].cpu().numpy()
+    assert 0.90 < (y == 0).mean() < 0.96
+    out = run_case(ops, flags, B, G, 64, seed=7, ridge=0.02, counts=y, threads=max(1, min(64, os.cpu_count() or 1)))
     check(out)
 
 

@@ -158,3 +158,45 @@ def test_callbacks():
     assert np.allclose(out, [1e-3, 1e-3, 1e-3, 1e-4, 1e-4, 1e-4, 1e-5])
     es = N.EarlyStopping(patience=2)
     assert [es.on_epoch_end(v) for v in [1.0, 0.9, 0.9, 0.95]] == [False, False, False, True]
+
+
+# ---------------------------------------------------------------------------------------------
+# tests/golden/fit_c2_oracle.npz (the fit trajectories the MI355X fit loop is compared with)
+# ---------------------------------------------------------------------------------------------
+def _fit_golden():
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'fit_c2_oracle.npz'))
+    return {k: g[k] for k in g.files}
+
+
+def test_fit_golden_fixture_is_what_the_oracle_computes():
+    """Re-derives a sample of the fixture (one fp64 and one fp32 trajectory) with the committed generator:
+    the fixture cannot drift away from oracle/net_np.py unnoticed.  fp64 trajectories are reproducible to
+    round-off across hosts; the fp32 one to its own chaos bound."""
+    from golden.make_fit_c2_golden import oracle_fit
+    gold = _fit_golden()
+    h, out = oracle_fit('zinb-conddisp', 1, np.float64)
+    np.testing.assert_allclose(h['loss'], gold['zinb-conddisp/1/f64/loss'], rtol=1e-9)
+    np.testing.assert_allclose(h['val_loss'], gold['zinb-conddisp/1/f64/val_loss'], rtol=1e-9)
+    h, out = oracle_fit('nb', 2, np.float32)
+    np.testing.assert_allclose(h['loss'], gold['nb/2/f32/loss'], rtol=1e-5)
+    np.testing.assert_allclose(h['val_loss'], gold['nb/2/f32/val_loss'], rtol=1e-5)
+
+
+def test_fp32_oracle_leaves_the_fp64_trajectory_at_some_seeds():
+    """Why tests/test_engine_gpu.py::test_fit_epoch_losses_match_oracle is a statement about a SET of seeds: the fp32
+    ORACLE itself (same restatement, fp32 arithmetic) stays within 5e-3 of the fp64 oracle at every seed, within 1e-7
+    at most seeds, and leaves the fp64 trajectory (> 1e-5: one ReLU-mask flip) at 1 of 10 zinb-conddisp seeds, 3 of 10
+    nb seeds, 2 of 4 zinb seeds.  A single-seed 1e-4 assertion would be luck; these counts are the yardstick."""
+    from golden.make_fit_c2_golden import SEEDS
+    gold = _fit_golden()
+    left = {}
+    for ae_type, seeds in SEEDS.items():
+        d = np.array([max(abs(a / b - 1) for q in ('loss', 'val_loss')
+                          for a, b in zip(gold['%s/%d/f32/%s' % (ae_type, s, q)], gold['%s/%d/f64/%s' % (ae_type, s, q)]))
+                      for s in seeds])
+        assert (d <= 5e-3).all(), (ae_type, d)
+        assert d.min() <= 1e-6, (ae_type, d)
+        left[ae_type] = int((d > 1e-5).sum())
+    assert left['zinb-conddisp'] >= 1 and left['nb'] >= 1, left
+    assert all(v <= len(SEEDS[k]) // 2 for k, v in left.items()), left

@@ -1,0 +1,79 @@
+// Probe of ds_read_b64_tr_b16 (gfx950 LDS transpose read) semantics: LDS holds lds16[i] = i; lane l supplies the
+// address of the 4 shorts [4l, 4l+4).  Prints, per lane and result element j, the LDS index received -- i.e. which
+// (source lane, position) each result element comes from.  Expected (MI355X guide): within every 16-lane group,
+// result[t][j] = data of lane 4j + (t >> 2), position t & 3.
+// Part 2: issue-slot model -- cycles per v_mfma_f32_32x32x16_bf16 with 0..12 independent VALU between consecutive
+// MFMAs of ONE wave (1 or 2 waves per SIMD), i.e. how much element-wise work hides in the MFMA shadow.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+
+__global__ void probe(unsigned short* out) {
+    __shared__ __attribute__((aligned(16))) unsigned short lds[1024];
+    for (int i = threadIdx.x; i < 1024; i += 64) lds[i] = (unsigned short)i;
+    __syncthreads();
+    const int l = threadIdx.x;
+    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds + 4 * l));
+    for (int j = 0; j < 4; ++j) out[l * 4 + j] = (unsigned short)v[j];
+}
+
+template <int NV>
+__global__ __launch_bounds__(512) void shadow(float* out, int iters, int waves_active) {
+    const int wave = threadIdx.x >> 6;
+    if (wave >= waves_active) return;
+    f32x16 a0 = {0}, a1 = {0}, a2 = {0}, a3 = {0};
+    union { bf16x8 v; unsigned short h[8]; } x, y;
+    for (int j = 0; j < 8; ++j) { x.h[j] = 0x3f80 + (threadIdx.x & 7); y.h[j] = 0x3f00 + j; }
+    float v[12];
+    for (int j = 0; j < 12; ++j) v[j] = threadIdx.x * 1e-3f + j;
+    const float c = 0.999f, d = 1e-3f;
+    for (int i = 0; i < iters; ++i) {
+#define STEP(acc) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x.v, y.v, acc, 0, 0, 0); \
+        _Pragma("unroll") for (int j = 0; j < NV; ++j) v[j] = fmaf(v[j], c, d);
+        STEP(a0) STEP(a1) STEP(a2) STEP(a3)
+#undef STEP
+    }
+    float r = a0[0] + a1[1] + a2[2] + a3[3];
+    for (int j = 0; j < 12; ++j) r += v[j];
+    if (r == 12345.678f) out[threadIdx.x] = r;
+}
+
+template <int NV>
+float run(int iters, int waves) {
+    float* out; hipMalloc(&out, 4096);
+    hipEvent_t s, e; hipEventCreate(&s); hipEventCreate(&e);
+    shadow<NV><<<256, 512>>>(out, iters, waves); hipDeviceSynchronize();
+    hipEventRecord(s);
+    for (int i = 0; i < 5; ++i) shadow<NV><<<256, 512>>>(out, iters, waves);
+    hipEventRecord(e); hipEventSynchronize(e);
+    float ms; hipEventElapsedTime(&ms, s, e); hipFree(out);
+    return ms / 5;
+}
+
+int main() {
+    unsigned short* d; hipMalloc(&d, 512);
+    probe<<<1, 64>>>(d);
+    std::vector<unsigned short> h(256);
+    hipMemcpy(h.data(), d, 512, hipMemcpyDeviceToHost);
+    int ok = 1;
+    for (int l = 0; l < 64; ++l) {
+        printf("lane %2d:", l);
+        for (int j = 0; j < 4; ++j) {
+            const int idx = h[l * 4 + j];
+            printf("  [src lane %2d pos %d]", idx >> 2, idx & 3);
+            const int t = l & 15, g = l & ~15;
+            if (idx != 4 * (g + 4 * j + (t >> 2)) + (t & 3)) ok = 0;
+        }
+        printf("\n");
+    }
+    printf("tr16 semantic as expected (result[t][j] = lane 4j + t/4, pos t%%4 within the 16-lane group): %s\n", ok ? "YES" : "NO");
+    const int iters = 4000;       // 16000 MFMAs per wave
+#define ROW(NV) { const float t4 = run<NV>(iters, 4), t8 = run<NV>(iters, 8); \
+        printf("VALU per MFMA %2d: 1 wave/SIMD %.3f ms = %.1f cyc/MFMA;  2 waves/SIMD %.3f ms = %.1f cyc per MFMA-pair-slot (per wave-MFMA %.1f)\n", \
+               NV, t4, t4 * 2.4e6 / (4.0 * iters), t8, t8 * 2.4e6 / (4.0 * iters), t8 * 2.4e6 / (8.0 * iters)); }
+    ROW(0) ROW(2) ROW(4) ROW(6) ROW(8) ROW(12)
+    return 0;
+}
