@@ -1,29 +1,43 @@
 // K-HEADS: the output heads of the autoencoder as ONE kernel -- forward GEMM of the three
 // Dense heads, NB / ZINB negative log-likelihood + gradient, weight/bias gradient and input
 // gradient -- so that the [cells x genes] pre-activation and gradient planes never exist in
-// HBM.  gfx950 (MI355X), wave64, fp32 MFMA (v_mfma_f32_32x32x2_f32, exact fp32).
+// HBM.  gfx950 (MI355X), wave64.
 //
 // Reference path replaced: dca/network.py:369-385 (pi / dispersion / mean Dense heads,
 // ColwiseMultLayer, SliceLayer, ZINB loss closure), dca/network.py:38-39, dca/layers.py:21,85,
 // dca/loss.py:72-156 and TensorFlow's autodiff of all of it.
 //
+// Arithmetic of the three matrix products: fp32 results on the bf16 matrix pipe.  Every fp32 operand is
+// split into three bf16 pieces (x = x1 + x2 + x3, round-to-nearest residuals) and the six products
+// a1b1, a1b2, a2b1, a1b3, a2b2, a3b1 are accumulated in fp32 by v_mfma_f32_32x32x16_bf16: the dropped terms
+// are below 2^-24 of sum|ab|, measured error 1.0e-7 of sum|ab| against 1.8e-7 for the fp32 MFMA
+// (tools/microbench/bf16x3_mfma.hip), at 6/16 of its matrix-pipe cycles.  The fp32 MFMA runs at the VECTOR
+// rate on gfx950 and shares the SIMD with the likelihood arithmetic; this form does not.
+// (The first implementation, on v_mfma_f32_32x32x2_f32, is kept below for A/B runs: DCA_HEADS_F32MFMA=1.)
+//
 // Work decomposition (gene-stationary):
-//   * a wave owns one 32-gene tile of every head and a strided set of 32-row batch tiles;
-//     a workgroup = kWG gene tiles x WR row slots; the [hL x 32 genes x heads] slice of the
-//     head weights sits in LDS for the lifetime of the workgroup, the wave's weight-gradient
-//     slice ([hL x 32] per head) in MFMA accumulators for the lifetime of the wave.
+//   * a workgroup owns ONE 32-gene tile of every head: its [hL x 32 x heads] slice of the head weights sits in
+//     LDS for the lifetime of the workgroup as bf16 pieces, ONE image serving both orientations (the forward
+//     contracts over hidden units and reads it with the transposing ds_read_b64_tr_b16, dH contracts over
+//     genes and reads it directly; a 16-byte-unit rotation per row keeps both conflict-free);
+//   * its 8 waves take strided 32-row batch tiles; a wave's weight-gradient slice ([hL x 32] per head) lives
+//     in MFMA accumulators for the lifetime of the wave;
+//   * the decoder output H is split once per launch by a small kernel into bf16 pieces in the two operand
+//     layouts the loop needs (rows x k for the forward, k x rows for dW): A operands are plain 16-byte loads;
 //   * per (row tile, gene tile):
-//       F   pre-activations  A = H W + b        32 rows x 32 genes x heads, K = hL
-//       Z   NLL + d NLL / d A   element-wise, through a wave-private LDS staging tile
-//       Bk  dW += H^T D   (D read from staging in exactly the MFMA B-operand layout)
-//           dH  = D W^T   (D read transposed from the same staging tile) -> partial per gene tile
-//     No workgroup barrier inside the loop: waves drift apart, so one wave's transcendental
-//     (VALU) phase overlaps its SIMD partner's MFMA phases.
+//       F   pre-activations  A = H W + b        32 rows x 32 genes x heads, K = 64
+//       Z   NLL + d NLL / d A   element-wise, through a wave-private fp32 LDS staging tile (the y = 0
+//           formulas densely, the non-zero elements compacted into 64-lane batches)
+//       dH  = D W^T   (D read transposed from the staging tile, split on the fly) -> partial per gene tile
+//       dW += H^T D   (a lane's staged D column IS its B operand)
+//     No workgroup barrier inside the loop: waves drift apart, one wave's element-wise phase runs beside
+//     its SIMD partner's matrix phases.
 //   * HBM traffic per element: y (4 B) + the dH partial (8 B written, 8 B re-read by the
 //     reduce) instead of 36 B for materialised pre-activations / gradients + 28 B K-ZINB.
 //   * deterministic: fixed summation orders everywhere (no atomics).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <type_traits>
 #include "dcahip.h"
 #include "zinb_math.hpp"
@@ -590,6 +604,570 @@ __global__ __launch_bounds__(64 * kWG * WR) void heads_fused_kernel(HeadsArgs p)
 #endif
 }
 
+// =====================================================================================================
+// bf16 x 3 implementation (the product path)
+// =====================================================================================================
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x2v = __attribute__((ext_vector_type(2))) __bf16;
+using f32x2v = __attribute__((ext_vector_type(2))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+using s16x4 = __attribute__((ext_vector_type(4))) short;
+
+constexpr int kWR2 = 8;                 // row slots (waves) per workgroup, one gene tile per workgroup
+constexpr int kHTile = 3 * 32 * 64;     // bf16 elements of one row tile of the split decoder output (3 pieces x 32 x 64)
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0)
+
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {           // v_cvt_pk_bf16_f32: a -> low half
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{a, b}, bf16x2v));
+}
+// x = p0 + p1 + p2 (bf16 each, round-to-nearest residuals), two values per call; |x - sum| <= 2^-26 |x|
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& p0, unsigned& p1, unsigned& p2) {
+    p0 = pk_bf16(x0, x1);
+    const float r0 = x0 - __uint_as_float(p0 << 16), r1 = x1 - __uint_as_float(p0 & 0xffff0000u);
+    p1 = pk_bf16(r0, r1);
+    const float q0 = r0 - __uint_as_float(p1 << 16), q1 = r1 - __uint_as_float(p1 & 0xffff0000u);
+    p2 = pk_bf16(q0, q1);
+}
+// eight fp32 values -> three MFMA operand fragments (element j of the fragment = value j)
+__device__ __forceinline__ void split8(const float (&x)[8], u32x4 (&f)[3]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        unsigned a, b, c;
+        split_pair(x[2 * j], x[2 * j + 1], a, b, c);
+        f[0][j] = a; f[1][j] = b; f[2][j] = c;
+    }
+}
+// the six products of one K = 16 step, small terms first
+#define MFMA_X3(A, Bf, ACC) { ACC = MFMA16(A[2], Bf[0], ACC); ACC = MFMA16(A[1], Bf[1], ACC); ACC = MFMA16(A[0], Bf[2], ACC); \
+                              ACC = MFMA16(A[1], Bf[0], ACC); ACC = MFMA16(A[0], Bf[1], ACC); ACC = MFMA16(A[0], Bf[0], ACC); }
+
+struct HeadsArgs2 {
+    long long* timing;
+    const unsigned short* HA;         // [NT][3][32 rows][64 k] bf16 pieces of the decoder output (forward A operand)
+    const unsigned short* HT;         // [NT][3][64 k][32 rows, order of the MFMA row map] (dW A operand)
+    const float* Wh; long ldw;
+    const float* bh;
+    const float* theta_w;
+    const float* y;  long ldy;
+    const float* sf;
+    const int* perm;
+    const long long* cursor;
+    float* ws_dw;  long dw_stride;   // [S][(hL + 2)][ldws]
+    float* ws_dh;                     // [NT][ntg][32][64]
+    int ntg;
+    const int* tile_order;
+    double* partials;
+    long plane, ldws;
+    int B, hL, G;
+    int S, NT;
+    float ridge, inv_n;
+};
+
+// Decoder output -> bf16 pieces, once per launch (B x 64 elements: ~1 us).  One 32-row tile per block.
+__global__ __launch_bounds__(256) void heads_split_h_kernel(const float* H, long ldh, int B, int hL,
+                                                            unsigned short* HA, unsigned short* HT) {
+    __shared__ unsigned short tr[3][64][32 + 2];
+    const int t = blockIdx.x, tid = threadIdx.x;
+    const int row = tid >> 3, k0 = (tid & 7) * 8;
+    const long grow = (long)t * 32 + row;
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = (grow < B && k0 + j < hL) ? H[grow * ldh + k0 + j] : 0.f;
+    u32x4 f[3];
+    split8(x, f);
+    // row -> position inside the tile's transposed image: the order in which a lane of the 32x32 MFMA result
+    // holds its rows (row bits 2 and 3 swapped), so that 8 consecutive positions are one K = 16 operand half
+    const int pos = (row & 0x13) | ((row & 4) << 1) | ((row & 8) >> 1);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        *reinterpret_cast<u32x4*>(HA + (((long)t * 3 + q) * 32 + row) * 64 + k0) = f[q];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tr[q][k0 + j][pos] = (unsigned short)(f[q][j >> 1] >> (16 * (j & 1)));
+    }
+    __syncthreads();
+    for (int c = tid; c < 3 * 64 * 4; c += 256) {           // 16-byte chunks of [3][64][32]
+        const int q = c >> 8, i = (c >> 2) & 63, part = c & 3;
+        u32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (unsigned)tr[q][i][part * 8 + 2 * j] | ((unsigned)tr[q][i][part * 8 + 2 * j + 1] << 16);
+        *reinterpret_cast<u32x4*>(HT + (((long)t * 3 + q) * 64 + i) * 32 + part * 8) = v;
+    }
+}
+
+template <bool HAS_PI, bool CONST_DISP, int WR>
+__global__ __launch_bounds__(64 * WR) void heads_fused_x3_kernel(HeadsArgs2 p) {
+    constexpr int NH = 1 + (CONST_DISP ? 0 : 1) + (HAS_PI ? 1 : 0);
+    constexpr int PI_H = NH - 1;
+    constexpr int KT = 64;
+    constexpr int ST_PLANE = kTG * kLdS;
+    constexpr int NP = NH + (CONST_DISP ? 1 : 0);
+    constexpr int TH_P = NH;
+    constexpr int ST_WAVE = NP * ST_PLANE;
+    constexpr int NTHREADS = 64 * WR;
+    constexpr int W_PIECE = 64 * 64;                       // bytes of one (head, piece) weight image: 64 k x 32 genes bf16
+    constexpr int W_FLOATS = NH * 3 * W_PIECE / 4;
+    constexpr int NRED = NH * 2 * 16 + NH + 1;
+    constexpr int LDS_FLOATS = W_FLOATS + WR * (ST_WAVE + kQCap);
+    static_assert(WR == 1 || (WR / 2) * NRED * 64 <= LDS_FLOATS, "dW reduce scratch");
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    __shared__ double lred[WR];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef DCA_HEADS_TIMING
+    const long long t_entry = __builtin_readcyclecounter();
+    long long t_loop0 = t_entry, t_loop1 = t_entry;
+#endif
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int r = wave;
+    const int s = blockIdx.x % p.S, gb = blockIdx.x / p.S;
+    const int gt = p.tile_order ? p.tile_order[gb] : gb;
+    const int g0 = gt * kTG;
+    const int gene = g0 + l31;
+    const bool tile_ok = g0 < p.G;
+    const bool gvalid = gene < p.G;
+    const long long cur = p.cursor ? *p.cursor : 0;
+
+    unsigned char* const Wimg = reinterpret_cast<unsigned char*>(lds);
+    float* St = lds + W_FLOATS + wave * ST_WAVE;
+    unsigned* Q = reinterpret_cast<unsigned*>(lds + W_FLOATS + WR * ST_WAVE) + wave * kQCap;
+
+    // ---- head weights of this gene tile -> LDS as bf16 pieces, image [head][piece][k][32 genes], the four
+    // 16-byte units of a row rotated by (k >> 2): conflict-free for the direct 16-byte reads of dH (lanes = rows k)
+    // and for the transposing reads of F (4 consecutive rows per lane group)
+    if (tile_ok) {
+        for (int idx = tid; idx < NH * 64 * 8; idx += NTHREADS) {
+            const int c4 = idx & 7, k = (idx >> 3) & 63, h = idx >> 9;
+            const int gcol = g0 + c4 * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < p.hL && gcol < p.plane)
+                v = *reinterpret_cast<const float4*>(p.Wh + (long)k * p.ldw + (long)h * p.plane + gcol);
+            if (gcol + 0 >= p.G) v.x = 0.f;
+            if (gcol + 1 >= p.G) v.y = 0.f;
+            if (gcol + 2 >= p.G) v.z = 0.f;
+            if (gcol + 3 >= p.G) v.w = 0.f;
+            unsigned a0, a1, a2, b0, b1, b2;
+            split_pair(v.x, v.y, a0, a1, a2);
+            split_pair(v.z, v.w, b0, b1, b2);
+            const int off = k * 64 + ((((c4 >> 1) + (k >> 2)) & 3) << 4) + ((c4 & 1) << 3);
+            *reinterpret_cast<u32x2*>(Wimg + (h * 3 + 0) * W_PIECE + off) = u32x2{a0, b0};
+            *reinterpret_cast<u32x2*>(Wimg + (h * 3 + 1) * W_PIECE + off) = u32x2{a1, b1};
+            *reinterpret_cast<u32x2*>(Wimg + (h * 3 + 2) * W_PIECE + off) = u32x2{a2, b2};
+        }
+    }
+    __syncthreads();
+
+    f32x16 dW[NH][2];
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) dW[h][ib][e] = 0.f;
+    float bsum[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) bsum[h] = 0.f;
+    float thsum = 0.f;
+    double dacc = 0.0;
+
+    if (tile_ok) {
+        float bias[NH];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) bias[h] = gvalid ? p.bh[(long)h * p.plane + gene] : 0.f;
+        const float thw = (CONST_DISP && gvalid) ? p.theta_w[gene] : 0.f;
+
+        const int gene_c = gvalid ? gene : p.G - 1;
+        const float* const ycol = p.y + gene_c;
+        const unsigned ldy_u = (unsigned)p.ldy;
+        const int tstep = p.S * WR;
+        int t = s * WR + r;
+        const long dh_tstride = (long)p.ntg * (kTR * KT);
+        float* const dh_base = p.ws_dh + (long)gt * (kTR * KT) + l31;
+        int srow_l = 0;
+        float sf_l = 1.f;
+        float yA[kZU], yB[kZU];
+        auto row_clamped = [&](int tt) { const int rl = tt * kTR + l31; return rl < p.B ? rl : p.B - 1; };
+        auto load_srow = [&](int tt) { const int rlc = row_clamped(tt); return p.perm ? p.perm[cur + rlc] : (int)(cur + rlc); };
+        // split decoder output through buffer resources: (per-lane offset fixed for the whole kernel) + (tile offset
+        // in an SGPR) + immediate
+        const __amdgpu_buffer_rsrc_t ha_rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<unsigned short*>(p.HA), 0, p.NT * (kHTile * 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t ht_rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<unsigned short*>(p.HT), 0, p.NT * (kHTile * 2), 0x00020000);
+        const int ha_lane = l31 * 128 + hi * 64;       // row l31, this lane half's 32 hidden units (4 K steps x 8)
+        const int ht_lane = l31 * 64 + hi * 16;        // hidden unit l31 (+ 32 ib), rows of K-step half hi
+        // forward A operands [piece] of one K step and dW A operands [piece][ib] of one K step: requested one step
+        // ahead of their use (the first forward step of the NEXT tile during the dW products of this one), never the
+        // whole tile at once -- the weight-gradient accumulators (96 registers) leave no room for that
+        u32x4 ha0[3];
+        auto load_ha = [&](int tt, int ks, u32x4 (&dst)[3]) {
+            const int so = tt * (kHTile * 2);
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                dst[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ha_rs, ha_lane + q * 4096 + ks * 16, so, 0));
+        };
+        auto load_ht = [&](int tt, int ks, u32x4 (&dst)[3][2]) {
+            const int so = tt * (kHTile * 2);
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int ib = 0; ib < 2; ++ib)
+                    dst[q][ib] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                        ht_rs, ht_lane + q * 4096 + ib * 2048 + ks * 32, so, 0));
+        };
+        // LDS addresses of the weight image.  Transposing read (F): lane t of a 16-lane group supplies the 8-byte
+        // chunk (row kk + t / 4, genes 16 (group & 1) + 4 (t & 3) ..) and receives rows kk .. kk + 3 of gene
+        // 16 (group & 1) + t.  kk = 32 hi + 8 ks (+ 4): its rotation (kk >> 2) & 3 = (2 ks (+ 1)) & 3 is a compile-time
+        // constant, the lane part of the address one of four precomputed values.
+        const int t16 = lane & 15, c8 = 4 * ((lane >> 4) & 1) + (t16 & 3);
+        int wtr[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+            wtr[rr] = hi * 2048 + (t16 >> 2) * 64 + ((((c8 >> 1) + rr) & 3) << 4) + ((c8 & 1) << 3);
+        // direct read (dH): lane = hidden unit l31 (+ 32 jb), 8 genes 16 gs + 8 hi: unit (2 gs + hi + rotation)
+        int wdr[2];
+#pragma unroll
+        for (int gs = 0; gs < 2; ++gs) wdr[gs] = l31 * 64 + (((2 * gs + hi + (l31 >> 2)) & 3) << 4);
+        auto w_tr = [&](int h, int q, int ks) {           // B operand of F: gene l31, k = 32 hi + 8 ks .. + 7
+            const unsigned char* b0 = Wimg + (h * 3 + q) * W_PIECE + ks * 512;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) s16x4*)(b0 + wtr[(2 * ks) & 3]));
+            const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) s16x4*)(b0 + 256 + wtr[(2 * ks + 1) & 3]));
+            u32x4 o;
+            const u32x2 a = __builtin_bit_cast(u32x2, lo), b = __builtin_bit_cast(u32x2, hi4);
+            o[0] = a[0]; o[1] = a[1]; o[2] = b[0]; o[3] = b[1];
+            return o;
+        };
+        auto w_dr = [&](int h, int q, int jb, int gs) {   // B operand of dH: hidden unit l31 + 32 jb, genes 16 gs + 8 hi ..
+            return *reinterpret_cast<const u32x4*>(Wimg + (h * 3 + q) * W_PIECE + jb * 2048 + wdr[gs]);
+        };
+
+        if (t < p.NT) {
+            srow_l = load_srow(t);
+            sf_l = p.sf[srow_l];
+            load_ha(t, 0, ha0);
+#pragma unroll
+            for (int j = 0; j < kZU; ++j) {
+                const int sr = __shfl(srow_l, rowmap(j, hi), 64);
+                yA[j] = ycol[(unsigned long long)(unsigned)sr * ldy_u];
+            }
+        }
+#ifdef DCA_HEADS_TIMING
+        long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        long long tlast = __builtin_readcyclecounter();
+        t_loop0 = tlast;
+#endif
+        int tile_no = wave >> 2;
+        for (; t < p.NT; t += tstep) {
+            if (WR == 8) { if ((tile_no++) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+            TSTAMP(0)
+            const int row0 = t * kTR;
+            const int tn = t + tstep < p.NT ? t + tstep : t;
+            // ---- F: pre-activations, K = 64 as 4 steps of 16 (lane half hi covers k in [32 hi, 32 hi + 32))
+            f32x16 acc[NH];
+#pragma unroll
+            for (int h = 0; h < NH; ++h)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[h][e] = 0.f;
+            {
+                u32x4 hb[2][3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) hb[0][q] = ha0[q];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    if (ks < 3) load_ha(t, ks + 1, hb[(ks + 1) & 1]);
+#pragma unroll
+                    for (int h = 0; h < NH; ++h) {
+                        u32x4 bf[3] = {w_tr(h, 0, ks), w_tr(h, 1, ks), w_tr(h, 2, ks)};
+                        MFMA_X3(hb[ks & 1], bf, acc[h])
+                    }
+                }
+            }
+            TSTAMP(1)
+            TSTAMP(2)
+            // ---- stage [gene][row] (row stride 1, gene stride 33)
+#pragma unroll
+            for (int h = 0; h < NH; ++h)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    St[h * ST_PLANE + l31 * kLdS + rowmap(e, hi)] = acc[h][e] + bias[h];
+            const int srow_n = load_srow(tn);
+            wave_sync();
+            TSTAMP(3)
+
+            // ---- Z: element-wise likelihood and gradient (dense y = 0 pass + compacted non-zero pass)
+            float lacc = 0.f;
+            int qn = 0;
+            auto z_dense = [&](auto fullv, int grp, const float (&yv)[kZU]) {
+                constexpr bool FULLV = decltype(fullv)::value;
+                float i_am[kZU], i_ad[kZU], i_ap[kZU];
+#pragma unroll
+                for (int j = 0; j < kZU; ++j) {
+                    const int row = rowmap(grp * kZU + j, hi);
+                    const int idx = l31 * kLdS + row;
+                    i_am[j] = St[idx];
+                    i_ad[j] = CONST_DISP ? thw : St[ST_PLANE + idx];
+                    i_ap[j] = HAS_PI ? St[PI_H * ST_PLANE + idx] : 0.f;
+                }
+                float o_m[kZU], o_d[kZU], o_p[kZU];
+                bool o_nz[kZU];
+#pragma unroll
+                for (int j = 0; j < kZU; ++j) {
+                    const int row = rowmap(grp * kZU + j, hi);
+                    const bool valid = FULLV || ((row0 + row < p.B) && gvalid);
+                    const float yj = yv[j];
+                    const bool nz = valid && (HAS_PI ? !(yj < kZeroThresh) : (yj != 0.f));
+                    if (HAS_PI) {
+                        float gmv, gdv, gpv;
+                        const float nll = zinb_zero_elem<CONST_DISP>(i_am[j], i_ad[j], i_ap[j], __shfl(sf_l, row, 64), p.ridge, gmv, gdv, gpv);
+                        const float sc = valid ? p.inv_n : 0.f;
+                        lacc += (valid && !nz) ? nll : 0.f;
+                        o_m[j] = gmv * sc;
+                        o_d[j] = gdv * sc;
+                        o_p[j] = gpv * sc;
+                    } else {
+                        float gmv, gdv;
+                        const float nll = nb_zero_elem<CONST_DISP>(i_am[j], i_ad[j], __shfl(sf_l, row, 64), gmv, gdv);
+                        const float sc = valid ? p.inv_n : 0.f;
+                        lacc += (valid && !nz) ? nll : 0.f;
+                        o_m[j] = gmv * sc;
+                        o_d[j] = gdv * sc;
+                        o_p[j] = 0.f;
+                    }
+                    o_nz[j] = nz;
+                }
+#pragma unroll
+                for (int j = 0; j < kZU; ++j) {
+                    const int row = rowmap(grp * kZU + j, hi);
+                    const int idx = l31 * kLdS + row;
+                    const bool nz = o_nz[j];
+                    const unsigned long long m = __ballot(nz);
+                    const int slot = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                    if (nz) {
+                        const float yj = yv[j];
+                        const unsigned y16 = (yj < 65535.f && yj == floorf(yj)) ? (unsigned)yj : 0xFFFFu;
+                        Q[slot] = (unsigned)idx | (y16 << 16);
+                    } else {
+                        St[idx] = o_m[j];
+                        if (CONST_DISP) St[TH_P * ST_PLANE + idx] = o_d[j]; else St[ST_PLANE + idx] = o_d[j];
+                        if (HAS_PI) St[PI_H * ST_PLANE + idx] = o_p[j];
+                    }
+                    qn += __popcll(m);
+                }
+            };
+            auto z_sparse = [&](int q0, int cnt) {
+                const bool act = lane < cnt;
+                const unsigned e = Q[q0 + (act ? lane : 0)];
+                const int idx = e & 2047;
+                const int gq = (idx * 1986) >> 16;          // idx / 33 for idx < 1056
+                const int row = idx - gq * kLdS;
+                const float sfr = __shfl(sf_l, row, 64);
+                const int sr = __shfl(srow_l, row, 64);
+                const float am = St[idx];
+                const float ad = CONST_DISP ? __shfl(thw, gq, 64) : St[ST_PLANE + idx];
+                const float ap = HAS_PI ? St[PI_H * ST_PLANE + idx] : 0.f;
+                float yq = (float)(e >> 16);
+                if ((e >> 16) == 0xFFFFu) yq = p.y[(long)sr * p.ldy + g0 + gq];
+                float o1, o2, o3 = 0.f, nll;
+                if (HAS_PI) {
+                    nll = zinb_nz_elem<CONST_DISP>(am, ad, ap, sfr, yq, p.ridge, o1, o2, o3);
+                } else {
+                    float dmu = 0.f, dth = 0.f, dpi = 0.f;
+                    const Heads hd = head_acts<HAS_PI, CONST_DISP>(am, ad, ap, sfr);
+                    nll = nll_elem<HAS_PI, true, true>(hd, yq, p.ridge, dmu, dth, dpi);
+                    o1 = dmu * hd.gm; o2 = dth * hd.gd;
+                }
+                lacc += act ? nll : 0.f;
+                if (act) {
+                    St[idx] = o1 * p.inv_n;
+                    const float od = o2 * p.inv_n;
+                    if (CONST_DISP) St[TH_P * ST_PLANE + idx] = od; else St[ST_PLANE + idx] = od;
+                    if (HAS_PI) St[PI_H * ST_PLANE + idx] = o3 * p.inv_n;
+                }
+            };
+            auto z_flush = [&](bool last) {
+                while (qn >= 64 || (last && qn > 0)) {
+                    const int c = qn < 64 ? qn : 64;
+                    wave_sync();
+                    z_sparse(qn - c, c);
+                    qn -= c;
+                }
+            };
+            auto load_y = [&](int srow_src, int grp, float (&yv)[kZU]) {
+#pragma unroll
+                for (int j = 0; j < kZU; ++j) {
+                    const int sr = __shfl(srow_src, rowmap(grp * kZU + j, hi), 64);
+                    yv[j] = ycol[(unsigned long long)(unsigned)sr * ldy_u];
+                }
+            };
+            auto z_loop = [&](auto fullv) {
+#pragma unroll 1
+                for (int it = 0; it < 16 / (2 * kZU); ++it) {
+                    const bool last = it + 1 == 16 / (2 * kZU);
+                    load_y(srow_l, 2 * it + 1, yB);
+                    z_dense(fullv, 2 * it, yA);
+                    z_flush(false);
+                    if (!last) load_y(srow_l, 2 * it + 2, yA);
+                    else load_y(srow_n, 0, yA);
+                    z_dense(fullv, 2 * it + 1, yB);
+                    z_flush(last);
+                }
+            };
+            if (row0 + kTR <= p.B && g0 + kTG <= p.G) z_loop(std::true_type{}); else z_loop(std::false_type{});
+            dacc += (double)lacc;
+            const float sf_n = p.sf[srow_n];
+            wave_sync();
+            TSTAMP(4)
+
+            // ---- dH[row, i] = sum_genes D[row, gene] W[i, gene]: A = D read transposed from the staging tile
+            // (row l31, 8 genes per K-step half) and split on the fly, B = the weight image read directly
+            u32x4 htb[2][3][2];
+            load_ht(t, 0, htb[0]);                   // first K step of the dW operands: in flight during the dH products
+            {
+                f32x16 dHa[2];
+#pragma unroll
+                for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) dHa[jb][e] = 0.f;
+#pragma unroll
+                for (int h = 0; h < NH; ++h)
+#pragma unroll
+                    for (int gs = 0; gs < 2; ++gs) {
+                        float dv[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) dv[j] = St[h * ST_PLANE + (16 * gs + 8 * hi + j) * kLdS + l31];
+                        u32x4 af[3];
+                        split8(dv, af);
+#pragma unroll
+                        for (int jb = 0; jb < 2; ++jb) {
+                            u32x4 bf[3] = {w_dr(h, 0, jb, gs), w_dr(h, 1, jb, gs), w_dr(h, 2, jb, gs)};
+                            MFMA_X3(af, bf, dHa[jb])
+                        }
+                    }
+                TSTAMP(7)
+                float* dst = dh_base + (long)t * dh_tstride;
+#pragma unroll
+                for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) dst[rowmap(e, hi) * KT + jb * 32] = dHa[jb][e];
+            }
+            load_ht(t, 1, htb[1]);
+            load_ha(tn, 0, ha0);                     // next tile's first forward step: in flight during the dW products
+            TSTAMP(5)
+            // ---- dW[i, gene] += sum_rows H[row, i] D[row, gene]: B = the lane's own staged D column (rows in
+            // the order of the MFMA row map = the order of the transposed H image), A = H^T pieces
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int h = 0; h < NH; ++h) {
+                    float dv[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        dv[j] = St[h * ST_PLANE + l31 * kLdS + rowmap(8 * ks + j, hi)];
+                        bsum[h] += dv[j];
+                    }
+                    u32x4 bf[3];
+                    split8(dv, bf);
+#pragma unroll
+                    for (int ib = 0; ib < 2; ++ib) {
+                        u32x4 af[3] = {htb[ks][0][ib], htb[ks][1][ib], htb[ks][2][ib]};
+                        MFMA_X3(af, bf, dW[h][ib])
+                    }
+                }
+            if (CONST_DISP) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) thsum += St[TH_P * ST_PLANE + l31 * kLdS + rowmap(e, hi)];
+            }
+            srow_l = srow_n;
+            sf_l = sf_n;
+            wave_sync();
+            TSTAMP(6)
+        }
+#ifdef DCA_HEADS_TIMING
+        t_loop1 = __builtin_readcyclecounter();
+        if (p.timing && lane == 0)
+            for (int i = 0; i < 8; ++i) p.timing[((long)blockIdx.x * WR + wave) * 10 + i] = tacc[i];
+#endif
+    }
+
+    // ---- loss: wave -> workgroup -> one partial per workgroup
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) dacc += __shfl_down(dacc, off, 64);
+    if (lane == 0) lred[wave] = dacc;
+    __syncthreads();                      // also: every wave is done with the LDS weights / staging
+    if (tid == 0) {
+        double v = 0.0;
+        for (int w = 0; w < WR; ++w) v += lred[w];
+        p.partials[blockIdx.x] = v;
+    }
+
+    // ---- dW / bias-gradient sums of the WR row slots: ordered tree through LDS
+    if (WR > 1) {
+        float* red = lds;
+#pragma unroll
+        for (int step = 1; step < WR; step *= 2) {
+            const int slot = r / (2 * step);
+            float* rs = red + (long)slot * NRED * 64 + lane;
+            if (r % (2 * step) == step) {
+                int n = 0;
+#pragma unroll
+                for (int h = 0; h < NH; ++h)
+#pragma unroll
+                    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) rs[(n++) * 64] = dW[h][ib][e];
+#pragma unroll
+                for (int h = 0; h < NH; ++h) rs[(n++) * 64] = bsum[h];
+                rs[(n++) * 64] = thsum;
+            }
+            __syncthreads();
+            if (r % (2 * step) == 0 && r + step < WR) {
+                int n = 0;
+#pragma unroll
+                for (int h = 0; h < NH; ++h)
+#pragma unroll
+                    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) dW[h][ib][e] += rs[(n++) * 64];
+#pragma unroll
+                for (int h = 0; h < NH; ++h) bsum[h] += rs[(n++) * 64];
+                thsum += rs[(n++) * 64];
+            }
+            __syncthreads();
+        }
+    }
+    if (r == 0 && tile_ok) {
+        float* out = p.ws_dw + (long)s * p.dw_stride;
+        const bool cw = gene < p.plane;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int i = ib * 32 + rowmap(e, hi);
+                    if (cw && i < p.hL) out[(long)i * p.ldws + (long)h * p.plane + gene] = dW[h][ib][e];
+                }
+            const float bv = bsum[h] + __shfl_xor(bsum[h], 32, 64);
+            if (cw && hi == 0) out[(long)p.hL * p.ldws + (long)h * p.plane + gene] = bv;
+        }
+        if (CONST_DISP) {
+            const float tv = thsum + __shfl_xor(thsum, 32, 64);
+            if (cw && hi == 0) out[(long)(p.hL + 1) * p.ldws + gene] = tv;
+        }
+    }
+#ifdef DCA_HEADS_TIMING
+    if (p.timing && lane == 0) {
+        long long* tp = p.timing + ((long)blockIdx.x * WR + wave) * 10;
+        tp[8] = t_loop0 - t_entry;
+        tp[9] = (long long)__builtin_readcyclecounter() - t_loop1;
+    }
+#endif
+}
+
 // gW[i, col] = sum_s ws[s][i][col], i = 0..hL (row hL = bias gradient), then the
 // ConstantDispersionLayer chain (dca/layers.py:17-21) on the per-gene theta sums.
 __global__ __launch_bounds__(256) void heads_reduce_dw_kernel(const float* ws, int S, long stride,
@@ -656,10 +1234,16 @@ __global__ __launch_bounds__(256) void heads_reduce_dh_kernel(const float* ws, i
 
 struct HeadsPlan {
     int HLB, WR, S, NT, ntg, ngb, grid;
-    long ldws, dw_stride, dw_bytes, dh_bytes;
+    long ldws, dw_stride, dw_bytes, dh_bytes, hs_bytes;
 };
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// DCA_HEADS_F32MFMA=1: the first implementation (fp32 MFMA, two gene tiles per workgroup), for A/B runs only
+inline bool use_f32_mfma() {
+    static const bool v = [] { const char* e = getenv("DCA_HEADS_F32MFMA"); return e && e[0] == '1'; }();
+    return v;
+}
 
 // a pure function of the shape: row slots per workgroup, batch splits, workspace layout
 bool make_heads_plan(int B, int hL, int G, long plane, int flags, HeadsPlan* out) {
@@ -668,13 +1252,15 @@ bool make_heads_plan(int B, int hL, int G, long plane, int flags, HeadsPlan* out
     if (B > (1 << 22)) return false;                 // H is addressed through a 32-bit buffer resource (B x 64 floats)
     const bool has_pi = flags & DCAHIP_NLL_HAS_PI, cdisp = flags & DCAHIP_NLL_CONST_DISP;
     const int NH = 1 + (cdisp ? 0 : 1) + (has_pi ? 1 : 0);
+    const bool f32 = use_f32_mfma();
+    const int wg_tiles = f32 ? kWG : 1;              // gene tiles per workgroup
     HeadsPlan p;
     p.HLB = 2;
     p.NT = (B + kTR - 1) / kTR;
     p.ntg = (G + kTG - 1) / kTG;
-    p.ngb = (p.ntg + kWG - 1) / kWG;
+    p.ngb = (p.ntg + wg_tiles - 1) / wg_tiles;
     if (p.ngb > kMaxGrid) return false;
-    p.WR = p.NT >= 4 ? 4 : 1;
+    p.WR = f32 ? (p.NT >= 4 ? 4 : 1) : (p.NT >= kWR2 ? kWR2 : 1);
     const int smax = (p.NT + p.WR - 1) / p.WR;
     double best = 1e300;
     p.S = 1;
@@ -690,6 +1276,7 @@ bool make_heads_plan(int B, int hL, int G, long plane, int flags, HeadsPlan* out
     p.dw_stride = (long)(hL + 2) * p.ldws;
     p.dw_bytes = (long)p.S * p.dw_stride * (long)sizeof(float);
     p.dh_bytes = (long)p.ntg * p.NT * kTR * (p.HLB * 32) * (long)sizeof(float);
+    p.hs_bytes = f32 ? 0 : 2L * p.NT * kHTile * 2;   // split decoder output, both layouts
     *out = p;
     return true;
 }
@@ -705,6 +1292,35 @@ void launch_fused(const HeadsPlan& pl, const HeadsArgs& a, hipStream_t s) {
 #undef DCA_LF
 }
 
+// C [32, 32] = A [32, K] B [K, 32] with the operand split and the six bf16 products of K-HEADS, one wave
+// (dcahip_x3_product_32x32: the accuracy contract of the matrix products, tested against fp64)
+__global__ __launch_bounds__(64) void x3_product_kernel(const float* A, const float* B, float* C, int K) {
+    const int lane = threadIdx.x, l31 = lane & 31, hi = lane >> 5;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        float av[8], bv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            av[j] = A[(long)l31 * K + k0 + 8 * hi + j];
+            bv[j] = B[(long)(k0 + 8 * hi + j) * 32 + l31];
+        }
+        u32x4 af[3], bf[3];
+        split8(av, af);
+        split8(bv, bf);
+        MFMA_X3(af, bf, acc)
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) C[rowmap(e, hi) * 32 + l31] = acc[e];
+}
+
+template <bool P, bool C>
+void launch_fused_x3(const HeadsPlan& pl, const HeadsArgs2& a, hipStream_t s) {
+    if (pl.WR == kWR2) hipLaunchKernelGGL((heads_fused_x3_kernel<P, C, kWR2>), dim3(pl.grid), dim3(64 * kWR2), 0, s, a);
+    else hipLaunchKernelGGL((heads_fused_x3_kernel<P, C, 1>), dim3(pl.grid), dim3(64), 0, s, a);
+}
+
 }  // namespace
 
 // sufficient for every batch of at most B rows (the plan of a smaller batch may split more)
@@ -714,13 +1330,20 @@ extern "C" long dcahip_heads_fused_workspace_bytes(int B, int hL, int G, long pl
     long smax = kMaxGrid / p.ngb;
     if (smax > p.NT) smax = p.NT;
     if (smax < 1) smax = 1;
-    return smax * p.dw_stride * (long)sizeof(float) + p.dh_bytes;
+    return smax * p.dw_stride * (long)sizeof(float) + p.dh_bytes + p.hs_bytes;
+}
+
+extern "C" int dcahip_x3_product_32x32(const float* A, const float* B, float* C, int K, void* stream) {
+    if (!A || !B || !C || K <= 0 || (K & 15)) return DCAHIP_EINVAL;
+    hipLaunchKernelGGL(x3_product_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), A, B, C, K);
+    return (int)hipGetLastError();
 }
 
 #ifdef DCA_HEADS_TIMING
 extern "C" void dcahip_heads_set_timing(long long* buf) { g_timing = buf; }
 #endif
 
+// (rounded up to the two tiles per workgroup of the fp32-MFMA variant; the product path reads the first ceil(G / 32))
 extern "C" int dcahip_heads_tile_order_len(int G) { return G > 0 ? (((G + kTG - 1) / kTG + kWG - 1) / kWG) * kWG : 0; }
 
 extern "C" int dcahip_heads_fused_ordered(const float* H, long ldh, const float* Wh, long ldw,
@@ -757,7 +1380,7 @@ extern "C" int dcahip_heads_fused_ordered(const float* H, long ldh, const float*
     if (!make_heads_plan(B, hL, G, plane, flags, &pl)) return DCAHIP_EINVAL;
     if (!H || !Wh || !bh || !y || !sf || !gW || !dH || !loss_partials || !workspace) return DCAHIP_EINVAL;
     if (cdisp && (!theta_w || !g_theta)) return DCAHIP_EINVAL;
-    if (workspace_bytes < pl.dw_bytes + pl.dh_bytes) return DCAHIP_EINVAL;
+    if (workspace_bytes < pl.dw_bytes + pl.dh_bytes + pl.hs_bytes) return DCAHIP_EINVAL;
     if (!al16(H) || !al16(Wh) || !al16(workspace) || (ldh & 3) || (ldw & 3) || ldh < ((hL + 3) & ~3))
         return DCAHIP_EINVAL;
     const int NH = 1 + (cdisp ? 0 : 1) + (has_pi ? 1 : 0);
@@ -765,13 +1388,27 @@ extern "C" int dcahip_heads_fused_ordered(const float* H, long ldh, const float*
     if (ldy < G || ldy > 0xffffffffL) return DCAHIP_EINVAL;
     float* ws_dh = static_cast<float*>(workspace);
     float* ws_dw = ws_dh + pl.dh_bytes / sizeof(float);
-    HeadsArgs a{g_timing, H, ldh, Wh, ldw, bh, theta_w, y, ldy, sf, perm, cursor, ws_dw, pl.dw_stride, ws_dh, pl.ntg,
-                tile_order, loss_partials, plane, pl.ldws, B, hL, G, pl.S, pl.NT, ridge, inv_n};
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (has_pi && cdisp) launch_fused<true, true>(pl, a, s);
-    else if (has_pi) launch_fused<true, false>(pl, a, s);
-    else if (cdisp) launch_fused<false, true>(pl, a, s);
-    else launch_fused<false, false>(pl, a, s);
+    if (use_f32_mfma()) {
+        HeadsArgs a{g_timing, H, ldh, Wh, ldw, bh, theta_w, y, ldy, sf, perm, cursor, ws_dw, pl.dw_stride, ws_dh, pl.ntg,
+                    tile_order, loss_partials, plane, pl.ldws, B, hL, G, pl.S, pl.NT, ridge, inv_n};
+        if (has_pi && cdisp) launch_fused<true, true>(pl, a, s);
+        else if (has_pi) launch_fused<true, false>(pl, a, s);
+        else if (cdisp) launch_fused<false, true>(pl, a, s);
+        else launch_fused<false, false>(pl, a, s);
+    } else {
+        unsigned short* HA = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(workspace) + pl.dh_bytes + pl.dw_bytes);
+        unsigned short* HT = HA + (long)pl.NT * kHTile;
+        hipLaunchKernelGGL(heads_split_h_kernel, dim3(pl.NT), dim3(256), 0, s, H, ldh, B, hL, HA, HT);
+        int rc0 = (int)hipGetLastError();
+        if (rc0 != 0) return rc0;
+        HeadsArgs2 a{g_timing, HA, HT, Wh, ldw, bh, theta_w, y, ldy, sf, perm, cursor, ws_dw, pl.dw_stride, ws_dh, pl.ntg,
+                     tile_order, loss_partials, plane, pl.ldws, B, hL, G, pl.S, pl.NT, ridge, inv_n};
+        if (has_pi && cdisp) launch_fused_x3<true, true>(pl, a, s);
+        else if (has_pi) launch_fused_x3<true, false>(pl, a, s);
+        else if (cdisp) launch_fused_x3<false, true>(pl, a, s);
+        else launch_fused_x3<false, false>(pl, a, s);
+    }
     int rc = (int)hipGetLastError();
     if (rc != 0) return rc;
     if (n_partials_out) *n_partials_out = pl.grid;

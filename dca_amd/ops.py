@@ -49,6 +49,9 @@ class HipOps:
     def heads_fused_workspace_bytes(self, B, hL, G, plane, flags):
         return self.L.dcahip_heads_fused_workspace_bytes(B, hL, G, plane, flags)
 
+    def x3_product_32x32(self, A, B, C, K):
+        hip.check(self.L.dcahip_x3_product_32x32(hip.ptr(A), hip.ptr(B), hip.ptr(C), K, hip.stream()), "x3_product_32x32")
+
     def heads_tile_order_len(self, G):
         return int(self.L.dcahip_heads_tile_order_len(G))
 

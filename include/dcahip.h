@@ -133,6 +133,12 @@ int dcahip_heads_fused(const float* H, long ldh, const float* Wh, long ldw, cons
                        float* gW, long ldg, float* g_theta, float* dH, long lddh,
                        double* loss_partials, int* n_partials_out,
                        void* workspace, long workspace_bytes, void* stream);
+/* The arithmetic of K-HEADS' three matrix products, exposed for testing: C [32, 32] = A [32, K] B [K, 32]
+ * (row-major fp32, K % 16 == 0) computed as the kernel does -- both operands split into three bf16 pieces
+ * (round-to-nearest residuals), the six products a1b1, a1b2, a2b1, a1b3, a2b2, a3b1 accumulated in fp32 by
+ * v_mfma_f32_32x32x16_bf16.  Contract (tests/test_heads_fused_gpu.py): |C - A B| <= 2.5e-7 sum|a b| per element,
+ * i.e. the accuracy of an fp32 dot product (the fp32 MFMA measures 1.8e-7 .. 2.1e-7 on the same inputs). */
+int dcahip_x3_product_32x32(const float* A, const float* B, float* C, int K, void* stream);
 /* Same, with the order in which workgroups take the 32-gene tiles: tile_order = device array of
  * dcahip_heads_tile_order_len(G) ints, a permutation of 0 .. ceil(G/32)-1 (padded with values >= ceil(G/32));
  * every 2 consecutive entries share a workgroup.  Results do not depend on it (each is per gene tile); a workgroup

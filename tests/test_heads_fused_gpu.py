@@ -202,3 +202,31 @@ def test_heads_fused_tile_order_changes_nothing(ops, flags, B, G):
                 assert abs(a[k][0] - b[k][0]) <= 1e-6 * abs(a[k][0])
             else:
                 assert np.array_equal(np.asarray(a[k][0]), np.asarray(b[k][0])), k
+
+
+@pytest.mark.parametrize('K', [64, 4096])
+@pytest.mark.parametrize('dist', ['uniform', 'lognormal'])
+def test_x3_products_are_fp32_accurate(ops, K, dist):
+    """The arithmetic contract of K-HEADS' matrix products (include/dcahip.h, dcahip_x3_product_32x32): three bf16
+    pieces per operand, six products, fp32 accumulation == the accuracy of an fp32 dot product.  Per element
+    |C - A B| <= 2.5e-7 sum|a b| against fp64, on K = 64 (the contraction length of the forward product) and
+    K = 4 096 (the weight gradient over a bench batch), for uniform operands and for operands spread over
+    +-4 e-folds (the fp32 MFMA measured 1.8e-7 / 2.1e-7 on the same inputs, three products 2e-6, plain bf16 1e-3:
+    tools/microbench/bf16x3_mfma.hip)."""
+    rng = np.random.RandomState(K + len(dist))
+    shape = lambda *s: rng.uniform(-1, 1, s) * (np.exp(4 * rng.uniform(-1, 1, s)) if dist == 'lognormal' else 1.0)
+    A = shape(32, K).astype(np.float32)
+    Bm = shape(K, 32).astype(np.float32)
+    C = torch.zeros(32, 32, device='cuda')
+    ops.x3_product_32x32(dev(A), dev(Bm), C, K)
+    torch.cuda.synchronize()
+    ref = A.astype(np.float64) @ Bm.astype(np.float64)
+    mag = np.abs(A.astype(np.float64)) @ np.abs(Bm.astype(np.float64))
+    err = np.abs(C.cpu().numpy().astype(np.float64) - ref) / mag
+    assert err.max() <= 2.5e-7, err.max()
+    # and it is not worse than a plain fp32 accumulation of the same dot products
+    c32 = np.zeros((32, 32), np.float32)
+    for k in range(K):
+        c32 += np.outer(A[:, k], Bm[k])
+    err32 = np.abs(c32.astype(np.float64) - ref) / mag
+    assert err.max() <= max(1.5 * err32.max(), 1.2e-7), (err.max(), err32.max())

@@ -41,6 +41,39 @@ __global__ __launch_bounds__(512) void shadow(float* out, int iters, int waves_a
     if (r == 12345.678f) out[threadIdx.x] = r;
 }
 
+// Part 3: dependent accumulation -- the six products of one K step go into ONE accumulator in K-HEADS; NACC = number
+// of accumulators the MFMA stream cycles over (1 = every MFMA waits for its predecessor's result)
+template <int NACC>
+__global__ __launch_bounds__(512) void chain(float* out, int iters, int waves_active) {
+    const int wave = threadIdx.x >> 6;
+    if (wave >= waves_active) return;
+    f32x16 a[NACC];
+    for (int k = 0; k < NACC; ++k) a[k] = f32x16{0};
+    union { bf16x8 v; unsigned short h[8]; } x, y;
+    for (int j = 0; j < 8; ++j) { x.h[j] = 0x3f80 + (threadIdx.x & 7); y.h[j] = 0x3f00 + j; }
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int rep = 0; rep < 12 / NACC; ++rep)
+#pragma unroll
+            for (int k = 0; k < NACC; ++k) a[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x.v, y.v, a[k], 0, 0, 0);
+    }
+    float r = 0.f;
+    for (int k = 0; k < NACC; ++k) r += a[k][k];
+    if (r == 12345.678f) out[threadIdx.x] = r;
+}
+
+template <int NACC>
+float run_chain(int iters, int waves) {
+    float* out; hipMalloc(&out, 4096);
+    hipEvent_t s, e; hipEventCreate(&s); hipEventCreate(&e);
+    chain<NACC><<<256, 512>>>(out, iters, waves); hipDeviceSynchronize();
+    hipEventRecord(s);
+    for (int i = 0; i < 5; ++i) chain<NACC><<<256, 512>>>(out, iters, waves);
+    hipEventRecord(e); hipEventSynchronize(e);
+    float ms; hipEventElapsedTime(&ms, s, e); hipFree(out);
+    return ms / 5;
+}
+
 template <int NV>
 float run(int iters, int waves) {
     float* out; hipMalloc(&out, 4096);
@@ -75,5 +108,9 @@ int main() {
         printf("VALU per MFMA %2d: 1 wave/SIMD %.3f ms = %.1f cyc/MFMA;  2 waves/SIMD %.3f ms = %.1f cyc per MFMA-pair-slot (per wave-MFMA %.1f)\n", \
                NV, t4, t4 * 2.4e6 / (4.0 * iters), t8, t8 * 2.4e6 / (4.0 * iters), t8 * 2.4e6 / (8.0 * iters)); }
     ROW(0) ROW(2) ROW(4) ROW(6) ROW(8) ROW(12)
+#define CROW(NA) { const float t4 = run_chain<NA>(1400, 4), t8 = run_chain<NA>(1400, 8); \
+        printf("accumulators %d: 1 wave/SIMD %.3f ms = %.1f cyc/MFMA;  2 waves/SIMD %.3f ms = %.1f cyc per wave-MFMA\n", \
+               NA, t4, t4 * 2.4e6 / (12.0 * 1400), t8, t8 * 2.4e6 / (2 * 12.0 * 1400)); }
+    CROW(1) CROW(2) CROW(3) CROW(4) CROW(6)
     return 0;
 }

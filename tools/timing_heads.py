@@ -23,11 +23,15 @@ sys.argv = [sys.argv[0]] + sys.argv[1:]
 exec(open(os.path.join(ROOT, 'tools', 'bench_heads.py')).read())
 t = tim.cpu().numpy().reshape(-1, 10)
 t = t[t.sum(1) > 0]
-names = ['loop-top', 'H->LDS', 'F (96 mfma)', 'staging stores', 'Z dense+sparse', 'dH: partial stores + Hd / hv load issue', 'dW (96 mfma)', 'dH: 96 mfma', 'PROLOGUE (W -> LDS)', 'EPILOGUE (dW tree + stores)']
+names_f32 = ['loop-top', 'H->LDS', 'F (96 mfma)', 'staging stores', 'Z dense+sparse', 'dH: partial stores + Hd / hv load issue', 'dW (96 mfma)', 'dH: 96 mfma', 'PROLOGUE (W -> LDS)', 'EPILOGUE (dW tree + stores)']
+names_x3 = ['loop-top', 'F (72 mfma, weight operands via transposing LDS reads)', '-', 'staging stores', 'Z dense+sparse',
+            'dH: partial stores + operand load issue', 'dW (72 mfma + D split)', 'dH (72 mfma + D split)', 'PROLOGUE (W split -> LDS)',
+            'EPILOGUE (dW tree + stores)']
+names = names_f32 if os.environ.get('DCA_HEADS_F32MFMA') == '1' else names_x3
 tot = t.sum(1).mean()
 print('waves', len(t), 'mean cycles per wave (s_memtime @100MHz ticks?)', tot)
 for i, nme in enumerate(names):
-    print('  %-16s %12.0f  %5.1f%%' % (nme, t[:, i].mean(), 100 * t[:, i].mean() / tot))
+    print('  %-50s %12.0f  %5.1f%%' % (nme, t[:, i].mean(), 100 * t[:, i].mean() / tot))
 # spread of the main-loop time inside a workgroup (8 waves): what the barrier in front of the dW tree waits for
 full = tim.cpu().numpy().reshape(-1, 10)
 nw = 8
