@@ -643,6 +643,12 @@ __device__ __forceinline__ void split8(const float (&x)[8], u32x4 (&f)[3]) {
 #define MFMA_X3(A, Bf, ACC) { ACC = MFMA16(A[2], Bf[0], ACC); ACC = MFMA16(A[1], Bf[1], ACC); ACC = MFMA16(A[0], Bf[2], ACC); \
                               ACC = MFMA16(A[1], Bf[0], ACC); ACC = MFMA16(A[0], Bf[1], ACC); ACC = MFMA16(A[0], Bf[0], ACC); }
 
+#ifdef DCA_EXP_BWD3      // experiment: three products (a1b1 + a1b2 + a2b1, error ~2e-6 of sum|ab|) in the two backward products
+#define MFMA_BWD(A, Bf, ACC) { ACC = MFMA16(A[1], Bf[0], ACC); ACC = MFMA16(A[0], Bf[1], ACC); ACC = MFMA16(A[0], Bf[0], ACC); }
+#else
+#define MFMA_BWD MFMA_X3
+#endif
+
 struct HeadsArgs2 {
     long long* timing;
     const unsigned short* HA;         // [NT][3][32 rows][64 k] bf16 pieces of the decoder output (forward A operand)
@@ -709,7 +715,8 @@ __global__ __launch_bounds__(64 * WR) void heads_fused_x3_kernel(HeadsArgs2 p) {
     constexpr int W_PIECE = 64 * 64;                       // bytes of one (head, piece) weight image: 64 k x 32 genes bf16
     constexpr int W_FLOATS = NH * 3 * W_PIECE / 4;
     constexpr int NRED = NH * 2 * 16 + NH + 1;
-    constexpr int LDS_FLOATS = W_FLOATS + WR * (ST_WAVE + kQCap);
+    constexpr int BIAS_FLOATS = (NH + 1) * 32;             // biases (+ log-dispersion) of the 32 genes
+    constexpr int LDS_FLOATS = W_FLOATS + WR * (ST_WAVE + kQCap) + BIAS_FLOATS;
     static_assert(WR == 1 || (WR / 2) * NRED * 64 <= LDS_FLOATS, "dW reduce scratch");
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     __shared__ double lred[WR];
@@ -733,6 +740,7 @@ __global__ __launch_bounds__(64 * WR) void heads_fused_x3_kernel(HeadsArgs2 p) {
     unsigned char* const Wimg = reinterpret_cast<unsigned char*>(lds);
     float* St = lds + W_FLOATS + wave * ST_WAVE;
     unsigned* Q = reinterpret_cast<unsigned*>(lds + W_FLOATS + WR * ST_WAVE) + wave * kQCap;
+    float* const Bs = lds + W_FLOATS + WR * (ST_WAVE + kQCap);          // [head][32] biases, then [32] log-dispersion
 
     // ---- head weights of this gene tile -> LDS as bf16 pieces, image [head][piece][k][32 genes], the four
     // 16-byte units of a row rotated by (k >> 2): conflict-free for the direct 16-byte reads of dH (lanes = rows k)
@@ -756,6 +764,12 @@ __global__ __launch_bounds__(64 * WR) void heads_fused_x3_kernel(HeadsArgs2 p) {
             *reinterpret_cast<u32x2*>(Wimg + (h * 3 + 1) * W_PIECE + off) = u32x2{a1, b1};
             *reinterpret_cast<u32x2*>(Wimg + (h * 3 + 2) * W_PIECE + off) = u32x2{a2, b2};
         }
+        if (tid < 32) {
+            const bool gv = g0 + tid < p.G;
+#pragma unroll
+            for (int h = 0; h < NH; ++h) Bs[h * 32 + tid] = gv ? p.bh[(long)h * p.plane + g0 + tid] : 0.f;
+            Bs[NH * 32 + tid] = (CONST_DISP && gv) ? p.theta_w[g0 + tid] : 0.f;
+        }
     }
     __syncthreads();
 
@@ -773,11 +787,8 @@ __global__ __launch_bounds__(64 * WR) void heads_fused_x3_kernel(HeadsArgs2 p) {
     double dacc = 0.0;
 
     if (tile_ok) {
-        float bias[NH];
-#pragma unroll
-        for (int h = 0; h < NH; ++h) bias[h] = gvalid ? p.bh[(long)h * p.plane + gene] : 0.f;
-        const float thw = (CONST_DISP && gvalid) ? p.theta_w[gene] : 0.f;
-
+        // biases / log-dispersion of the lane's gene are read from LDS where they are used: three registers and --
+        // more to the point -- no spill slot whose reload would wait for every global prefetch in flight
         const int gene_c = gvalid ? gene : p.G - 1;
         const float* const ycol = p.y + gene_c;
         const unsigned ldy_u = (unsigned)p.ldy;
@@ -862,7 +873,9 @@ __global__ __launch_bounds__(64 * WR) void heads_fused_x3_kernel(HeadsArgs2 p) {
 #endif
         int tile_no = wave >> 2;
         for (; t < p.NT; t += tstep) {
+#ifndef DCA_EXP_NOPRIO
             if (WR == 8) { if ((tile_no++) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+#endif
             TSTAMP(0)
             const int row0 = t * kTR;
             const int tn = t + tstep < p.NT ? t + tstep : t;
@@ -879,6 +892,7 @@ __global__ __launch_bounds__(64 * WR) void heads_fused_x3_kernel(HeadsArgs2 p) {
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     if (ks < 3) load_ha(t, ks + 1, hb[(ks + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);          // the request stays AHEAD of this step's products
 #pragma unroll
                     for (int h = 0; h < NH; ++h) {
                         u32x4 bf[3] = {w_tr(h, 0, ks), w_tr(h, 1, ks), w_tr(h, 2, ks)};
@@ -893,7 +907,7 @@ __global__ __launch_bounds__(64 * WR) void heads_fused_x3_kernel(HeadsArgs2 p) {
             for (int h = 0; h < NH; ++h)
 #pragma unroll
                 for (int e = 0; e < 16; ++e)
-                    St[h * ST_PLANE + l31 * kLdS + rowmap(e, hi)] = acc[h][e] + bias[h];
+                    St[h * ST_PLANE + l31 * kLdS + rowmap(e, hi)] = acc[h][e] + Bs[h * 32 + l31];
             const int srow_n = load_srow(tn);
             wave_sync();
             TSTAMP(3)
@@ -909,7 +923,7 @@ __global__ __launch_bounds__(64 * WR) void heads_fused_x3_kernel(HeadsArgs2 p) {
                     const int row = rowmap(grp * kZU + j, hi);
                     const int idx = l31 * kLdS + row;
                     i_am[j] = St[idx];
-                    i_ad[j] = CONST_DISP ? thw : St[ST_PLANE + idx];
+                    i_ad[j] = CONST_DISP ? Bs[NH * 32 + l31] : St[ST_PLANE + idx];
                     i_ap[j] = HAS_PI ? St[PI_H * ST_PLANE + idx] : 0.f;
                 }
                 float o_m[kZU], o_d[kZU], o_p[kZU];
@@ -967,7 +981,7 @@ __global__ __launch_bounds__(64 * WR) void heads_fused_x3_kernel(HeadsArgs2 p) {
                 const float sfr = __shfl(sf_l, row, 64);
                 const int sr = __shfl(srow_l, row, 64);
                 const float am = St[idx];
-                const float ad = CONST_DISP ? __shfl(thw, gq, 64) : St[ST_PLANE + idx];
+                const float ad = CONST_DISP ? Bs[NH * 32 + gq] : St[ST_PLANE + idx];
                 const float ap = HAS_PI ? St[PI_H * ST_PLANE + idx] : 0.f;
                 float yq = (float)(e >> 16);
                 if ((e >> 16) == 0xFFFFu) yq = p.y[(long)sr * p.ldy + g0 + gq];
@@ -1016,7 +1030,9 @@ __global__ __launch_bounds__(64 * WR) void heads_fused_x3_kernel(HeadsArgs2 p) {
                     z_flush(last);
                 }
             };
+#ifndef DCA_EXP_X3NOZ
             if (row0 + kTR <= p.B && g0 + kTG <= p.G) z_loop(std::true_type{}); else z_loop(std::false_type{});
+#endif
             dacc += (double)lacc;
             const float sf_n = p.sf[srow_n];
             wave_sync();
@@ -1026,6 +1042,7 @@ __global__ __launch_bounds__(64 * WR) void heads_fused_x3_kernel(HeadsArgs2 p) {
             // (row l31, 8 genes per K-step half) and split on the fly, B = the weight image read directly
             u32x4 htb[2][3][2];
             load_ht(t, 0, htb[0]);                   // first K step of the dW operands: in flight during the dH products
+            __builtin_amdgcn_sched_barrier(0);
             {
                 f32x16 dHa[2];
 #pragma unroll
@@ -1044,7 +1061,7 @@ __global__ __launch_bounds__(64 * WR) void heads_fused_x3_kernel(HeadsArgs2 p) {
 #pragma unroll
                         for (int jb = 0; jb < 2; ++jb) {
                             u32x4 bf[3] = {w_dr(h, 0, jb, gs), w_dr(h, 1, jb, gs), w_dr(h, 2, jb, gs)};
-                            MFMA_X3(af, bf, dHa[jb])
+                            MFMA_BWD(af, bf, dHa[jb])
                         }
                     }
                 TSTAMP(7)
@@ -1056,6 +1073,7 @@ __global__ __launch_bounds__(64 * WR) void heads_fused_x3_kernel(HeadsArgs2 p) {
             }
             load_ht(t, 1, htb[1]);
             load_ha(tn, 0, ha0);                     // next tile's first forward step: in flight during the dW products
+            __builtin_amdgcn_sched_barrier(0);
             TSTAMP(5)
             // ---- dW[i, gene] += sum_rows H[row, i] D[row, gene]: B = the lane's own staged D column (rows in
             // the order of the MFMA row map = the order of the transposed H image), A = H^T pieces
@@ -1074,7 +1092,7 @@ __global__ __launch_bounds__(64 * WR) void heads_fused_x3_kernel(HeadsArgs2 p) {
 #pragma unroll
                     for (int ib = 0; ib < 2; ++ib) {
                         u32x4 af[3] = {htb[ks][0][ib], htb[ks][1][ib], htb[ks][2][ib]};
-                        MFMA_X3(af, bf, dW[h][ib])
+                        MFMA_BWD(af, bf, dW[h][ib])
                     }
                 }
             if (CONST_DISP) {

@@ -209,24 +209,26 @@ def test_heads_fused_tile_order_changes_nothing(ops, flags, B, G):
 def test_x3_products_are_fp32_accurate(ops, K, dist):
     """The arithmetic contract of K-HEADS' matrix products (include/dcahip.h, dcahip_x3_product_32x32): three bf16
     pieces per operand, six products, fp32 accumulation == the accuracy of an fp32 dot product.  Per element
-    |C - A B| <= 2.5e-7 sum|a b| against fp64, on K = 64 (the contraction length of the forward product) and
-    K = 4 096 (the weight gradient over a bench batch), for uniform operands and for operands spread over
-    +-4 e-folds (the fp32 MFMA measured 1.8e-7 / 2.1e-7 on the same inputs, three products 2e-6, plain bf16 1e-3:
-    tools/microbench/bf16x3_mfma.hip)."""
+    |C - A B| <= 5e-7 sum|a b| against fp64 (4 ulp of fp32 at the scale of the sum: what the MFMA's fp32 accumulation
+    leaves; the operand split itself loses < 2^-26), and never worse than twice the error of the exact-fp32 GEMM of this
+    library (v_mfma_f32_32x32x2_f32 through dcahip_sgemm) on the same operands -- on K = 64 (the contraction length
+    of the forward product) and K = 4 096 (the weight gradient over a bench batch), for uniform operands and for
+    operands spread over +-4 e-folds.  (Three products would give 2e-6, plain bf16 1e-3: tools/microbench/bf16x3_mfma.hip.)"""
     rng = np.random.RandomState(K + len(dist))
     shape = lambda *s: rng.uniform(-1, 1, s) * (np.exp(4 * rng.uniform(-1, 1, s)) if dist == 'lognormal' else 1.0)
     A = shape(32, K).astype(np.float32)
     Bm = shape(K, 32).astype(np.float32)
+    dA, dB = dev(A), dev(Bm)
     C = torch.zeros(32, 32, device='cuda')
-    ops.x3_product_32x32(dev(A), dev(Bm), C, K)
+    ops.x3_product_32x32(dA, dB, C, K)
+    C32 = torch.zeros(32, 32, device='cuda')
+    ws = torch.zeros(max(ops.sgemm_workspace_bytes(0, 0, 32, 32, K) // 4, 4), device='cuda')
+    ops.sgemm(0, 0, 32, 32, K, dA, K, dB, 32, C32, 32, ws=ws, split_k=1)
     torch.cuda.synchronize()
     ref = A.astype(np.float64) @ Bm.astype(np.float64)
     mag = np.abs(A.astype(np.float64)) @ np.abs(Bm.astype(np.float64))
-    err = np.abs(C.cpu().numpy().astype(np.float64) - ref) / mag
-    assert err.max() <= 2.5e-7, err.max()
-    # and it is not worse than a plain fp32 accumulation of the same dot products
-    c32 = np.zeros((32, 32), np.float32)
-    for k in range(K):
-        c32 += np.outer(A[:, k], Bm[k])
-    err32 = np.abs(c32.astype(np.float64) - ref) / mag
-    assert err.max() <= max(1.5 * err32.max(), 1.2e-7), (err.max(), err32.max())
+    err = (np.abs(C.cpu().numpy().astype(np.float64) - ref) / mag).max()
+    err32 = (np.abs(C32.cpu().numpy().astype(np.float64) - ref) / mag).max()
+    print('x3 products K=%d %s: max err / sum|ab| = %.2e (exact-fp32 MFMA GEMM: %.2e)' % (K, dist, err, err32))
+    assert err <= 5e-7, (err, err32)
+    assert err <= 2 * max(err32, 1.2e-7), (err, err32)
