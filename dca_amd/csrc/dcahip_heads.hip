@@ -903,11 +903,17 @@ __global__ __launch_bounds__(64 * WR) void heads_fused_x3_kernel(HeadsArgs2 p) {
             TSTAMP(1)
             TSTAMP(2)
             // ---- stage [gene][row] (row stride 1, gene stride 33)
+            {
+                float bias[NH];                      // read once per tile (the stores below could alias Bs for all the compiler knows)
 #pragma unroll
-            for (int h = 0; h < NH; ++h)
+                for (int h = 0; h < NH; ++h) bias[h] = Bs[h * 32 + l31];
 #pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    St[h * ST_PLANE + l31 * kLdS + rowmap(e, hi)] = acc[h][e] + Bs[h * 32 + l31];
+                for (int h = 0; h < NH; ++h)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        St[h * ST_PLANE + l31 * kLdS + rowmap(e, hi)] = acc[h][e] + bias[h];
+            }
+            const float thw = CONST_DISP ? Bs[NH * 32 + l31] : 0.f;
             const int srow_n = load_srow(tn);
             wave_sync();
             TSTAMP(3)
@@ -923,7 +929,7 @@ __global__ __launch_bounds__(64 * WR) void heads_fused_x3_kernel(HeadsArgs2 p) {
                     const int row = rowmap(grp * kZU + j, hi);
                     const int idx = l31 * kLdS + row;
                     i_am[j] = St[idx];
-                    i_ad[j] = CONST_DISP ? Bs[NH * 32 + l31] : St[ST_PLANE + idx];
+                    i_ad[j] = CONST_DISP ? thw : St[ST_PLANE + idx];
                     i_ap[j] = HAS_PI ? St[PI_H * ST_PLANE + idx] : 0.f;
                 }
                 float o_m[kZU], o_d[kZU], o_p[kZU];

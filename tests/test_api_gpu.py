@@ -1,0 +1,59 @@
+"""The drop-in surface on the MI355X with the real kernels (HipOps): checkpoint -> resume is bit-for-bit, best-epoch
+weights file, dca() end to end.  (tests/test_api_cpu.py covers the same host logic on CPU with oracle-backed ops.)"""
+import numpy as np
+import pandas as pd
+import pytest
+
+from conftest import synth_counts
+from dca_amd._anndata import AnnData
+from dca_amd.network import AE_types
+
+pytestmark = pytest.mark.gpu
+
+
+def _prepared(n=300, G=120, seed=0):
+    from dca_amd import io
+    ad = AnnData(synth_counts(n, G, seed).astype(np.float32),
+                 obs=pd.DataFrame(index=['c%d' % i for i in range(n)]),
+                 var=pd.DataFrame(index=['g%d' % i for i in range(G)]))
+    ad = io.read_dataset(ad, transpose=False, test_split=False, copy=False)
+    return io.normalize(ad, size_factors=True, logtrans_input=True, normalize_input=True)
+
+
+@pytest.mark.parametrize('ae_type,optimizer', [('zinb-conddisp', 'RMSprop'), ('nb', 'Adam')])
+def test_checkpoint_resume_is_bit_exact_on_the_gpu(tmp_path, ae_type, optimizer):
+    """train(checkpoint=True) writes the full training state (parameters, optimizer slots, BN moving statistics,
+    step / dropout counters, lr, callback counters, history) after every epoch; resume=True continues from it.
+    With the HIP kernels (deterministic: fixed summation orders, no atomics) 5 epochs == 2 epochs + resume to 5,
+    bit for bit: history, every parameter, the optimizer slots.  Reference: dca/train.py:64-69 keeps only
+    best-val_loss weights (ModelCheckpoint); that file is checked as well."""
+    from dca_amd.train import train
+    out_a, out_b = str(tmp_path / 'a'), str(tmp_path / 'b')
+
+    def run(outdir, epochs, resume):
+        np.random.seed(3)
+        ad = _prepared()
+        net = AE_types[ae_type](input_size=ad.n_vars, hidden_size=(64, 32, 64), hidden_dropout=0.1, file_path=outdir)
+        net.seed = 0
+        net.build()
+        assert type(net.engine.ops).__name__ == 'HipOps'
+        h = train(ad, net, output_dir=outdir, optimizer=optimizer, epochs=epochs, batch_size=32, save_weights=True,
+                  verbose=False, checkpoint=True, resume=resume, early_stop=0, reduce_lr=2)
+        return h, net
+
+    h5, net5 = run(out_a, 5, False)
+    run(out_b, 2, False)
+    h25, net25 = run(out_b, 5, True)
+    assert h25.history == h5.history
+    p5, p25 = net5.engine.get_params(), net25.engine.get_params()
+    for k in p5:
+        np.testing.assert_array_equal(p5[k], p25[k], err_msg=k)
+    np.testing.assert_array_equal(net5.engine.ms.cpu().numpy(), net25.engine.ms.cpu().numpy())
+    if net5.engine.slot2 is not None:
+        np.testing.assert_array_equal(net5.engine.slot2.cpu().numpy(), net25.engine.slot2.cpu().numpy())
+    best = int(np.argmin(h5.history['val_loss']))
+    z = np.load(str(tmp_path / 'a' / 'weights.npz'))
+    assert set(z.files) == set(p5)
+    if best == 4:
+        for k in p5:
+            np.testing.assert_array_equal(z[k], p5[k])
