@@ -10,8 +10,16 @@ before the timed region starts.
   python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torchrun)
 
 Prints ONE JSON line on rank 0 (contract in the repository task statement), with
-  roofline      live HIP-event timing of the dominant kernel inside the timed region
+  roofline      the dominant kernel: HIP events around each of its launches (on the launch stream).  With the step
+                replayed as a hipGraph the individual launches are invisible, so the events come from eager steps of
+                the same workload run right AFTER the timed region (config.launch says which); the rocprofv3
+                kernel trace of the same command (profiles/) reports the same averages
   cpu_baseline  the oracle's torch-CPU port of the same step on the host cores (rank 0, N=1)
+  config.batch32   the reference-default batch (dca/train.py:37) measured in the same process after the timed
+                   region: ms/step, cells/s, kernel launches per step (N = 1 only)
+  config.epoch     SURVEY 8d's end-to-end epoch at the bench batch: 3 timed epochs (after 1 warm-up) over all
+                   train rows incl. the last partial batch, device-synchronised at the epoch ends, plus the
+                   validation pass over the held-out 10 % (N = 1 only)
 """
 import argparse
 import json
@@ -101,6 +109,98 @@ def cpu_baseline(Xh, Yh, sfh, params, hidden, B, budget_s):
             'cells_per_s_batch32': v32, 'cells_per_s_bench_batch': vB, 'host_cores': os.cpu_count()}
 
 
+def graph_kernel_nodes(graph):
+    """Kernel nodes of a captured step (hipGraphGetNodes / hipGraphNodeGetType through libamdhip64)."""
+    import ctypes
+    try:
+        hip = ctypes.CDLL('libamdhip64.so')
+        g = ctypes.c_void_p(graph.raw_cuda_graph())
+        n = ctypes.c_size_t(0)
+        if hip.hipGraphGetNodes(g, None, ctypes.byref(n)) != 0:
+            return None
+        nodes = (ctypes.c_void_p * n.value)()
+        if hip.hipGraphGetNodes(g, nodes, ctypes.byref(n)) != 0:
+            return None
+        kernels = 0
+        for i in range(n.value):
+            ty = ctypes.c_int(-1)
+            hip.hipGraphNodeGetType(ctypes.c_void_p(nodes[i]), ctypes.byref(ty))
+            kernels += ty.value == 0                      # hipGraphNodeTypeKernel
+        return int(kernels)
+    except Exception:
+        return None
+
+
+def capture_step(eng, b, counts):
+    try:
+        g = torch.cuda.CUDAGraph(keep_graph=True)
+    except TypeError:
+        g = torch.cuda.CUDAGraph()
+    st = torch.cuda.Stream(); st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        with torch.cuda.graph(g, stream=st):
+            eng.train_step(b, b, counts, b)
+    torch.cuda.current_stream().wait_stream(st)
+    return g
+
+
+def after_measurements(eng, args, B, n_train, n_val, G, dev):
+    """Same process, same resident matrix, after the timed region (one GPU): the reference-default batch 32 and
+    the end-to-end epoch (all train rows incl. the last partial batch + the validation pass)."""
+    out = {}
+    gen = torch.Generator(device='cpu'); gen.manual_seed(99)
+    # ---- batch 32 (dca/train.py:37 default): hipGraph replay, 400 timed steps
+    b32, k32 = 32, 400
+    eng.perm = torch.randperm(n_train, generator=gen, dtype=torch.int32)[:(k32 + 8) * b32].to(dev)
+    eng.hist = torch.zeros(k32 + 16, dtype=torch.float32, device=dev)
+    eng.cursor.zero_(); eng.acc.zero_()
+    eng.train_step(b32, b32, [b32], b32)
+    try:
+        g32 = capture_step(eng, b32, [b32])
+        launches = graph_kernel_nodes(g32) if hasattr(g32, 'raw_cuda_graph') else None
+        for _ in range(5):
+            g32.replay()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(k32):
+            g32.replay()
+        torch.cuda.synchronize(); el = time.perf_counter() - t0
+        out['batch32'] = {'ms_per_step': 1e3 * el / k32, 'cells_per_s': k32 * b32 / el, 'launches': launches,
+                          'steps': k32, 'launch': 'hipGraph replay'}
+    except Exception as e:
+        out['batch32'] = {'error': str(e)}
+    # ---- one epoch at the bench batch: train rows in shuffled order, last partial batch included, then validation
+    steps_full, b_last = n_train // B, n_train % B
+    gB = capture_step_warm(eng, B)
+    times = []
+    for ep in range(4):
+        eng.perm = torch.randperm(n_train, generator=gen, dtype=torch.int32).to(dev)
+        eng.hist = torch.zeros(steps_full + 4, dtype=torch.float32, device=dev)
+        eng.cursor.zero_(); eng.acc.zero_()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(steps_full):
+            gB.replay()
+        if b_last:
+            eng.train_step(b_last, b_last, [b_last], B)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        if n_val:
+            eng.eval_loss_sum(n_train, n_train + n_val, 1.0 / (float(n_val) * G))
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        if ep > 0:
+            times.append((t1 - t0, t2 - t1))
+    tr = float(np.mean([t[0] for t in times])); va = float(np.mean([t[1] for t in times]))
+    acc = eng.acc.cpu().numpy()
+    out['epoch'] = {'train_s': tr, 'validation_s': va, 'train_cells': n_train, 'validation_cells': n_val,
+                    'cells_per_s_train_only': n_train / tr, 'cells_per_s_incl_validation': n_train / (tr + va),
+                    'timed_epochs': len(times), 'val_loss_last': float(acc[1]), 'loss_last': float(acc[0]) / n_train}
+    return out
+
+
+def capture_step_warm(eng, B):
+    eng.cursor.zero_()
+    eng.train_step(B, B, [B], B)
+    return capture_step(eng, B, [B])
+
+
 def main():
     args = parse()
     from dca_amd import dist as ddist, synth
@@ -116,22 +216,24 @@ def main():
     n_train_global = int(args.cells * 0.9)               # validation_split=0.1 tail is not trained on
     t0, n_local = ddist.shard(n_train_global, W, rank)
     n_local = n_train_global // W                         # equal shards (all-gather of stats)
+    n_val = args.cells - n_train_global if W == 1 else 0  # one GPU: the held-out rows sit behind the train rows
+    n_store = n_local + n_val
 
     # ---- synthetic data, generated and normalised in HBM (not timed)
-    Y = synth.generate_counts(n_local, G, device=dev, row_offset=rank)
+    Y = synth.generate_counts(n_store, G, device=dev, row_offset=rank)
     # K-PREP (dca_amd/prep.py): size factors, log1p, per-gene z-score on the resident counts;
     # with N ranks the median library size and the gene statistics are global
     from dca_amd import prep
     from dca_amd.ops import HipOps
     pops = HipOps()
-    counts = prep.cell_counts(pops, Y, n_local, G)
+    counts = prep.cell_counts(pops, Y, n_store, G)
     med = (comm.all_gather(counts).flatten() if W > 1 else counts).median()
     sf = counts / med
-    X = prep.transform(pops, Y, n_local, G, sf, True, True, comm if W > 1 else None)
+    X = prep.transform(pops, Y, n_store, G, sf, True, True, comm if W > 1 else None)
     eng = Engine('zinb-conddisp', G, G, hidden, True, 0.0, comm=comm)
     eng.init_params(0)
     eng.attach_device_data(X, Y, sf)
-    eng.reserve(B)
+    eng.reserve(max(B, 1024) if W == 1 else B)           # validation runs in chunks of up to 1024 rows
     eng.clip = 5.0
     eng.set_lr(1e-3)
     total_steps = args.warmup + args.steps
@@ -249,6 +351,10 @@ def main():
                                           'algorithmic HBM bytes %.0f' % m['algorithmic_hbm_bytes'])
             break
 
+    extra = {}
+    if W == 1:
+        extra = after_measurements(eng, args, B, n_local, n_val, G, dev)
+
     if rank == 0:
         out = {
             'metric': 'cells/sec training (ZINB AE, 68k x 20k)',
@@ -262,7 +368,11 @@ def main():
                                       else 'not a BASELINE shape: ad-hoc run', n_train_global, W),
                        'batch_per_gpu': B, 'global_batch': B * W, 'hidden': list(hidden),
                        'parallelism': 'dp%d' % W, 'launch': 'hipGraph replay' if use_graph else 'eager',
-                       'optimizer': 'RMSprop+clipvalue', 'params': int(eng.lay.P)},
+                       'optimizer': 'RMSprop+clipvalue', 'params': int(eng.lay.P),
+                       'arithmetic': 'fp32 results: matrix products as three-way bf16 splits, six products, fp32 accumulation '
+                                     '(fp32-dot-product accuracy, tests/test_heads_fused_gpu.py::test_x3_products_are_fp32_accurate); '
+                                     'likelihood in fp32',
+                       **extra},
             'loss_first': float(losses[0]), 'loss_last': float(losses[total_steps - 1]),
             'roofline': roof, 'kernels': kernels,
         }

@@ -16,6 +16,7 @@
 // contiguous sources are stored with one aligned ds_write_b128 per lane.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "dcahip.h"
 
 namespace {
@@ -248,6 +249,243 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     }
 }
 
+
+// =====================================================================================================
+// fp32 GEMM on the bf16 matrix pipe: every operand element is split into three bf16 pieces (x = x1 + x2 + x3,
+// round-to-nearest residuals) on its way into LDS and the six products a1b1, a1b2, a2b1, a1b3, a2b2, a3b1 are
+// accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  The dropped terms are below 2^-24 of sum|ab|: the result has the
+// accuracy of an fp32 dot product (measured on the MI355X against the exact-fp32 MFMA above: 9.6e-8 vs 1.6e-7 of
+// sum|ab| at K = 64, 1.1e-7 vs 1.2e-7 at K = 4096; tests/test_heads_fused_gpu.py::test_x3_products_are_fp32_accurate)
+// at 6/16 of the matrix-pipe cycles -- the fp32 MFMA runs at the vector rate on gfx950.
+//
+// LDS images (per piece): a k-contiguous source is stored [row][32 k] (64-byte rows, the four 16-byte units of a
+// row rotated by row >> 2: the fragment read -- one ds_read_b128 per lane, lanes = rows -- is conflict-free); an
+// m/n-contiguous source is stored as it comes, [k][cols], and read with the transposing ds_read_b64_tr_b16 (row
+// stride = 64 bytes modulo 128, so the four k rows of a lane group fall into different bank quarters).
+// =====================================================================================================
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x2v = __attribute__((ext_vector_type(2))) __bf16;
+using f32x2v = __attribute__((ext_vector_type(2))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+using s16x4 = __attribute__((ext_vector_type(4))) short;
+
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{a, b}, bf16x2v));
+}
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& p0, unsigned& p1, unsigned& p2) {
+    p0 = pk_bf16(x0, x1);
+    const float r0 = x0 - __uint_as_float(p0 << 16), r1 = x1 - __uint_as_float(p0 & 0xffff0000u);
+    p1 = pk_bf16(r0, r1);
+    const float q0 = r0 - __uint_as_float(p1 << 16), q1 = r1 - __uint_as_float(p1 & 0xffff0000u);
+    p2 = pk_bf16(q0, q1);
+}
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0)
+
+// image of one operand tile: DIM rows/cols x 32 k, three pieces
+template <bool KC, int DIM>
+struct X3Image {
+    static constexpr int STRIDE = KC ? 64 : (DIM * 2 + ((DIM * 2) % 128 == 64 ? 0 : 64 - (DIM * 2) % 128 + ((DIM * 2) % 128 > 64 ? 128 : 0)));
+    static constexpr int PIECE = KC ? DIM * 64 : 32 * STRIDE;       // bytes
+    static constexpr int BYTES = 3 * PIECE;
+    static_assert(KC || STRIDE % 128 == 64, "transposed-read images: row stride = 64 bytes modulo 128 (four k rows -> four bank quarters)");
+    static_assert(KC || STRIDE % 8 == 0, "8-byte aligned rows");
+
+    // ---- stores (registers of the tile loaders above -> pieces)
+    template <int ROWS, int V>
+    static __device__ __forceinline__ void store(unsigned char* S, const KContig<ROWS, 32, V>& l) {
+        static_assert(KC, "layout");
+        using L = KContig<ROWS, 32, V>;
+        const int t = threadIdx.x;
+        const int k = (t % L::TK) * V, mr = t / L::TK;
+#pragma unroll
+        for (int i = 0; i < L::PASSES; ++i) {
+            const int m = mr + i * L::RPP;
+            unsigned char* row = S + m * 64;
+            if (V == 4) {
+                unsigned a0, a1, a2, b0, b1, b2;
+                split_pair(l.r[i][0], l.r[i][1 % V], a0, a1, a2);
+                split_pair(l.r[i][2 % V], l.r[i][3 % V], b0, b1, b2);
+                const int off = ((((k >> 3) + (m >> 2)) & 3) << 4) + (((k >> 2) & 1) << 3);
+                *reinterpret_cast<u32x2*>(row + off) = u32x2{a0, b0};
+                *reinterpret_cast<u32x2*>(row + PIECE + off) = u32x2{a1, b1};
+                *reinterpret_cast<u32x2*>(row + 2 * PIECE + off) = u32x2{a2, b2};
+            } else {
+                unsigned a0, a1, a2;
+                split_pair(l.r[i][0], 0.f, a0, a1, a2);
+                const int off = ((((k >> 3) + (m >> 2)) & 3) << 4) + ((k & 7) << 1);
+                *reinterpret_cast<unsigned short*>(row + off) = (unsigned short)a0;
+                *reinterpret_cast<unsigned short*>(row + PIECE + off) = (unsigned short)a1;
+                *reinterpret_cast<unsigned short*>(row + 2 * PIECE + off) = (unsigned short)a2;
+            }
+        }
+    }
+    template <int COLS, int V>
+    static __device__ __forceinline__ void store(unsigned char* S, const MNContig<COLS, 32, V>& l, float (&csum)[V], bool colsum) {
+        static_assert(!KC, "layout");
+        using L = MNContig<COLS, 32, V>;
+        const int t = threadIdx.x;
+        const int c = (t % L::TC) * V, kr = t / L::TC;
+#pragma unroll
+        for (int i = 0; i < L::PASSES; ++i) {
+            const int k = kr + i * L::KPP;
+            if (k < 32) {
+                unsigned char* row = S + k * STRIDE + c * 2;
+                if (colsum) {
+#pragma unroll
+                    for (int j = 0; j < V; ++j) csum[j] += l.r[i][j];
+                }
+                if (V == 4) {
+                    unsigned a0, a1, a2, b0, b1, b2;
+                    split_pair(l.r[i][0], l.r[i][1 % V], a0, a1, a2);
+                    split_pair(l.r[i][2 % V], l.r[i][3 % V], b0, b1, b2);
+                    *reinterpret_cast<u32x2*>(row) = u32x2{a0, b0};
+                    *reinterpret_cast<u32x2*>(row + PIECE) = u32x2{a1, b1};
+                    *reinterpret_cast<u32x2*>(row + 2 * PIECE) = u32x2{a2, b2};
+                } else {
+                    unsigned a0, a1, a2;
+                    split_pair(l.r[i][0], 0.f, a0, a1, a2);
+                    *reinterpret_cast<unsigned short*>(row) = (unsigned short)a0;
+                    *reinterpret_cast<unsigned short*>(row + PIECE) = (unsigned short)a1;
+                    *reinterpret_cast<unsigned short*>(row + 2 * PIECE) = (unsigned short)a2;
+                }
+            }
+        }
+    }
+    // ---- MFMA operand fragment: row/col `idx0 + (lane & 31)`, k = 16 ks + 8 (lane >> 5) .. + 7, piece q
+    static __device__ __forceinline__ u32x4 frag(const unsigned char* S, int idx0, int ks, int q, int lane) {
+        const int l31 = lane & 31, hi = lane >> 5;
+        if (KC) {
+            const int m = idx0 + l31;
+            return *reinterpret_cast<const u32x4*>(S + q * PIECE + m * 64 + (((2 * ks + hi + (m >> 2)) & 3) << 4));
+        } else {
+            const int t16 = lane & 15;
+            const unsigned char* b = S + q * PIECE + (16 * ks + 8 * hi + (t16 >> 2)) * STRIDE
+                                     + (idx0 + 16 * ((lane >> 4) & 1) + 4 * (t16 & 3)) * 2;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(b));
+            const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(b + 4 * STRIDE));
+            const u32x2 a = __builtin_bit_cast(u32x2, lo), c = __builtin_bit_cast(u32x2, hi4);
+            return u32x4{a[0], a[1], c[0], c[1]};
+        }
+    }
+};
+
+template <int BM, int BN, int WGM, int WGN, bool TA, bool TB, int V>
+__global__ __launch_bounds__(256) void gemm_x3_kernel(GemmArgs p) {
+    static_assert(WGM * WGN == 4, "4 waves per workgroup");
+    constexpr int BK = 32;
+    constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
+    constexpr bool A_KC = !TA, B_KC = TB;
+    using IA = X3Image<A_KC, BM>;
+    using IB = X3Image<B_KC, BN>;
+    __shared__ __attribute__((aligned(16))) unsigned char As[IA::BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[IB::BYTES];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    int id = blockIdx.x;
+    const int s = id % p.split; id /= p.split;
+    const int nt = id % p.ntiles;
+    const int mt = id / p.ntiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int kbeg = s * p.kslab;
+    const int kend = min(p.K, kbeg + p.kslab);
+    const RowMap amap{p.perm, p.cursor ? *p.cursor : 0};
+    const Identity ident;
+
+    typename LoaderSel<A_KC, BM, BK, V>::T la;
+    typename LoaderSel<B_KC, BN, BK, V>::T lb;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const bool do_colsum = TA && p.colsum && mt == 0;        // B is n-contiguous there (TN): column sums at store time
+    float csum[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) csum[j] = 0.f;
+    float dummy[V];
+
+    const int wm0 = (wave / WGN) * WM, wn0 = (wave % WGN) * WN;
+    const int nchunks = (kend - kbeg + BK - 1) / BK;
+
+    la.load(p.A, p.lda, m0, p.M, kbeg, kend, amap);
+    lb.load(p.B, p.ldb, n0, p.N, kbeg, kend, ident);
+    for (int c = 0; c < nchunks; ++c) {
+        if constexpr (A_KC) IA::store(As, la); else IA::store(As, la, dummy, false);
+        if constexpr (B_KC) IB::store(Bs, lb); else IB::store(Bs, lb, csum, do_colsum);
+        __syncthreads();
+        if (c + 1 < nchunks) {
+            const int k0 = kbeg + (c + 1) * BK;
+            la.load(p.A, p.lda, m0, p.M, k0, kend, amap);
+            lb.load(p.B, p.ldb, n0, p.N, k0, kend, ident);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            u32x4 a[TM][3], b[TN][3];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) a[i][q] = IA::frag(As, wm0 + i * 32, ks, q, lane);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) b[j][q] = IB::frag(Bs, wn0 + j * 32, ks, q, lane);
+            // six products per accumulator, small terms first, round-robin over the accumulators
+#pragma unroll
+            for (int pr = 0; pr < 6; ++pr) {
+                constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = MFMA16(a[i][PA[pr]], b[j][PB[pr]], acc[i][j]);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue ------------------------------------------------------------------------
+    const int Mo = p.M + (p.colsum ? 1 : 0);
+    float* out = p.split > 1 ? p.ws + (long)s * Mo * p.N : p.C;
+    const long ldo = p.split > 1 ? (long)p.N : p.ldc;
+    const bool add_bias = p.split == 1 && p.bias != nullptr;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn0 + j * 32 + (lane & 31);
+        const float bv = (add_bias && n < p.N) ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < p.M && n < p.N) out[(long)m * ldo + n] = acc[i][j][r] + bv;
+            }
+        }
+    }
+    if constexpr (TA) {
+        if (do_colsum) {
+            // column sums of B (the bias gradient): per-thread partial sums of the rows this thread stored, combined over
+            // the KPP row groups in fixed order
+            using L = MNContig<BN, BK, V>;
+            float* red = reinterpret_cast<float*>(As);             // safe: the last loop iteration ended with a barrier
+            const int c = (t % L::TC) * V, kr = t / L::TC;
+            static_assert(L::KPP * BN * 4 <= IA::BYTES, "column-sum scratch");
+#pragma unroll
+            for (int j = 0; j < V; ++j) red[kr * BN + c + j] = csum[j];
+            __syncthreads();
+            if (t < BN) {
+                float v = 0.f;
+                for (int q = 0; q < L::KPP; ++q) v += red[q * BN + t];
+                const int n = n0 + t;
+                if (n < p.N) out[(long)p.M * ldo + n] = v;
+            }
+        }
+    }
+}
+
 // C[m,n] = bias[n] + sum_s ws[s][m][n]  (ordered: deterministic).  GL threads split the S slabs of
 // one output (many slabs of a small C: the batch-32 regime), combined in fixed order through LDS.
 template <int GL>
@@ -326,9 +564,16 @@ Plan make_plan(int M, int N, int K, int split_k) {
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// DCA_GEMM_F32MFMA=1: the exact-fp32 MFMA kernel (A/B runs and the yardstick of the accuracy test)
+inline bool use_f32_mfma() {
+    static const bool v = [] { const char* e = getenv("DCA_GEMM_F32MFMA"); return e && e[0] == '1'; }();
+    return v;
+}
+
 template <int BM, int BN, int WGM, int WGN>
-int launch_cfg(const GemmArgs& a, int ta, int tb, bool vec, int grid, hipStream_t s) {
-#define DCA_L(TA, TB, V) hipLaunchKernelGGL((gemm_kernel<BM, BN, kBK, WGM, WGN, TA, TB, V>), dim3(grid), dim3(256), 0, s, a)
+int launch_cfg(const GemmArgs& a, int ta, int tb, bool vec, int grid, hipStream_t s, bool exact) {
+#define DCA_L(TA, TB, V) do { if (exact) hipLaunchKernelGGL((gemm_kernel<BM, BN, kBK, WGM, WGN, TA, TB, V>), dim3(grid), dim3(256), 0, s, a); \
+                              else hipLaunchKernelGGL((gemm_x3_kernel<BM, BN, WGM, WGN, TA, TB, V>), dim3(grid), dim3(256), 0, s, a); } while (0)
     if (!ta && !tb) { if (vec) DCA_L(false, false, 4); else DCA_L(false, false, 1); }
     else if (ta && !tb) { if (vec) DCA_L(true, false, 4); else DCA_L(true, false, 1); }
     else if (!ta && tb) { if (vec) DCA_L(false, true, 4); else DCA_L(false, true, 1); }
@@ -365,10 +610,11 @@ extern "C" int dcahip_sgemm(int ta, int tb, int M, int N, int K, const float* A,
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int grid = p.mtiles * p.ntiles * p.split;
     int rc;
-    if (p.cfg == 0) rc = launch_cfg<128, 64, 4, 1>(a, ta, tb, vec, grid, s);
-    else if (p.cfg == 1) rc = launch_cfg<64, 128, 1, 4>(a, ta, tb, vec, grid, s);
-    else if (p.cfg == 3) rc = launch_cfg<64, 64, 2, 2>(a, ta, tb, vec, grid, s);
-    else rc = launch_cfg<128, 128, 2, 2>(a, ta, tb, vec, grid, s);
+    const bool exact = use_f32_mfma() || (split_k < 0);
+    if (p.cfg == 0) rc = launch_cfg<128, 64, 4, 1>(a, ta, tb, vec, grid, s, exact);
+    else if (p.cfg == 1) rc = launch_cfg<64, 128, 1, 4>(a, ta, tb, vec, grid, s, exact);
+    else if (p.cfg == 3) rc = launch_cfg<64, 64, 2, 2>(a, ta, tb, vec, grid, s, exact);
+    else rc = launch_cfg<128, 128, 2, 2>(a, ta, tb, vec, grid, s, exact);
     if (rc != 0) return rc;
     if (p.split > 1) {
         const int Mo = M + (colsum_row ? 1 : 0);

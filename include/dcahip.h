@@ -156,16 +156,21 @@ int dcahip_heads_fused_ordered(const float* H, long ldh, const float* Wh, long l
                                void* workspace, long workspace_bytes, const int* tile_order, void* stream);
 
 /*
- * C[M,N] = op(A) * op(B) (+ bias) on the fp32 MFMA pipe (v_mfma_f32_32x32x2_f32), LDS-tiled,
- * deterministic split-K through `workspace`.  Replaces the MatMul/BiasAdd kernels of every
- * keras Dense layer forward and backward (dca/network.py:124-126,369-380 and autodiff).
+ * C[M,N] = op(A) * op(B) (+ bias), fp32 in / fp32 out, LDS-tiled, deterministic split-K through `workspace`.
+ * Arithmetic: every operand element is split into three bf16 pieces and the six products a1b1, a1b2, a2b1, a1b3,
+ * a2b2, a3b1 are accumulated in fp32 on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16) -- the accuracy of an fp32
+ * dot product (dcahip_x3_product_32x32 states the contract) at 6/16 of the cycles of the fp32 MFMA, which runs at the
+ * vector rate on gfx950.  split_k < 0 selects the exact-fp32 MFMA kernel (v_mfma_f32_32x32x2_f32, a k-ordered fmaf
+ * chain) with the library's split heuristic: the yardstick of the accuracy tests.
+ * Replaces the MatMul/BiasAdd kernels of every keras Dense layer forward and backward
+ * (dca/network.py:124-126,369-380 and autodiff).
  *   ta == 0: A stored [M,K] (lda >= K)      ta == 1: A stored [K,M]   (C = A^T B, weight grads)
  *   tb == 0: B stored [K,N]                 tb == 1: B stored [N,K]   (C = A B^T, input grads)
  *   bias     : [N] added to every row of C, or NULL
  *   perm/cursor : gather on A's STORAGE rows (batch rows: m index if ta==0, k index if ta==1)
  *   colsum_row  : if non-zero (ta==1 only) additionally writes colsum_k B[k,:] into row M of
  *                 C (C + M*ldc): the Dense bias gradient, free while B streams through LDS
- *   split_k  : 0 = library heuristic (a pure function of the shape), else forced
+ *   split_k  : 0 = library heuristic (a pure function of the shape), > 0 forced, < 0 exact-fp32 kernel + heuristic
  *   workspace: >= dcahip_sgemm_workspace_bytes(...) bytes, may be NULL when that is 0
  */
 int dcahip_sgemm(int ta, int tb, int M, int N, int K,

@@ -222,8 +222,8 @@ def test_x3_products_are_fp32_accurate(ops, K, dist):
     C = torch.zeros(32, 32, device='cuda')
     ops.x3_product_32x32(dA, dB, C, K)
     C32 = torch.zeros(32, 32, device='cuda')
-    ws = torch.zeros(max(ops.sgemm_workspace_bytes(0, 0, 32, 32, K) // 4, 4), device='cuda')
-    ops.sgemm(0, 0, 32, 32, K, dA, K, dB, 32, C32, 32, ws=ws, split_k=1)
+    ws = torch.zeros(max(ops.sgemm_workspace_bytes(0, 0, 32, 32, K, False, -1) // 4, 4), device='cuda')
+    ops.sgemm(0, 0, 32, 32, K, dA, K, dB, 32, C32, 32, ws=ws, split_k=-1)       # split_k < 0: the exact-fp32 MFMA kernel
     torch.cuda.synchronize()
     ref = A.astype(np.float64) @ Bm.astype(np.float64)
     mag = np.abs(A.astype(np.float64)) @ np.abs(Bm.astype(np.float64))
