@@ -144,17 +144,31 @@ def capture_step(eng, b, counts):
     return g
 
 
+def _mark(msg):
+    if os.environ.get('DCA_BENCH_TRACE'):
+        torch.cuda.synchronize()
+        print('bench: ' + msg, file=sys.stderr, flush=True)
+
+
 def after_measurements(eng, args, B, n_train, n_val, G, dev):
     """Same process, same resident matrix, after the timed region (one GPU): the reference-default batch 32 and
     the end-to-end epoch (all train rows incl. the last partial batch + the validation pass)."""
     out = {}
     gen = torch.Generator(device='cpu'); gen.manual_seed(99)
-    # ---- batch 32 (dca/train.py:37 default): hipGraph replay, 400 timed steps
+    # captured steps hold the addresses of eng.perm / eng.hist: ONE buffer each for everything below, refilled in place
     b32, k32 = 32, 400
-    eng.perm = torch.randperm(n_train, generator=gen, dtype=torch.int32)[:(k32 + 8) * b32].to(dev)
-    eng.hist = torch.zeros(k32 + 16, dtype=torch.float32, device=dev)
-    eng.cursor.zero_(); eng.acc.zero_()
+    eng.perm = torch.zeros(max(n_train, (k32 + 8) * b32), dtype=torch.int32, device=dev)
+    eng.hist = torch.zeros(max(n_train // b32, k32) + 16, dtype=torch.float32, device=dev)
+
+    def new_order(count):
+        eng.perm[:count].copy_(torch.randperm(n_train, generator=gen, dtype=torch.int32)[:count])
+        eng.cursor.zero_(); eng.acc.zero_()
+
+    # ---- batch 32 (dca/train.py:37 default): hipGraph replay, 400 timed steps
+    new_order((k32 + 8) * b32)
+    _mark('batch-32 eager step')
     eng.train_step(b32, b32, [b32], b32)
+    _mark('batch-32 capture')
     try:
         g32 = capture_step(eng, b32, [b32])
         launches = graph_kernel_nodes(g32) if hasattr(g32, 'raw_cuda_graph') else None
@@ -168,14 +182,15 @@ def after_measurements(eng, args, B, n_train, n_val, G, dev):
                           'steps': k32, 'launch': 'hipGraph replay'}
     except Exception as e:
         out['batch32'] = {'error': str(e)}
+    _mark('epoch timing')
     # ---- one epoch at the bench batch: train rows in shuffled order, last partial batch included, then validation
     steps_full, b_last = n_train // B, n_train % B
-    gB = capture_step_warm(eng, B)
+    new_order(n_train)
+    eng.train_step(B, B, [B], B)
+    gB = capture_step(eng, B, [B])
     times = []
     for ep in range(4):
-        eng.perm = torch.randperm(n_train, generator=gen, dtype=torch.int32).to(dev)
-        eng.hist = torch.zeros(steps_full + 4, dtype=torch.float32, device=dev)
-        eng.cursor.zero_(); eng.acc.zero_()
+        new_order(n_train)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(steps_full):
             gB.replay()
@@ -193,12 +208,6 @@ def after_measurements(eng, args, B, n_train, n_val, G, dev):
                     'cells_per_s_train_only': n_train / tr, 'cells_per_s_incl_validation': n_train / (tr + va),
                     'timed_epochs': len(times), 'val_loss_last': float(acc[1]), 'loss_last': float(acc[0]) / n_train}
     return out
-
-
-def capture_step_warm(eng, B):
-    eng.cursor.zero_()
-    eng.train_step(B, B, [B], B)
-    return capture_step(eng, B, [B])
 
 
 def main():
@@ -352,8 +361,10 @@ def main():
             break
 
     extra = {}
+    _mark('timed region and kernel timing done')
     if W == 1:
         extra = after_measurements(eng, args, B, n_local, n_val, G, dev)
+    _mark('after-measurements done')
 
     if rank == 0:
         out = {

@@ -52,64 +52,45 @@ def dca(adata,
     """
     assert is_anndata(adata), 'adata must be an AnnData instance'
     assert mode in ('denoise', 'latent'), '%s is not a valid mode.' % mode
+    _seed_host_generators(random_state)
 
-    # set seed for reproducibility
-    random.seed(random_state)
-    np.random.seed(random_state)
+    # counts -> AnnData with .raw and the train/test column (api.py:156-160); copy=True works on a private copy
+    work = read_dataset(adata, transpose=False, test_split=False, copy=copy, check_counts=check_counts)
+    keep_gene, _ = filter_genes_mask(work.X, min_counts=1)
+    assert keep_gene.all(), 'Please remove all-zero genes before using DCA.'            # api.py:163-164
+    # cell / gene indices must survive untouched, so no count filtering inside normalize (api.py:166-170)
+    work = normalize(work, filter_min_counts=False, size_factors=normalize_per_cell,
+                     normalize_input=scale, logtrans_input=log1p)
+
+    net = _make_network(ae_type, work.n_vars, random_state,
+                        dict(network_kwds, hidden_size=hidden_size, hidden_dropout=hidden_dropout,
+                             batchnorm=batchnorm, activation=activation, init=init))
+    fit_kwds = dict(training_kwds, epochs=epochs, reduce_lr=reduce_lr, early_stop=early_stop,
+                    batch_size=batch_size, optimizer=optimizer, verbose=verbose, threads=threads,
+                    learning_rate=learning_rate)
+    history = train(work[work.obs.dca_split == 'train'], net, **fit_kwds)               # api.py:203
+
+    predicted = net.predict(work, mode, return_info, copy)      # in place unless copy (network.py:188-211)
+    result = predicted if copy else work
+    if return_info:
+        result.uns['dca_loss_history'] = history.history
+    # api.py:208-211: what comes back depends on (copy, return_model)
+    if copy:
+        return (result, net) if return_model else result
+    return net if return_model else None
+
+
+def _seed_host_generators(seed):
+    """api.py:150-153: python's and numpy's global generators (the per-epoch shuffles draw from numpy's)."""
+    random.seed(seed)
+    np.random.seed(seed)
     os.environ['PYTHONHASHSEED'] = '0'
 
-    # this creates adata.raw with raw counts and copies adata if copy==True
-    adata = read_dataset(adata,
-                         transpose=False,
-                         test_split=False,
-                         copy=copy,
-                         check_counts=check_counts)
 
-    # check for zero genes
-    nonzero_genes, _ = filter_genes_mask(adata.X, min_counts=1)
-    assert nonzero_genes.all(), 'Please remove all-zero genes before using DCA.'
-
-    adata = normalize(adata,
-                      filter_min_counts=False,  # no filtering, keep cell and gene idxs same
-                      size_factors=normalize_per_cell,
-                      normalize_input=scale,
-                      logtrans_input=log1p)
-
-    network_kwds = {**network_kwds,
-                    'hidden_size': hidden_size,
-                    'hidden_dropout': hidden_dropout,
-                    'batchnorm': batchnorm,
-                    'activation': activation,
-                    'init': init
-                    }
-
-    input_size = output_size = adata.n_vars
-    net = AE_types[ae_type](input_size=input_size,
-                            output_size=output_size,
-                            **network_kwds)
-    net.seed = random_state
+def _make_network(ae_type, n_genes, seed, kwds):
+    """AE_types lookup, save() before build() as the reference does (api.py:181-188, train.py:170-171)."""
+    net = AE_types[ae_type](input_size=n_genes, output_size=n_genes, **kwds)
+    net.seed = seed
     net.save()
     net.build()
-
-    training_kwds = {**training_kwds,
-                     'epochs': epochs,
-                     'reduce_lr': reduce_lr,
-                     'early_stop': early_stop,
-                     'batch_size': batch_size,
-                     'optimizer': optimizer,
-                     'verbose': verbose,
-                     'threads': threads,
-                     'learning_rate': learning_rate
-                     }
-
-    hist = train(adata[adata.obs.dca_split == 'train'], net, **training_kwds)
-    res = net.predict(adata, mode, return_info, copy)
-    adata = res if copy else adata
-
-    if return_info:
-        adata.uns['dca_loss_history'] = hist.history
-
-    if return_model:
-        return (adata, net) if copy else net
-    else:
-        return adata if copy else None
+    return net

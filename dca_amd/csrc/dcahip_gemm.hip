@@ -570,6 +570,11 @@ inline bool use_f32_mfma() {
     return v;
 }
 
+inline bool force_x3() {            // DCA_GEMM_X3=1: split-bf16 kernel for every layout (A/B runs)
+    static const bool v = [] { const char* e = getenv("DCA_GEMM_X3"); return e && e[0] == '1'; }();
+    return v;
+}
+
 template <int BM, int BN, int WGM, int WGN>
 int launch_cfg(const GemmArgs& a, int ta, int tb, bool vec, int grid, hipStream_t s, bool exact) {
 #define DCA_L(TA, TB, V) do { if (exact) hipLaunchKernelGGL((gemm_kernel<BM, BN, kBK, WGM, WGN, TA, TB, V>), dim3(grid), dim3(256), 0, s, a); \
@@ -610,7 +615,13 @@ extern "C" int dcahip_sgemm(int ta, int tb, int M, int N, int K, const float* A,
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int grid = p.mtiles * p.ntiles * p.split;
     int rc;
-    const bool exact = use_f32_mfma() || (split_k < 0);
+    // Which arithmetic (a pure function of the layout and the shape; results of both are fp32-accurate):
+    //   NT (both operands k-contiguous: direct 16-byte LDS operand reads)       split-bf16, measured 1.35x - 2.1x faster
+    //   NN with >= 128 columns (B through the transposing read)                 split-bf16, 1.07x - 1.13x
+    //   NN with fewer columns, TN                                               exact fp32 MFMA (the split kernel's larger LDS
+    //       images cost more occupancy than the shorter matrix phase returns on these latency-bound shapes: 0.158 vs 0.157 ms
+    //       and 0.195 vs 0.150 ms on the first layer at B = 4096; profiles/r02e_gemm_ab.txt)
+    const bool exact = use_f32_mfma() || split_k < 0 || (ta && !force_x3()) || (!ta && !tb && N < 128 && !force_x3());
     if (p.cfg == 0) rc = launch_cfg<128, 64, 4, 1>(a, ta, tb, vec, grid, s, exact);
     else if (p.cfg == 1) rc = launch_cfg<64, 128, 1, 4>(a, ta, tb, vec, grid, s, exact);
     else if (p.cfg == 3) rc = launch_cfg<64, 64, 2, 2>(a, ta, tb, vec, grid, s, exact);

@@ -276,79 +276,54 @@ def train(adata, network, output_dir=None, optimizer='RMSprop', learning_rate=No
 
 
 def train_with_args(args):
-    """The CLI pipeline of dca/train.py:103-191 (seed 42, read -> normalize with count filtering
-    -> build -> train -> predict(mode='full', return_info=True) -> write TSVs)."""
+    """The command-line pipeline (dca/train.py:103-191): fixed seed 42, read -> normalize (with count filtering) ->
+    network -> train -> predict(mode='full', return_info=True) -> result files.  ``--hyper`` hands over to the
+    hyper-parameter search and returns (train.py:119-122)."""
     import random
     from . import io
     from .network import AE_types
 
-    random.seed(42)
-    np.random.seed(42)
+    seed = 42
+    random.seed(seed)
+    np.random.seed(seed)
     os.environ['PYTHONHASHSEED'] = '0'
-
-    if args.hyper:                              # train.py:119-122: do hyperpar optimization and exit
+    if args.hyper:
         from .hyper import hyper
-        hyper(args)
-        return
+        return hyper(args)
 
-    adata = io.read_dataset(args.input,
-                            transpose=(not args.transpose),  # assume gene x cell by default
-                            check_counts=args.checkcounts,
+    # the CLI reads gene x cell tables unless --transpose says otherwise
+    adata = io.read_dataset(args.input, transpose=not args.transpose, check_counts=args.checkcounts,
                             test_split=args.testsplit)
-    adata = io.normalize(adata,
-                         size_factors=args.sizefactors,
-                         logtrans_input=args.loginput,
+    adata = io.normalize(adata, size_factors=args.sizefactors, logtrans_input=args.loginput,
                          normalize_input=args.norminput)
 
+    subset = None                                   # --denoisesubset: the loss sees these output genes only
     if args.denoisesubset:
-        genelist = list(set(io.read_genelist(args.denoisesubset)))
-        assert len(set(genelist) - set(adata.var_names.values)) == 0, \
-            'Gene list is not overlapping with genes from the dataset'
-        output_size = len(genelist)
-    else:
-        genelist = None
-        output_size = adata.n_vars
+        subset = list(set(io.read_genelist(args.denoisesubset)))
+        unknown = set(subset) - set(adata.var_names.values)
+        assert len(unknown) == 0, 'Gene list is not overlapping with genes from the dataset'
+    n_out = len(subset) if subset else adata.n_vars
 
-    hidden_size = [int(x) for x in args.hiddensize.split(',')]
-    hidden_dropout = [float(x) for x in args.dropoutrate.split(',')]
-    if len(hidden_dropout) == 1:
-        hidden_dropout = hidden_dropout[0]
-
+    widths = [int(w) for w in args.hiddensize.split(',')]
+    rates = [float(r) for r in args.dropoutrate.split(',')]
     assert args.type in AE_types, 'loss type not supported'
-    net = AE_types[args.type](input_size=adata.n_vars,
-                              output_size=output_size,
-                              hidden_size=hidden_size,
-                              l2_coef=args.l2, l1_coef=args.l1,
-                              l2_enc_coef=args.l2enc, l1_enc_coef=args.l1enc,
-                              ridge=args.ridge,
-                              hidden_dropout=hidden_dropout,
-                              input_dropout=args.inputdropout,
-                              batchnorm=args.batchnorm,
-                              activation=args.activation,
-                              init=args.init,
-                              debug=args.debug,
-                              file_path=args.outputdir)
-    net.seed = 42
+    net = AE_types[args.type](input_size=adata.n_vars, output_size=n_out, hidden_size=widths,
+                              hidden_dropout=rates[0] if len(rates) == 1 else rates,
+                              input_dropout=args.inputdropout, batchnorm=args.batchnorm,
+                              activation=args.activation, init=args.init, ridge=args.ridge,
+                              l1_coef=args.l1, l2_coef=args.l2, l1_enc_coef=args.l1enc, l2_enc_coef=args.l2enc,
+                              debug=args.debug, file_path=args.outputdir)
+    net.seed = seed
     net.save()
     net.build()
 
-    mask = (adata.obs.dca_split == 'train').values
-    train(adata[mask], net,
-          output_dir=args.outputdir,
-          learning_rate=args.learningrate,
-          epochs=args.epochs, batch_size=args.batchsize,
-          early_stop=args.earlystop,
-          reduce_lr=args.reducelr,
-          output_subset=genelist,
-          optimizer=args.optimizer,
-          clip_grad=args.gradclip,
-          save_weights=args.saveweights,
-          tensorboard=args.tensorboard)
+    in_train = (adata.obs.dca_split == 'train').values
+    train(adata[in_train], net, output_dir=args.outputdir, optimizer=args.optimizer,
+          learning_rate=args.learningrate, epochs=args.epochs, batch_size=args.batchsize,
+          reduce_lr=args.reducelr, early_stop=args.earlystop, clip_grad=args.gradclip,
+          output_subset=subset, save_weights=args.saveweights, tensorboard=args.tensorboard)
 
-    if genelist:
-        predict_columns = adata.var_names[[np.where(adata.var_names == x)[0][0] for x in genelist]]
-    else:
-        predict_columns = adata.var_names
-
+    names = adata.var_names
+    columns = names[[int(np.where(names == g)[0][0]) for g in subset]] if subset else names
     net.predict(adata, mode='full', return_info=True)
-    net.write(adata, args.outputdir, mode='full', colnames=predict_columns)
+    net.write(adata, args.outputdir, mode='full', colnames=columns)

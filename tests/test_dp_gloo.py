@@ -88,10 +88,17 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize('ae,bn,n,B', [('zinb-conddisp', True, 60, 16), ('zinb-conddisp', True, 38, 16), ('zinb-conddisp', True, 37, 16),
-                                       ('nb', True, 50, 8), ('zinb', False, 60, 16)])
-def test_two_rank_dp_equals_single_process_and_oracle(ae, bn, n, B):
-    G, hs, epochs, seed, W = 14, (6, 3, 6), 3, 17, 2
+@pytest.mark.parametrize('ae,bn,n,B,W', [('zinb-conddisp', True, 60, 16, 2), ('zinb-conddisp', True, 38, 16, 2), ('zinb-conddisp', True, 37, 16, 2),
+                                         ('nb', True, 50, 8, 2), ('zinb', False, 60, 16, 2),
+                                         # 4 ranks, 18 train rows = shards of 5, 5, 4, 4 at 4 rows per rank and step: in the last
+                                         # step of every epoch ranks 2 and 3 are EMPTY (they still join every collective);
+                                         # 2 validation rows = shards 1, 1, 0, 0
+                                         ('zinb-conddisp', True, 20, 16, 4), ('nb', True, 23, 8, 4)])
+def test_two_rank_dp_equals_single_process_and_oracle(ae, bn, n, B, W):
+    G, hs, epochs, seed = 14, (6, 3, 6), 3, 17
+    if W == 4 and n == 20:
+        shards = [ddist.shard(int(n * 0.9), W, r)[1] for r in range(W)]
+        assert shards == [5, 5, 4, 4] and B // W == 4           # => two empty ranks in the last step
     cfg = (n, G, hs, ae, bn, B, epochs, seed)
     ctx = mp.get_context('spawn')
     q = ctx.Queue()

@@ -79,3 +79,31 @@ def test_two_ranks_on_one_gpu_equal_single_process(ae, n, B):
         if k[0] == 'b' and k[1:].isdigit():
             continue
         np.testing.assert_allclose(p_dp[k], p1[k], rtol=2e-3, atol=2e-3, err_msg=k)
+
+
+def test_bench_multi_rank_branch_runs_on_one_gpu():
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank), with gloo as the
+    exchange backend because the test box has one GPU (DCA_AMD_DIST_BACKEND=gloo; RCCL needs a GPU per rank).  Keeps
+    the multi-rank branch of the bench alive: sharded generation, global K-PREP statistics (all-gather of the
+    library sizes, all-reduce of the gene moments), the eager step with both gradient buckets, the max-over-ranks
+    timing, ONE JSON line from rank 0 with whole-job cells/s and weak scaling."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DCA_AMD_DIST_BACKEND='gloo', MASTER_ADDR='127.0.0.1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '2',
+           '--cells', '6000', '--genes', '2000', '--batch-size', '256']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['scaling'] == 'weak' and out['steps'] == 3
+    assert out['config']['global_batch'] == 512 and out['config']['parallelism'] == 'dp2'
+    assert out['config']['launch'] == 'eager'                     # collectives are not captured
+    assert np.isfinite(out['value']) and out['value'] > 0
+    assert abs(out['value'] - 3 * 512 / (out['ms_per_step'] * 3e-3)) < 1e-6 * out['value']
+    assert np.isfinite(out['loss_first']) and np.isfinite(out['loss_last'])
+    assert out['cpu_baseline'] is None                            # rank 0 at N = 1 only

@@ -308,8 +308,13 @@ def test_full_size_step_fused_equals_separate(ops, c3):
 
 @pytest.mark.parametrize('optimizer', __import__('_opt_cases').OPTIMIZERS)
 def test_other_optimizers_fit_matches_oracle(ops, optimizer):
+    """Per-epoch loss / val_loss of a 3-epoch fit against the fp64 oracle: 1e-4 for the optimizers that are linear or
+    smooth in the gradient; 5e-4 for the sign-normalising ones (Adam, Adamax, Nadam, Adadelta: update ~ g / |g|-scale),
+    where a gradient component at the fp32 noise floor moves its parameter by O(lr) in a direction the rounding picks
+    -- the exact-fp32 and the split-bf16 matrix products are equally accurate (test_x3_products_are_fp32_accurate) but
+    round differently, and the trajectories separate at the 1e-4 level from the first epoch on."""
     from _opt_cases import run_fit_parity
-    run_fit_parity(ops, optimizer=optimizer, rtol=1e-4)
+    run_fit_parity(ops, optimizer=optimizer, rtol=5e-4 if optimizer in ('Adam', 'Adamax', 'Nadam', 'Adadelta') else 1e-4)
 
 
 @pytest.mark.parametrize('reg', __import__('_opt_cases').REG_CASES)
