@@ -206,7 +206,9 @@ def after_measurements(eng, args, B, n_train, n_val, G, dev):
     acc = eng.acc.cpu().numpy()
     out['epoch'] = {'train_s': tr, 'validation_s': va, 'train_cells': n_train, 'validation_cells': n_val,
                     'cells_per_s_train_only': n_train / tr, 'cells_per_s_incl_validation': n_train / (tr + va),
-                    'timed_epochs': len(times), 'val_loss_last': float(acc[1]), 'loss_last': float(acc[0]) / n_train}
+                    'timed_epochs': len(times), 'val_loss_last': float(acc[1]), 'loss_last': float(acc[0]) / n_train,
+                    'steps_per_epoch': steps_full + (1 if b_last else 0), 'last_batch': b_last,
+                    'train_s_each': [round(t[0], 6) for t in times]}
     return out
 
 

@@ -653,6 +653,9 @@ struct HeadsArgs2 {
     long long* timing;
     const unsigned short* HA;         // [NT][3][32 rows][64 k] bf16 pieces of the decoder output (forward A operand)
     const unsigned short* HT;         // [NT][3][64 k][32 rows, order of the MFMA row map] (dW A operand)
+    const float* H; long ldh;         // the decoder output itself: single-wave workgroups (batches below 256 rows) split it on the fly
+    float* gW; long ldg;              // S == 1: weight / bias gradients go straight to their destination (no partial buffer)
+    float* g_theta;
     const float* Wh; long ldw;
     const float* bh;
     const float* theta_w;
@@ -814,19 +817,47 @@ __global__ __launch_bounds__(64 * WR) void heads_fused_x3_kernel(HeadsArgs2 p) {
         // whole tile at once -- the weight-gradient accumulators (96 registers) leave no room for that
         u32x4 ha0[3];
         auto load_ha = [&](int tt, int ks, u32x4 (&dst)[3]) {
-            const int so = tt * (kHTile * 2);
+            if constexpr (WR == 1) {
+                // small batches: no split pass in front of the kernel -- row l31 of the tile, hidden units 32 hi + 8 ks ..
+                const int row = tt * kTR + l31;
+                float x[8];
 #pragma unroll
-            for (int q = 0; q < 3; ++q)
-                dst[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ha_rs, ha_lane + q * 4096 + ks * 16, so, 0));
+                for (int j = 0; j < 8; ++j) {
+                    const int kk = 32 * hi + 8 * ks + j;
+                    x[j] = (row < p.B && kk < p.hL) ? p.H[(long)row * p.ldh + kk] : 0.f;
+                }
+                split8(x, dst);
+            } else {
+                const int so = tt * (kHTile * 2);
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    dst[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ha_rs, ha_lane + q * 4096 + ks * 16, so, 0));
+            }
         };
         auto load_ht = [&](int tt, int ks, u32x4 (&dst)[3][2]) {
-            const int so = tt * (kHTile * 2);
+            if constexpr (WR == 1) {
 #pragma unroll
-            for (int q = 0; q < 3; ++q)
+                for (int ib = 0; ib < 2; ++ib) {
+                    const int i = l31 + 32 * ib;              // hidden unit; rows of K-step ks in the order of the MFMA row map
+                    float x[8];
 #pragma unroll
-                for (int ib = 0; ib < 2; ++ib)
-                    dst[q][ib] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                        ht_rs, ht_lane + q * 4096 + ib * 2048 + ks * 32, so, 0));
+                    for (int j = 0; j < 8; ++j) {
+                        const int row = tt * kTR + rowmap(8 * ks + j, hi);
+                        x[j] = (row < p.B && i < p.hL) ? p.H[(long)row * p.ldh + i] : 0.f;
+                    }
+                    u32x4 f[3];
+                    split8(x, f);
+                    dst[0][ib] = f[0]; dst[1][ib] = f[1]; dst[2][ib] = f[2];
+                }
+            } else {
+                const int so = tt * (kHTile * 2);
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+#pragma unroll
+                    for (int ib = 0; ib < 2; ++ib)
+                        dst[q][ib] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                            ht_rs, ht_lane + q * 4096 + ib * 2048 + ks * 32, so, 0));
+            }
         };
         // LDS addresses of the weight image.  Transposing read (F): lane t of a 16-lane group supplies the 8-byte
         // chunk (row kk + t / 4, genes 16 (group & 1) + 4 (t & 3) ..) and receives rows kk .. kk + 3 of gene
@@ -1164,7 +1195,9 @@ __global__ __launch_bounds__(64 * WR) void heads_fused_x3_kernel(HeadsArgs2 p) {
         }
     }
     if (r == 0 && tile_ok) {
-        float* out = p.ws_dw + (long)s * p.dw_stride;
+        const bool direct = p.S == 1;                // one batch split: no partial buffer, no reduce launch
+        float* out = direct ? p.gW : p.ws_dw + (long)s * p.dw_stride;
+        const long ldo = direct ? p.ldg : p.ldws;
         const bool cw = gene < p.plane;
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
@@ -1173,14 +1206,21 @@ __global__ __launch_bounds__(64 * WR) void heads_fused_x3_kernel(HeadsArgs2 p) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int i = ib * 32 + rowmap(e, hi);
-                    if (cw && i < p.hL) out[(long)i * p.ldws + (long)h * p.plane + gene] = dW[h][ib][e];
+                    if (cw && i < p.hL) out[(long)i * ldo + (long)h * p.plane + gene] = dW[h][ib][e];
                 }
             const float bv = bsum[h] + __shfl_xor(bsum[h], 32, 64);
-            if (cw && hi == 0) out[(long)p.hL * p.ldws + (long)h * p.plane + gene] = bv;
+            if (cw && hi == 0) out[(long)p.hL * ldo + (long)h * p.plane + gene] = bv;
         }
         if (CONST_DISP) {
             const float tv = thsum + __shfl_xor(thsum, 32, 64);
-            if (cw && hi == 0) out[(long)(p.hL + 1) * p.ldws + gene] = tv;
+            if (direct) {                            // ConstantDispersionLayer chain (dca/layers.py:17-21)
+                if (gvalid && hi == 0) {
+                    const float e = expf(p.theta_w[gene]);
+                    p.g_theta[gene] = (e >= 1e-3f && e <= 1e4f) ? tv * e : 0.f;
+                }
+            } else if (cw && hi == 0) {
+                out[(long)(p.hL + 1) * ldo + gene] = tv;
+            }
         }
     }
 #ifdef DCA_HEADS_TIMING
@@ -1220,7 +1260,9 @@ __global__ __launch_bounds__(256) void heads_reduce_dw_kernel(const float* ws, i
 // one output quad, combined in fixed order through LDS.
 template <int GL>
 __global__ __launch_bounds__(256) void heads_reduce_dh_kernel(const float* ws, int ntg, int B, int Bpad,
-                                                              int KT, int hL, float* dH, long lddh) {
+                                                              int KT, int hL, float* dH, long lddh,
+                                                              const double* loss_partials, int n_partials,
+                                                              double loss_scale, float* loss_out) {
     constexpr int OUT = 256 / GL;
     __shared__ float4 red[256];
     const int o = threadIdx.x % OUT, gl = threadIdx.x / OUT;
@@ -1253,6 +1295,24 @@ __global__ __launch_bounds__(256) void heads_reduce_dh_kernel(const float* ws, i
         if (i + 1 < hL) d[1] = v.y;
         if (i + 2 < hL) d[2] = v.z;
         if (i + 3 < hL) d[3] = v.w;
+    }
+    // optionally the work of dcahip_loss_finalize on this launch (block 0): batch loss = scale * sum of the workgroup
+    // partials, nan -> inf (dca/loss.py:146-148)
+    if (loss_out && blockIdx.x == 0) {
+        __shared__ double lsum[256];
+        double a = 0.0;
+        for (int i = threadIdx.x; i < n_partials; i += 256) a += loss_partials[i];
+        lsum[threadIdx.x] = a;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if ((int)threadIdx.x < st) lsum[threadIdx.x] += lsum[threadIdx.x + st];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            float lf = (float)(lsum[0] * loss_scale);
+            if (isnan(lf)) lf = INFINITY;
+            *loss_out = lf;
+        }
     }
 }
 
@@ -1379,6 +1439,15 @@ extern "C" int dcahip_heads_fused_ordered(const float* H, long ldh, const float*
                                           void* workspace, long workspace_bytes, const int* tile_order,
                                           void* stream);
 
+extern "C" int dcahip_heads_fused_loss(const float* H, long ldh, const float* Wh, long ldw,
+                                       const float* bh, long plane, const float* theta_w,
+                                       const float* y, long ldy, const float* sf, const int* perm,
+                                       const long long* cursor, int B, int hL, int G, float ridge,
+                                       float inv_n, int flags, float* gW, long ldg, float* g_theta,
+                                       float* dH, long lddh, double* loss_partials, int* n_partials_out,
+                                       void* workspace, long workspace_bytes, const int* tile_order,
+                                       float* loss_out, void* stream);
+
 extern "C" int dcahip_heads_fused(const float* H, long ldh, const float* Wh, long ldw,
                                   const float* bh, long plane, const float* theta_w,
                                   const float* y, long ldy, const float* sf, const int* perm,
@@ -1399,6 +1468,19 @@ extern "C" int dcahip_heads_fused_ordered(const float* H, long ldh, const float*
                                           float* dH, long lddh, double* loss_partials, int* n_partials_out,
                                           void* workspace, long workspace_bytes, const int* tile_order,
                                           void* stream) {
+    return dcahip_heads_fused_loss(H, ldh, Wh, ldw, bh, plane, theta_w, y, ldy, sf, perm, cursor, B, hL, G, ridge,
+                                   inv_n, flags, gW, ldg, g_theta, dH, lddh, loss_partials, n_partials_out,
+                                   workspace, workspace_bytes, tile_order, nullptr, stream);
+}
+
+extern "C" int dcahip_heads_fused_loss(const float* H, long ldh, const float* Wh, long ldw,
+                                       const float* bh, long plane, const float* theta_w,
+                                       const float* y, long ldy, const float* sf, const int* perm,
+                                       const long long* cursor, int B, int hL, int G, float ridge,
+                                       float inv_n, int flags, float* gW, long ldg, float* g_theta,
+                                       float* dH, long lddh, double* loss_partials, int* n_partials_out,
+                                       void* workspace, long workspace_bytes, const int* tile_order,
+                                       float* loss_out, void* stream) {
     const bool has_pi = flags & DCAHIP_NLL_HAS_PI, cdisp = flags & DCAHIP_NLL_CONST_DISP;
     HeadsPlan pl;
     if (!make_heads_plan(B, hL, G, plane, flags, &pl)) return DCAHIP_EINVAL;
@@ -1413,6 +1495,7 @@ extern "C" int dcahip_heads_fused_ordered(const float* H, long ldh, const float*
     float* ws_dh = static_cast<float*>(workspace);
     float* ws_dw = ws_dh + pl.dh_bytes / sizeof(float);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    bool direct_dw = false;
     if (use_f32_mfma()) {
         HeadsArgs a{g_timing, H, ldh, Wh, ldw, bh, theta_w, y, ldy, sf, perm, cursor, ws_dw, pl.dw_stride, ws_dh, pl.ntg,
                     tile_order, loss_partials, plane, pl.ldws, B, hL, G, pl.S, pl.NT, ridge, inv_n};
@@ -1423,10 +1506,13 @@ extern "C" int dcahip_heads_fused_ordered(const float* H, long ldh, const float*
     } else {
         unsigned short* HA = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(workspace) + pl.dh_bytes + pl.dw_bytes);
         unsigned short* HT = HA + (long)pl.NT * kHTile;
-        hipLaunchKernelGGL(heads_split_h_kernel, dim3(pl.NT), dim3(256), 0, s, H, ldh, B, hL, HA, HT);
-        int rc0 = (int)hipGetLastError();
-        if (rc0 != 0) return rc0;
-        HeadsArgs2 a{g_timing, HA, HT, Wh, ldw, bh, theta_w, y, ldy, sf, perm, cursor, ws_dw, pl.dw_stride, ws_dh, pl.ntg,
+        if (pl.WR != 1) {                    // single-wave workgroups (batches below 256 rows) split H themselves
+            hipLaunchKernelGGL(heads_split_h_kernel, dim3(pl.NT), dim3(256), 0, s, H, ldh, B, hL, HA, HT);
+            int rc0 = (int)hipGetLastError();
+            if (rc0 != 0) return rc0;
+        }
+        direct_dw = pl.S == 1;
+        HeadsArgs2 a{g_timing, HA, HT, H, ldh, gW, ldg, g_theta, Wh, ldw, bh, theta_w, y, ldy, sf, perm, cursor, ws_dw, pl.dw_stride, ws_dh, pl.ntg,
                      tile_order, loss_partials, plane, pl.ldws, B, hL, G, pl.S, pl.NT, ridge, inv_n};
         if (has_pi && cdisp) launch_fused_x3<true, true>(pl, a, s);
         else if (has_pi) launch_fused_x3<true, false>(pl, a, s);
@@ -1436,7 +1522,7 @@ extern "C" int dcahip_heads_fused_ordered(const float* H, long ldh, const float*
     int rc = (int)hipGetLastError();
     if (rc != 0) return rc;
     if (n_partials_out) *n_partials_out = pl.grid;
-    {
+    if (!direct_dw) {
         const long total = (long)(hL + 1) * pl.ldws;
         long gr = (total + 255) / 256;
         if (gr > 2048) gr = 2048;
@@ -1451,10 +1537,10 @@ extern "C" int dcahip_heads_fused_ordered(const float* H, long ldh, const float*
         const long nq = (long)B * (KT / 4);
         if (nq >= 64L * 512) {
             hipLaunchKernelGGL(heads_reduce_dh_kernel<4>, dim3((int)((nq + 63) / 64)), dim3(256), 0, s,
-                               ws_dh, pl.ntg, B, pl.NT * kTR, KT, hL, dH, lddh);
+                               ws_dh, pl.ntg, B, pl.NT * kTR, KT, hL, dH, lddh, loss_partials, pl.grid, (double)inv_n, loss_out);
         } else {
             hipLaunchKernelGGL(heads_reduce_dh_kernel<16>, dim3((int)((nq + 15) / 16)), dim3(256), 0, s,
-                               ws_dh, pl.ntg, B, pl.NT * kTR, KT, hL, dH, lddh);
+                               ws_dh, pl.ntg, B, pl.NT * kTR, KT, hL, dH, lddh, loss_partials, pl.grid, (double)inv_n, loss_out);
         }
         rc = (int)hipGetLastError();
     }

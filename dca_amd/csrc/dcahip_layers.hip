@@ -303,6 +303,59 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
     }
 }
 
+// ---- small batches (B <= kFusedRows, one GPU): statistics AND apply in one launch, one workgroup per 64 columns --
+// the reference-default batch of 32 cells (dca/train.py:37) spends its step in launch gaps, not in kernels.  Same
+// formulas as col_moments_kernel + bn_relu_apply_kernel with a single chunk (bit-identical results for B <= 64).
+constexpr int kFusedRows = 256;
+
+__global__ __launch_bounds__(256) void bn_relu_small_kernel(BnApplyArgs a) {
+    __shared__ float sm[256];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
+    const bool cv = c < a.H;
+    float s = 0.f;
+    if (cv) for (int i = ty; i < a.B; i += 4) s += a.Z[(long)i * a.ldz + c];
+    const float mean = wg_rowlane_sum(s, sm) / (float)a.B;
+    float q = 0.f;
+    if (cv) for (int i = ty; i < a.B; i += 4) { const float d = a.Z[(long)i * a.ldz + c] - mean; q += d * d; }
+    const float m2 = wg_rowlane_sum(q, sm);
+    if (!cv) return;
+    const float var = (float)((double)m2 / (double)a.B);             // biased variance
+    const float inv = 1.f / sqrtf(var + a.eps);
+    if (ty == 0) {
+        a.mm[c] = a.mm[c] - (a.mm[c] - mean) * (1.f - a.momentum);
+        a.mv[c] = a.mv[c] - (a.mv[c] - var) * (1.f - a.momentum);
+        if (a.inv_std) a.inv_std[c] = inv;
+    }
+    const float beta = a.beta ? a.beta[c] : 0.f;
+    for (int i = ty; i < a.B; i += 4) {
+        const float xh = (a.Z[(long)i * a.ldz + c] - mean) * inv;
+        if (a.xhat) a.xhat[(long)i * a.ldx + c] = xh;
+        a.Hout[(long)i * a.ldh + c] = act_fwd(a.relu, xh + beta);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_small_kernel(BnBwdArgs a) {
+    __shared__ float sm[256];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
+    const bool cv = c < a.H;
+    float s1 = 0.f, s2 = 0.f;
+    if (cv) for (int i = ty; i < a.B; i += 4) {
+        const float dy = a.dH[(long)i * a.ldd + c] * act_grad(a.act, a.Hact[(long)i * a.ldh + c]);
+        s1 += dy; s2 += dy * a.xhat[(long)i * a.ldx + c];
+    }
+    const float t1 = wg_rowlane_sum(s1, sm);
+    const float t2 = wg_rowlane_sum(s2, sm);
+    if (!cv) return;
+    if (ty == 0 && a.dbeta) a.dbeta[c] = t1;
+    const float m1 = t1 / a.n_total, m2 = t2 / a.n_total, inv = a.inv_std[c];
+    for (int i = ty; i < a.B; i += 4) {
+        const float dy = a.dH[(long)i * a.ldd + c] * act_grad(a.act, a.Hact[(long)i * a.ldh + c]);
+        a.dZ[(long)i * a.ldz + c] = inv * (dy - m1 - a.xhat[(long)i * a.ldx + c] * m2);
+    }
+}
+
 __global__ __launch_bounds__(256) void relu_bwd_kernel(const float* dH, long ldd, const float* Hact,
                                                        long ldh, int B, int H, float* dZ, long ldz, int act) {
     const long total = (long)B * H;
@@ -339,9 +392,24 @@ __global__ __launch_bounds__(256) void colsum_chain_kernel(const float* x, long 
     }
 }
 
+// the end-of-step bookkeeping (dcahip_step_end) riding on the optimizer launch: block 0 records the batch loss and
+// advances the batch cursor -- nothing else in this kernel reads either
+struct StepEnd {
+    const float* loss; double weight; float* hist; int rows_per_slot; double* acc; long long* cursor; int advance; int on;
+};
+
 __global__ __launch_bounds__(256) void rmsprop_clip_kernel(float* w, const float* g, float* ms,
                                                            long n, const float* lrp, float rho,
-                                                           float eps, float clip) {
+                                                           float eps, float clip, StepEnd se) {
+    if (se.on && blockIdx.x == 0 && threadIdx.x == 0) {
+        const long long c = se.cursor ? *se.cursor : 0;
+        if (se.loss) {
+            const float l = *se.loss;
+            if (se.hist) se.hist[se.rows_per_slot > 0 ? c / se.rows_per_slot : 0] = l;
+            if (se.acc) *se.acc += (double)l * se.weight;
+        }
+        if (se.cursor) *se.cursor = c + se.advance;
+    }
     const float lr = *lrp;
     const long nv = n >> 2;
     const long stride = (long)gridDim.x * 256;
@@ -426,6 +494,28 @@ extern "C" int dcahip_bn_bwd_apply(const float* dH, long ldd, const float* Hact,
     const int grid = (B + kApplyRows - 1) / kApplyRows;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 2 * H * sizeof(float),
                        static_cast<hipStream_t>(stream), a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dcahip_bn_fused_max_rows() { return kFusedRows; }
+
+extern "C" int dcahip_bn_relu_train_small(const float* Z, long ldz, int B, int H, const float* beta,
+                                          float* moving_mean, float* moving_var, float momentum, float eps,
+                                          int act, float* Hout, long ldh, float* xhat, long ldx,
+                                          float* inv_std, void* stream) {
+    if (!Z || !Hout || !moving_mean || !moving_var || B <= 0 || B > kFusedRows || H <= 0) return DCAHIP_EINVAL;
+    BnApplyArgs a{Z, ldz, B, H, nullptr, nullptr, 0, beta, moving_mean, moving_var, momentum, eps,
+                  act, Hout, ldh, xhat, ldx, inv_std};
+    hipLaunchKernelGGL(bn_relu_small_kernel, dim3((H + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dcahip_bn_bwd_small(const float* dH, long ldd, const float* Hact, long ldh,
+                                   const float* xhat, long ldx, const float* inv_std, float n_total,
+                                   int B, int H, float* dZ, long ldz, float* dbeta, int act, void* stream) {
+    if (!dH || !Hact || !xhat || !inv_std || !dZ || B <= 0 || B > kFusedRows || H <= 0) return DCAHIP_EINVAL;
+    BnBwdArgs a{dH, ldd, Hact, ldh, xhat, ldx, inv_std, nullptr, 0, n_total, B, H, dZ, ldz, dbeta, act};
+    hipLaunchKernelGGL(bn_bwd_small_kernel, dim3((H + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return (int)hipGetLastError();
 }
 
@@ -637,6 +727,21 @@ extern "C" int dcahip_rmsprop_clip(float* w, const float* g, float* ms, long n, 
     if (grid > 2048) grid = 2048;
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(rmsprop_clip_kernel, dim3((int)grid), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), w, g, ms, n, lr, rho, eps, clip);
+                       static_cast<hipStream_t>(stream), w, g, ms, n, lr, rho, eps, clip, StepEnd{nullptr, 0.0, nullptr, 0, nullptr, nullptr, 0, 0});
+    return (int)hipGetLastError();
+}
+
+extern "C" int dcahip_rmsprop_clip_end(float* w, const float* g, float* ms, long n, const float* lr,
+                                       float rho, float eps, float clip, const float* loss, double weight,
+                                       float* hist, int rows_per_slot, double* acc, long long* cursor, int advance,
+                                       void* stream) {
+    if (!w || !g || !ms || !lr || n <= 0) return DCAHIP_EINVAL;
+    if (!al16(w) || !al16(g) || !al16(ms)) return DCAHIP_EINVAL;
+    long grid = ((n >> 2) + 255) / 256;
+    if (grid > 2048) grid = 2048;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(rmsprop_clip_kernel, dim3((int)grid), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), w, g, ms, n, lr, rho, eps, clip,
+                       StepEnd{loss, weight, hist, rows_per_slot, acc, cursor, advance, 1});
     return (int)hipGetLastError();
 }

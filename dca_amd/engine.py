@@ -627,7 +627,12 @@ class Engine:
                           self.ldh[i], bias=bi, ws=self.ws)
             if lay.batchnorm:
                 beta = lay.view(w, 'beta%d' % i)
-                if training:
+                if training and self._bn_small(B):
+                    # one launch: batch statistics, moving averages, normalisation, activation
+                    ops.bn_relu_train_small(self.Z[i], self.ldh[i], B, h, beta, self.mm[i], self.mv[i], BN_MOMENTUM,
+                                            BN_EPS, self.act, self.H[i], self.ldh[i], self.XH[i], self.ldh[i],
+                                            self.inv_std[i])
+                elif training:
                     entries, cnts, E = self._batch_moments(i, B, h, counts)
                     ops.bn_relu_apply(self.Z[i], self.ldh[i], B, h, entries, cnts, E, beta,
                                       self.mm[i], self.mv[i], BN_MOMENTUM, BN_EPS, self.act, self.H[i],
@@ -649,6 +654,11 @@ class Engine:
             self.Hcur[i] = cur
             K = h
         return K
+
+    def _bn_small(self, B):
+        """Small batches on one GPU take the single-launch batch-norm kernels (the reference-default batch of 32 is
+        bound by launch gaps, not by kernels)."""
+        return self.comm.world == 1 and 0 < B <= getattr(self.ops, 'bn_fused_max_rows', 0)
 
     def _batch_moments(self, i, B, h, counts):
         """Batch statistics of layer i as (entries, counts, E) for bn_relu_apply.  One GPU: the
@@ -752,6 +762,12 @@ class Engine:
                 self._pending = None
         if self.reg is not None:           # after the exchange: every rank adds the same terms once
             ops.l1l2_apply(self.reg, w, g, g[lay.P:], self.reg_ws)
+        fused_end = self.opt_kind == 'rmsprop' and not self.has_dropout and hasattr(ops, 'rmsprop_clip_end')
+        if fused_end:            # optimizer + end-of-step bookkeeping in one launch
+            with self._t('rmsprop_clip'):
+                ops.rmsprop_clip_end(w, g, self.ms, lay.P, self.lr, RMS_RHO, RMS_EPS, self.clip, g[lay.P:], float(Bg),
+                                     self.hist, rows_per_slot or max(self.Bmax, 1), self.acc, self.cursor, B)
+            return
         if self.opt_kind == 'rmsprop':
             with self._t('rmsprop_clip'):
                 ops.rmsprop_clip(w, g, self.ms, lay.P, self.lr, RMS_RHO, RMS_EPS, self.clip)
@@ -795,15 +811,14 @@ class Engine:
         KL = self._hidden_forward(B, ('perm',), True, self.counts_world)
         if self.ws_heads is not None:
             with self._t('heads_fused'):
-                n = ops.heads_fused(self.Hcur[-1], self.ldh[-1], lay.view(w, 'Wh'), lay.NH,
+                ops.heads_fused(self.Hcur[-1], self.ldh[-1], lay.view(w, 'Wh'), lay.NH,
                                     lay.view(w, 'bh'), lay.Gp,
                                     lay.view(w, 'theta_w') if lay.const_disp else None, self.Y,
                                     self.ldy, self.sf, self.perm, self.cursor, B, KL, lay.G_out,
                                     self.ridge, inv_n, self.flags, lay.view(g, 'Wh'), lay.NH,
                                     lay.view(g, 'theta_w') if lay.const_disp else None,
                                     self.dH[-1], self.ldh[-1], self.partials, self.ws_heads,
-                                    tile_order=self.tile_order)
-            ops.loss_finalize(self.partials, n, inv_n, g[lay.P:])
+                                    tile_order=self.tile_order, loss_out=g[lay.P:])
         else:
             self._heads_backward_unfused(B, KL, inv_n)
         self._launch_heads_bucket()
@@ -817,7 +832,11 @@ class Engine:
             if self.prelu:              # dL/d(PReLU out) -> dL/d(its input) in place, slope gradients
                 ops.prelu_bwd(self.dH[i], self.ldh[i], self.H[i], self.ldh[i], lay.view(w, 'alpha%d' % i), B, h,
                               lay.view(g, 'alpha%d' % i), self.ws_prelu)
-            if lay.batchnorm:
+            if lay.batchnorm and self._bn_small(B):
+                ops.bn_bwd_small(self.dH[i], self.ldh[i], self.H[i], self.ldh[i], self.XH[i], self.ldh[i],
+                                 self.inv_std[i], float(Bg), B, h, self.dZ[i], self.ldh[i],
+                                 lay.view(g, 'beta%d' % i), self.act)
+            elif lay.batchnorm:
                 ops.bn_bwd_sums(self.dH[i], self.ldh[i], self.H[i], self.ldh[i], self.XH[i],
                                 self.ldh[i], B, h, self.bpart[i], self.act)
                 E = ops.col_moments_chunks(B)

@@ -57,6 +57,11 @@ _SIGNATURES = {
                                               _c.c_int, _c.c_float, _c.c_float, _c.c_int, _f32p, _c.c_long,
                                               _f32p, _f32p, _c.c_long, _f64p, _c.POINTER(_c.c_int), _vp,
                                               _c.c_long, _i32p, _vp]),
+    'dcahip_heads_fused_loss': (_c.c_int, [_f32p, _c.c_long, _f32p, _c.c_long, _f32p, _c.c_long, _f32p,
+                                           _f32p, _c.c_long, _f32p, _i32p, _i64p, _c.c_int, _c.c_int,
+                                           _c.c_int, _c.c_float, _c.c_float, _c.c_int, _f32p, _c.c_long,
+                                           _f32p, _f32p, _c.c_long, _f64p, _c.POINTER(_c.c_int), _vp,
+                                           _c.c_long, _i32p, _f32p, _vp]),
     'dcahip_sgemm': (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _f32p, _c.c_long,
                                 _f32p, _c.c_long, _f32p, _c.c_long, _f32p, _i32p, _i64p, _c.c_int,
                                 _c.c_int, _vp, _c.c_long, _vp]),
@@ -72,6 +77,13 @@ _SIGNATURES = {
     'dcahip_bn_bwd_apply': (_c.c_int, [_f32p, _c.c_long, _f32p, _c.c_long, _f32p, _c.c_long, _f32p,
                                        _f32p, _c.c_int, _c.c_float, _c.c_int, _c.c_int, _f32p,
                                        _c.c_long, _f32p, _c.c_int, _vp]),
+    'dcahip_bn_fused_max_rows': (_c.c_int, []),
+    'dcahip_bn_relu_train_small': (_c.c_int, [_f32p, _c.c_long, _c.c_int, _c.c_int, _f32p, _f32p, _f32p, _c.c_float,
+                                              _c.c_float, _c.c_int, _f32p, _c.c_long, _f32p, _c.c_long, _f32p, _vp]),
+    'dcahip_bn_bwd_small': (_c.c_int, [_f32p, _c.c_long, _f32p, _c.c_long, _f32p, _c.c_long, _f32p, _c.c_float,
+                                       _c.c_int, _c.c_int, _f32p, _c.c_long, _f32p, _c.c_int, _vp]),
+    'dcahip_rmsprop_clip_end': (_c.c_int, [_f32p, _f32p, _f32p, _c.c_long, _f32p, _c.c_float, _c.c_float, _c.c_float,
+                                           _f32p, _c.c_double, _f32p, _c.c_int, _f64p, _i64p, _c.c_int, _vp]),
     'dcahip_relu_bwd': (_c.c_int, [_f32p, _c.c_long, _f32p, _c.c_long, _c.c_int, _c.c_int, _f32p,
                                    _c.c_long, _c.c_int, _vp]),
     'dcahip_relu_fwd': (_c.c_int, [_f32p, _c.c_long, _c.c_int, _c.c_int, _f32p, _c.c_long, _c.c_int, _vp]),

@@ -2,7 +2,7 @@
 
 Same search space (hyper.py:19-43), same objective construction (data_fn: normalize with the sampled
 flags, hyper.py:45-57; model_fn: AE_types[aetype] with the sampled architecture / regularisation,
-RMSprop(lr, clipvalue=5), hyper.py:59-83; 20 % of the cells held out, the loss on them is minimised,
+RMSprop(lr, clipvalue=5), hyper.py:59-83; a random 20 % of the cells held out, the loss on them is minimised,
 hyper.py:85-95), same outputs (`<outputdir>/hyperopt_results/best.json`, `trials.pickle`).  The
 proposal distribution is plain random search over that space (numpy RandomState(42)); hyperopt's
 TPE sampler is a third-party algorithm that is not part of this path.  A trial that fails (a
@@ -54,7 +54,11 @@ def sample(rng):
 def evaluate(adata, params, epochs, debug=False, seed=0):
     """Trains one configuration; returns the best held-out loss and the history."""
     d, m = params['data'], params['model']
-    ad = io.normalize(adata.copy(), size_factors=d['norm_input_sf'], logtrans_input=d['norm_input_log'],
+    # kopt.CompileFN(valid_split=.2) holds out a RANDOM fifth of the cells (hyper.py:85-95); train() takes the
+    # validation rows from the tail (Keras validation_split), so the cells are permuted once -- the same permutation
+    # for every trial (seed 42): trials are ranked on the same held-out cells
+    order = np.random.RandomState(42).permutation(adata.n_obs)
+    ad = io.normalize(adata[order].copy(), size_factors=d['norm_input_sf'], logtrans_input=d['norm_input_log'],
                       normalize_input=d['norm_input_zeromean'])
     net = AE_types[m['aetype']](input_size=ad.n_vars, hidden_size=m['hidden_size'], l2_coef=0.0, l1_coef=0.0,
                                 l2_enc_coef=0.0, l1_enc_coef=m['l1_enc_coef'], ridge=m['ridge'],

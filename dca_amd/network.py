@@ -8,10 +8,12 @@ inference forward per chunk of cells and emits mean*sf, dispersion, dropout and 
 code together (the reference runs 3-4 separate Keras predict passes, network.py:188-211,
 395-405).
 
-Implemented on the MI355X path: zinb-conddisp (the north-star class, network.py:366-421),
-zinb (:496-550), nb-conddisp (:293-339), nb (:249-290), poisson (:233-246), normal (:143-156).
-The remaining keys (*-shared, *-fork, zinb-elempi) are registered and raise NotImplementedError
-at build() -- head-layout variants queued behind the hot path.
+Every key of the reference's ``AE_types`` builds and trains on the MI355X path: zinb-conddisp (the north-star
+class, network.py:366-421), zinb (:496-550), nb-conddisp (:293-339), nb (:249-290) through the fused K-HEADS kernel;
+poisson (:233-246), normal (:143-156), nb-shared / zinb-shared (:343-362, 464-491), nb-fork / zinb-fork (:553-760) and
+zinb-elempi (:424-461) through the separate head kernels (engine.AE_HEADS).  Weight files are ``.npz`` archives of
+the named parameters (``save_weights`` / ``load_weights``), not Keras HDF5: weights written by the reference cannot
+be loaded and vice versa.
 """
 import os
 import pickle
@@ -165,8 +167,8 @@ class Autoencoder():
         X = adata.X
         sf = np.asarray(adata.obs['size_factors'].values, dtype=np.float32)
         dd = getattr(adata, '_dca_device', None)
-        if dd is not None and dd.n == n and dd.G == lay_G(eng) and dd.X.device == eng.dev:
-            eng.attach_device_data(dd.X, dd.Y, dd.sf)      # K-PREP's tensors are still in HBM
+        if dd is not None and dd.n == n and dd.G == lay_G(eng) and dd.X.device == eng.dev and dd.matches(X):
+            eng.attach_device_data(dd.X, dd.Y, dd.sf)      # K-PREP's tensors are still in HBM and still ARE adata.X
         else:
             eng.load_data(X, None, sf)
         chunk = min(chunk, n)

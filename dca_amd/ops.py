@@ -56,14 +56,15 @@ class HipOps:
         return int(self.L.dcahip_heads_tile_order_len(G))
 
     def heads_fused(self, H, ldh, Wh, ldw, bh, plane, theta_w, Y, ldy, sf, perm, cursor, B, hL, G,
-                    ridge, inv_n, flags, gW, ldg, g_theta, dH, lddh, partials, ws, tile_order=None):
+                    ridge, inv_n, flags, gW, ldg, g_theta, dH, lddh, partials, ws, tile_order=None, loss_out=None):
+        """loss_out (a device float): the call also finishes the batch loss there (no loss_finalize launch needed)."""
         n = ctypes.c_int(0)
         p = hip.ptr
-        hip.check(self.L.dcahip_heads_fused_ordered(p(H), ldh, p(Wh), ldw, p(bh), plane, p(theta_w), p(Y), ldy,
-                                                    p(sf), p(perm), p(cursor), B, hL, G, ridge, inv_n, flags,
-                                                    p(gW), ldg, p(g_theta), p(dH), lddh, p(partials),
-                                                    ctypes.byref(n), p(ws), ws.numel() * ws.element_size(),
-                                                    p(tile_order), hip.stream()), 'heads_fused')
+        hip.check(self.L.dcahip_heads_fused_loss(p(H), ldh, p(Wh), ldw, p(bh), plane, p(theta_w), p(Y), ldy,
+                                                 p(sf), p(perm), p(cursor), B, hL, G, ridge, inv_n, flags,
+                                                 p(gW), ldg, p(g_theta), p(dH), lddh, p(partials),
+                                                 ctypes.byref(n), p(ws), ws.numel() * ws.element_size(),
+                                                 p(tile_order), p(loss_out), hip.stream()), 'heads_fused')
         return n.value
 
     # ------------------------------------------------------------------ gemm
@@ -108,6 +109,21 @@ class HipOps:
         hip.check(self.L.dcahip_bn_bwd_apply(p(dH), ldd, p(Hact), ldh, p(xhat), ldx, p(inv_std),
                                              p(sums), E, float(n_total), B, H, p(dZ), ldz, p(dbeta),
                                              act, hip.stream()), 'bn_bwd_apply')
+
+    @property
+    def bn_fused_max_rows(self):
+        return int(self.L.dcahip_bn_fused_max_rows())
+
+    def bn_relu_train_small(self, Z, ldz, B, H, beta, mm, mv, momentum, eps, act, Hout, ldh, xhat, ldx, inv_std):
+        p = hip.ptr
+        hip.check(self.L.dcahip_bn_relu_train_small(p(Z), ldz, B, H, p(beta), p(mm), p(mv), momentum, eps, int(act),
+                                                    p(Hout), ldh, p(xhat), ldx, p(inv_std), hip.stream()),
+                  'bn_relu_train_small')
+
+    def bn_bwd_small(self, dH, ldd, Hact, ldh, xhat, ldx, inv_std, n_total, B, H, dZ, ldz, dbeta, act=1):
+        p = hip.ptr
+        hip.check(self.L.dcahip_bn_bwd_small(p(dH), ldd, p(Hact), ldh, p(xhat), ldx, p(inv_std), float(n_total), B, H,
+                                             p(dZ), ldz, p(dbeta), act, hip.stream()), 'bn_bwd_small')
 
     def relu_bwd(self, dH, ldd, Hact, ldh, B, H, dZ, ldz, act=1):
         p = hip.ptr
@@ -213,6 +229,12 @@ class HipOps:
         hip.check(self.L.dcahip_prep_scale(p(X), ldx, n, G, p(mean), p(stdv), hip.stream()), 'prep_scale')
 
     # ------------------------------------------------------------------ optimizer
+    def rmsprop_clip_end(self, w, g, ms, n, lr, rho, eps, clip, loss, weight, hist, rows_per_slot, acc, cursor, advance):
+        p = hip.ptr
+        hip.check(self.L.dcahip_rmsprop_clip_end(p(w), p(g), p(ms), n, p(lr), rho, eps, clip, p(loss), weight, p(hist),
+                                                 rows_per_slot, p(acc), p(cursor), advance, hip.stream()),
+                  'rmsprop_clip_end')
+
     def rmsprop_clip(self, w, g, ms, n, lr, rho, eps, clip):
         p = hip.ptr
         hip.check(self.L.dcahip_rmsprop_clip(p(w), p(g), p(ms), n, p(lr), rho, eps, clip,

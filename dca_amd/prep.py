@@ -21,8 +21,24 @@ class DeviceData:
     """Preprocessed tensors resident on the device: X [n, ldx] (network input), Y [n, ldy]
     (raw counts, the loss target), sf [n]."""
 
-    def __init__(self, X, Y, sf, n, G):
+    def __init__(self, X, Y, sf, n, G, host_x=None):
         self.X, self.Y, self.sf, self.n, self.G = X, Y, sf, n, G
+        # what adata.X held when these tensors were made: train() / predict() use the resident tensors only while the
+        # host matrix still is that matrix (the reference always feeds the CURRENT adata.X, network.py:188-211)
+        self.host_mark = fingerprint(host_x) if host_x is not None else None
+
+    def matches(self, host_x):
+        return self.host_mark is None or fingerprint(host_x) == self.host_mark
+
+
+def fingerprint(X):
+    """Cheap content mark of a host matrix: shape + fp64 sums of ~64 evenly spaced rows and of the last row."""
+    n = X.shape[0]
+    rows = X[::max(1, n // 64)]
+    rows = rows.toarray() if hasattr(rows, 'toarray') else np.asarray(rows)
+    last = X[n - 1:n]
+    last = last.toarray() if hasattr(last, 'toarray') else np.asarray(last)
+    return (tuple(X.shape), float(rows.sum(dtype=np.float64)), float(last.sum(dtype=np.float64)))
 
 
 def _r4(x):
@@ -144,4 +160,4 @@ def normalize_device(adata, filter_min_counts=True, size_factors=True, normalize
         X = Y
     if to_host:
         adata.X = X[:, :G].cpu().numpy()
-    return adata, DeviceData(X, Y, sf_d, n, G)
+    return adata, DeviceData(X, Y, sf_d, n, G, host_x=adata.X if to_host else None)

@@ -161,6 +161,8 @@ def fit_engine(eng, n_train_global, n_val_global, nt_local, nv_local, t0_global,
             break
     if n_val_global == 0:
         del hist.history['val_loss']
+    if rl is None:
+        del hist.history['lr']         # Keras logs 'lr' only when ReduceLROnPlateau is among the callbacks (train.py:70-72)
     return hist
 
 
@@ -237,7 +239,7 @@ def train(adata, network, output_dir=None, optimizer='RMSprop', learning_rate=No
     dd = getattr(adata, '_dca_device', None)
     if comm.world == 1 and dd is not None and not output_subset and use_raw_as_output and \
             dd.n == n and dd.G == X.shape[1] == eng.lay.G_in == eng.lay.G_out and \
-            dd.X.device == eng.dev:
+            dd.X.device == eng.dev and dd.matches(X):
         eng.attach_device_data(dd.X, dd.Y, dd.sf)      # K-PREP left the tensors in HBM
     elif comm.world == 1:
         eng.load_data(X, Y, sf)
@@ -257,8 +259,14 @@ def train(adata, network, output_dir=None, optimizer='RMSprop', learning_rate=No
             return
         if save_weights:
             cur = h.history['val_loss'][-1] if 'val_loss' in h.history and h.history['val_loss'] else None
-            if cur is None or cur < best['val']:
-                best['val'] = np.inf if cur is None else cur
+            if cur is None:
+                # Keras ModelCheckpoint(monitor='val_loss', save_best_only=True) without validation data warns
+                # ("Can save best model only with val_loss available, skipping") and writes nothing (train.py:64-69)
+                if not best.get('warned'):
+                    print('dca: save_weights: no val_loss available (validation_split=0), skipping the weights file')
+                    best['warned'] = True
+            elif cur < best['val']:
+                best['val'] = cur
                 network.save_weights(os.path.join(output_dir, 'weights.npz'))
         if checkpoint:
             eng.save_state(state_path, st)

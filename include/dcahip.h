@@ -154,6 +154,17 @@ int dcahip_heads_fused_ordered(const float* H, long ldh, const float* Wh, long l
                                float* gW, long ldg, float* g_theta, float* dH, long lddh,
                                double* loss_partials, int* n_partials_out,
                                void* workspace, long workspace_bytes, const int* tile_order, void* stream);
+/* Same; when loss_out != NULL the batch loss (inv_n * sum of the partials, nan -> inf: what dcahip_loss_finalize
+ * computes) is written there by the last launch of the call -- one launch less per step. */
+int dcahip_heads_fused_loss(const float* H, long ldh, const float* Wh, long ldw, const float* bh,
+                            long plane, const float* theta_w,
+                            const float* y, long ldy, const float* sf,
+                            const int* perm, const long long* cursor,
+                            int B, int hL, int G, float ridge, float inv_n, int flags,
+                            float* gW, long ldg, float* g_theta, float* dH, long lddh,
+                            double* loss_partials, int* n_partials_out,
+                            void* workspace, long workspace_bytes, const int* tile_order,
+                            float* loss_out, void* stream);
 
 /*
  * C[M,N] = op(A) * op(B) (+ bias), fp32 in / fp32 out, LDS-tiled, deterministic split-K through `workspace`.
@@ -207,6 +218,19 @@ int dcahip_bn_relu_apply(const float* Z, long ldz, int B, int H,
                          float momentum, float eps, int relu,
                          float* Hout, long ldh, float* xhat, long ldx, float* inv_std,
                          void* stream);
+
+/* Batch normalisation for small batches on one GPU (B <= dcahip_bn_fused_max_rows()): batch statistics, moving
+ * averages, normalisation + activation (dcahip_col_moments + dcahip_bn_relu_apply) in ONE launch, and the backward
+ * pass (dcahip_bn_bwd_sums + dcahip_bn_bwd_apply) in one: the reference-default batch of 32 cells (dca/train.py:37)
+ * is bound by launch gaps.  Same arguments and formulas as the two-call forms (bit-identical for B <= 64). */
+int dcahip_bn_fused_max_rows(void);
+int dcahip_bn_relu_train_small(const float* Z, long ldz, int B, int H, const float* beta,
+                               float* moving_mean, float* moving_var, float momentum, float eps,
+                               int act, float* Hout, long ldh, float* xhat, long ldx,
+                               float* inv_std, void* stream);
+int dcahip_bn_bwd_small(const float* dH, long ldd, const float* Hact, long ldh,
+                        const float* xhat, long ldx, const float* inv_std, float n_total,
+                        int B, int H, float* dZ, long ldz, float* dbeta, int act, void* stream);
 
 /*
  * Backward of ReLU + batch norm.  mask = the forward output h (h > 0 <=> pre-ReLU > 0).
@@ -288,6 +312,12 @@ int dcahip_prep_scale(float* X, long ldx, int n, int G, const float* mean, const
  */
 int dcahip_rmsprop_clip(float* w, const float* g, float* ms, long n, const float* lr,
                         float rho, float eps, float clip, void* stream);
+/* The same launch followed by what dcahip_step_end does (loss slot -> history / epoch accumulator, batch cursor
+ * += advance): one launch less per step, which is what the reference-default batch of 32 is made of. */
+int dcahip_rmsprop_clip_end(float* w, const float* g, float* ms, long n, const float* lr,
+                            float rho, float eps, float clip, const float* loss, double weight,
+                            float* hist, int rows_per_slot, double* acc, long long* cursor, int advance,
+                            void* stream);
 
 /*
  * K-OPT: the other Keras optimizers selectable through dca/train.py:54-57 and the l1 / l2 kernel

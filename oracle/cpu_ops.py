@@ -121,9 +121,9 @@ class CpuRefOps:
         return ((G + 31) // 32 + 1) // 2 * 2
 
     def heads_fused(self, H, ldh, Wh, ldw, bh, plane, theta_w, Y, ldy, sf, perm, cursor, B, hL, G,
-                    ridge, inv_n, flags, gW, ldg, g_theta, dH, lddh, partials, ws, tile_order=None):
-        """Contract of dcahip_heads_fused = the composition of the separate entry points (tile_order only
-        changes which workgroup computes what)."""
+                    ridge, inv_n, flags, gW, ldg, g_theta, dH, lddh, partials, ws, tile_order=None, loss_out=None):
+        """Contract of dcahip_heads_fused_loss = the composition of the separate entry points (tile_order only
+        changes which workgroup computes what; loss_out = dcahip_loss_finalize on the partials)."""
         has_pi, cdisp = bool(flags & 1), bool(flags & 2)
         nh = 1 + (0 if cdisp else 1) + (1 if has_pi else 0)
         NH = nh * plane
@@ -141,6 +141,8 @@ class CpuRefOps:
         if cdisp:
             self.colsum_chain(d_disp, NH + plane, B, G, theta_w, g_theta)
         self.sgemm(0, 1, B, hL, NH, D, NH + plane, Wh, ldw, dH, lddh)
+        if loss_out is not None:
+            self.loss_finalize(partials, n, inv_n, loss_out)
         return n
 
     # ------------------------------------------------------------------ gemm
