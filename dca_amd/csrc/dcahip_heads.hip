@@ -664,8 +664,8 @@ struct HeadsArgs2 {
     const int* perm;
     const long long* cursor;
     float* ws_dw;  long dw_stride;   // [S][(hL + 2)][ldws]
-    float* ws_dh;                     // [NT][ntg][32][64]
-    int ntg;
+    float* ws_dh;                     // [NT][npart][32][64]: one partial per workgroup of the row tile's batch split
+    int npart, nitems;                // partials per row tile (= grid / S), work items (= S x gene tiles)
     const int* tile_order;
     double* partials;
     long plane, ldws;
@@ -732,13 +732,21 @@ __global__ __launch_bounds__(64 * WR) void heads_fused_x3_kernel(HeadsArgs2 p) {
 #endif
     const int l31 = lane & 31, hi = lane >> 5;
     const int r = wave;
-    const int s = blockIdx.x % p.S, gb = blockIdx.x / p.S;
+    const long long cur = p.cursor ? *p.cursor : 0;
+    double dacc = 0.0;
+    // Persistent workgroups: workgroup w takes the work items (batch split s, gene tile) w, w + grid, w + 2 grid, ...
+    // (grid is a multiple of S, so s = w % S for all of them and every item of a wave visits the same row tiles).
+    // The input gradient of those row tiles is ACCUMULATED over the workgroup's gene tiles in a workgroup-private
+    // slice of the workspace (the first item writes, the others add): grid / S partial sums per row instead of one
+    // per gene tile -- 5x fewer bytes to store and to reduce at G = 20 000.  Static assignment: deterministic.
+    bool first_item = true;
+    for (int item = blockIdx.x; item < p.nitems; item += gridDim.x, first_item = false) {
+    const int s = item % p.S, gb = item / p.S;
     const int gt = p.tile_order ? p.tile_order[gb] : gb;
     const int g0 = gt * kTG;
     const int gene = g0 + l31;
     const bool tile_ok = g0 < p.G;
     const bool gvalid = gene < p.G;
-    const long long cur = p.cursor ? *p.cursor : 0;
 
     unsigned char* const Wimg = reinterpret_cast<unsigned char*>(lds);
     float* St = lds + W_FLOATS + wave * ST_WAVE;
@@ -787,7 +795,6 @@ __global__ __launch_bounds__(64 * WR) void heads_fused_x3_kernel(HeadsArgs2 p) {
 #pragma unroll
     for (int h = 0; h < NH; ++h) bsum[h] = 0.f;
     float thsum = 0.f;
-    double dacc = 0.0;
 
     if (tile_ok) {
         // biases / log-dispersion of the lane's gene are read from LDS where they are used: three registers and --
@@ -797,8 +804,9 @@ __global__ __launch_bounds__(64 * WR) void heads_fused_x3_kernel(HeadsArgs2 p) {
         const unsigned ldy_u = (unsigned)p.ldy;
         const int tstep = p.S * WR;
         int t = s * WR + r;
-        const long dh_tstride = (long)p.ntg * (kTR * KT);
-        float* const dh_base = p.ws_dh + (long)gt * (kTR * KT) + l31;
+        const long dh_tstride = (long)p.npart * (kTR * KT);
+        float* const dh_part = p.ws_dh + (long)(blockIdx.x / p.S) * (kTR * KT);            // this workgroup's partials
+        const int dh_lane = (4 * hi * KT + l31) * 4;
         int srow_l = 0;
         float sf_l = 1.f;
         float yA[kZU], yB[kZU];
@@ -1081,11 +1089,26 @@ __global__ __launch_bounds__(64 * WR) void heads_fused_x3_kernel(HeadsArgs2 p) {
             load_ht(t, 0, htb[0]);                   // first K step of the dW operands: in flight during the dH products
             __builtin_amdgcn_sched_barrier(0);
             {
+                // the accumulators start from what the workgroup's earlier gene tiles left for this row tile (no extra
+                // registers; the operand reads and splits below cover part of the load latency)
                 f32x16 dHa[2];
+                // the 8 KB partial of (this workgroup, row tile t) through a buffer resource: scalar base, ONE per-lane
+                // offset, immediates -- 32 separate 64-bit addresses would not fit the register file
+                const __amdgpu_buffer_rsrc_t dh_rs = __builtin_amdgcn_make_buffer_rsrc(
+                    dh_part + (long)t * dh_tstride, 0, kTR * KT * 4, 0x00020000);
+                if (first_item) {
 #pragma unroll
-                for (int jb = 0; jb < 2; ++jb)
+                    for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) dHa[jb][e] = 0.f;
+                        for (int e = 0; e < 16; ++e) dHa[jb][e] = 0.f;
+                } else {
+#pragma unroll
+                    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e)
+                            dHa[jb][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                dh_rs, dh_lane + (((rowmap(e, 0) * KT + jb * 32) * 4) & 4095), ((rowmap(e, 0) * KT + jb * 32) * 4) & ~4095, 0));
+                }
 #pragma unroll
                 for (int h = 0; h < NH; ++h)
 #pragma unroll
@@ -1102,11 +1125,13 @@ __global__ __launch_bounds__(64 * WR) void heads_fused_x3_kernel(HeadsArgs2 p) {
                         }
                     }
                 TSTAMP(7)
-                float* dst = dh_base + (long)t * dh_tstride;
 #pragma unroll
                 for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) dst[rowmap(e, hi) * KT + jb * 32] = dHa[jb][e];
+                    for (int e = 0; e < 16; ++e)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dHa[jb][e]), dh_rs,
+                                                              dh_lane + (((rowmap(e, 0) * KT + jb * 32) * 4) & 4095),
+                                                              ((rowmap(e, 0) * KT + jb * 32) * 4) & ~4095, 0);   // 12-bit immediate + scalar offset
             }
             load_ht(t, 1, htb[1]);
             load_ha(tn, 0, ha0);                     // next tile's first forward step: in flight during the dW products
@@ -1144,20 +1169,11 @@ __global__ __launch_bounds__(64 * WR) void heads_fused_x3_kernel(HeadsArgs2 p) {
 #ifdef DCA_HEADS_TIMING
         t_loop1 = __builtin_readcyclecounter();
         if (p.timing && lane == 0)
-            for (int i = 0; i < 8; ++i) p.timing[((long)blockIdx.x * WR + wave) * 10 + i] = tacc[i];
+            for (int i = 0; i < 8; ++i) p.timing[((long)blockIdx.x * WR + wave) * 10 + i] += tacc[i];
 #endif
     }
 
-    // ---- loss: wave -> workgroup -> one partial per workgroup
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) dacc += __shfl_down(dacc, off, 64);
-    if (lane == 0) lred[wave] = dacc;
-    __syncthreads();                      // also: every wave is done with the LDS weights / staging
-    if (tid == 0) {
-        double v = 0.0;
-        for (int w = 0; w < WR; ++w) v += lred[w];
-        p.partials[blockIdx.x] = v;
-    }
+    __syncthreads();                      // every wave is done with the LDS weights / staging of this item
 
     // ---- dW / bias-gradient sums of the WR row slots: ordered tree through LDS
     if (WR > 1) {
@@ -1222,6 +1238,19 @@ __global__ __launch_bounds__(64 * WR) void heads_fused_x3_kernel(HeadsArgs2 p) {
                 out[(long)(p.hL + 1) * ldo + gene] = tv;
             }
         }
+    }
+    __syncthreads();                      // the reduce scratch (and the weight image) are free for the next item
+    }   // work items
+
+    // ---- loss: wave -> workgroup -> one partial per workgroup
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) dacc += __shfl_down(dacc, off, 64);
+    if (lane == 0) lred[wave] = dacc;
+    __syncthreads();
+    if (tid == 0) {
+        double v = 0.0;
+        for (int w = 0; w < WR; ++w) v += lred[w];
+        p.partials[blockIdx.x] = v;
     }
 #ifdef DCA_HEADS_TIMING
     if (p.timing && lane == 0) {
@@ -1318,8 +1347,13 @@ __global__ __launch_bounds__(256) void heads_reduce_dh_kernel(const float* ws, i
 
 struct HeadsPlan {
     int HLB, WR, S, NT, ntg, ngb, grid;
+    int nitems, npart;                   // split-bf16 path: work items (S x gene tiles), dH partials per row tile
     long ldws, dw_stride, dw_bytes, dh_bytes, hs_bytes;
 };
+
+// resident workgroups of the split-bf16 kernel: its LDS (up to 149 KB with 8 waves, 51 KB with one) admits one
+// 8-wave or three single-wave workgroups per CU
+inline int x3_resident(int WR) { return WR == 1 ? 3 * kCUs : kCUs; }
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -1355,11 +1389,18 @@ bool make_heads_plan(int B, int hL, int G, long plane, int flags, HeadsPlan* out
         const double cost = (double)rounds * (tiles + 0.75);
         if (cost < best - 1e-9) { best = cost; p.S = S; }
     }
-    p.grid = p.S * p.ngb;
+    p.nitems = p.S * p.ngb;
+    p.grid = p.nitems;
+    p.npart = p.ntg;
+    if (!f32) {                                      // persistent: as many workgroups as are resident, a multiple of S
+        const int res = x3_resident(p.WR) / p.S * p.S;
+        if (p.grid > res) p.grid = res;
+        p.npart = p.grid / p.S;
+    }
     p.ldws = (long)NH * plane;
     p.dw_stride = (long)(hL + 2) * p.ldws;
     p.dw_bytes = (long)p.S * p.dw_stride * (long)sizeof(float);
-    p.dh_bytes = (long)p.ntg * p.NT * kTR * (p.HLB * 32) * (long)sizeof(float);
+    p.dh_bytes = (long)p.npart * p.NT * kTR * (p.HLB * 32) * (long)sizeof(float);
     p.hs_bytes = f32 ? 0 : 2L * p.NT * kHTile * 2;   // split decoder output, both layouts
     *out = p;
     return true;
@@ -1414,7 +1455,13 @@ extern "C" long dcahip_heads_fused_workspace_bytes(int B, int hL, int G, long pl
     long smax = kMaxGrid / p.ngb;
     if (smax > p.NT) smax = p.NT;
     if (smax < 1) smax = 1;
-    return smax * p.dw_stride * (long)sizeof(float) + p.dh_bytes + p.hs_bytes;
+    long dh = p.dh_bytes;
+    if (!use_f32_mfma()) {                           // smaller batches: fewer row tiles, possibly more (single-wave) workgroups
+        const long a = (long)p.NT * kCUs, b = 7L * 3 * kCUs;
+        dh = (a > b ? a : b) * kTR * (p.HLB * 32) * (long)sizeof(float);
+        if (dh < p.dh_bytes) dh = p.dh_bytes;
+    }
+    return smax * p.dw_stride * (long)sizeof(float) + dh + p.hs_bytes;
 }
 
 extern "C" int dcahip_x3_product_32x32(const float* A, const float* B, float* C, int K, void* stream) {
@@ -1512,8 +1559,8 @@ extern "C" int dcahip_heads_fused_loss(const float* H, long ldh, const float* Wh
             if (rc0 != 0) return rc0;
         }
         direct_dw = pl.S == 1;
-        HeadsArgs2 a{g_timing, HA, HT, H, ldh, gW, ldg, g_theta, Wh, ldw, bh, theta_w, y, ldy, sf, perm, cursor, ws_dw, pl.dw_stride, ws_dh, pl.ntg,
-                     tile_order, loss_partials, plane, pl.ldws, B, hL, G, pl.S, pl.NT, ridge, inv_n};
+        HeadsArgs2 a{g_timing, HA, HT, H, ldh, gW, ldg, g_theta, Wh, ldw, bh, theta_w, y, ldy, sf, perm, cursor, ws_dw, pl.dw_stride, ws_dh,
+                     pl.npart, pl.nitems, tile_order, loss_partials, plane, pl.ldws, B, hL, G, pl.S, pl.NT, ridge, inv_n};
         if (has_pi && cdisp) launch_fused_x3<true, true>(pl, a, s);
         else if (has_pi) launch_fused_x3<true, false>(pl, a, s);
         else if (cdisp) launch_fused_x3<false, true>(pl, a, s);
@@ -1537,10 +1584,10 @@ extern "C" int dcahip_heads_fused_loss(const float* H, long ldh, const float* Wh
         const long nq = (long)B * (KT / 4);
         if (nq >= 64L * 512) {
             hipLaunchKernelGGL(heads_reduce_dh_kernel<4>, dim3((int)((nq + 63) / 64)), dim3(256), 0, s,
-                               ws_dh, pl.ntg, B, pl.NT * kTR, KT, hL, dH, lddh, loss_partials, pl.grid, (double)inv_n, loss_out);
+                               ws_dh, pl.npart, B, pl.NT * kTR, KT, hL, dH, lddh, loss_partials, pl.grid, (double)inv_n, loss_out);
         } else {
             hipLaunchKernelGGL(heads_reduce_dh_kernel<16>, dim3((int)((nq + 15) / 16)), dim3(256), 0, s,
-                               ws_dh, pl.ntg, B, pl.NT * kTR, KT, hL, dH, lddh, loss_partials, pl.grid, (double)inv_n, loss_out);
+                               ws_dh, pl.npart, B, pl.NT * kTR, KT, hL, dH, lddh, loss_partials, pl.grid, (double)inv_n, loss_out);
         }
         rc = (int)hipGetLastError();
     }

@@ -303,21 +303,34 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
     }
 }
 
-// ---- small batches (B <= kFusedRows, one GPU): statistics AND apply in one launch, one workgroup per 64 columns --
-// the reference-default batch of 32 cells (dca/train.py:37) spends its step in launch gaps, not in kernels.  Same
-// formulas as col_moments_kernel + bn_relu_apply_kernel with a single chunk (bit-identical results for B <= 64).
-constexpr int kFusedRows = 256;
+// ---- small batches (B <= kFusedRows = 64 rows, one GPU): statistics AND apply in one launch, one workgroup per 64
+// columns -- the reference-default batch of 32 cells (dca/train.py:37) spends its step in launch gaps and dependent
+// memory round trips, not in arithmetic.  Same formulas as col_moments_kernel + bn_relu_apply_kernel with one chunk.
+constexpr int kFusedRows = 64;
 
+// RPT = rows per thread (4 row lanes): the column slab is read ONCE into registers -- at 32 rows these kernels are
+// a chain of dependent memory round trips, not arithmetic
+template <int RPT>
 __global__ __launch_bounds__(256) void bn_relu_small_kernel(BnApplyArgs a) {
     __shared__ float sm[256];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + tx;
     const bool cv = c < a.H;
+    float z[RPT];
     float s = 0.f;
-    if (cv) for (int i = ty; i < a.B; i += 4) s += a.Z[(long)i * a.ldz + c];
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int i = ty + 4 * k;
+        z[k] = (cv && i < a.B) ? a.Z[(long)i * a.ldz + c] : 0.f;
+        s += z[k];
+    }
     const float mean = wg_rowlane_sum(s, sm) / (float)a.B;
     float q = 0.f;
-    if (cv) for (int i = ty; i < a.B; i += 4) { const float d = a.Z[(long)i * a.ldz + c] - mean; q += d * d; }
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const float d = z[k] - mean;
+        q += (ty + 4 * k < a.B) ? d * d : 0.f;
+    }
     const float m2 = wg_rowlane_sum(q, sm);
     if (!cv) return;
     const float var = (float)((double)m2 / (double)a.B);             // biased variance
@@ -328,31 +341,42 @@ __global__ __launch_bounds__(256) void bn_relu_small_kernel(BnApplyArgs a) {
         if (a.inv_std) a.inv_std[c] = inv;
     }
     const float beta = a.beta ? a.beta[c] : 0.f;
-    for (int i = ty; i < a.B; i += 4) {
-        const float xh = (a.Z[(long)i * a.ldz + c] - mean) * inv;
-        if (a.xhat) a.xhat[(long)i * a.ldx + c] = xh;
-        a.Hout[(long)i * a.ldh + c] = act_fwd(a.relu, xh + beta);
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int i = ty + 4 * k;
+        if (i < a.B) {
+            const float xh = (z[k] - mean) * inv;
+            if (a.xhat) a.xhat[(long)i * a.ldx + c] = xh;
+            a.Hout[(long)i * a.ldh + c] = act_fwd(a.relu, xh + beta);
+        }
     }
 }
 
+template <int RPT>
 __global__ __launch_bounds__(256) void bn_bwd_small_kernel(BnBwdArgs a) {
     __shared__ float sm[256];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + tx;
     const bool cv = c < a.H;
+    float dy[RPT], xh[RPT];
     float s1 = 0.f, s2 = 0.f;
-    if (cv) for (int i = ty; i < a.B; i += 4) {
-        const float dy = a.dH[(long)i * a.ldd + c] * act_grad(a.act, a.Hact[(long)i * a.ldh + c]);
-        s1 += dy; s2 += dy * a.xhat[(long)i * a.ldx + c];
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int i = ty + 4 * k;
+        const bool ok = cv && i < a.B;
+        dy[k] = ok ? a.dH[(long)i * a.ldd + c] * act_grad(a.act, a.Hact[(long)i * a.ldh + c]) : 0.f;
+        xh[k] = ok ? a.xhat[(long)i * a.ldx + c] : 0.f;
+        s1 += dy[k]; s2 += dy[k] * xh[k];
     }
     const float t1 = wg_rowlane_sum(s1, sm);
     const float t2 = wg_rowlane_sum(s2, sm);
     if (!cv) return;
     if (ty == 0 && a.dbeta) a.dbeta[c] = t1;
     const float m1 = t1 / a.n_total, m2 = t2 / a.n_total, inv = a.inv_std[c];
-    for (int i = ty; i < a.B; i += 4) {
-        const float dy = a.dH[(long)i * a.ldd + c] * act_grad(a.act, a.Hact[(long)i * a.ldh + c]);
-        a.dZ[(long)i * a.ldz + c] = inv * (dy - m1 - a.xhat[(long)i * a.ldx + c] * m2);
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int i = ty + 4 * k;
+        if (i < a.B) a.dZ[(long)i * a.ldz + c] = inv * (dy[k] - m1 - xh[k] * m2);
     }
 }
 
@@ -506,7 +530,7 @@ extern "C" int dcahip_bn_relu_train_small(const float* Z, long ldz, int B, int H
     if (!Z || !Hout || !moving_mean || !moving_var || B <= 0 || B > kFusedRows || H <= 0) return DCAHIP_EINVAL;
     BnApplyArgs a{Z, ldz, B, H, nullptr, nullptr, 0, beta, moving_mean, moving_var, momentum, eps,
                   act, Hout, ldh, xhat, ldx, inv_std};
-    hipLaunchKernelGGL(bn_relu_small_kernel, dim3((H + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(bn_relu_small_kernel<kFusedRows / 4>, dim3((H + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return (int)hipGetLastError();
 }
 
@@ -515,7 +539,7 @@ extern "C" int dcahip_bn_bwd_small(const float* dH, long ldd, const float* Hact,
                                    int B, int H, float* dZ, long ldz, float* dbeta, int act, void* stream) {
     if (!dH || !Hact || !xhat || !inv_std || !dZ || B <= 0 || B > kFusedRows || H <= 0) return DCAHIP_EINVAL;
     BnBwdArgs a{dH, ldd, Hact, ldh, xhat, ldx, inv_std, nullptr, 0, n_total, B, H, dZ, ldz, dbeta, act};
-    hipLaunchKernelGGL(bn_bwd_small_kernel, dim3((H + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(bn_bwd_small_kernel<kFusedRows / 4>, dim3((H + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return (int)hipGetLastError();
 }
 

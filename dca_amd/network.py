@@ -174,15 +174,31 @@ class Autoencoder():
         chunk = min(chunk, n)
         eng.reserve(chunk)
         lay = eng.lay
-        outs = {}
+        cols = {}
         for k in want:
-            cols = lay.hidden[eng.center] if k == 'latent' else lay.G_out
+            cols[k] = lay.hidden[eng.center] if k == 'latent' else lay.G_out
             if (k == 'dispersion' and 'disp' in lay.shared) or (k == 'dropout' and 'pi' in lay.shared):
-                cols = 1                                  # Dense(1) heads of the *-shared networks
-            outs[k] = np.empty((n, cols), dtype=np.float32)
-        # results leave through two pinned staging buffers per output: the device -> host copy of
-        # chunk i runs asynchronously while the host moves chunk i-1 into the result arrays
+                cols[k] = 1                               # Dense(1) heads of the *-shared networks
         pinned = eng.dev.type == 'cuda'
+        if pinned:
+            # The [n, G] result arrays the caller receives ARE page-locked buffers: every chunk goes device -> final
+            # array in one asynchronous copy (PCIe-bound, ~50 GB/s) -- no staging buffer, no host-side memcpy of the
+            # 3 x n x G floats (that copy, not the GPU, was the cost of predict(): DESIGN.md 6).
+            try:
+                outs_t = {k: torch.empty((n, cols[k]), dtype=torch.float32, pin_memory=True) for k in want}
+            except RuntimeError:                          # not enough lockable memory: pageable results, staged copies
+                outs_t = None
+            if outs_t is not None:
+                for s0 in range(0, n, chunk):
+                    b = min(chunk, n - s0)
+                    res = eng.predict_chunk(s0, b, want)
+                    for k in want:                        # same stream: the next chunk's kernels queue behind these copies
+                        outs_t[k][s0:s0 + b].copy_(res[k], non_blocking=True)
+                torch.cuda.current_stream().synchronize()
+                return {k: v.numpy() for k, v in outs_t.items()}
+        outs = {k: np.empty((n, cols[k]), dtype=np.float32) for k in want}
+        # fallback: two pinned staging buffers per output, the device -> host copy of chunk i runs while the host moves
+        # chunk i-1 into the (pageable) result arrays
         stage = {k: [torch.empty((chunk, outs[k].shape[1]), dtype=torch.float32, pin_memory=pinned)
                      for _ in range(2)] for k in want}
         events = [torch.cuda.Event() for _ in range(2)] if pinned else None

@@ -222,7 +222,7 @@ int dcahip_bn_relu_apply(const float* Z, long ldz, int B, int H,
 /* Batch normalisation for small batches on one GPU (B <= dcahip_bn_fused_max_rows()): batch statistics, moving
  * averages, normalisation + activation (dcahip_col_moments + dcahip_bn_relu_apply) in ONE launch, and the backward
  * pass (dcahip_bn_bwd_sums + dcahip_bn_bwd_apply) in one: the reference-default batch of 32 cells (dca/train.py:37)
- * is bound by launch gaps.  Same arguments and formulas as the two-call forms (bit-identical for B <= 64). */
+ * is bound by launch gaps.  Same arguments and formulas as the two-call forms (one chunk of up to 64 rows). */
 int dcahip_bn_fused_max_rows(void);
 int dcahip_bn_relu_train_small(const float* Z, long ldz, int B, int H, const float* beta,
                                float* moving_mean, float* moving_var, float momentum, float eps,
