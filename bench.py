@@ -202,7 +202,7 @@ def after_measurements(eng, args, B, n_train, n_val, G, dev):
         torch.cuda.synchronize(); t2 = time.perf_counter()
         if ep > 0:
             times.append((t1 - t0, t2 - t1))
-    tr = float(np.mean([t[0] for t in times])); va = float(np.mean([t[1] for t in times]))
+    tr = float(np.median([t[0] for t in times])); va = float(np.median([t[1] for t in times]))
     acc = eng.acc.cpu().numpy()
     out['epoch'] = {'train_s': tr, 'validation_s': va, 'train_cells': n_train, 'validation_cells': n_val,
                     'cells_per_s_train_only': n_train / tr, 'cells_per_s_incl_validation': n_train / (tr + va),

@@ -734,14 +734,23 @@ __global__ __launch_bounds__(64 * WR) void heads_fused_x3_kernel(HeadsArgs2 p) {
     const int r = wave;
     const long long cur = p.cursor ? *p.cursor : 0;
     double dacc = 0.0;
-    // Persistent workgroups: workgroup w takes the work items (batch split s, gene tile) w, w + grid, w + 2 grid, ...
-    // (grid is a multiple of S, so s = w % S for all of them and every item of a wave visits the same row tiles).
+    // Persistent workgroups: workgroup w = (batch split s = w % S, lane wq = w / S) takes one gene tile per round
+    // (every item of a wave visits the same row tiles: those of split s).
     // The input gradient of those row tiles is ACCUMULATED over the workgroup's gene tiles in a workgroup-private
     // slice of the workspace (the first item writes, the others add): grid / S partial sums per row instead of one
     // per gene tile -- 5x fewer bytes to store and to reduce at G = 20 000.  Static assignment: deterministic.
+    // Gene tiles arrive sorted by cost (tile_order): round j hands them out in forward order on even rounds and in
+    // reverse on odd ones, so no workgroup collects the heaviest tile of every round.
     bool first_item = true;
-    for (int item = blockIdx.x; item < p.nitems; item += gridDim.x, first_item = false) {
-    const int s = item % p.S, gb = item / p.S;
+    const int s_wg = blockIdx.x % p.S, wq = blockIdx.x / p.S;
+    const int ngb = p.nitems / p.S;
+    const int full = ngb / p.npart, rem = ngb - full * p.npart;          // the last round is partial
+    const int nrounds = full + ((rem > 0 && ((full & 1) ? p.npart - 1 - wq : wq) < rem) ? 1 : 0);
+#pragma unroll 1
+    for (int j = 0; j < nrounds; ++j) {
+    const int gb = j * p.npart + ((j & 1) ? p.npart - 1 - wq : wq);
+    int s = s_wg;
+    asm volatile("" : "+s"(s));              // opaque per round: what depends on it is recomputed, not kept live across rounds
     const int gt = p.tile_order ? p.tile_order[gb] : gb;
     const int g0 = gt * kTG;
     const int gene = g0 + l31;
@@ -1105,9 +1114,11 @@ __global__ __launch_bounds__(64 * WR) void heads_fused_x3_kernel(HeadsArgs2 p) {
 #pragma unroll
                     for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
-                        for (int e = 0; e < 16; ++e)
-                            dHa[jb][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                dh_rs, dh_lane + (((rowmap(e, 0) * KT + jb * 32) * 4) & 4095), ((rowmap(e, 0) * KT + jb * 32) * 4) & ~4095, 0));
+                        for (int e = 0; e < 16; ++e) {
+                            const unsigned u = __builtin_amdgcn_raw_buffer_load_b32(
+                                dh_rs, dh_lane + (((rowmap(e, 0) * KT + jb * 32) * 4) & 4095), ((rowmap(e, 0) * KT + jb * 32) * 4) & ~4095, 0);
+                            dHa[jb][e] = __uint_as_float(u);
+                        }
                 }
 #pragma unroll
                 for (int h = 0; h < NH; ++h)
@@ -1128,10 +1139,12 @@ __global__ __launch_bounds__(64 * WR) void heads_fused_x3_kernel(HeadsArgs2 p) {
 #pragma unroll
                 for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e)
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dHa[jb][e]), dh_rs,
+                    for (int e = 0; e < 16; ++e) {
+                        const float v = dHa[jb][e];          // (a bit_cast of the vector element itself stores element 0)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), dh_rs,
                                                               dh_lane + (((rowmap(e, 0) * KT + jb * 32) * 4) & 4095),
                                                               ((rowmap(e, 0) * KT + jb * 32) * 4) & ~4095, 0);   // 12-bit immediate + scalar offset
+                    }
             }
             load_ht(t, 1, htb[1]);
             load_ha(tn, 0, ha0);                     // next tile's first forward step: in flight during the dW products
@@ -1240,6 +1253,7 @@ __global__ __launch_bounds__(64 * WR) void heads_fused_x3_kernel(HeadsArgs2 p) {
         }
     }
     __syncthreads();                      // the reduce scratch (and the weight image) are free for the next item
+    first_item = false;
     }   // work items
 
     // ---- loss: wave -> workgroup -> one partial per workgroup
