@@ -115,6 +115,16 @@ class MiniAnnData:
             idx = idx.values
         idx = np.arange(self.n_obs)[idx]
         cidx = np.arange(self.n_vars)[cols]
+        if len(idx) == self.n_obs and len(cidx) == self.n_vars and (idx == np.arange(self.n_obs)).all() \
+                and (cidx == np.arange(self.n_vars)).all():
+            # selecting everything: a view-like object sharing the matrices, as anndata's own (lazy) views do -- dca()
+            # takes adata[adata.obs.dca_split == 'train'] of a dataset without a test split (api.py:203), and copying
+            # two 5.5 GB matrices there cost more than the GPU training
+            out = MiniAnnData(self._X, self.obs, self.var, dict(self.obsm), dict(self.uns), self._raw)
+            dd = getattr(self, '_dca_device', None)
+            if dd is not None:
+                out._dca_device = dd
+            return out
         X = self._X[idx][:, cidx]
         raw = None
         if self._raw is not None:

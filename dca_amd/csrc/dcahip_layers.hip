@@ -461,9 +461,35 @@ __global__ __launch_bounds__(256) void rmsprop_clip_kernel(float* w, const float
     }
 }
 
+// dst [C, R] = src [R, C]^T through 32 x 33 LDS tiles (coalesced on both sides)
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src, long lds_, int R, int C,
+                                                        float* __restrict__ dst, long ldd) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + ty + 8 * k, c = c0 + tx;
+        tile[ty + 8 * k][tx] = (r < R && c < C) ? src[(long)r * lds_ + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + ty + 8 * k, r = r0 + tx;
+        if (c < C && r < R) dst[(long)c * ldd + r] = tile[tx][ty + 8 * k];
+    }
+}
+
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
+
+extern "C" int dcahip_transpose(const float* src, long ld_src, int R, int C, float* dst, long ld_dst, void* stream) {
+    if (!src || !dst || R <= 0 || C <= 0 || ld_src < C || ld_dst < R) return DCAHIP_EINVAL;
+    hipLaunchKernelGGL(transpose_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), src, ld_src, R, C, dst, ld_dst);
+    return (int)hipGetLastError();
+}
 
 extern "C" int dcahip_col_moments_chunks(int B) { return n_chunks(B); }
 

@@ -293,3 +293,31 @@ extern "C" long dcahost_format_f64(const double* v, long n, char* out, long cap)
     if (!v || !out || n < 0) return DCAHOST_EINVAL;
     return format_values<double>(v, n, out, cap);
 }
+
+
+// ---- result matrices: pinned staging buffer -> the caller's (pageable) [n, G] array, on several threads.
+// One thread moves ~6 GB/s and takes every first-touch page fault of a fresh array itself; predict() hands back
+// 3 x 5.5 GB at BASELINE configs[2] (dca/network.py:188-211, 395-405).
+extern "C" int dcahost_parallel_copy(void* dst, const void* src, long nbytes, int nthreads) {
+    if (!dst || !src || nbytes < 0) return DCAHOST_EINVAL;
+    if (nthreads <= 0) {
+        nthreads = (int)std::thread::hardware_concurrency();
+        if (nthreads > 32) nthreads = 32;
+        if (nthreads < 1) nthreads = 1;
+    }
+    const long min_piece = 1L << 20;
+    if (nbytes < 2 * min_piece || nthreads == 1) { std::memcpy(dst, src, (size_t)nbytes); return DCAHOST_OK; }
+    long pieces = nbytes / min_piece;
+    if (pieces < nthreads) nthreads = (int)pieces;
+    const long per = ((nbytes / nthreads) + 4095) & ~4095L;          // page-aligned shares
+    std::vector<std::thread> pool;
+    pool.reserve(nthreads);
+    for (int t = 0; t < nthreads; ++t) {
+        const long off = (long)t * per;
+        if (off >= nbytes) break;
+        const long len = off + per > nbytes ? nbytes - off : per;
+        pool.emplace_back([=] { std::memcpy(static_cast<char*>(dst) + off, static_cast<const char*>(src) + off, (size_t)len); });
+    }
+    for (auto& th : pool) th.join();
+    return DCAHOST_OK;
+}

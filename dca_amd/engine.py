@@ -306,6 +306,7 @@ class Engine:
             if lay.elempi else None
         self.ws_heads = None
         self._pending = None        # in-flight all-reduce of the heads bucket (data parallel)
+        self.W0T = None             # transposed first-layer kernel (throughput batches)
         self.opt_kind = 'rmsprop'   # train.py:54-57 picks the Keras optimizer by name
         self.slot2 = None
         self.m_sched = None         # Nadam: running product of the momentum schedule
@@ -591,6 +592,11 @@ class Engine:
                 need = max(need, ops.sgemm_workspace_bytes(0, 0, b, nc, lay.hL))
                 need = max(need, ops.sgemm_workspace_bytes(1, 0, lay.hL, nc, b, True))
                 need = max(need, ops.sgemm_workspace_bytes(0, 1, b, lay.hL, nc))
+        self.W0T = None
+        if hasattr(ops, 'transpose') and B >= 256:
+            self.W0T = torch.zeros(lay.hidden[0], _r4(lay.G_in), **f32)
+            for b in cand:
+                need = max(need, ops.sgemm_workspace_bytes(0, 1, b, lay.hidden[0], lay.G_in))
         self.ws = torch.zeros(max(need // 4, 4), **f32)
         nb = ops.heads_fused_workspace_bytes(B, K, lay.G_out, lay.Gp, self.flags) if self.use_fused else 0
         self.ws_heads = torch.zeros(nb // 4, **f32) if nb > 0 else None
@@ -615,6 +621,13 @@ class Engine:
                     with self._t('gemm_enc0_fwd'):
                         ops.sgemm(0, 0, B, h, K, self.Xb, self.ldx, Wi, h, self.Z[0], self.ldh[0],
                                   bias=bi, ws=self.ws)
+                elif rows_from[0] == 'perm' and self._enc0_nt(B):
+                    # throughput batches: W0 transposed once per step, the forward product in the NT form (both operands
+                    # contiguous along the genes: the fast operand path of K-GEMM)
+                    with self._t('gemm_enc0_fwd'):
+                        ops.transpose(Wi, h, K, h, self.W0T, self.ldx)
+                        ops.sgemm(0, 1, B, h, K, self.X, self.ldx, self.W0T, self.ldx, self.Z[0], self.ldh[0],
+                                  bias=bi, perm=self.perm, cursor=self.cursor, ws=self.ws)
                 elif rows_from[0] == 'perm':
                     with self._t('gemm_enc0_fwd'):
                         ops.sgemm(0, 0, B, h, K, self.X, self.ldx, Wi, h, self.Z[0], self.ldh[0],
@@ -654,6 +667,9 @@ class Engine:
             self.Hcur[i] = cur
             K = h
         return K
+
+    def _enc0_nt(self, B):
+        return self.W0T is not None and B >= 256 and os.environ.get('DCA_AMD_ENC0_NT', '1') != '0'
 
     def _bn_small(self, B):
         """Small batches on one GPU take the single-launch batch-norm kernels (the reference-default batch of 32 is

@@ -18,6 +18,7 @@ _SIGNATURES = {
                                              ctypes.c_long, _cpp, _cpp, ctypes.c_int]),
     'dcahost_format_f32': (ctypes.c_long, [ctypes.c_void_p, ctypes.c_long, ctypes.c_char_p, ctypes.c_long]),
     'dcahost_format_f64': (ctypes.c_long, [ctypes.c_void_p, ctypes.c_long, ctypes.c_char_p, ctypes.c_long]),
+    'dcahost_parallel_copy': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_int]),
 }
 
 
@@ -82,3 +83,11 @@ def format_values(values):
     if n < 0:
         raise ValueError('dcahost_format failed')
     return buf.raw[:n]
+
+
+def parallel_copy(dst, src, threads=0):
+    """dst[...] = src for two C-contiguous numpy arrays of equal byte size, on several host threads."""
+    assert dst.flags['C_CONTIGUOUS'] and src.flags['C_CONTIGUOUS'] and dst.nbytes == src.nbytes
+    rc = lib().dcahost_parallel_copy(dst.ctypes.data, src.ctypes.data, dst.nbytes, threads)
+    if rc != 0:
+        raise RuntimeError('dcahost_parallel_copy failed (%d)' % rc)

@@ -46,6 +46,20 @@ class override_ops:
         _test_ops_factory = self.prev
 
 
+_stage_cache = {}
+
+
+def _staging(want, cols, chunk, pinned):
+    """Two staging buffers [chunk, cols] per requested output, page-locked when a GPU is present; cached per shape."""
+    out = {}
+    for k in want:
+        key = (k, chunk, cols[k], pinned)
+        if key not in _stage_cache:
+            _stage_cache[key] = [torch.empty((chunk, cols[k]), dtype=torch.float32, pin_memory=pinned) for _ in range(2)]
+        out[k] = _stage_cache[key]
+    return out
+
+
 def lay_G(eng):
     return eng.lay.G_in
 
@@ -180,49 +194,44 @@ class Autoencoder():
             if (k == 'dispersion' and 'disp' in lay.shared) or (k == 'dropout' and 'pi' in lay.shared):
                 cols[k] = 1                               # Dense(1) heads of the *-shared networks
         pinned = eng.dev.type == 'cuda'
-        if pinned:
-            # The [n, G] result arrays the caller receives ARE page-locked buffers: every chunk goes device -> final
-            # array in one asynchronous copy (PCIe-bound, ~50 GB/s) -- no staging buffer, no host-side memcpy of the
-            # 3 x n x G floats (that copy, not the GPU, was the cost of predict(): DESIGN.md 6).
-            try:
-                outs_t = {k: torch.empty((n, cols[k]), dtype=torch.float32, pin_memory=True) for k in want}
-            except RuntimeError:                          # not enough lockable memory: pageable results, staged copies
-                outs_t = None
-            if outs_t is not None:
-                for s0 in range(0, n, chunk):
-                    b = min(chunk, n - s0)
-                    res = eng.predict_chunk(s0, b, want)
-                    for k in want:                        # same stream: the next chunk's kernels queue behind these copies
-                        outs_t[k][s0:s0 + b].copy_(res[k], non_blocking=True)
-                torch.cuda.current_stream().synchronize()
-                return {k: v.numpy() for k, v in outs_t.items()}
         outs = {k: np.empty((n, cols[k]), dtype=np.float32) for k in want}
-        # fallback: two pinned staging buffers per output, the device -> host copy of chunk i runs while the host moves
-        # chunk i-1 into the (pageable) result arrays
-        stage = {k: [torch.empty((chunk, outs[k].shape[1]), dtype=torch.float32, pin_memory=pinned)
-                     for _ in range(2)] for k in want}
+        # Results leave through two page-locked staging buffers per output (kept for the life of the process: locking
+        # pages costs about as much as copying them): the device -> host copy of chunk i runs asynchronously while a
+        # pool of host threads moves chunk i-1 into the caller's arrays (include/dcahost.h dcahost_parallel_copy; one
+        # thread alone is slower than the PCIe link and takes every first-touch page fault itself).
+        stage = _staging(want, cols, chunk, pinned)
         events = [torch.cuda.Event() for _ in range(2)] if pinned else None
+        from . import hostlib
+
+        def drain(slot, start, rows):
+            if pinned:
+                events[slot].synchronize()
+            for k in want:
+                hostlib.parallel_copy(outs[k][start:start + rows], stage[k][slot][:rows].numpy())
+
+        trace = os.environ.get('DCA_AMD_PREDICT_TRACE')
+        import time as _time
+        t_launch = t_drain = 0.0
+        t_all = _time.perf_counter()
         prev = None
         for ci, s in enumerate(range(0, n, chunk)):
             b = min(chunk, n - s)
+            t0 = _time.perf_counter()
             res = eng.predict_chunk(s, b, want)
             for k in want:
                 stage[k][ci % 2][:b].copy_(res[k], non_blocking=pinned)
             if pinned:
                 events[ci % 2].record()
+            t1 = _time.perf_counter()
             if prev is not None:
-                pi, ps, pb = prev
-                if pinned:
-                    events[pi].synchronize()
-                for k in want:
-                    outs[k][ps:ps + pb] = stage[k][pi][:pb].numpy()
+                drain(*prev)
+            t_launch += t1 - t0; t_drain += _time.perf_counter() - t1
             prev = (ci % 2, s, b)
         if prev is not None:
-            pi, ps, pb = prev
-            if pinned:
-                events[pi].synchronize()
-            for k in want:
-                outs[k][ps:ps + pb] = stage[k][pi][:pb].numpy()
+            drain(*prev)
+        if trace:
+            print('dca: predict trace: %d cells, outputs %s: enqueue %.2f s, wait + host copies %.2f s, loop total %.2f s'
+                  % (n, sorted(want), t_launch, t_drain, _time.perf_counter() - t_all))
         return outs
 
     def predict(self, adata, mode='denoise', return_info=False, copy=False):

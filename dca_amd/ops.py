@@ -79,6 +79,9 @@ class HipOps:
                                       p(bias), p(perm), p(cursor), int(colsum_row), split_k, p(ws),
                                       wsb, hip.stream()), 'sgemm')
 
+    def transpose(self, src, ld_src, R, C, dst, ld_dst):
+        hip.check(self.L.dcahip_transpose(hip.ptr(src), ld_src, R, C, hip.ptr(dst), ld_dst, hip.stream()), 'transpose')
+
     # ------------------------------------------------------------------ batch norm
     def col_moments_chunks(self, B):
         return self.L.dcahip_col_moments_chunks(B)

@@ -190,6 +190,10 @@ int dcahip_sgemm(int ta, int tb, int M, int N, int K,
                  int colsum_row, int split_k, void* workspace, long workspace_bytes,
                  void* stream);
 long dcahip_sgemm_workspace_bytes(int ta, int tb, int M, int N, int K, int colsum_row, int split_k);
+/* dst [C, ld_dst] = src [R, ld_src]^T.  The first Dense layer's kernel W0 [genes, h1] is transposed once per step at
+ * throughput batches so that its forward product X W0 runs in the NT form (both operands contiguous along the
+ * contraction: the fast operand path of dcahip_sgemm). */
+int dcahip_transpose(const float* src, long ld_src, int R, int C, float* dst, long ld_dst, void* stream);
 
 /*
  * Batch normalisation (center=True, scale=False, eps inside rsqrt) + ReLU, training mode.

@@ -47,6 +47,10 @@ int dcahost_write_tsv_f64(const char* path, const double* data, long nrows, long
 long dcahost_format_f32(const float* v, long n, char* out, long cap);
 long dcahost_format_f64(const double* v, long n, char* out, long cap);
 
+/* memcpy on nthreads threads (<= 0: one per hardware thread, at most 32), page-aligned shares: moves the result
+ * matrices of predict() from the pinned staging buffers into the caller's arrays (dca/network.py:188-211, 395-405). */
+int dcahost_parallel_copy(void* dst, const void* src, long nbytes, int nthreads);
+
 #ifdef __cplusplus
 }
 #endif
