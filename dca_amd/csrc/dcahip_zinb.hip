@@ -11,6 +11,7 @@
 // dca/layers.py:21,85, dca/loss.py:72-114 (NB.loss), dca/loss.py:122-156 (ZINB.loss).
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdlib.h>
 #include "dcahip.h"
 #include "zinb_math.hpp"
 
@@ -116,6 +117,110 @@ __global__ __launch_bounds__(256) void zinb_nll_kernel(NllArgs a) {
     if (threadIdx.x == 0) a.partials[blockIdx.y * gridDim.x + blockIdx.x] = r;
 }
 
+// ---- NB / ZINB, 16-byte aligned operands: the training / validation kernel of the separate-head path (decoders
+// wider than 64 hidden units, validation).  Same decomposition as above -- one quad of genes per lane, rows strided
+// over grid.y -- but the two branches of the likelihood are no longer evaluated under divergence:
+//   * dense pass: the y = 0 formulas for every element (zinb_zero_elem / nb_zero_elem: ~100 VALU, the form K-HEADS
+//     uses); the ~7 % non-zero elements are queued per wave in LDS (pre-activations, count, size factor, destination);
+//   * sparse pass: whenever a wave holds 64 entries it evaluates the NB branch (lgamma / digamma differences) with
+//     all lanes busy and overwrites the three gradient values of those elements (4-byte stores behind the dense
+//     16-byte stores of the same wave: `s_waitcnt vmcnt(0)` in between orders them).
+// Before: both branches for every wave-row (~370 VALU per element) at 3.0-3.2 TB/s = 0.38-0.40 of the HBM peak.
+constexpr int kNzCap = 64 + 256;      // entries per wave: < 64 left over + up to 4 x 64 pushed per row
+struct NzEntry { float am, ad, ap, y, sf; unsigned dof; };
+
+template <bool HAS_PI, bool CONST_DISP, bool GRAD>
+__global__ __launch_bounds__(256) void zinb_nll_compact_kernel(NllArgs a) {
+    constexpr int V = 4;
+    __shared__ NzEntry queue[4][kNzCap];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    NzEntry* Q = queue[wave];
+    const int nvec = (a.G + V - 1) / V;
+    const int nseg = (nvec + 255) >> 8;
+    const long long cur = a.cursor ? *a.cursor : 0;
+    double dacc = 0.0;
+    int qn = 0;
+    float lsp = 0.f;
+    auto flush = [&](bool all) {
+        while (qn >= 64 || (all && qn > 0)) {
+            const int c = qn < 64 ? qn : 64;
+            const bool act = lane < c;
+            const NzEntry e = Q[qn - c + (act ? lane : 0)];
+            float o1, o2, o3 = 0.f, nll;
+            if (HAS_PI) {
+                nll = zinb_nz_elem<CONST_DISP>(e.am, e.ad, e.ap, e.sf, e.y, a.ridge, o1, o2, o3);
+            } else {
+                float dmu = 0.f, dth = 0.f, dpi = 0.f;
+                const Heads hd = head_acts<false, CONST_DISP>(e.am, e.ad, 0.f, e.sf);
+                nll = nll_elem<false, true, true>(hd, e.y, a.ridge, dmu, dth, dpi);
+                o1 = dmu * hd.gm; o2 = dth * hd.gd;
+            }
+            lsp += act ? nll : 0.f;
+            if (GRAD && act) {
+                __builtin_amdgcn_s_waitcnt(0x0f70);                       // vmcnt(0): the dense stores of these addresses are done
+                a.d_mean[e.dof] = o1 * a.inv_n;
+                a.d_disp[e.dof] = o2 * a.inv_n;
+                if (HAS_PI) a.d_pi[e.dof] = o3 * a.inv_n;
+            }
+            qn -= c;
+        }
+    };
+    for (int seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
+        const int q = seg * 256 + threadIdx.x;
+        const bool qv = q < nvec;
+        const int g = (qv ? q : 0) * V;
+        float vd[V] = {0.f, 0.f, 0.f, 0.f};
+        if (CONST_DISP && qv) ldv<V>(a.theta_w + g, vd);
+        for (int row = blockIdx.y; row < a.B; row += gridDim.y) {
+            const long srow = a.perm ? (long)a.perm[cur + row] : (long)(cur + row);
+            const float sf = a.sf[srow];
+            const long ao = (long)row * a.lda + g;
+            const long dof = (long)row * a.ldd + g;
+            float vm[V] = {0.f, 0.f, 0.f, 0.f}, vp[V] = {0.f, 0.f, 0.f, 0.f}, vy[V] = {0.f, 0.f, 0.f, 0.f};
+            if (qv) {
+                ldv<V>(a.a_mean + ao, vm);
+                if (!CONST_DISP) ldv<V>(a.a_disp + ao, vd);
+                if (HAS_PI) ldv<V>(a.a_pi + ao, vp);
+                ldv<V>(a.y + srow * a.ldy + g, vy);
+            }
+            float om[V], od[V], op[V];
+            float lacc = 0.f;
+            bool nz[V];
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const bool valid = qv && (g + j) < a.G;
+                nz[j] = valid && (HAS_PI ? !(vy[j] < kZeroThresh) : (vy[j] != 0.f));
+                float gmv, gdv, gpv = 0.f, nll;
+                if (HAS_PI) nll = zinb_zero_elem<CONST_DISP>(vm[j], vd[j], vp[j], sf, a.ridge, gmv, gdv, gpv);
+                else nll = nb_zero_elem<CONST_DISP>(vm[j], vd[j], sf, gmv, gdv);
+                lacc += (valid && !nz[j]) ? nll : 0.f;
+                const float sc = valid ? a.inv_n : 0.f;
+                om[j] = gmv * sc; od[j] = gdv * sc; op[j] = gpv * sc;
+            }
+            if (GRAD && qv) {
+                stv<V>(a.d_mean + dof, om);
+                stv<V>(a.d_disp + dof, od);
+                if (HAS_PI) stv<V>(a.d_pi + dof, op);
+            }
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const unsigned long long m = __ballot(nz[j]);
+                if (m) {
+                    const int slot = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                    if (nz[j]) Q[slot] = NzEntry{vm[j], vd[j], vp[j], vy[j], sf, (unsigned)(dof + j)};
+                    qn += __popcll(m);
+                }
+            }
+            dacc += (double)lacc;
+            flush(false);
+        }
+    }
+    flush(true);
+    dacc += (double)lsp;
+    const double r = block_reduce_sum(dacc);
+    if (threadIdx.x == 0) a.partials[blockIdx.y * gridDim.x + blockIdx.x] = r;
+}
+
 __global__ __launch_bounds__(256) void loss_finalize_kernel(const double* partials, int n,
                                                             double scale, float* out) {
     double v = 0.0;
@@ -195,7 +300,11 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 
 template <bool HAS_PI, bool CONST_DISP, bool GRAD>
 int launch_nll(const NllArgs& a, bool vec, dim3 grid, hipStream_t s) {
-    if (vec) hipLaunchKernelGGL((zinb_nll_kernel<HAS_PI, CONST_DISP, GRAD, 4>), grid, dim3(256), 0, s, a);
+    // the compacted kernel addresses gradient elements with 32 bits
+    static const bool plain = [] { const char* e = getenv("DCA_ZINB_PLAIN"); return e && e[0] == '1'; }();
+    const bool fits = !GRAD || (long)a.B * a.ldd < (1L << 32);
+    if (vec && fits && !plain) hipLaunchKernelGGL((zinb_nll_compact_kernel<HAS_PI, CONST_DISP, GRAD>), grid, dim3(256), 0, s, a);
+    else if (vec) hipLaunchKernelGGL((zinb_nll_kernel<HAS_PI, CONST_DISP, GRAD, 4>), grid, dim3(256), 0, s, a);
     else     hipLaunchKernelGGL((zinb_nll_kernel<HAS_PI, CONST_DISP, GRAD, 1>), grid, dim3(256), 0, s, a);
     return (int)hipGetLastError();
 }
