@@ -118,7 +118,9 @@ def test_zinb_nll_vs_oracle(ops, flags, B, G, edge):
                       None, None, None, 0, part)
     ops.loss_finalize(part, n2, inv_n, loss)
     torch.cuda.synchronize()
-    assert abs(loss.item() - got) <= 1e-6 * abs(got)
+    # (the loss-only instantiation drops the gradient arithmetic, so its sums associate differently: same tolerance
+    # class as against the oracle, not bit-equality)
+    assert abs(loss.item() - got) <= (3e-5 if edge else 3e-6) * abs(got)
 
 
 @pytest.mark.parametrize('flag,B,G', [(4, 8, 40), (4, 33, 1000), (8, 16, 203), (8, 5, 6)])
