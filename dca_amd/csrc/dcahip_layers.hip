@@ -380,6 +380,197 @@ __global__ __launch_bounds__(256) void bn_bwd_small_kernel(BnBwdArgs a) {
     }
 }
 
+// ---- small batches: a whole hidden layer per launch ---------------------------------------------------------------
+// At the reference-default batch of 32 cells (dca/train.py:37) every kernel of the hidden stack is a few microseconds
+// of dependent memory round trips; these two do Dense -> BatchNormalization -> activation (dca/network.py:124-135) and
+// its whole backward (d beta, dZ, weight / bias gradient, input gradient) in one launch each.  B <= 64 rows,
+// K <= 64 inputs; the backward additionally h <= 64 units (one workgroup owns the layer).
+constexpr int kSmallK = 64;
+
+struct DenseSmallArgs {
+    const float* Hp; long ldp;          // layer input [B, K]
+    const float* W; long ldw;           // kernel [K, h]
+    const float* bias;                  // [h]
+    int B, K, H;
+    int batchnorm;
+    const float* beta; float* mm; float* mv; float momentum, eps; int act;
+    float* Z; long ldz;                 // pre-activation (the latent code of the centre layer), may be NULL
+    float* xhat; long ldx; float* Hout; long ldh; float* inv_std;
+};
+
+__global__ __launch_bounds__(256) void dense_bn_small_kernel(DenseSmallArgs a) {
+    __shared__ __attribute__((aligned(16))) float Hs[kFusedRows][kSmallK + 4];
+    __shared__ float sm[256];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
+    const bool cv = c < a.H;
+    const int K4 = (a.K + 3) & ~3;
+    for (int idx = threadIdx.x; idx < a.B * K4; idx += 256) {
+        const int r = idx / K4, k = idx - r * K4;
+        Hs[r][k] = k < a.K ? a.Hp[(long)r * a.ldp + k] : 0.f;
+    }
+    __syncthreads();
+    constexpr int RPT = kFusedRows / 4;
+    float z[RPT];
+    const float b = cv ? a.bias[c] : 0.f;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) z[k] = b;
+    for (int kk = 0; kk < K4; kk += 4) {
+        float w[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w[q] = (cv && kk + q < a.K) ? a.W[(long)(kk + q) * a.ldw + c] : 0.f;
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int i = ty + 4 * k;
+            if (i < a.B) {                                   // wave-uniform (ty is)
+                const float4 hv = *reinterpret_cast<const float4*>(&Hs[i][kk]);
+                z[k] = fmaf(hv.w, w[3], fmaf(hv.z, w[2], fmaf(hv.y, w[1], fmaf(hv.x, w[0], z[k]))));
+            }
+        }
+    }
+    if (a.Z && cv) {
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) { const int i = ty + 4 * k; if (i < a.B) a.Z[(long)i * a.ldz + c] = z[k]; }
+    }
+    if (!a.batchnorm) {
+        if (cv) {
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) { const int i = ty + 4 * k; if (i < a.B) a.Hout[(long)i * a.ldh + c] = act_fwd(a.act, z[k]); }
+        }
+        return;
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) s += (ty + 4 * k < a.B) ? z[k] : 0.f;
+    const float mean = wg_rowlane_sum(s, sm) / (float)a.B;
+    float q2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) { const float d = z[k] - mean; q2 += (ty + 4 * k < a.B) ? d * d : 0.f; }
+    const float m2 = wg_rowlane_sum(q2, sm);
+    if (!cv) return;
+    const float var = (float)((double)m2 / (double)a.B);
+    const float inv = 1.f / sqrtf(var + a.eps);
+    if (ty == 0) {
+        a.mm[c] = a.mm[c] - (a.mm[c] - mean) * (1.f - a.momentum);
+        a.mv[c] = a.mv[c] - (a.mv[c] - var) * (1.f - a.momentum);
+        if (a.inv_std) a.inv_std[c] = inv;
+    }
+    const float beta = a.beta ? a.beta[c] : 0.f;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int i = ty + 4 * k;
+        if (i < a.B) {
+            const float xh = (z[k] - mean) * inv;
+            if (a.xhat) a.xhat[(long)i * a.ldx + c] = xh;
+            a.Hout[(long)i * a.ldh + c] = act_fwd(a.act, xh + beta);
+        }
+    }
+}
+
+struct DenseSmallBwdArgs {
+    const float* dH; long ldd;          // gradient w.r.t. the layer output [B, h]
+    const float* Hact; long ldh;        // layer output
+    const float* xhat; long ldx; const float* inv_std;
+    const float* Hp; long ldp;          // layer input [B, K]
+    const float* W; long ldw;           // kernel [K, h]
+    int B, K, H; int batchnorm; float n_total; int act;
+    float* gW; long ldg;                // [K + 1, h]: weight gradient, row K = bias gradient
+    float* dbeta;
+    float* dHp; long lddp;              // gradient w.r.t. the layer input [B, K]
+};
+
+__global__ __launch_bounds__(256) void dense_bn_bwd_small_kernel(DenseSmallBwdArgs a) {
+    __shared__ float dZs[kFusedRows][kSmallK + 1];
+    __shared__ float Hs[kFusedRows][kSmallK + 1];
+    __shared__ float Ws[kSmallK][kSmallK + 1];
+    __shared__ float sm[256];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    constexpr int RPT = kFusedRows / 4;
+    // ---- phase 1: dZ (batch-norm backward, or the activation derivative alone) -> LDS; operands -> LDS
+    {
+        const int c = tx;
+        const bool cv = c < a.H;
+        float dy[RPT], xh[RPT];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int i = ty + 4 * k;
+            const bool ok = cv && i < a.B;
+            dy[k] = ok ? a.dH[(long)i * a.ldd + c] * act_grad(a.act, a.Hact[(long)i * a.ldh + c]) : 0.f;
+            xh[k] = (ok && a.batchnorm) ? a.xhat[(long)i * a.ldx + c] : 0.f;
+            s1 += dy[k]; s2 += dy[k] * xh[k];
+        }
+        float m1 = 0.f, m2 = 0.f, inv = 1.f;
+        if (a.batchnorm) {
+            const float t1 = wg_rowlane_sum(s1, sm);
+            const float t2 = wg_rowlane_sum(s2, sm);
+            if (cv && ty == 0 && a.dbeta) a.dbeta[c] = t1;
+            m1 = t1 / a.n_total; m2 = t2 / a.n_total; inv = cv ? a.inv_std[c] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int i = ty + 4 * k;
+            if (i < a.B) dZs[i][c] = cv ? (a.batchnorm ? inv * (dy[k] - m1 - xh[k] * m2) : dy[k]) : 0.f;
+        }
+        for (int idx = threadIdx.x; idx < a.B * a.K; idx += 256) {
+            const int r = idx / a.K, k = idx - r * a.K;
+            Hs[r][k] = a.Hp[(long)r * a.ldp + k];
+        }
+        for (int idx = threadIdx.x; idx < a.K * a.H; idx += 256) {
+            const int k = idx / a.H, cc = idx - k * a.H;
+            Ws[k][cc] = a.W[(long)k * a.ldw + cc];
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: gW[k, c] = sum_r Hp[r, k] dZ[r, c]; row K = sum_r dZ[r, c]
+    {
+        const int c = tx;
+        if (c < a.H) {
+            float acc[kSmallK / 4];
+#pragma unroll
+            for (int j = 0; j < kSmallK / 4; ++j) acc[j] = 0.f;
+            float cs = 0.f;
+            for (int r = 0; r < a.B; ++r) {
+                const float d = dZs[r][c];
+                cs += d;
+#pragma unroll
+                for (int j = 0; j < kSmallK / 4; ++j) {
+                    const int k = ty + 4 * j;
+                    acc[j] = fmaf(k < a.K ? Hs[r][k] : 0.f, d, acc[j]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < kSmallK / 4; ++j) {
+                const int k = ty + 4 * j;
+                if (k < a.K) a.gW[(long)k * a.ldg + c] = acc[j];
+            }
+            if (ty == 0) a.gW[(long)a.K * a.ldg + c] = cs;
+        }
+    }
+    // ---- phase 3: dHp[r, k] = sum_c dZ[r, c] W[k, c]
+    if (a.dHp) {
+        const int k = tx;
+        if (k < a.K) {
+            float acc[RPT];
+#pragma unroll
+            for (int j = 0; j < RPT; ++j) acc[j] = 0.f;
+            for (int c = 0; c < a.H; ++c) {
+                const float w = Ws[k][c];
+#pragma unroll
+                for (int j = 0; j < RPT; ++j) {
+                    const int r = ty + 4 * j;
+                    acc[j] = fmaf(r < a.B ? dZs[r][c] : 0.f, w, acc[j]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < RPT; ++j) {
+                const int r = ty + 4 * j;
+                if (r < a.B) a.dHp[(long)r * a.lddp + k] = acc[j];
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void relu_bwd_kernel(const float* dH, long ldd, const float* Hact,
                                                        long ldh, int B, int H, float* dZ, long ldz, int act) {
     const long total = (long)B * H;
@@ -566,6 +757,35 @@ extern "C" int dcahip_bn_bwd_small(const float* dH, long ldd, const float* Hact,
     if (!dH || !Hact || !xhat || !inv_std || !dZ || B <= 0 || B > kFusedRows || H <= 0) return DCAHIP_EINVAL;
     BnBwdArgs a{dH, ldd, Hact, ldh, xhat, ldx, inv_std, nullptr, 0, n_total, B, H, dZ, ldz, dbeta, act};
     hipLaunchKernelGGL(bn_bwd_small_kernel<kFusedRows / 4>, dim3((H + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dcahip_dense_small_max_k() { return kSmallK; }
+
+extern "C" int dcahip_dense_bn_small(const float* Hp, long ldp, const float* W, long ldw, const float* bias,
+                                     int B, int K, int H, int batchnorm, const float* beta,
+                                     float* moving_mean, float* moving_var, float momentum, float eps, int act,
+                                     float* Z, long ldz, float* xhat, long ldx, float* Hout, long ldh,
+                                     float* inv_std, void* stream) {
+    if (!Hp || !W || !bias || !Hout || B <= 0 || B > kFusedRows || K <= 0 || K > kSmallK || H <= 0) return DCAHIP_EINVAL;
+    if (batchnorm && (!moving_mean || !moving_var)) return DCAHIP_EINVAL;
+    DenseSmallArgs a{Hp, ldp, W, ldw, bias, B, K, H, batchnorm, beta, moving_mean, moving_var, momentum, eps, act,
+                     Z, ldz, xhat, ldx, Hout, ldh, inv_std};
+    hipLaunchKernelGGL(dense_bn_small_kernel, dim3((H + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dcahip_dense_bn_bwd_small(const float* dH, long ldd, const float* Hact, long ldh,
+                                         const float* xhat, long ldx, const float* inv_std,
+                                         const float* Hp, long ldp, const float* W, long ldw,
+                                         int B, int K, int H, int batchnorm, float n_total, int act,
+                                         float* gW, long ldg, float* dbeta, float* dHp, long lddp, void* stream) {
+    if (!dH || !Hact || !Hp || !W || !gW || B <= 0 || B > kFusedRows || K <= 0 || K > kSmallK || H <= 0 || H > kSmallK)
+        return DCAHIP_EINVAL;
+    if (batchnorm && (!xhat || !inv_std)) return DCAHIP_EINVAL;
+    DenseSmallBwdArgs a{dH, ldd, Hact, ldh, xhat, ldx, inv_std, Hp, ldp, W, ldw, B, K, H, batchnorm, n_total, act,
+                        gW, ldg, dbeta, dHp, lddp};
+    hipLaunchKernelGGL(dense_bn_bwd_small_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return (int)hipGetLastError();
 }
 

@@ -635,6 +635,17 @@ class Engine:
                 else:
                     ops.sgemm(0, 0, B, h, K, self.X[rows_from[1]:], self.ldx, Wi, h, self.Z[0],
                               self.ldh[0], bias=bi, ws=self.ws)
+            elif training and self._layer_small(B, i):
+                # small batches: Dense -> BatchNormalization -> activation of this layer in ONE launch
+                ops.dense_bn_small(self.Hcur[i - 1], self.ldh[i - 1], Wi, h, bi, B, K, h, lay.batchnorm,
+                                   lay.view(w, 'beta%d' % i) if lay.batchnorm else None,
+                                   self.mm[i] if lay.batchnorm else None, self.mv[i] if lay.batchnorm else None,
+                                   BN_MOMENTUM, BN_EPS, self.act, self.Z[i], self.ldh[i],
+                                   self.XH[i] if lay.batchnorm else None, self.ldh[i], self.H[i], self.ldh[i],
+                                   self.inv_std[i])
+                self.Hcur[i] = self.H[i]
+                K = h
+                continue
             else:
                 ops.sgemm(0, 0, B, h, K, self.Hcur[i - 1], self.ldh[i - 1], Wi, h, self.Z[i],
                           self.ldh[i], bias=bi, ws=self.ws)
@@ -670,6 +681,13 @@ class Engine:
 
     def _enc0_nt(self, B):
         return self.W0T is not None and B >= 256 and os.environ.get('DCA_AMD_ENC0_NT', '1') != '0'
+
+    def _layer_small(self, B, i):
+        """Hidden layer i >= 1 at a small batch on one GPU: whole-layer kernels (forward and backward)."""
+        if i < 1 or not self._bn_small(B) or self.prelu or self.has_dropout or not hasattr(self.ops, 'dense_bn_small'):
+            return False
+        kmax = self.ops.dense_small_max_k
+        return self.lay.hidden[i - 1] <= kmax and self.lay.hidden[i] <= kmax
 
     def _bn_small(self, B):
         """Small batches on one GPU take the single-launch batch-norm kernels (the reference-default batch of 32 is
@@ -848,6 +866,16 @@ class Engine:
             if self.prelu:              # dL/d(PReLU out) -> dL/d(its input) in place, slope gradients
                 ops.prelu_bwd(self.dH[i], self.ldh[i], self.H[i], self.ldh[i], lay.view(w, 'alpha%d' % i), B, h,
                               lay.view(g, 'alpha%d' % i), self.ws_prelu)
+            if self._layer_small(B, i):
+                # the layer's whole backward in one launch: d beta, dZ, weight / bias gradient, input gradient
+                Kp = lay.hidden[i - 1]
+                ops.dense_bn_bwd_small(self.dH[i], self.ldh[i], self.H[i], self.ldh[i],
+                                       self.XH[i] if lay.batchnorm else None, self.ldh[i], self.inv_std[i],
+                                       self.Hcur[i - 1], self.ldh[i - 1], lay.view(w, 'W%d' % i), h, B, Kp, h,
+                                       lay.batchnorm, float(Bg), self.act, lay.view(g, 'W%d' % i), h,
+                                       lay.view(g, 'beta%d' % i) if lay.batchnorm else None,
+                                       self.dH[i - 1], self.ldh[i - 1])
+                continue
             if lay.batchnorm and self._bn_small(B):
                 ops.bn_bwd_small(self.dH[i], self.ldh[i], self.H[i], self.ldh[i], self.XH[i], self.ldh[i],
                                  self.inv_std[i], float(Bg), B, h, self.dZ[i], self.ldh[i],

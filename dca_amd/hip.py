@@ -79,6 +79,13 @@ _SIGNATURES = {
                                        _f32p, _c.c_int, _c.c_float, _c.c_int, _c.c_int, _f32p,
                                        _c.c_long, _f32p, _c.c_int, _vp]),
     'dcahip_bn_fused_max_rows': (_c.c_int, []),
+    'dcahip_dense_small_max_k': (_c.c_int, []),
+    'dcahip_dense_bn_small': (_c.c_int, [_f32p, _c.c_long, _f32p, _c.c_long, _f32p, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
+                                         _f32p, _f32p, _f32p, _c.c_float, _c.c_float, _c.c_int, _f32p, _c.c_long, _f32p,
+                                         _c.c_long, _f32p, _c.c_long, _f32p, _vp]),
+    'dcahip_dense_bn_bwd_small': (_c.c_int, [_f32p, _c.c_long, _f32p, _c.c_long, _f32p, _c.c_long, _f32p, _f32p, _c.c_long,
+                                             _f32p, _c.c_long, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_float, _c.c_int,
+                                             _f32p, _c.c_long, _f32p, _f32p, _c.c_long, _vp]),
     'dcahip_bn_relu_train_small': (_c.c_int, [_f32p, _c.c_long, _c.c_int, _c.c_int, _f32p, _f32p, _f32p, _c.c_float,
                                               _c.c_float, _c.c_int, _f32p, _c.c_long, _f32p, _c.c_long, _f32p, _vp]),
     'dcahip_bn_bwd_small': (_c.c_int, [_f32p, _c.c_long, _f32p, _c.c_long, _f32p, _c.c_long, _f32p, _c.c_float,

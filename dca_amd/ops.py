@@ -128,6 +128,24 @@ class HipOps:
         hip.check(self.L.dcahip_bn_bwd_small(p(dH), ldd, p(Hact), ldh, p(xhat), ldx, p(inv_std), float(n_total), B, H,
                                              p(dZ), ldz, p(dbeta), act, hip.stream()), 'bn_bwd_small')
 
+    @property
+    def dense_small_max_k(self):
+        return int(self.L.dcahip_dense_small_max_k())
+
+    def dense_bn_small(self, Hp, ldp, W, ldw, bias, B, K, H, batchnorm, beta, mm, mv, momentum, eps, act, Z, ldz,
+                       xhat, ldx, Hout, ldh, inv_std):
+        p = hip.ptr
+        hip.check(self.L.dcahip_dense_bn_small(p(Hp), ldp, p(W), ldw, p(bias), B, K, H, int(batchnorm), p(beta), p(mm), p(mv),
+                                               momentum, eps, int(act), p(Z), ldz, p(xhat), ldx, p(Hout), ldh, p(inv_std),
+                                               hip.stream()), 'dense_bn_small')
+
+    def dense_bn_bwd_small(self, dH, ldd, Hact, ldh, xhat, ldx, inv_std, Hp, ldp, W, ldw, B, K, H, batchnorm, n_total, act,
+                           gW, ldg, dbeta, dHp, lddp):
+        p = hip.ptr
+        hip.check(self.L.dcahip_dense_bn_bwd_small(p(dH), ldd, p(Hact), ldh, p(xhat), ldx, p(inv_std), p(Hp), ldp, p(W), ldw,
+                                                   B, K, H, int(batchnorm), float(n_total), int(act), p(gW), ldg, p(dbeta),
+                                                   p(dHp), lddp, hip.stream()), 'dense_bn_bwd_small')
+
     def relu_bwd(self, dH, ldd, Hact, ldh, B, H, dZ, ldz, act=1):
         p = hip.ptr
         hip.check(self.L.dcahip_relu_bwd(p(dH), ldd, p(Hact), ldh, B, H, p(dZ), ldz, act, hip.stream()),

@@ -228,6 +228,23 @@ int dcahip_bn_relu_apply(const float* Z, long ldz, int B, int H,
  * pass (dcahip_bn_bwd_sums + dcahip_bn_bwd_apply) in one: the reference-default batch of 32 cells (dca/train.py:37)
  * is bound by launch gaps.  Same arguments and formulas as the two-call forms (one chunk of up to 64 rows). */
 int dcahip_bn_fused_max_rows(void);
+/* A whole hidden layer per launch for the same small batches (B <= dcahip_bn_fused_max_rows(), K <= dcahip_dense_small_max_k()
+ * inputs): Dense -> BatchNormalization (batchnorm != 0) -> activation forward (dca/network.py:124-135; Z receives the
+ * pre-activation when non-NULL: the latent code of the centre layer), and its backward: d beta, the weight gradient gW
+ * [K, h] with the bias gradient in row K, the gradient w.r.t. the layer input dHp (NULL for none); the backward needs
+ * h <= dcahip_dense_small_max_k() as well (one workgroup owns the layer).  Equivalent to dcahip_sgemm + the batch-norm
+ * kernels (+ 2 x dcahip_sgemm backward) on the same operands. */
+int dcahip_dense_small_max_k(void);
+int dcahip_dense_bn_small(const float* Hp, long ldp, const float* W, long ldw, const float* bias,
+                          int B, int K, int H, int batchnorm, const float* beta,
+                          float* moving_mean, float* moving_var, float momentum, float eps, int act,
+                          float* Z, long ldz, float* xhat, long ldx, float* Hout, long ldh,
+                          float* inv_std, void* stream);
+int dcahip_dense_bn_bwd_small(const float* dH, long ldd, const float* Hact, long ldh,
+                              const float* xhat, long ldx, const float* inv_std,
+                              const float* Hp, long ldp, const float* W, long ldw,
+                              int B, int K, int H, int batchnorm, float n_total, int act,
+                              float* gW, long ldg, float* dbeta, float* dHp, long lddp, void* stream);
 int dcahip_bn_relu_train_small(const float* Z, long ldz, int B, int H, const float* beta,
                                float* moving_mean, float* moving_var, float momentum, float eps,
                                int act, float* Hout, long ldh, float* xhat, long ldx,

@@ -86,6 +86,59 @@ float run(int iters, int waves) {
     return ms / 5;
 }
 
+// Part 4: packed fp32 -- does v_pk_fma_f32 (two fp32 FMAs per lane) issue at the rate of one v_fma_f32?  PK = 0: 16
+// independent v_fma_f32 chains, PK = 1: 8 independent v_pk_fma_f32 chains (same flops); waves 4-7 optionally run bf16 MFMAs
+// on the same SIMDs (which: 1 = VALU waves only, 3 = both).
+typedef __attribute__((ext_vector_type(2))) float f32x2p;
+template <int PK>
+__global__ __launch_bounds__(512) void packed(float* out, int iters, int which) {
+    const int wave = threadIdx.x >> 6;
+    float r = 0.f;
+    if (wave < 4) {
+        const float c = 0.999f, d = 1e-3f;
+        if (PK == 0) {
+            float v[16];
+            for (int j = 0; j < 16; ++j) v[j] = threadIdx.x * 1e-3f + j;
+            for (int i = 0; i < iters; ++i) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) v[j] = fmaf(v[j], c, d);
+            }
+            for (int j = 0; j < 16; ++j) r += v[j];
+        } else {
+            f32x2p v[8];
+            const f32x2p cc = {c, c}, dd = {d, d};
+            for (int j = 0; j < 8; ++j) v[j] = f32x2p{threadIdx.x * 1e-3f + j, threadIdx.x * 2e-3f + j};
+            for (int i = 0; i < iters; ++i) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = __builtin_elementwise_fma(v[j], cc, dd);
+            }
+            for (int j = 0; j < 8; ++j) r += v[j][0] + v[j][1];
+        }
+    } else if (which & 2) {
+        f32x16 a0 = {0}, a1 = {0};
+        union { bf16x8 v; unsigned short h[8]; } x, y;
+        for (int j = 0; j < 8; ++j) { x.h[j] = 0x3f80 + (threadIdx.x & 7); y.h[j] = 0x3f00 + j; }
+        for (int i = 0; i < iters / 4; ++i) {
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x.v, y.v, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(y.v, x.v, a1, 0, 0, 0);
+        }
+        r = a0[0] + a1[1];
+    }
+    if (r == 12345.678f) out[threadIdx.x] = r;
+}
+
+template <int PK>
+float run_packed(int iters, int which) {
+    float* out; hipMalloc(&out, 4096);
+    hipEvent_t s, e; hipEventCreate(&s); hipEventCreate(&e);
+    packed<PK><<<256, 512>>>(out, iters, which); hipDeviceSynchronize();
+    hipEventRecord(s);
+    for (int i = 0; i < 5; ++i) packed<PK><<<256, 512>>>(out, iters, which);
+    hipEventRecord(e); hipEventSynchronize(e);
+    float ms; hipEventElapsedTime(&ms, s, e); hipFree(out);
+    return ms / 5;
+}
+
 int main() {
     unsigned short* d; hipMalloc(&d, 512);
     probe<<<1, 64>>>(d);
@@ -112,5 +165,11 @@ int main() {
         printf("accumulators %d: 1 wave/SIMD %.3f ms = %.1f cyc/MFMA;  2 waves/SIMD %.3f ms = %.1f cyc per wave-MFMA\n", \
                NA, t4, t4 * 2.4e6 / (12.0 * 1400), t8, t8 * 2.4e6 / (2 * 12.0 * 1400)); }
     CROW(1) CROW(2) CROW(3) CROW(4) CROW(6)
+    {
+        const int it = 20000;        // 16 fp32 FMAs per lane and iteration in both forms
+        const float s1 = run_packed<0>(it, 1), p1 = run_packed<1>(it, 1), s3 = run_packed<0>(it, 3), p3 = run_packed<1>(it, 3);
+        printf("16 fp32 FMA / iteration: v_fma_f32 x16 %.3f ms (%.2f cyc per instruction), v_pk_fma_f32 x8 %.3f ms (%.2f cyc per instruction);  "
+               "beside a partner wave's bf16 MFMAs: %.3f / %.3f ms\n", s1, s1 * 2.4e6 / (16.0 * it), p1, p1 * 2.4e6 / (8.0 * it), s3, p3);
+    }
     return 0;
 }
