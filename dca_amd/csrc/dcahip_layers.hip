@@ -405,26 +405,30 @@ __global__ __launch_bounds__(256) void dense_bn_small_kernel(DenseSmallArgs a) {
     const int c = blockIdx.x * 64 + tx;
     const bool cv = c < a.H;
     const int K4 = (a.K + 3) & ~3;
-    for (int idx = threadIdx.x; idx < a.B * K4; idx += 256) {
-        const int r = idx / K4, k = idx - r * K4;
-        Hs[r][k] = k < a.K ? a.Hp[(long)r * a.ldp + k] : 0.f;
-    }
-    __syncthreads();
     constexpr int RPT = kFusedRows / 4;
     float z[RPT];
     const float b = cv ? a.bias[c] : 0.f;
 #pragma unroll
     for (int k = 0; k < RPT; ++k) z[k] = b;
-    for (int kk = 0; kk < K4; kk += 4) {
-        float w[4];
+    // the lane's weight column: every load is in flight before the first product (one memory round trip, not K / 4)
+    float wcol[kSmallK];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) w[q] = (cv && kk + q < a.K) ? a.W[(long)(kk + q) * a.ldw + c] : 0.f;
+    for (int kk = 0; kk < kSmallK; ++kk) wcol[kk] = (cv && kk < a.K) ? a.W[(long)kk * a.ldw + c] : 0.f;
+    for (int idx = threadIdx.x; idx < a.B * K4; idx += 256) {
+        const int r = idx / K4, k = idx - r * K4;
+        Hs[r][k] = k < a.K ? a.Hp[(long)r * a.ldp + k] : 0.f;
+    }
+    __syncthreads();
 #pragma unroll
-        for (int k = 0; k < RPT; ++k) {
-            const int i = ty + 4 * k;
-            if (i < a.B) {                                   // wave-uniform (ty is)
-                const float4 hv = *reinterpret_cast<const float4*>(&Hs[i][kk]);
-                z[k] = fmaf(hv.w, w[3], fmaf(hv.z, w[2], fmaf(hv.y, w[1], fmaf(hv.x, w[0], z[k]))));
+    for (int kk = 0; kk < kSmallK; kk += 4) {
+        if (kk < K4) {
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) {
+                const int i = ty + 4 * k;
+                if (i < a.B) {                               // wave-uniform (ty is)
+                    const float4 hv = *reinterpret_cast<const float4*>(&Hs[i][kk]);
+                    z[k] = fmaf(hv.w, wcol[kk + 3], fmaf(hv.z, wcol[kk + 2], fmaf(hv.y, wcol[kk + 1], fmaf(hv.x, wcol[kk], z[k]))));
+                }
             }
         }
     }
@@ -479,14 +483,26 @@ struct DenseSmallBwdArgs {
     float* dHp; long lddp;              // gradient w.r.t. the layer input [B, K]
 };
 
+constexpr int kBwdWGs = 8;      // workgroups of the small-batch layer backward: each recomputes dZ (cheap) and takes 1/8 of the products
+
 __global__ __launch_bounds__(256) void dense_bn_bwd_small_kernel(DenseSmallBwdArgs a) {
     __shared__ float dZs[kFusedRows][kSmallK + 1];
     __shared__ float Hs[kFusedRows][kSmallK + 1];
     __shared__ float Ws[kSmallK][kSmallK + 1];
     __shared__ float sm[256];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int wg = blockIdx.x;
     constexpr int RPT = kFusedRows / 4;
-    // ---- phase 1: dZ (batch-norm backward, or the activation derivative alone) -> LDS; operands -> LDS
+    // operands of the two products -> LDS (requested first: in flight during the statistics below)
+    for (int idx = threadIdx.x; idx < a.B * a.K; idx += 256) {
+        const int r = idx / a.K, k = idx - r * a.K;
+        Hs[r][k] = a.Hp[(long)r * a.ldp + k];
+    }
+    for (int idx = threadIdx.x; idx < a.K * a.H; idx += 256) {
+        const int k = idx / a.H, cc = idx - k * a.H;
+        Ws[k][cc] = a.W[(long)k * a.ldw + cc];
+    }
+    // ---- phase 1 (every workgroup): dZ = batch-norm backward of dH * act'(H), or the activation derivative alone
     {
         const int c = tx;
         const bool cv = c < a.H;
@@ -504,7 +520,7 @@ __global__ __launch_bounds__(256) void dense_bn_bwd_small_kernel(DenseSmallBwdAr
         if (a.batchnorm) {
             const float t1 = wg_rowlane_sum(s1, sm);
             const float t2 = wg_rowlane_sum(s2, sm);
-            if (cv && ty == 0 && a.dbeta) a.dbeta[c] = t1;
+            if (wg == 0 && cv && ty == 0 && a.dbeta) a.dbeta[c] = t1;
             m1 = t1 / a.n_total; m2 = t2 / a.n_total; inv = cv ? a.inv_std[c] : 0.f;
         }
 #pragma unroll
@@ -512,59 +528,53 @@ __global__ __launch_bounds__(256) void dense_bn_bwd_small_kernel(DenseSmallBwdAr
             const int i = ty + 4 * k;
             if (i < a.B) dZs[i][c] = cv ? (a.batchnorm ? inv * (dy[k] - m1 - xh[k] * m2) : dy[k]) : 0.f;
         }
-        for (int idx = threadIdx.x; idx < a.B * a.K; idx += 256) {
-            const int r = idx / a.K, k = idx - r * a.K;
-            Hs[r][k] = a.Hp[(long)r * a.ldp + k];
-        }
-        for (int idx = threadIdx.x; idx < a.K * a.H; idx += 256) {
-            const int k = idx / a.H, cc = idx - k * a.H;
-            Ws[k][cc] = a.W[(long)k * a.ldw + cc];
-        }
     }
     __syncthreads();
-    // ---- phase 2: gW[k, c] = sum_r Hp[r, k] dZ[r, c]; row K = sum_r dZ[r, c]
+    // ---- phase 2: gW[k, c] = sum_r Hp[r, k] dZ[r, c] for the input units k = wg, wg + 8, ..; wg 0 adds row K = sum_r dZ[r, c]
     {
         const int c = tx;
         if (c < a.H) {
-            float acc[kSmallK / 4];
+            constexpr int NK = kSmallK / (4 * kBwdWGs);      // k's per thread: k = wg + 8 (ty + 4 j)
+            float acc[NK];
 #pragma unroll
-            for (int j = 0; j < kSmallK / 4; ++j) acc[j] = 0.f;
+            for (int j = 0; j < NK; ++j) acc[j] = 0.f;
             float cs = 0.f;
             for (int r = 0; r < a.B; ++r) {
                 const float d = dZs[r][c];
                 cs += d;
 #pragma unroll
-                for (int j = 0; j < kSmallK / 4; ++j) {
-                    const int k = ty + 4 * j;
+                for (int j = 0; j < NK; ++j) {
+                    const int k = wg + kBwdWGs * (ty + 4 * j);
                     acc[j] = fmaf(k < a.K ? Hs[r][k] : 0.f, d, acc[j]);
                 }
             }
 #pragma unroll
-            for (int j = 0; j < kSmallK / 4; ++j) {
-                const int k = ty + 4 * j;
+            for (int j = 0; j < NK; ++j) {
+                const int k = wg + kBwdWGs * (ty + 4 * j);
                 if (k < a.K) a.gW[(long)k * a.ldg + c] = acc[j];
             }
-            if (ty == 0) a.gW[(long)a.K * a.ldg + c] = cs;
+            if (wg == 0 && ty == 0) a.gW[(long)a.K * a.ldg + c] = cs;
         }
     }
-    // ---- phase 3: dHp[r, k] = sum_c dZ[r, c] W[k, c]
+    // ---- phase 3: dHp[r, k] = sum_c dZ[r, c] W[k, c] for the rows r = wg + 8 ty + 32 j
     if (a.dHp) {
         const int k = tx;
         if (k < a.K) {
-            float acc[RPT];
+            constexpr int NR = kFusedRows / (4 * kBwdWGs);
+            float acc[NR];
 #pragma unroll
-            for (int j = 0; j < RPT; ++j) acc[j] = 0.f;
+            for (int j = 0; j < NR; ++j) acc[j] = 0.f;
             for (int c = 0; c < a.H; ++c) {
                 const float w = Ws[k][c];
 #pragma unroll
-                for (int j = 0; j < RPT; ++j) {
-                    const int r = ty + 4 * j;
+                for (int j = 0; j < NR; ++j) {
+                    const int r = wg + kBwdWGs * (ty + 4 * j);
                     acc[j] = fmaf(r < a.B ? dZs[r][c] : 0.f, w, acc[j]);
                 }
             }
 #pragma unroll
-            for (int j = 0; j < RPT; ++j) {
-                const int r = ty + 4 * j;
+            for (int j = 0; j < NR; ++j) {
+                const int r = wg + kBwdWGs * (ty + 4 * j);
                 if (r < a.B) a.dHp[(long)r * a.lddp + k] = acc[j];
             }
         }
@@ -785,7 +795,7 @@ extern "C" int dcahip_dense_bn_bwd_small(const float* dH, long ldd, const float*
     if (batchnorm && (!xhat || !inv_std)) return DCAHIP_EINVAL;
     DenseSmallBwdArgs a{dH, ldd, Hact, ldh, xhat, ldx, inv_std, Hp, ldp, W, ldw, B, K, H, batchnorm, n_total, act,
                         gW, ldg, dbeta, dHp, lddp};
-    hipLaunchKernelGGL(dense_bn_bwd_small_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(dense_bn_bwd_small_kernel, dim3(kBwdWGs), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return (int)hipGetLastError();
 }
 
