@@ -25,10 +25,10 @@ constexpr int kApplyRows = 16;   // rows per workgroup in the apply kernels (256
 //   0 linear  1 relu  2 tanh  3 sigmoid  4 elu  5 selu  6 softplus  7 softsign  8 LeakyReLU(0.3)
 constexpr float kSeluScale = 1.0507009873554805f, kSeluAlpha = 1.6732632423543772f;
 
-__device__ __forceinline__ float act_fwd(int a, float x) {
+// relu / linear inline; the other activations out of line: the small-batch kernels unroll over their rows, and eight
+// inlined libm bodies per row made them instruction-fetch bound (10 000-line kernels that run once per step)
+__device__ __attribute__((noinline)) float act_fwd_other(int a, float x) {
     switch (a) {
-        case 0: return x;
-        case 1: return fmaxf(x, 0.f);
         case 2: return tanhf(x);
         case 3: { const float e = expf(-fabsf(x)); const float s = 1.f / (1.f + e); return x >= 0.f ? s : e * s; }
         case 4: return x > 0.f ? x : expm1f(x);
@@ -38,12 +38,15 @@ __device__ __forceinline__ float act_fwd(int a, float x) {
         default: return x > 0.f ? x : 0.3f * x;
     }
 }
+__device__ __forceinline__ float act_fwd(int a, float x) {
+    if (a == 1) return fmaxf(x, 0.f);
+    if (a == 0) return x;
+    return act_fwd_other(a, x);
+}
 
 // derivative expressed through the OUTPUT h = act(x) (what the backward pass has at hand)
-__device__ __forceinline__ float act_grad(int a, float h) {
+__device__ __attribute__((noinline)) float act_grad_other(int a, float h) {
     switch (a) {
-        case 0: return 1.f;
-        case 1: return h > 0.f ? 1.f : 0.f;
         case 2: return 1.f - h * h;
         case 3: return h * (1.f - h);
         case 4: return h > 0.f ? 1.f : h + 1.f;
@@ -52,6 +55,11 @@ __device__ __forceinline__ float act_grad(int a, float h) {
         case 7: { const float t = 1.f - fabsf(h); return t * t; }
         default: return h > 0.f ? 1.f : 0.3f;
     }
+}
+__device__ __forceinline__ float act_grad(int a, float h) {
+    if (a == 1) return h > 0.f ? 1.f : 0.f;
+    if (a == 0) return 1.f;
+    return act_grad_other(a, h);
 }
 
 __host__ __device__ inline int n_chunks(int B) {
@@ -398,38 +406,38 @@ struct DenseSmallArgs {
     float* xhat; long ldx; float* Hout; long ldh; float* inv_std;
 };
 
+// RPT = rows per thread (8 for batches of up to 32 rows, 16 up to 64): small code matters more than anything else
+// here -- the kernel runs once per step, from a cold instruction cache
+template <int RPT>
 __global__ __launch_bounds__(256) void dense_bn_small_kernel(DenseSmallArgs a) {
     __shared__ __attribute__((aligned(16))) float Hs[kFusedRows][kSmallK + 4];
+    __shared__ float Ws[kSmallK][64];
     __shared__ float sm[256];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + tx;
+    const int c0 = blockIdx.x * 64, c = c0 + tx;
     const bool cv = c < a.H;
     const int K4 = (a.K + 3) & ~3;
-    constexpr int RPT = kFusedRows / 4;
-    float z[RPT];
-    const float b = cv ? a.bias[c] : 0.f;
-#pragma unroll
-    for (int k = 0; k < RPT; ++k) z[k] = b;
-    // the lane's weight column: every load is in flight before the first product (one memory round trip, not K / 4)
-    float wcol[kSmallK];
-#pragma unroll
-    for (int kk = 0; kk < kSmallK; ++kk) wcol[kk] = (cv && kk < a.K) ? a.W[(long)kk * a.ldw + c] : 0.f;
+    // both operands -> LDS, every load in flight at once (one memory round trip)
+    for (int idx = threadIdx.x; idx < K4 * 64; idx += 256) {
+        const int k = idx >> 6, cc = idx & 63;
+        Ws[k][cc] = (k < a.K && c0 + cc < a.H) ? a.W[(long)k * a.ldw + c0 + cc] : 0.f;
+    }
     for (int idx = threadIdx.x; idx < a.B * K4; idx += 256) {
         const int r = idx / K4, k = idx - r * K4;
         Hs[r][k] = k < a.K ? a.Hp[(long)r * a.ldp + k] : 0.f;
     }
+    float z[RPT];
+    const float b = cv ? a.bias[c] : 0.f;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) z[k] = b;
     __syncthreads();
+#pragma unroll 1
+    for (int kk = 0; kk < K4; kk += 4) {
+        const float w0 = Ws[kk][tx], w1 = Ws[kk + 1][tx], w2 = Ws[kk + 2][tx], w3 = Ws[kk + 3][tx];
 #pragma unroll
-    for (int kk = 0; kk < kSmallK; kk += 4) {
-        if (kk < K4) {
-#pragma unroll
-            for (int k = 0; k < RPT; ++k) {
-                const int i = ty + 4 * k;
-                if (i < a.B) {                               // wave-uniform (ty is)
-                    const float4 hv = *reinterpret_cast<const float4*>(&Hs[i][kk]);
-                    z[k] = fmaf(hv.w, wcol[kk + 3], fmaf(hv.z, wcol[kk + 2], fmaf(hv.y, wcol[kk + 1], fmaf(hv.x, wcol[kk], z[k]))));
-                }
-            }
+        for (int k = 0; k < RPT; ++k) {
+            const float4 hv = *reinterpret_cast<const float4*>(&Hs[ty + 4 * k][kk]);      // rows beyond B: finite garbage, never stored
+            z[k] = fmaf(hv.w, w3, fmaf(hv.z, w2, fmaf(hv.y, w1, fmaf(hv.x, w0, z[k]))));
         }
     }
     if (a.Z && cv) {
@@ -485,6 +493,7 @@ struct DenseSmallBwdArgs {
 
 constexpr int kBwdWGs = 8;      // workgroups of the small-batch layer backward: each recomputes dZ (cheap) and takes 1/8 of the products
 
+template <int RPT>
 __global__ __launch_bounds__(256) void dense_bn_bwd_small_kernel(DenseSmallBwdArgs a) {
     __shared__ float dZs[kFusedRows][kSmallK + 1];
     __shared__ float Hs[kFusedRows][kSmallK + 1];
@@ -492,7 +501,6 @@ __global__ __launch_bounds__(256) void dense_bn_bwd_small_kernel(DenseSmallBwdAr
     __shared__ float sm[256];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int wg = blockIdx.x;
-    constexpr int RPT = kFusedRows / 4;
     // operands of the two products -> LDS (requested first: in flight during the statistics below)
     for (int idx = threadIdx.x; idx < a.B * a.K; idx += 256) {
         const int r = idx / a.K, k = idx - r * a.K;
@@ -560,7 +568,7 @@ __global__ __launch_bounds__(256) void dense_bn_bwd_small_kernel(DenseSmallBwdAr
     if (a.dHp) {
         const int k = tx;
         if (k < a.K) {
-            constexpr int NR = kFusedRows / (4 * kBwdWGs);
+            constexpr int NR = RPT / kBwdWGs;            // rows per thread of this workgroup
             float acc[NR];
 #pragma unroll
             for (int j = 0; j < NR; ++j) acc[j] = 0.f;
@@ -757,7 +765,8 @@ extern "C" int dcahip_bn_relu_train_small(const float* Z, long ldz, int B, int H
     if (!Z || !Hout || !moving_mean || !moving_var || B <= 0 || B > kFusedRows || H <= 0) return DCAHIP_EINVAL;
     BnApplyArgs a{Z, ldz, B, H, nullptr, nullptr, 0, beta, moving_mean, moving_var, momentum, eps,
                   act, Hout, ldh, xhat, ldx, inv_std};
-    hipLaunchKernelGGL(bn_relu_small_kernel<kFusedRows / 4>, dim3((H + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    if (B <= 32) hipLaunchKernelGGL(bn_relu_small_kernel<8>, dim3((H + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    else hipLaunchKernelGGL(bn_relu_small_kernel<kFusedRows / 4>, dim3((H + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return (int)hipGetLastError();
 }
 
@@ -766,7 +775,8 @@ extern "C" int dcahip_bn_bwd_small(const float* dH, long ldd, const float* Hact,
                                    int B, int H, float* dZ, long ldz, float* dbeta, int act, void* stream) {
     if (!dH || !Hact || !xhat || !inv_std || !dZ || B <= 0 || B > kFusedRows || H <= 0) return DCAHIP_EINVAL;
     BnBwdArgs a{dH, ldd, Hact, ldh, xhat, ldx, inv_std, nullptr, 0, n_total, B, H, dZ, ldz, dbeta, act};
-    hipLaunchKernelGGL(bn_bwd_small_kernel<kFusedRows / 4>, dim3((H + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    if (B <= 32) hipLaunchKernelGGL(bn_bwd_small_kernel<8>, dim3((H + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    else hipLaunchKernelGGL(bn_bwd_small_kernel<kFusedRows / 4>, dim3((H + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return (int)hipGetLastError();
 }
 
@@ -781,7 +791,8 @@ extern "C" int dcahip_dense_bn_small(const float* Hp, long ldp, const float* W, 
     if (batchnorm && (!moving_mean || !moving_var)) return DCAHIP_EINVAL;
     DenseSmallArgs a{Hp, ldp, W, ldw, bias, B, K, H, batchnorm, beta, moving_mean, moving_var, momentum, eps, act,
                      Z, ldz, xhat, ldx, Hout, ldh, inv_std};
-    hipLaunchKernelGGL(dense_bn_small_kernel, dim3((H + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    if (B <= 32) hipLaunchKernelGGL(dense_bn_small_kernel<8>, dim3((H + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    else hipLaunchKernelGGL(dense_bn_small_kernel<16>, dim3((H + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return (int)hipGetLastError();
 }
 
@@ -795,7 +806,8 @@ extern "C" int dcahip_dense_bn_bwd_small(const float* dH, long ldd, const float*
     if (batchnorm && (!xhat || !inv_std)) return DCAHIP_EINVAL;
     DenseSmallBwdArgs a{dH, ldd, Hact, ldh, xhat, ldx, inv_std, Hp, ldp, W, ldw, B, K, H, batchnorm, n_total, act,
                         gW, ldg, dbeta, dHp, lddp};
-    hipLaunchKernelGGL(dense_bn_bwd_small_kernel, dim3(kBwdWGs), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    if (B <= 32) hipLaunchKernelGGL(dense_bn_bwd_small_kernel<8>, dim3(kBwdWGs), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    else hipLaunchKernelGGL(dense_bn_bwd_small_kernel<16>, dim3(kBwdWGs), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return (int)hipGetLastError();
 }
 
