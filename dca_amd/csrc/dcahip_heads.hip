@@ -766,23 +766,42 @@ __global__ __launch_bounds__(64 * WR) void heads_fused_x3_kernel(HeadsArgs2 p) {
     // 16-byte units of a row rotated by (k >> 2): conflict-free for the direct 16-byte reads of dH (lanes = rows k)
     // and for the transposing reads of F (4 consecutive rows per lane group)
     if (tile_ok) {
-        for (int idx = tid; idx < NH * 64 * 8; idx += NTHREADS) {
-            const int c4 = idx & 7, k = (idx >> 3) & 63, h = idx >> 9;
-            const int gcol = g0 + c4 * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (k < p.hL && gcol < p.plane)
-                v = *reinterpret_cast<const float4*>(p.Wh + (long)k * p.ldw + (long)h * p.plane + gcol);
-            if (gcol + 0 >= p.G) v.x = 0.f;
-            if (gcol + 1 >= p.G) v.y = 0.f;
-            if (gcol + 2 >= p.G) v.z = 0.f;
-            if (gcol + 3 >= p.G) v.w = 0.f;
-            unsigned a0, a1, a2, b0, b1, b2;
-            split_pair(v.x, v.y, a0, a1, a2);
-            split_pair(v.z, v.w, b0, b1, b2);
-            const int off = k * 64 + ((((c4 >> 1) + (k >> 2)) & 3) << 4) + ((c4 & 1) << 3);
-            *reinterpret_cast<u32x2*>(Wimg + (h * 3 + 0) * W_PIECE + off) = u32x2{a0, b0};
-            *reinterpret_cast<u32x2*>(Wimg + (h * 3 + 1) * W_PIECE + off) = u32x2{a1, b1};
-            *reinterpret_cast<u32x2*>(Wimg + (h * 3 + 2) * W_PIECE + off) = u32x2{a2, b2};
+        // batches of UNR independent 16-byte loads (clamped addresses, zeroed afterwards): one memory round trip per
+        // batch -- a load-split-store loop costs one per ITERATION, 24 of them for a single-wave workgroup
+        constexpr int UNR = WR == 1 ? 8 : 3;
+        constexpr int ITEMS = NH * 64 * 8;
+        static_assert(ITEMS % (NTHREADS * UNR) == 0 || WR != 1, "single-wave prologue batches");
+        for (int base = tid; base < ITEMS; base += NTHREADS * UNR) {
+            float4 v[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int idx = base + u * NTHREADS;
+                const int c4 = idx & 7, kq = (idx >> 3) & 63, h = (idx >> 9) < NH ? (idx >> 9) : NH - 1;
+                const int kc = kq < p.hL ? kq : p.hL - 1;
+                long gcol = g0 + c4 * 4;
+                if (gcol > p.plane - 4) gcol = p.plane - 4;
+                v[u] = *reinterpret_cast<const float4*>(p.Wh + (long)kc * p.ldw + (long)h * p.plane + gcol);
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int idx = base + u * NTHREADS;
+                if (idx >= ITEMS) continue;
+                const int c4 = idx & 7, kq = (idx >> 3) & 63, h = idx >> 9;
+                const int gcol = g0 + c4 * 4;
+                const bool kv = kq < p.hL && gcol <= p.plane - 4;
+                float4 w = v[u];
+                if (!kv || gcol + 0 >= p.G) w.x = 0.f;
+                if (!kv || gcol + 1 >= p.G) w.y = 0.f;
+                if (!kv || gcol + 2 >= p.G) w.z = 0.f;
+                if (!kv || gcol + 3 >= p.G) w.w = 0.f;
+                unsigned a0, a1, a2, b0, b1, b2;
+                split_pair(w.x, w.y, a0, a1, a2);
+                split_pair(w.z, w.w, b0, b1, b2);
+                const int off = kq * 64 + ((((c4 >> 1) + (kq >> 2)) & 3) << 4) + ((c4 & 1) << 3);
+                *reinterpret_cast<u32x2*>(Wimg + (h * 3 + 0) * W_PIECE + off) = u32x2{a0, b0};
+                *reinterpret_cast<u32x2*>(Wimg + (h * 3 + 1) * W_PIECE + off) = u32x2{a1, b1};
+                *reinterpret_cast<u32x2*>(Wimg + (h * 3 + 2) * W_PIECE + off) = u32x2{a2, b2};
+            }
         }
         if (tid < 32) {
             const bool gv = g0 + tid < p.G;
@@ -837,11 +856,13 @@ __global__ __launch_bounds__(64 * WR) void heads_fused_x3_kernel(HeadsArgs2 p) {
             if constexpr (WR == 1) {
                 // small batches: no split pass in front of the kernel -- row l31 of the tile, hidden units 32 hi + 8 ks ..
                 const int row = tt * kTR + l31;
+                const float* hp = p.H + (long)(row < p.B ? row : p.B - 1) * p.ldh;
                 float x[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
+                for (int j = 0; j < 8; ++j) {                      // unconditional loads (clamped), zeroed afterwards
                     const int kk = 32 * hi + 8 * ks + j;
-                    x[j] = (row < p.B && kk < p.hL) ? p.H[(long)row * p.ldh + kk] : 0.f;
+                    const float v = hp[kk < p.hL ? kk : p.hL - 1];
+                    x[j] = (row < p.B && kk < p.hL) ? v : 0.f;
                 }
                 split8(x, dst);
             } else {
@@ -860,7 +881,8 @@ __global__ __launch_bounds__(64 * WR) void heads_fused_x3_kernel(HeadsArgs2 p) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const int row = tt * kTR + rowmap(8 * ks + j, hi);
-                        x[j] = (row < p.B && i < p.hL) ? p.H[(long)row * p.ldh + i] : 0.f;
+                        const float v = p.H[(long)(row < p.B ? row : p.B - 1) * p.ldh + (i < p.hL ? i : p.hL - 1)];
+                        x[j] = (row < p.B && i < p.hL) ? v : 0.f;
                     }
                     u32x4 f[3];
                     split8(x, f);
