@@ -90,3 +90,44 @@ def test_read_text_transpose_and_write_text_matrix(tmp_path):
     g = str(tmp_path / 'genes.txt')
     open(g, 'w').write('g1\ng3\ng1\n')
     assert sorted(io.read_genelist(g)) == ['g1', 'g3']
+
+
+def test_identity_selection_shares_the_matrices_and_partial_selection_copies():
+    """dca() takes adata[adata.obs.dca_split == 'train'] (dca/api.py:203); without a test split that selects every
+    cell, and anndata's own views do not copy there either."""
+    import pandas as pd
+    from dca_amd._anndata import MiniAnnData
+    y = synth_counts(30, 12, 1).astype(np.float32)
+    ad = MiniAnnData(y, obs=pd.DataFrame({'dca_split': ['train'] * 30}, index=['c%d' % i for i in range(30)]))
+    ad.raw = ad.copy()
+    everything = ad[ad.obs.dca_split == 'train']
+    assert everything.X is ad.X and everything.raw.X is ad.raw.X
+    assert list(everything.obs.index) == list(ad.obs.index)
+    part = ad[np.arange(30) % 2 == 0]
+    assert part.X is not ad.X and part.shape == (15, 12)
+    np.testing.assert_array_equal(part.X, y[::2])
+
+
+def test_device_cache_mark_follows_the_host_matrix():
+    """prep.DeviceData.matches: K-PREP's resident tensors are reused only while adata.X still is the matrix they were
+    made from (the reference always feeds the current adata.X, dca/network.py:188-211)."""
+    from dca_amd import prep
+    x = np.random.RandomState(0).rand(200, 17).astype(np.float32)
+    dd = prep.DeviceData(None, None, None, 200, 17, host_x=x)
+    assert dd.matches(x) and dd.matches(x.copy())
+    x2 = x.copy(); x2[199, 3] += 1.0                       # the last row is always part of the mark
+    assert not dd.matches(x2)
+    assert not dd.matches(x[:100])
+    assert prep.DeviceData(None, None, None, 200, 17).matches(x2)      # no mark taken (to_host=False): always reused
+
+
+def test_parallel_host_copy():
+    from dca_amd import hostlib
+    a = np.random.RandomState(1).rand(3000, 1001).astype(np.float32)
+    b = np.zeros((5000, 1001), np.float32)
+    hostlib.parallel_copy(b[1000:4000], a, threads=5)
+    np.testing.assert_array_equal(b[1000:4000], a)
+    assert (b[:1000] == 0).all() and (b[4000:] == 0).all()
+    small = np.arange(10, dtype=np.float32); out = np.empty_like(small)
+    hostlib.parallel_copy(out, small)
+    np.testing.assert_array_equal(out, small)

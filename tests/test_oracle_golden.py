@@ -200,3 +200,22 @@ def test_fp32_oracle_leaves_the_fp64_trajectory_at_some_seeds():
         left[ae_type] = int((d > 1e-5).sum())
     assert left['zinb-conddisp'] >= 1 and left['nb'] >= 1, left
     assert all(v <= len(SEEDS[k]) // 2 for k, v in left.items()), left
+
+
+def test_threaded_likelihood_equals_the_single_call():
+    """oracle.zinb_np.rows_in_parallel (used for benchmark-size comparisons only) is the single-call result: identical
+    element-wise outputs, sums to fp64 re-association."""
+    rng = np.random.RandomState(3)
+    B, G = 96, 257
+    am, ad, ap = rng.normal(0, 1, (B, G)), rng.normal(0, 1, (B, G)), rng.normal(0, 1, (B, G))
+    y = rng.poisson(0.3, (B, G)).astype(float); sf = rng.lognormal(0, .3, B); tw = rng.normal(0, 1, G)
+    nt = float(B * G)
+    for tw_ in (None, tw):
+        a = Z.zinb_loss_and_grads(am, None if tw_ is not None else ad, ap, y, sf, 0.05, nt, tw_)
+        b = Z.rows_in_parallel(Z.zinb_loss_and_grads, (am, None if tw_ is not None else ad, ap, y, sf), 5, ridge=0.05, n_total=nt, theta_w=tw_)
+        for u, v in zip(a, b):
+            np.testing.assert_allclose(np.asarray(u), np.asarray(v), rtol=1e-12, atol=1e-18)
+        a = Z.nb_loss_and_grads(am, None if tw_ is not None else ad, y, sf, nt, tw_)
+        b = Z.rows_in_parallel(Z.nb_loss_and_grads, (am, None if tw_ is not None else ad, y, sf), 5, n_total=nt, theta_w=tw_)
+        for u, v in zip(a, b):
+            np.testing.assert_allclose(np.asarray(u), np.asarray(v), rtol=1e-12, atol=1e-18)
