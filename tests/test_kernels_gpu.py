@@ -221,6 +221,11 @@ GEMM_SHAPES = [
     (0, 1, 130, 32, 64, False, False, False, 0),     # dH mid layer
     (0, 1, 257, 190, 99, False, False, False, 0),    # cfg 128x128, NT, odd
     (0, 0, 17, 5, 9, False, False, False, 0),        # unaligned ld -> scalar loads
+    # skinny outputs over many rows (the first layer at throughput batches: the A-direct kernel), every layout
+    (0, 0, 2100, 64, 300, True, True, False, 0),     # enc0 fwd, gathered rows, ragged M and K
+    (0, 1, 2049, 33, 517, False, False, False, 3),   # NT, odd N, forced split
+    (1, 0, 2500, 64, 260, True, False, True, 0),     # dW0: gathered K rows + bias-gradient row
+    (1, 0, 2051, 64, 99, True, False, True, 2),      # dW0, ragged, forced split
 ]
 
 

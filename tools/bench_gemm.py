@@ -34,6 +34,11 @@ for sk in (0, 16, 32, 48):
     if ops.sgemm_workspace_bytes(0, 0, B, h, G, False, sk) > ws.numel() * 4: continue
     t = timeit(lambda: ops.sgemm(0, 0, B, h, G, X, G, W0, h, Z, h, bias=W0[G], perm=perm, cursor=cur, split_k=sk, ws=ws))
     print('enc0 fwd  NN M=%d N=%d K=%d split_k=%3d: %.3f ms %.1f TF/s' % (B, h, G, sk, t, fl / t / 1e9))
+W0T = W0[:G].t().contiguous()
+for sk in (0, 16, 32, 48):
+    if ops.sgemm_workspace_bytes(0, 1, B, h, G, False, sk) > ws.numel() * 4: continue
+    t = timeit(lambda: ops.sgemm(0, 1, B, h, G, X, G, W0T, G, Z, h, bias=W0[G], perm=perm, cursor=cur, split_k=sk, ws=ws))
+    print('enc0 fwd  NT M=%d N=%d K=%d split_k=%3d: %.3f ms %.1f TF/s' % (B, h, G, sk, t, fl / t / 1e9))
 for sk in (0, 4, 6, 8):
     if ops.sgemm_workspace_bytes(1, 0, G, h, B, True, sk) > ws.numel() * 4: continue
     t = timeit(lambda: ops.sgemm(1, 0, G, h, B, X, G, dZ, h, gW, h, perm=perm, cursor=cur, colsum_row=True, split_k=sk, ws=ws))
