@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const bool do_colsum = TA && p.colsum && mt == 0;
+    const bool do_colsum = !TB && p.colsum && mt == 0;
     constexpr int NPH = 256 / BN > 0 ? 256 / BN : 1;   // column-sum phases (BN <= 256)
     const int cn = t % BN, cph = t / BN;
     float csum = 0.f;
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(GemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const bool do_colsum = TA && p.colsum && mt == 0;        // B is n-contiguous there (TN): column sums at store time
+    const bool do_colsum = !TB && p.colsum && mt == 0;       // B is n-contiguous there (TN, NN): column sums at store time
     float csum[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) csum[j] = 0.f;
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(GemmArgs p) {
             }
         }
     }
-    if constexpr (TA) {
+    if constexpr (!TB) {
         if (do_colsum) {
             // column sums of B (the bias gradient): per-thread partial sums of the rows this thread stored, combined over
             // the KPP row groups in fixed order
@@ -604,7 +604,7 @@ extern "C" int dcahip_sgemm(int ta, int tb, int M, int N, int K, const float* A,
                             void* workspace, long workspace_bytes, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C) return DCAHIP_EINVAL;
     if (ta && tb) return DCAHIP_EINVAL;
-    if (colsum_row && !ta) return DCAHIP_EINVAL;
+    if (colsum_row && tb) return DCAHIP_EINVAL;          // the column sums are taken where B is stored [K, N]
     const Plan p = make_plan(M, N, K, split_k);
     const long need = dcahip_sgemm_workspace_bytes(ta, tb, M, N, K, colsum_row, split_k);
     if (need > 0 && (!workspace || workspace_bytes < need)) return DCAHIP_EINVAL;

@@ -670,16 +670,24 @@ __global__ __launch_bounds__(256) void rmsprop_clip_kernel(float* w, const float
     }
 }
 
-// dst [C, R] = src [R, C]^T through 32 x 33 LDS tiles (coalesced on both sides)
+// dst [C, R] = src [R, C]^T through 32 x 33 LDS tiles (coalesced on both sides); source row r = perm[cursor + r] when
+// perm is given (the minibatch gather of the training step)
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src, long lds_, int R, int C,
-                                                        float* __restrict__ dst, long ldd) {
+                                                        float* __restrict__ dst, long ldd,
+                                                        const int* __restrict__ perm, const long long* __restrict__ cursor) {
     __shared__ float tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const long long cur = (perm && cursor) ? *cursor : 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int r = r0 + ty + 8 * k, c = c0 + tx;
-        tile[ty + 8 * k][tx] = (r < R && c < C) ? src[(long)r * lds_ + c] : 0.f;
+        float v = 0.f;
+        if (r < R && c < C) {
+            const long sr = perm ? (long)perm[cur + r] : (long)r;
+            v = src[sr * lds_ + c];
+        }
+        tile[ty + 8 * k][tx] = v;
     }
     __syncthreads();
 #pragma unroll
@@ -693,11 +701,16 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 
 }  // namespace
 
-extern "C" int dcahip_transpose(const float* src, long ld_src, int R, int C, float* dst, long ld_dst, void* stream) {
+extern "C" int dcahip_transpose_rows(const float* src, long ld_src, const int* perm, const long long* cursor, int R, int C,
+                                     float* dst, long ld_dst, void* stream) {
     if (!src || !dst || R <= 0 || C <= 0 || ld_src < C || ld_dst < R) return DCAHIP_EINVAL;
     hipLaunchKernelGGL(transpose_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), src, ld_src, R, C, dst, ld_dst);
+                       static_cast<hipStream_t>(stream), src, ld_src, R, C, dst, ld_dst, perm, cursor);
     return (int)hipGetLastError();
+}
+
+extern "C" int dcahip_transpose(const float* src, long ld_src, int R, int C, float* dst, long ld_dst, void* stream) {
+    return dcahip_transpose_rows(src, ld_src, nullptr, nullptr, R, C, dst, ld_dst, stream);
 }
 
 extern "C" int dcahip_col_moments_chunks(int B) { return n_chunks(B); }

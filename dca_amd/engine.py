@@ -307,6 +307,7 @@ class Engine:
         self.ws_heads = None
         self._pending = None        # in-flight all-reduce of the heads bucket (data parallel)
         self.W0T = None             # transposed first-layer kernel (throughput batches)
+        self.WhT = self.HT = self.XT = None     # wide networks: transposed head weights / last activations / minibatch
         self.opt_kind = 'rmsprop'   # train.py:54-57 picks the Keras optimizer by name
         self.slot2 = None
         self.m_sched = None         # Nadam: running product of the momentum schedule
@@ -592,14 +593,30 @@ class Engine:
                 need = max(need, ops.sgemm_workspace_bytes(0, 0, b, nc, lay.hL))
                 need = max(need, ops.sgemm_workspace_bytes(1, 0, lay.hL, nc, b, True))
                 need = max(need, ops.sgemm_workspace_bytes(0, 1, b, lay.hL, nc))
-        self.W0T = None
+        nb = ops.heads_fused_workspace_bytes(B, lay.hidden[-1], lay.G_out, lay.Gp, self.flags) if self.use_fused else 0
+        self.ws_heads = torch.zeros(nb // 4, **f32) if nb > 0 else None
+        self.W0T = self.WhT = self.HT = self.XT = None
         if hasattr(ops, 'transpose') and B >= 256:
             self.W0T = torch.zeros(lay.hidden[0], _r4(lay.G_in), **f32)
             for b in cand:
                 need = max(need, ops.sgemm_workspace_bytes(0, 1, b, lay.hidden[0], lay.G_in))
+            if self._wide_transposed(B):
+                # separate-kernel heads of a wide decoder (> 64 units) and a wide first layer at throughput batches: every
+                # product in the form whose operands K-GEMM reads fastest (A contiguous along the contraction) -- the
+                # head weights, the last hidden activations and the minibatch of X are transposed once per step
+                hin = lay.hidden[-1]
+                self.ldb_t = _r4(B)
+                self.WhT = torch.zeros(lay.NH, _r4(lay.hL), **f32)
+                self.HT = torch.zeros(hin, self.ldb_t, **f32)
+                if lay.hidden[0] >= 128:
+                    self.XT = torch.zeros(lay.G_in, self.ldb_t, **f32)
+                for b in cand:
+                    for _c0, nc, _h0 in self._head_blocks():
+                        need = max(need, ops.sgemm_workspace_bytes(0, 1, b, nc, lay.hL))
+                        need = max(need, ops.sgemm_workspace_bytes(0, 0, lay.hL, nc, b, True))
+                    if self.XT is not None:
+                        need = max(need, ops.sgemm_workspace_bytes(0, 0, lay.G_in, lay.hidden[0], b, True))
         self.ws = torch.zeros(max(need // 4, 4), **f32)
-        nb = ops.heads_fused_workspace_bytes(B, K, lay.G_out, lay.Gp, self.flags) if self.use_fused else 0
-        self.ws_heads = torch.zeros(nb // 4, **f32) if nb > 0 else None
 
     # ------------------------------------------------------------------ forward pieces
     def _hidden_forward(self, B, rows_from, training, counts=None):
@@ -682,6 +699,11 @@ class Engine:
     def _enc0_nt(self, B):
         return self.W0T is not None and B >= 256 and os.environ.get('DCA_AMD_ENC0_NT', '1') != '0'
 
+    def _wide_transposed(self, B):
+        """Throughput batches of a network whose heads run as separate kernels: transposed operand copies (see reserve)."""
+        return (self.ws_heads is None and B >= 256 and hasattr(self.ops, 'transpose')
+                and os.environ.get('DCA_AMD_WIDE_T', '1') != '0')
+
     def _layer_small(self, B, i):
         """Hidden layer i >= 1 at a small batch on one GPU: whole-layer kernels (forward and backward)."""
         if i < 1 or not self._bn_small(B) or self.prelu or self.has_dropout or not hasattr(self.ops, 'dense_bn_small'):
@@ -721,9 +743,15 @@ class Engine:
         lay, ops = self.lay, self.ops
         Wh, bh = lay.view(self.w, 'Wh'), lay.view(self.w, 'bh')
         with self._t('gemm_heads_fwd'):
-            for c0, nc, h0 in self._head_blocks():
-                ops.sgemm(0, 0, B, nc, lay.hL, self.Hcur[-1][:, h0:], self.ldh[-1], Wh[:, c0:], lay.NH,
-                          self.A[:, c0:], lay.ldA, bias=bh[c0:], ws=self.ws)
+            if self.WhT is not None and B >= 256:
+                ops.transpose(Wh, lay.NH, lay.hL, lay.NH, self.WhT, self.WhT.shape[1])
+                for c0, nc, h0 in self._head_blocks():
+                    ops.sgemm(0, 1, B, nc, lay.hL, self.Hcur[-1][:, h0:], self.ldh[-1], self.WhT[c0:], self.WhT.shape[1],
+                              self.A[:, c0:], lay.ldA, bias=bh[c0:], ws=self.ws)
+            else:
+                for c0, nc, h0 in self._head_blocks():
+                    ops.sgemm(0, 0, B, nc, lay.hL, self.Hcur[-1][:, h0:], self.ldh[-1], Wh[:, c0:], lay.NH,
+                              self.A[:, c0:], lay.ldA, bias=bh[c0:], ws=self.ws)
         if lay.elempi:               # m = -(Dense output) in place; dropout logit = k m + c
             ops.elempi_fwd(self._plane(self.A, 'mean'), lay.ldA, lay.view(self.w, 'pi_k'), lay.view(self.w, 'pi_c'),
                            B, lay.G_out, self._plane(self.A, 'pi'), lay.ldA)
@@ -904,6 +932,10 @@ class Engine:
                     if self.in_drop > 0.0:
                         ops.sgemm(1, 0, Kp, h, B, self.Xb, self.ldx, self.dZ[0], self.ldh[0], gW, h,
                                   colsum_row=True, ws=self.ws)
+                    elif self.XT is not None and B >= 256:
+                        ops.transpose(self.X, self.ldx, B, Kp, self.XT, self.ldb_t, perm=self.perm, cursor=self.cursor)
+                        ops.sgemm(0, 0, Kp, h, B, self.XT, self.ldb_t, self.dZ[0], self.ldh[0], gW, h,
+                                  colsum_row=True, ws=self.ws)
                     else:
                         ops.sgemm(1, 0, Kp, h, B, self.X, self.ldx, self.dZ[0], self.ldh[0], gW, h,
                                   perm=self.perm, cursor=self.cursor, colsum_row=True, ws=self.ws)
@@ -924,9 +956,16 @@ class Engine:
         ops.loss_finalize(self.partials, n, inv_n, g[lay.P:])
         gWh, Wh = lay.view(g, 'Wh'), lay.view(w, 'Wh')
         with self._t('gemm_heads_dW'):
-            for c0, nc, h0 in self._head_blocks():      # colsum_row: the bias gradient lands in row hL = 'bh'
-                ops.sgemm(1, 0, lay.hL, nc, B, self.Hcur[-1][:, h0:], self.ldh[-1], self.D[:, c0:], self.ldD,
-                          gWh[:, c0:], lay.NH, colsum_row=True, ws=self.ws)
+            if self.HT is not None and B >= 256:
+                hin = self.HT.shape[0]
+                ops.transpose(self.Hcur[-1], self.ldh[-1], B, hin, self.HT, self.ldb_t)
+                for c0, nc, h0 in self._head_blocks():
+                    ops.sgemm(0, 0, lay.hL, nc, B, self.HT[h0:], self.ldb_t, self.D[:, c0:], self.ldD,
+                              gWh[:, c0:], lay.NH, colsum_row=True, ws=self.ws)
+            else:
+                for c0, nc, h0 in self._head_blocks():      # colsum_row: the bias gradient lands in row hL = 'bh'
+                    ops.sgemm(1, 0, lay.hL, nc, B, self.Hcur[-1][:, h0:], self.ldh[-1], self.D[:, c0:], self.ldD,
+                              gWh[:, c0:], lay.NH, colsum_row=True, ws=self.ws)
         if lay.const_disp:
             ops.colsum_chain(self.Dth, self.ldD, B, lay.G_out, lay.view(w, 'theta_w'),
                              lay.view(g, 'theta_w'))

@@ -58,6 +58,7 @@ _SIGNATURES = {
                                               _f32p, _f32p, _c.c_long, _f64p, _c.POINTER(_c.c_int), _vp,
                                               _c.c_long, _i32p, _vp]),
     'dcahip_transpose': (_c.c_int, [_f32p, _c.c_long, _c.c_int, _c.c_int, _f32p, _c.c_long, _vp]),
+    'dcahip_transpose_rows': (_c.c_int, [_f32p, _c.c_long, _i32p, _i64p, _c.c_int, _c.c_int, _f32p, _c.c_long, _vp]),
     'dcahip_heads_fused_loss': (_c.c_int, [_f32p, _c.c_long, _f32p, _c.c_long, _f32p, _c.c_long, _f32p,
                                            _f32p, _c.c_long, _f32p, _i32p, _i64p, _c.c_int, _c.c_int,
                                            _c.c_int, _c.c_float, _c.c_float, _c.c_int, _f32p, _c.c_long,

@@ -79,8 +79,10 @@ class HipOps:
                                       p(bias), p(perm), p(cursor), int(colsum_row), split_k, p(ws),
                                       wsb, hip.stream()), 'sgemm')
 
-    def transpose(self, src, ld_src, R, C, dst, ld_dst):
-        hip.check(self.L.dcahip_transpose(hip.ptr(src), ld_src, R, C, hip.ptr(dst), ld_dst, hip.stream()), 'transpose')
+    def transpose(self, src, ld_src, R, C, dst, ld_dst, perm=None, cursor=None):
+        """dst [C, R] = src[rows]^T; rows = perm[cursor : cursor + R] when perm is given."""
+        hip.check(self.L.dcahip_transpose_rows(hip.ptr(src), ld_src, hip.ptr(perm), hip.ptr(cursor), R, C,
+                                               hip.ptr(dst), ld_dst, hip.stream()), 'transpose')
 
     # ------------------------------------------------------------------ batch norm
     def col_moments_chunks(self, B):

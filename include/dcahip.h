@@ -194,6 +194,11 @@ long dcahip_sgemm_workspace_bytes(int ta, int tb, int M, int N, int K, int colsu
  * throughput batches so that its forward product X W0 runs in the NT form (both operands contiguous along the
  * contraction: the fast operand path of dcahip_sgemm). */
 int dcahip_transpose(const float* src, long ld_src, int R, int C, float* dst, long ld_dst, void* stream);
+/* The same with gathered source rows: dst[c][r] = src[perm[*cursor + r]][c] (perm NULL: r).  Wide networks at throughput
+ * batches (first layer >= 128 units): the minibatch of the resident matrix is transposed once per step and the first
+ * layer's weight gradient X^T dZ runs as a plain product of a k-contiguous A (see dcahip_sgemm). */
+int dcahip_transpose_rows(const float* src, long ld_src, const int* perm, const long long* cursor, int R, int C,
+                          float* dst, long ld_dst, void* stream);
 
 /*
  * Batch normalisation (center=True, scale=False, eps inside rsqrt) + ReLU, training mode.

@@ -167,7 +167,18 @@ class CpuRefOps:
             out = out + _vec(bias, N).astype(np.float64)
         _mat(C, M, N, ldc)[:] = out
         if colsum_row:
+            assert not tb, 'column sums are taken where B is stored [K, N]'
             torch.as_strided(C, (N,), (1,), C.storage_offset() + M * ldc).numpy()[:] = b.sum(axis=0)
+
+    def transpose(self, src, ld_src, R, C, dst, ld_dst, perm=None, cursor=None):
+        """dcahip_transpose_rows: dst [C, R] = src[rows]^T, rows = perm[cursor : cursor + R] when perm is given."""
+        if perm is not None:
+            c = int(cursor.item()) if cursor is not None else 0
+            rows = perm[c:c + R].numpy().astype(np.int64)
+            a = _mat(src, int(rows.max()) + 1, C, ld_src)[rows]
+        else:
+            a = _mat(src, R, C, ld_src)
+        _mat(dst, C, R, ld_dst)[:] = a.T
 
     # ------------------------------------------------------------------ batch norm
     def col_moments_chunks(self, B):

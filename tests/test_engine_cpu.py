@@ -30,6 +30,23 @@ def test_single_step_matches_oracle(ae_type, batchnorm, n, G, hs):
         np.testing.assert_allclose(newp[k], ref.p[k], rtol=2e-4, atol=2e-6, err_msg=k)
 
 
+@pytest.mark.parametrize('ae_type,hs', [('zinb-conddisp', (128, 16, 70)), ('nb', (130,)), ('zinb-fork', (128, 8, 66))])
+def test_wide_network_at_a_throughput_batch_takes_the_transposed_products(ae_type, hs):
+    """Decoder wider than 64 units (heads as separate kernels) at B >= 256: the head weights, the last activations and
+    (first layer >= 128 units) the minibatch of X are transposed once per step and every product runs with A contiguous
+    along the contraction (engine._wide_transposed) -- same numbers as the straight-line oracle."""
+    n, G, B = 300, 37, 262
+    X, Y, sf, p = make_problem(n, G, hs, ae_type, True, seed=11)
+    rows = np.random.RandomState(2).permutation(n)[:B]
+    ref = oracle_net(ae_type, p, hs, True, 0.0)
+    rl, rg = ref.loss_and_grads(X[rows].astype(np.float64), Y[rows].astype(np.float64), sf[rows].astype(np.float64))
+    eng = make_engine(CpuRefOps(), ae_type, G, hs, True, 0.0, p, X, Y, sf)
+    loss, g, _ = run_single_step(eng, rows)
+    assert eng.WhT is not None and eng.HT is not None and eng.XT is not None and eng.ws_heads is None
+    assert abs(loss - rl) < 2e-6 * abs(rl)
+    assert_grads_close(g, rg, rtol=1e-4, atol_scale=1e-6)
+
+
 @pytest.mark.parametrize('ae_type', ['zinb-conddisp', 'nb'])
 def test_fit_loop_matches_oracle(ae_type):
     from dca_amd.train import fit_engine

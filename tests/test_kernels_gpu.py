@@ -226,6 +226,10 @@ GEMM_SHAPES = [
     (0, 1, 2049, 33, 517, False, False, False, 3),   # NT, odd N, forced split
     (1, 0, 2500, 64, 260, True, False, True, 0),     # dW0: gathered K rows + bias-gradient row
     (1, 0, 2051, 64, 99, True, False, True, 2),      # dW0, ragged, forced split
+    # weight gradients of wide networks: A = the transposed copy (k-contiguous), column sums of B in the NN form
+    (0, 0, 128, 700, 300, False, False, True, 0),
+    (0, 0, 64, 3000, 260, False, False, True, 2),
+    (0, 0, 333, 130, 257, False, False, True, 0),
 ]
 
 
@@ -275,6 +279,25 @@ def test_sgemm_vs_numpy(ops, ta, tb, M, N, K, gather, bias, colsum, split):
         np.testing.assert_allclose(out[M, :N], cs, rtol=0, atol=2e-6 * np.abs(Bv).sum(axis=0).max() + 1e-6)
     # nothing outside the [Mo, N] window is touched
     assert (out[Mo:, :] == 123.0).all() and (out[:, N:] == 123.0).all()
+
+
+@pytest.mark.parametrize('R,C,gather', [(1, 1, False), (37, 203, True), (300, 64, False), (2048, 1000, True)])
+def test_transpose_rows(ops, R, C, gather):
+    rng = np.random.RandomState(R + C)
+    n_store = R + 7 if gather else R
+    lds = C + (-C) % 4 + 4
+    src = rng.uniform(-1, 1, (n_store, lds)).astype(np.float32)
+    ldd = R + (-R) % 4
+    dst = torch.full((C + 1, ldd), 7.0, device='cuda')
+    cur = 3
+    perm = rng.permutation(n_store)[:R + cur].astype(np.int32) if gather else None
+    ops.transpose(dev(src), lds, R, C, dst, ldd, perm=torch.as_tensor(perm).cuda() if gather else None,
+                  cursor=torch.tensor([cur], dtype=torch.int64, device='cuda') if gather else None)
+    torch.cuda.synchronize()
+    out = dst.cpu().numpy()
+    rows = src[perm[cur:cur + R]] if gather else src
+    np.testing.assert_array_equal(out[:C, :R], rows[:, :C].T)
+    assert (out[C:] == 7.0).all() and (out[:, R:] == 7.0).all()
 
 
 # ------------------------------------------------------------------------------- batch norm
