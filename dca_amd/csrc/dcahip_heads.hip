@@ -1382,6 +1382,7 @@ __global__ __launch_bounds__(256) void heads_reduce_dh_kernel(const float* ws, i
 }
 
 struct HeadsPlan {
+    bool small;                          // one row tile: the four-wave kernel, one workgroup per gene tile
     int HLB, WR, S, NT, ntg, ngb, grid;
     int nitems, npart;                   // split-bf16 path: work items (S x gene tiles), dH partials per row tile
     long ldws, dw_stride, dw_bytes, dh_bytes, hs_bytes;
@@ -1396,6 +1397,12 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 // DCA_HEADS_F32MFMA=1: the first implementation (fp32 MFMA, two gene tiles per workgroup), for A/B runs only
 inline bool use_f32_mfma() {
     static const bool v = [] { const char* e = getenv("DCA_HEADS_F32MFMA"); return e && e[0] == '1'; }();
+    return v;
+}
+
+// DCA_HEADS_SMALL=0: batches of one row tile through the persistent kernel (single-wave workgroups), for A/B runs
+inline bool use_small_kernel() {
+    static const bool v = [] { const char* e = getenv("DCA_HEADS_SMALL"); return !(e && e[0] == '0'); }();
     return v;
 }
 
@@ -1428,7 +1435,10 @@ bool make_heads_plan(int B, int hL, int G, long plane, int flags, HeadsPlan* out
     p.nitems = p.S * p.ngb;
     p.grid = p.nitems;
     p.npart = p.ntg;
-    if (!f32) {                                      // persistent: as many workgroups as are resident, a multiple of S
+    p.small = !f32 && p.NT == 1 && p.ntg <= kMaxGrid && use_small_kernel();
+    if (p.small) {                                   // S = 1, one partial per gene tile
+        p.grid = p.ntg;
+    } else if (!f32) {                               // persistent: as many workgroups as are resident, a multiple of S
         const int res = x3_resident(p.WR) / p.S * p.S;
         if (p.grid > res) p.grid = res;
         p.npart = p.grid / p.S;
@@ -1451,6 +1461,361 @@ void launch_fused(const HeadsPlan& pl, const HeadsArgs& a, hipStream_t s) {
     if (pl.WR == 4) { if (full) DCA_LF(4, true); else DCA_LF(4, false); }
     else            { if (full) DCA_LF(1, true); else DCA_LF(1, false); }
 #undef DCA_LF
+}
+
+// =====================================================================================================
+// K-HEADS for ONE row tile (B <= 32 -- the reference's default batch size, dca/api.py:33): one gene tile per
+// workgroup, FOUR waves working on it together.  With a lone wave per tile (the persistent kernel above at NT = 1) the
+// 625 tiles of G = 20 000 leave three quarters of the SIMDs idle and every phase is one wave's dependent chain:
+// measured 41 us, of which 10 launch + weight prologue, 13 the likelihood pass, 18 the three products and their stores
+// (tools/_dbg experiment builds).  Here
+//   F   : wave h < NH computes head h (24 MFMA),
+//   Z   : wave w takes the row-slot group w (4 of the 16 slots of each lane half) -- dense pass + its own non-zero queue,
+//   dW  : wave h < NH accumulates and stores head h (24 MFMA), while
+//   dH  : wave 3 multiplies all heads (72 MFMA) and stores the tile's partial sum,
+// all through one weight image and one staging tile in LDS; operands, arithmetic and the order of every sum are
+// those of the persistent kernel (same products, same six-term order; the loss partial of the tile is the sum of its
+// four waves' in wave order).
+// =====================================================================================================
+template <bool HAS_PI, bool CONST_DISP>
+__global__ __launch_bounds__(256) void heads_fused_small_kernel(HeadsArgs2 p) {
+    constexpr int NH = 1 + (CONST_DISP ? 0 : 1) + (HAS_PI ? 1 : 0);
+    constexpr int PI_H = NH - 1;
+    constexpr int KT = 64;
+    constexpr int ST_PLANE = kTG * kLdS;
+    constexpr int NP = NH + (CONST_DISP ? 1 : 0);
+    constexpr int TH_P = NH;
+    constexpr int ST_TILE = NP * ST_PLANE;
+    constexpr int W_PIECE = 64 * 64;
+    constexpr int W_FLOATS = NH * 3 * W_PIECE / 4;
+    constexpr int BIAS_FLOATS = (NH + 1) * 32;
+    constexpr int NW = 4;
+    static_assert(NW * kZU == 16, "one Z group per wave");
+    constexpr int LDS_FLOATS = W_FLOATS + ST_TILE + NW * kQCap + BIAS_FLOATS;
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    __shared__ double lred[NW];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const long long cur = p.cursor ? *p.cursor : 0;
+    const int gb = blockIdx.x;
+    const int gt = p.tile_order ? p.tile_order[gb] : gb;
+    const int g0 = gt * kTG;
+    float* const dh_out = p.ws_dh + (long)gb * (kTR * KT);
+    if (g0 >= p.G) {                         // padding entry of the tile order: an all-zero partial, no loss
+        for (int i = tid; i < kTR * KT; i += 256) dh_out[i] = 0.f;
+        if (tid == 0) p.partials[gb] = 0.0;
+        return;
+    }
+    const int gene = g0 + l31;
+    const bool gvalid = gene < p.G;
+
+    unsigned char* const Wimg = reinterpret_cast<unsigned char*>(lds);
+    float* const St = lds + W_FLOATS;
+    unsigned* const Q = reinterpret_cast<unsigned*>(lds + W_FLOATS + ST_TILE) + wave * kQCap;
+    float* const Bs = lds + W_FLOATS + ST_TILE + NW * kQCap;
+
+    // ---- requests that do not depend on the weights, in flight during the weight prologue: storage rows, size
+    // factors, the counts of this wave's Z group, the decoder rows (both operand orientations) of the product waves
+    const int rl = l31 < p.B ? l31 : p.B - 1;
+    const int srow_l = p.perm ? p.perm[cur + rl] : (int)(cur + rl);
+    const float sf_l = p.sf[srow_l];
+    const float* const ycol = p.y + (gvalid ? gene : p.G - 1);
+    float yv[kZU];
+#pragma unroll
+    for (int j = 0; j < kZU; ++j) {
+        const int sr = __shfl(srow_l, rowmap(wave * kZU + j, hi), 64);
+        yv[j] = ycol[(unsigned long long)(unsigned)sr * (unsigned)p.ldy];
+    }
+    float hx[4][8], htx[2][2][8];
+    if (wave < NH) {
+        const float* hp = p.H + (long)rl * p.ldh;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {            // row l31, hidden units 32 hi + 8 ks ..; unconditional (clamped) loads
+                const int kk = 32 * hi + 8 * ks + j;
+                hx[ks][j] = hp[kk < p.hL ? kk : p.hL - 1];
+            }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {        // hidden unit l31 + 32 ib, rows in the order of the MFMA row map
+                    const int row = rowmap(8 * ks + j, hi), i = l31 + 32 * ib;
+                    htx[ks][ib][j] = p.H[(long)(row < p.B ? row : p.B - 1) * p.ldh + (i < p.hL ? i : p.hL - 1)];
+                }
+    }
+
+    // ---- head weights of the gene tile -> bf16 pieces in LDS (image and rotation of the persistent kernel)
+    {
+        constexpr int UNR = 2 * NH;                  // NH * 64 * 8 sixteen-byte items over 256 threads: one batch of loads
+        float4 v[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int idx = tid + u * 256;
+            const int c4 = idx & 7, kq = (idx >> 3) & 63, h = idx >> 9;
+            const int kc = kq < p.hL ? kq : p.hL - 1;
+            long gcol = g0 + c4 * 4;
+            if (gcol > p.plane - 4) gcol = p.plane - 4;
+            v[u] = *reinterpret_cast<const float4*>(p.Wh + (long)kc * p.ldw + (long)h * p.plane + gcol);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int idx = tid + u * 256;
+            const int c4 = idx & 7, kq = (idx >> 3) & 63, h = idx >> 9;
+            const int gcol = g0 + c4 * 4;
+            const bool kv = kq < p.hL && gcol <= p.plane - 4;
+            float4 w = v[u];
+            if (!kv || gcol + 0 >= p.G) w.x = 0.f;
+            if (!kv || gcol + 1 >= p.G) w.y = 0.f;
+            if (!kv || gcol + 2 >= p.G) w.z = 0.f;
+            if (!kv || gcol + 3 >= p.G) w.w = 0.f;
+            unsigned a0, a1, a2, b0, b1, b2;
+            split_pair(w.x, w.y, a0, a1, a2);
+            split_pair(w.z, w.w, b0, b1, b2);
+            const int off = kq * 64 + ((((c4 >> 1) + (kq >> 2)) & 3) << 4) + ((c4 & 1) << 3);
+            *reinterpret_cast<u32x2*>(Wimg + (h * 3 + 0) * W_PIECE + off) = u32x2{a0, b0};
+            *reinterpret_cast<u32x2*>(Wimg + (h * 3 + 1) * W_PIECE + off) = u32x2{a1, b1};
+            *reinterpret_cast<u32x2*>(Wimg + (h * 3 + 2) * W_PIECE + off) = u32x2{a2, b2};
+        }
+        if (tid < 32) {
+            const bool gv = g0 + tid < p.G;
+#pragma unroll
+            for (int h = 0; h < NH; ++h) Bs[h * 32 + tid] = gv ? p.bh[(long)h * p.plane + g0 + tid] : 0.f;
+            Bs[NH * 32 + tid] = (CONST_DISP && gv) ? p.theta_w[g0 + tid] : 0.f;
+        }
+    }
+    __syncthreads();
+
+    // LDS addresses of the weight image (see the persistent kernel)
+    const int t16 = lane & 15, c8 = 4 * ((lane >> 4) & 1) + (t16 & 3);
+    int wtr[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+        wtr[rr] = hi * 2048 + (t16 >> 2) * 64 + ((((c8 >> 1) + rr) & 3) << 4) + ((c8 & 1) << 3);
+    int wdr[2];
+#pragma unroll
+    for (int gs = 0; gs < 2; ++gs) wdr[gs] = l31 * 64 + (((2 * gs + hi + (l31 >> 2)) & 3) << 4);
+    auto w_tr = [&](int h, int q, int ks) {           // B operand of F: gene l31, k = 32 hi + 8 ks .. + 7
+        const unsigned char* b0 = Wimg + (h * 3 + q) * W_PIECE + ks * 512;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(b0 + wtr[(2 * ks) & 3]));
+        const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(b0 + 256 + wtr[(2 * ks + 1) & 3]));
+        u32x4 o;
+        const u32x2 a = __builtin_bit_cast(u32x2, lo), b = __builtin_bit_cast(u32x2, hi4);
+        o[0] = a[0]; o[1] = a[1]; o[2] = b[0]; o[3] = b[1];
+        return o;
+    };
+    auto w_dr = [&](int h, int q, int jb, int gs) {   // B operand of dH: hidden unit l31 + 32 jb, genes 16 gs + 8 hi ..
+        return *reinterpret_cast<const u32x4*>(Wimg + (h * 3 + q) * W_PIECE + jb * 2048 + wdr[gs]);
+    };
+
+    // ---- F: wave h computes the pre-activations of head h and stages them [gene][row]
+    if (wave < NH) {
+        const int h = wave;
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = (l31 < p.B && 32 * hi + 8 * ks + j < p.hL) ? hx[ks][j] : 0.f;
+            u32x4 af[3];
+            split8(x, af);
+            u32x4 bf[3] = {w_tr(h, 0, ks), w_tr(h, 1, ks), w_tr(h, 2, ks)};
+            MFMA_X3(af, bf, acc)
+        }
+        const float bias = Bs[h * 32 + l31];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) St[h * ST_PLANE + l31 * kLdS + rowmap(e, hi)] = acc[e] + bias;
+    }
+    __syncthreads();
+
+    // ---- Z: element-wise likelihood and gradient of this wave's four row slots per lane half
+    double dacc = 0.0;
+    {
+        const float thw = CONST_DISP ? Bs[NH * 32 + l31] : 0.f;
+        float lacc = 0.f;
+        int qn = 0;
+        float i_am[kZU], i_ad[kZU], i_ap[kZU];
+#pragma unroll
+        for (int j = 0; j < kZU; ++j) {
+            const int idx = l31 * kLdS + rowmap(wave * kZU + j, hi);
+            i_am[j] = St[idx];
+            i_ad[j] = CONST_DISP ? thw : St[ST_PLANE + idx];
+            i_ap[j] = HAS_PI ? St[PI_H * ST_PLANE + idx] : 0.f;
+        }
+        float o_m[kZU], o_d[kZU], o_p[kZU];
+        bool o_nz[kZU];
+#pragma unroll
+        for (int j = 0; j < kZU; ++j) {
+            const int row = rowmap(wave * kZU + j, hi);
+            const bool valid = (row < p.B) && gvalid;
+            const float yj = yv[j];
+            const bool nz = valid && (HAS_PI ? !(yj < kZeroThresh) : (yj != 0.f));
+            const float sc = valid ? p.inv_n : 0.f;
+            if (HAS_PI) {
+                float gmv, gdv, gpv;
+                const float nll = zinb_zero_elem<CONST_DISP>(i_am[j], i_ad[j], i_ap[j], __shfl(sf_l, row, 64), p.ridge, gmv, gdv, gpv);
+                lacc += (valid && !nz) ? nll : 0.f;
+                o_m[j] = gmv * sc; o_d[j] = gdv * sc; o_p[j] = gpv * sc;
+            } else {
+                float gmv, gdv;
+                const float nll = nb_zero_elem<CONST_DISP>(i_am[j], i_ad[j], __shfl(sf_l, row, 64), gmv, gdv);
+                lacc += (valid && !nz) ? nll : 0.f;
+                o_m[j] = gmv * sc; o_d[j] = gdv * sc; o_p[j] = 0.f;
+            }
+            o_nz[j] = nz;
+        }
+#pragma unroll
+        for (int j = 0; j < kZU; ++j) {
+            const int idx = l31 * kLdS + rowmap(wave * kZU + j, hi);
+            const bool nz = o_nz[j];
+            const unsigned long long m = __ballot(nz);
+            const int slot = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            if (nz) {
+                const float yj = yv[j];
+                const unsigned y16 = (yj < 65535.f && yj == floorf(yj)) ? (unsigned)yj : 0xFFFFu;
+                Q[slot] = (unsigned)idx | (y16 << 16);
+            } else {
+                St[idx] = o_m[j];
+                if (CONST_DISP) St[TH_P * ST_PLANE + idx] = o_d[j]; else St[ST_PLANE + idx] = o_d[j];
+                if (HAS_PI) St[PI_H * ST_PLANE + idx] = o_p[j];
+            }
+            qn += __popcll(m);
+        }
+        // compacted non-zero entries, 64 per pass
+        while (qn > 0) {
+            const int c = qn < 64 ? qn : 64;
+            wave_sync();
+            const int q0 = qn - c;
+            const bool act = lane < c;
+            const unsigned e = Q[q0 + (act ? lane : 0)];
+            const int idx = e & 2047;
+            const int gq = (idx * 1986) >> 16;          // idx / 33 for idx < 1056
+            const int row = idx - gq * kLdS;
+            const float sfr = __shfl(sf_l, row, 64);
+            const int sr = __shfl(srow_l, row, 64);
+            const float am = St[idx];
+            const float ad = CONST_DISP ? Bs[NH * 32 + gq] : St[ST_PLANE + idx];
+            const float ap = HAS_PI ? St[PI_H * ST_PLANE + idx] : 0.f;
+            float yq = (float)(e >> 16);
+            if ((e >> 16) == 0xFFFFu) yq = p.y[(long)sr * p.ldy + g0 + gq];
+            float o1, o2, o3 = 0.f, nll;
+            if (HAS_PI) {
+                nll = zinb_nz_elem<CONST_DISP>(am, ad, ap, sfr, yq, p.ridge, o1, o2, o3);
+            } else {
+                float dmu = 0.f, dth = 0.f, dpi = 0.f;
+                const Heads hd = head_acts<HAS_PI, CONST_DISP>(am, ad, ap, sfr);
+                nll = nll_elem<HAS_PI, true, true>(hd, yq, p.ridge, dmu, dth, dpi);
+                o1 = dmu * hd.gm; o2 = dth * hd.gd;
+            }
+            lacc += act ? nll : 0.f;
+            if (act) {
+                St[idx] = o1 * p.inv_n;
+                const float od = o2 * p.inv_n;
+                if (CONST_DISP) St[TH_P * ST_PLANE + idx] = od; else St[ST_PLANE + idx] = od;
+                if (HAS_PI) St[PI_H * ST_PLANE + idx] = o3 * p.inv_n;
+            }
+            qn -= c;
+        }
+        dacc = (double)lacc;
+    }
+    __syncthreads();
+
+    if (wave == NW - 1) {
+        // ---- dH[row, i] = sum_genes D[row, gene] W[i, gene], all heads: the tile's partial sum
+        f32x16 dHa[2];
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) dHa[jb][e] = 0.f;
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+#pragma unroll
+            for (int gs = 0; gs < 2; ++gs) {
+                float dv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dv[j] = St[h * ST_PLANE + (16 * gs + 8 * hi + j) * kLdS + l31];
+                u32x4 af[3];
+                split8(dv, af);
+#pragma unroll
+                for (int jb = 0; jb < 2; ++jb) {
+                    u32x4 bf[3] = {w_dr(h, 0, jb, gs), w_dr(h, 1, jb, gs), w_dr(h, 2, jb, gs)};
+                    MFMA_BWD(af, bf, dHa[jb])
+                }
+            }
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float v = dHa[jb][e];
+                dh_out[rowmap(e, hi) * KT + jb * 32 + l31] = v;
+            }
+        if (CONST_DISP) {                            // ConstantDispersionLayer chain (dca/layers.py:17-21)
+            float thsum = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) thsum += St[TH_P * ST_PLANE + l31 * kLdS + rowmap(e, hi)];
+            const float tv = thsum + __shfl_xor(thsum, 32, 64);
+            if (gvalid && hi == 0) {
+                const float ex = expf(p.theta_w[gene]);
+                p.g_theta[gene] = (ex >= 1e-3f && ex <= 1e4f) ? tv * ex : 0.f;
+            }
+        }
+    } else if (wave < NH) {
+        // ---- dW[i, gene] = sum_rows H[row, i] D[row, gene] of head h, straight to the gradient buffer (one batch split)
+        const int h = wave;
+        f32x16 dW[2];
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) dW[ib][e] = 0.f;
+        float bsum = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            float dv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                dv[j] = St[h * ST_PLANE + l31 * kLdS + rowmap(8 * ks + j, hi)];
+                bsum += dv[j];
+            }
+            u32x4 bf[3];
+            split8(dv, bf);
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib) {
+                float x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    x[j] = (rowmap(8 * ks + j, hi) < p.B && l31 + 32 * ib < p.hL) ? htx[ks][ib][j] : 0.f;
+                u32x4 af[3];
+                split8(x, af);
+                MFMA_BWD(af, bf, dW[ib])
+            }
+        }
+        const bool cw = gene < p.plane;
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int i = ib * 32 + rowmap(e, hi);
+                const float v = dW[ib][e];
+                if (cw && i < p.hL) p.gW[(long)i * p.ldg + (long)h * p.plane + gene] = v;
+            }
+        const float bv = bsum + __shfl_xor(bsum, 32, 64);
+        if (cw && hi == 0) p.gW[(long)p.hL * p.ldg + (long)h * p.plane + gene] = bv;
+    }
+
+    // ---- loss: wave -> workgroup (wave order) -> one partial per tile
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) dacc += __shfl_down(dacc, off, 64);
+    if (lane == 0) lred[wave] = dacc;
+    __syncthreads();
+    if (tid == 0) p.partials[gb] = ((lred[0] + lred[1]) + lred[2]) + lred[3];
 }
 
 // C [32, 32] = A [32, K] B [K, 32] with the operand split and the six bf16 products of K-HEADS, one wave
@@ -1478,7 +1843,8 @@ __global__ __launch_bounds__(64) void x3_product_kernel(const float* A, const fl
 
 template <bool P, bool C>
 void launch_fused_x3(const HeadsPlan& pl, const HeadsArgs2& a, hipStream_t s) {
-    if (pl.WR == kWR2) hipLaunchKernelGGL((heads_fused_x3_kernel<P, C, kWR2>), dim3(pl.grid), dim3(64 * kWR2), 0, s, a);
+    if (pl.small) hipLaunchKernelGGL((heads_fused_small_kernel<P, C>), dim3(pl.grid), dim3(256), 0, s, a);
+    else if (pl.WR == kWR2) hipLaunchKernelGGL((heads_fused_x3_kernel<P, C, kWR2>), dim3(pl.grid), dim3(64 * kWR2), 0, s, a);
     else hipLaunchKernelGGL((heads_fused_x3_kernel<P, C, 1>), dim3(pl.grid), dim3(64), 0, s, a);
 }
 
@@ -1493,7 +1859,7 @@ extern "C" long dcahip_heads_fused_workspace_bytes(int B, int hL, int G, long pl
     if (smax < 1) smax = 1;
     long dh = p.dh_bytes;
     if (!use_f32_mfma()) {                           // smaller batches: fewer row tiles, possibly more (single-wave) workgroups
-        const long a = (long)p.NT * kCUs, b = 7L * 3 * kCUs;
+        const long a = (long)p.NT * kCUs, b = 7L * 3 * kCUs > kMaxGrid ? 7L * 3 * kCUs : (long)kMaxGrid;
         dh = (a > b ? a : b) * kTR * (p.HLB * 32) * (long)sizeof(float);
         if (dh < p.dh_bytes) dh = p.dh_bytes;
     }
