@@ -131,7 +131,8 @@ def graph_kernel_nodes(graph):
         return None
 
 
-def capture_step(eng, b, counts):
+def capture_step(eng, b, counts, k=1):
+    """k consecutive training steps in one hipGraph (the device cursor advances inside the graph)."""
     try:
         g = torch.cuda.CUDAGraph(keep_graph=True)
     except TypeError:
@@ -139,7 +140,8 @@ def capture_step(eng, b, counts):
     st = torch.cuda.Stream(); st.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(st):
         with torch.cuda.graph(g, stream=st):
-            eng.train_step(b, b, counts, b)
+            for _ in range(k):
+                eng.train_step(b, b, counts, b)
     torch.cuda.current_stream().wait_stream(st)
     return g
 
@@ -172,14 +174,16 @@ def after_measurements(eng, args, B, n_train, n_val, G, dev):
     try:
         g32 = capture_step(eng, b32, [b32])
         launches = graph_kernel_nodes(g32) if hasattr(g32, 'raw_cuda_graph') else None
-        for _ in range(5):
-            g32.replay()
+        ks = 8                               # steps per graph launch, as the fit loop replays them (dca_amd/train.py)
+        g32k = capture_step(eng, b32, [b32], ks)
+        g32k.replay()
+        new_order((k32 + 8) * b32)
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        for _ in range(k32):
-            g32.replay()
+        for _ in range(k32 // ks):
+            g32k.replay()
         torch.cuda.synchronize(); el = time.perf_counter() - t0
         out['batch32'] = {'ms_per_step': 1e3 * el / k32, 'cells_per_s': k32 * b32 / el, 'launches': launches,
-                          'steps': k32, 'launch': 'hipGraph replay'}
+                          'steps': k32, 'launch': 'hipGraph replay, %d steps per graph' % ks}
     except Exception as e:
         out['batch32'] = {'error': str(e)}
     _mark('epoch timing')

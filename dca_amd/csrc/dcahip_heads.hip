@@ -1339,10 +1339,17 @@ __global__ __launch_bounds__(256) void heads_reduce_dh_kernel(const float* ws, i
         const long tq = (long)kTR * q4;                      // quads of one (row tile, gene tile) partial
         const long t = quad / tq, within = quad - t * tq;
         const float4* src = reinterpret_cast<const float4*>(ws) + t * ntg * tq + within;
-#pragma unroll 4
-        for (int gt = gl; gt < ntg; gt += GL) {
-            const float4 x = src[(long)gt * tq];
-            v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+        // batches of 8 independent loads (one memory round trip per batch), added in tile order
+        for (int gt0 = gl; gt0 < ntg; gt0 += 8 * GL) {
+            float4 x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int gt = gt0 + u * GL;
+                x[u] = src[(long)(gt < ntg ? gt : gl) * tq];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (gt0 + u * GL < ntg) { v.x += x[u].x; v.y += x[u].y; v.z += x[u].z; v.w += x[u].w; }
         }
     }
     red[threadIdx.x] = v;
@@ -1984,7 +1991,10 @@ extern "C" int dcahip_heads_fused_loss(const float* H, long ldh, const float* Wh
     {
         const int KT = pl.HLB * 32;
         const long nq = (long)B * (KT / 4);
-        if (nq >= 64L * 512) {
+        if (nq <= 1024 && pl.npart >= 256) {             // one or two row tiles: many partials per output, few outputs
+            hipLaunchKernelGGL(heads_reduce_dh_kernel<64>, dim3((int)((nq + 3) / 4)), dim3(256), 0, s,
+                               ws_dh, pl.npart, B, pl.NT * kTR, KT, hL, dH, lddh, loss_partials, pl.grid, (double)inv_n, loss_out);
+        } else if (nq >= 64L * 512) {
             hipLaunchKernelGGL(heads_reduce_dh_kernel<4>, dim3((int)((nq + 63) / 64)), dim3(256), 0, s,
                                ws_dh, pl.npart, B, pl.NT * kTR, KT, hL, dH, lddh, loss_partials, pl.grid, (double)inv_n, loss_out);
         } else {

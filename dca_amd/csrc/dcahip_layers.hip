@@ -395,6 +395,37 @@ __global__ __launch_bounds__(256) void bn_bwd_small_kernel(BnBwdArgs a) {
 // K <= 64 inputs; the backward additionally h <= 64 units (one workgroup owns the layer).
 constexpr int kSmallK = 64;
 
+// Operands of a small layer -> LDS with EVERY load in flight at once: fixed trip counts, unconditional loads from
+// clamped addresses, zeroing at the store.  (A `for (idx ...) lds[..] = cond ? g[..] : 0` loop compiles to one
+// load - wait - store round trip per iteration: 24 dependent round trips per layer at the reference batch size.)
+// Ws[k][cc] = W[k, c0 + cc] (k < K, c0 + cc < H), 64 x 64;  Hs[r][k] = Hp[r, k] (k < K), rows r < 4 * RPT.
+template <int RPT, int LDW, int LDH>
+__device__ __forceinline__ void small_operands_to_lds(const float* W, long ldw, int K, int H, int c0,
+                                                       const float* Hp, long ldp, int B,
+                                                       float (*Ws)[LDW], float (*Hs)[LDH]) {
+    float wv[16], hv[RPT];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int idx = threadIdx.x + 256 * u, k = idx >> 6, cc = idx & 63;
+        wv[u] = W[(long)(k < K ? k : K - 1) * ldw + (c0 + cc < H ? c0 + cc : H - 1)];
+    }
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) {
+        const int idx = threadIdx.x + 256 * u, r = idx >> 6, k = idx & 63;
+        hv[u] = Hp[(long)(r < B ? r : B - 1) * ldp + (k < K ? k : K - 1)];
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int idx = threadIdx.x + 256 * u, k = idx >> 6, cc = idx & 63;
+        Ws[k][cc] = (k < K && c0 + cc < H) ? wv[u] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) {
+        const int idx = threadIdx.x + 256 * u, r = idx >> 6, k = idx & 63;
+        Hs[r][k] = k < K ? hv[u] : 0.f;
+    }
+}
+
 struct DenseSmallArgs {
     const float* Hp; long ldp;          // layer input [B, K]
     const float* W; long ldw;           // kernel [K, h]
@@ -417,17 +448,14 @@ __global__ __launch_bounds__(256) void dense_bn_small_kernel(DenseSmallArgs a) {
     const int c0 = blockIdx.x * 64, c = c0 + tx;
     const bool cv = c < a.H;
     const int K4 = (a.K + 3) & ~3;
-    // both operands -> LDS, every load in flight at once (one memory round trip)
-    for (int idx = threadIdx.x; idx < K4 * 64; idx += 256) {
-        const int k = idx >> 6, cc = idx & 63;
-        Ws[k][cc] = (k < a.K && c0 + cc < a.H) ? a.W[(long)k * a.ldw + c0 + cc] : 0.f;
-    }
-    for (int idx = threadIdx.x; idx < a.B * K4; idx += 256) {
-        const int r = idx / K4, k = idx - r * K4;
-        Hs[r][k] = k < a.K ? a.Hp[(long)r * a.ldp + k] : 0.f;
-    }
+    // everything the kernel reads from memory is requested here, in one batch
+    const int cc_ = cv ? c : a.H - 1;
+    const float b_in = a.bias[cc_];
+    const float mm_in = a.batchnorm ? a.mm[cc_] : 0.f, mv_in = a.batchnorm ? a.mv[cc_] : 0.f;
+    const float beta_in = (a.batchnorm && a.beta) ? a.beta[cc_] : 0.f;
+    small_operands_to_lds<RPT>(a.W, a.ldw, a.K, a.H, c0, a.Hp, a.ldp, a.B, Ws, Hs);
     float z[RPT];
-    const float b = cv ? a.bias[c] : 0.f;
+    const float b = cv ? b_in : 0.f;
 #pragma unroll
     for (int k = 0; k < RPT; ++k) z[k] = b;
     __syncthreads();
@@ -463,11 +491,11 @@ __global__ __launch_bounds__(256) void dense_bn_small_kernel(DenseSmallArgs a) {
     const float var = (float)((double)m2 / (double)a.B);
     const float inv = 1.f / sqrtf(var + a.eps);
     if (ty == 0) {
-        a.mm[c] = a.mm[c] - (a.mm[c] - mean) * (1.f - a.momentum);
-        a.mv[c] = a.mv[c] - (a.mv[c] - var) * (1.f - a.momentum);
+        a.mm[c] = mm_in - (mm_in - mean) * (1.f - a.momentum);
+        a.mv[c] = mv_in - (mv_in - var) * (1.f - a.momentum);
         if (a.inv_std) a.inv_std[c] = inv;
     }
-    const float beta = a.beta ? a.beta[c] : 0.f;
+    const float beta = beta_in;
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         const int i = ty + 4 * k;
@@ -475,6 +503,129 @@ __global__ __launch_bounds__(256) void dense_bn_small_kernel(DenseSmallArgs a) {
             const float xh = (z[k] - mean) * inv;
             if (a.xhat) a.xhat[(long)i * a.ldx + c] = xh;
             a.Hout[(long)i * a.ldh + c] = act_fwd(a.act, xh + beta);
+        }
+    }
+}
+
+// ---- small batches: the hidden stack behind the first layer's product in ONE launch -------------------------------
+// [batch norm + activation of layer 0] -> [Dense + batch norm + activation] x (n - 1), one workgroup, stage after
+// stage (every layer at most 64 units wide: the reference's 64-32-64).  The stages are the formulas of
+// bn_relu_small_kernel / dense_bn_small_kernel; what is saved is two launches and their gaps on a step that is bound
+// by exactly those (12 -> 10 launches at batch 32).
+constexpr int kChainMax = 4;
+
+struct SmallLayer {                     // = dcahip_small_layer (include/dcahip.h)
+    const float* W; long ldw;           // kernel [K, h]; NULL: this entry normalises its own Z (the first layer)
+    const float* bias;
+    int K, H;
+    const float* beta; float* mm; float* mv;
+    float* Z; long ldz; float* xhat; long ldx; float* Hout; long ldh; float* inv_std;
+};
+
+struct SmallChainArgs {
+    SmallLayer l[kChainMax];
+    const float* Hin; long ldin;        // input of the first entry when it has a kernel
+    int n, B, batchnorm, act;
+    float momentum, eps;
+};
+
+template <int RPT>
+__global__ __launch_bounds__(256) void hidden_small_chain_kernel(SmallChainArgs a) {
+    __shared__ __attribute__((aligned(16))) float Hs[kFusedRows][kSmallK + 4];
+    __shared__ float Ws[2][kSmallK][64];        // kernel of the current stage / of the next one (requested a stage ahead)
+    __shared__ float sm[256];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = tx;
+    if (a.l[0].W) small_operands_to_lds<RPT>(a.l[0].W, a.l[0].ldw, a.l[0].K, a.l[0].H, 0, a.Hin, a.ldin, a.B, Ws[0], Hs);
+#pragma unroll 1
+    for (int st = 0; st < a.n; ++st) {
+        const SmallLayer& L = a.l[st];
+        const bool cv = c < L.H;
+        // everything this stage reads from memory is requested here: the NEXT stage's kernel (it does not depend on
+        // this stage) and the per-column inputs; the activations travel from stage to stage through LDS
+        const bool has_next = st + 1 < a.n;
+        const SmallLayer& Nx = a.l[has_next ? st + 1 : st];
+        float wn[16];
+        if (has_next) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int idx = threadIdx.x + 256 * u, k = idx >> 6, cc = idx & 63;
+                wn[u] = Nx.W[(long)(k < Nx.K ? k : Nx.K - 1) * Nx.ldw + (cc < Nx.H ? cc : Nx.H - 1)];
+            }
+        }
+        const int cc_ = cv ? c : L.H - 1;
+        const float mm_in = a.batchnorm ? L.mm[cc_] : 0.f, mv_in = a.batchnorm ? L.mv[cc_] : 0.f;
+        const float beta_in = (a.batchnorm && L.beta) ? L.beta[cc_] : 0.f;
+        float z[RPT];
+        if (L.W) {
+            const int K4 = (L.K + 3) & ~3;
+            const float b = cv ? L.bias[cc_] : 0.f;
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) z[k] = b;
+            __syncthreads();            // Ws[st & 1] and Hs (the previous stage's output) are complete
+            const float (*Wc)[64] = Ws[st & 1];
+#pragma unroll 1
+            for (int kk = 0; kk < K4; kk += 4) {
+                const float w0 = Wc[kk][tx], w1 = Wc[kk + 1][tx], w2 = Wc[kk + 2][tx], w3 = Wc[kk + 3][tx];
+#pragma unroll
+                for (int k = 0; k < RPT; ++k) {
+                    const float4 hv = *reinterpret_cast<const float4*>(&Hs[ty + 4 * k][kk]);      // rows beyond B: never stored
+                    z[k] = fmaf(hv.w, w3, fmaf(hv.z, w2, fmaf(hv.y, w1, fmaf(hv.x, w0, z[k]))));
+                }
+            }
+            if (L.Z && cv) {
+#pragma unroll
+                for (int k = 0; k < RPT; ++k) { const int i = ty + 4 * k; if (i < a.B) L.Z[(long)i * L.ldz + c] = z[k]; }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) {
+                const int i = ty + 4 * k;
+                z[k] = L.Z[(long)(i < a.B ? i : a.B - 1) * L.ldz + cc_];
+            }
+        }
+        float hout[RPT];
+        if (!a.batchnorm) {
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) hout[k] = act_fwd(a.act, z[k]);
+            __syncthreads();            // every thread is done reading Hs
+        } else {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) s += (cv && ty + 4 * k < a.B) ? z[k] : 0.f;
+            const float mean = wg_rowlane_sum(s, sm) / (float)a.B;
+            float q2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) { const float d = z[k] - mean; q2 += (cv && ty + 4 * k < a.B) ? d * d : 0.f; }
+            const float m2 = wg_rowlane_sum(q2, sm);
+            const float var = (float)((double)m2 / (double)a.B);             // biased variance
+            const float inv = 1.f / sqrtf(var + a.eps);
+            if (cv && ty == 0) {
+                L.mm[c] = mm_in - (mm_in - mean) * (1.f - a.momentum);
+                L.mv[c] = mv_in - (mv_in - var) * (1.f - a.momentum);
+                if (L.inv_std) L.inv_std[c] = inv;
+            }
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) {
+                const int i = ty + 4 * k;
+                const float xh = (z[k] - mean) * inv;
+                if (cv && i < a.B && L.xhat) L.xhat[(long)i * L.ldx + c] = xh;
+                hout[k] = act_fwd(a.act, xh + beta_in);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int i = ty + 4 * k;
+            if (cv && i < a.B) L.Hout[(long)i * L.ldh + c] = hout[k];
+            Hs[i][c] = cv ? hout[k] : 0.f;          // the next stage's input (columns beyond this layer's width: zero)
+        }
+        if (has_next) {
+            float (*Wn)[64] = Ws[(st + 1) & 1];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int idx = threadIdx.x + 256 * u, k = idx >> 6, cc = idx & 63;
+                Wn[k][cc] = (k < Nx.K && cc < Nx.H) ? wn[u] : 0.f;
+            }
         }
     }
 }
@@ -501,15 +652,9 @@ __global__ __launch_bounds__(256) void dense_bn_bwd_small_kernel(DenseSmallBwdAr
     __shared__ float sm[256];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int wg = blockIdx.x;
-    // operands of the two products -> LDS (requested first: in flight during the statistics below)
-    for (int idx = threadIdx.x; idx < a.B * a.K; idx += 256) {
-        const int r = idx / a.K, k = idx - r * a.K;
-        Hs[r][k] = a.Hp[(long)r * a.ldp + k];
-    }
-    for (int idx = threadIdx.x; idx < a.K * a.H; idx += 256) {
-        const int k = idx / a.H, cc = idx - k * a.H;
-        Ws[k][cc] = a.W[(long)k * a.ldw + cc];
-    }
+    // per-column scale, then the operands of the two products -> LDS: one batch of loads (see small_operands_to_lds)
+    const float inv_in = a.batchnorm ? a.inv_std[tx < a.H ? tx : a.H - 1] : 1.f;
+    small_operands_to_lds<RPT>(a.W, a.ldw, a.K, a.H, 0, a.Hp, a.ldp, a.B, Ws, Hs);
     // ---- phase 1 (every workgroup): dZ = batch-norm backward of dH * act'(H), or the activation derivative alone
     {
         const int c = tx;
@@ -520,8 +665,11 @@ __global__ __launch_bounds__(256) void dense_bn_bwd_small_kernel(DenseSmallBwdAr
         for (int k = 0; k < RPT; ++k) {
             const int i = ty + 4 * k;
             const bool ok = cv && i < a.B;
-            dy[k] = ok ? a.dH[(long)i * a.ldd + c] * act_grad(a.act, a.Hact[(long)i * a.ldh + c]) : 0.f;
-            xh[k] = (ok && a.batchnorm) ? a.xhat[(long)i * a.ldx + c] : 0.f;
+            const int ic = i < a.B ? i : a.B - 1, ccl = cv ? c : a.H - 1;      // unconditional loads (clamped), masked below
+            const float dh_v = a.dH[(long)ic * a.ldd + ccl], ha_v = a.Hact[(long)ic * a.ldh + ccl];
+            const float xh_v = a.batchnorm ? a.xhat[(long)ic * a.ldx + ccl] : 0.f;
+            dy[k] = ok ? dh_v * act_grad(a.act, ha_v) : 0.f;
+            xh[k] = ok ? xh_v : 0.f;
             s1 += dy[k]; s2 += dy[k] * xh[k];
         }
         float m1 = 0.f, m2 = 0.f, inv = 1.f;
@@ -529,7 +677,7 @@ __global__ __launch_bounds__(256) void dense_bn_bwd_small_kernel(DenseSmallBwdAr
             const float t1 = wg_rowlane_sum(s1, sm);
             const float t2 = wg_rowlane_sum(s2, sm);
             if (wg == 0 && cv && ty == 0 && a.dbeta) a.dbeta[c] = t1;
-            m1 = t1 / a.n_total; m2 = t2 / a.n_total; inv = cv ? a.inv_std[c] : 0.f;
+            m1 = t1 / a.n_total; m2 = t2 / a.n_total; inv = cv ? inv_in : 0.f;
         }
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
@@ -806,6 +954,28 @@ extern "C" int dcahip_dense_bn_small(const float* Hp, long ldp, const float* W, 
                      Z, ldz, xhat, ldx, Hout, ldh, inv_std};
     if (B <= 32) hipLaunchKernelGGL(dense_bn_small_kernel<8>, dim3((H + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     else hipLaunchKernelGGL(dense_bn_small_kernel<16>, dim3((H + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dcahip_hidden_small_chain(const dcahip_small_layer* layers, int n, const float* Hin, long ldin, int B,
+                                         int batchnorm, float momentum, float eps, int act, void* stream) {
+    if (!layers || n < 1 || n > kChainMax || B <= 0 || B > kFusedRows) return DCAHIP_EINVAL;
+    SmallChainArgs a{};
+    for (int i = 0; i < n; ++i) {
+        const dcahip_small_layer& q = layers[i];
+        if (q.H <= 0 || q.H > 64 || !q.Hout) return DCAHIP_EINVAL;
+        if (q.W) {
+            if (!q.bias || q.K <= 0 || q.K > kSmallK) return DCAHIP_EINVAL;
+            if (i == 0 && !Hin) return DCAHIP_EINVAL;
+            if (i > 0 && q.K != layers[i - 1].H) return DCAHIP_EINVAL;
+        } else if (!q.Z) return DCAHIP_EINVAL;
+        if (batchnorm && (!q.moving_mean || !q.moving_var)) return DCAHIP_EINVAL;
+        a.l[i] = SmallLayer{q.W, q.ldw, q.bias, q.K, q.H, q.beta, q.moving_mean, q.moving_var, q.Z, q.ldz, q.xhat, q.ldx,
+                            q.Hout, q.ldh, q.inv_std};
+    }
+    a.Hin = Hin; a.ldin = ldin; a.n = n; a.B = B; a.batchnorm = batchnorm; a.act = act; a.momentum = momentum; a.eps = eps;
+    if (B <= 32) hipLaunchKernelGGL(hidden_small_chain_kernel<8>, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    else hipLaunchKernelGGL(hidden_small_chain_kernel<16>, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return (int)hipGetLastError();
 }
 

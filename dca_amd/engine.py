@@ -652,6 +652,8 @@ class Engine:
                 else:
                     ops.sgemm(0, 0, B, h, K, self.X[rows_from[1]:], self.ldx, Wi, h, self.Z[0],
                               self.ldh[0], bias=bi, ws=self.ws)
+            elif training and i == 1 and self._stack_small(B):
+                break       # the rest of the stack ran inside the chain launch below
             elif training and self._layer_small(B, i):
                 # small batches: Dense -> BatchNormalization -> activation of this layer in ONE launch
                 ops.dense_bn_small(self.Hcur[i - 1], self.ldh[i - 1], Wi, h, bi, B, K, h, lay.batchnorm,
@@ -666,6 +668,15 @@ class Engine:
             else:
                 ops.sgemm(0, 0, B, h, K, self.Hcur[i - 1], self.ldh[i - 1], Wi, h, self.Z[i],
                           self.ldh[i], bias=bi, ws=self.ws)
+            if training and i == 0 and self._stack_small(B):
+                # small batches, every layer at most 64 units: batch norm + activation of this layer and the whole stack
+                # behind it (Dense -> BatchNormalization -> activation per layer) in ONE launch
+                ops.hidden_small_chain([self._chain_entry(j) for j in range(len(lay.hidden))], None, 0, B, True,
+                                       BN_MOMENTUM, BN_EPS, self.act)
+                for j, hj in enumerate(lay.hidden):
+                    self.Hcur[j] = self.H[j]
+                    K = hj
+                continue
             if lay.batchnorm:
                 beta = lay.view(w, 'beta%d' % i)
                 if training and self._bn_small(B):
@@ -703,6 +714,22 @@ class Engine:
         """Throughput batches of a network whose heads run as separate kernels: transposed operand copies (see reserve)."""
         return (self.ws_heads is None and B >= 256 and hasattr(self.ops, 'transpose')
                 and os.environ.get('DCA_AMD_WIDE_T', '1') != '0')
+
+    def _stack_small(self, B):
+        """The whole hidden stack behind the first product in one launch (batch-normalised, every layer small)."""
+        L = len(self.lay.hidden)
+        return (self.lay.batchnorm and 2 <= L <= 4 and hasattr(self.ops, 'hidden_small_chain') and self._bn_small(B)
+                and all(self._layer_small(B, i) for i in range(1, L)) and self.lay.hidden[0] <= 64
+                and os.environ.get('DCA_AMD_SMALL_CHAIN', '1') != '0')
+
+    def _chain_entry(self, j):
+        lay, w = self.lay, self.w
+        d = dict(H=lay.hidden[j], beta=lay.view(w, 'beta%d' % j), moving_mean=self.mm[j], moving_var=self.mv[j],
+                 Z=self.Z[j], ldz=self.ldh[j], xhat=self.XH[j], ldx=self.ldh[j], Hout=self.H[j], ldh=self.ldh[j],
+                 inv_std=self.inv_std[j])
+        if j > 0:
+            d.update(W=lay.view(w, 'W%d' % j), ldw=lay.hidden[j], bias=lay.view(w, 'b%d' % j), K=lay.hidden[j - 1])
+        return d
 
     def _layer_small(self, B, i):
         """Hidden layer i >= 1 at a small batch on one GPU: whole-layer kernels (forward and backward)."""

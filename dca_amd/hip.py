@@ -22,6 +22,14 @@ NLL_MSE = 8
 REG_MAX_SEGS = 16
 
 
+class SmallLayer(_c.Structure):
+    """dcahip_small_layer (include/dcahip.h)."""
+    _fields_ = [('W', _c.c_void_p), ('ldw', _c.c_long), ('bias', _c.c_void_p), ('K', _c.c_int), ('H', _c.c_int),
+                ('beta', _c.c_void_p), ('moving_mean', _c.c_void_p), ('moving_var', _c.c_void_p),
+                ('Z', _c.c_void_p), ('ldz', _c.c_long), ('xhat', _c.c_void_p), ('ldx', _c.c_long),
+                ('Hout', _c.c_void_p), ('ldh', _c.c_long), ('inv_std', _c.c_void_p)]
+
+
 class RegDesc(_c.Structure):
     """dcahip_reg_desc (include/dcahip.h)."""
     _fields_ = [('nseg', _c.c_int), ('start', _c.c_long * REG_MAX_SEGS), ('end', _c.c_long * REG_MAX_SEGS),
@@ -58,6 +66,8 @@ _SIGNATURES = {
                                               _f32p, _f32p, _c.c_long, _f64p, _c.POINTER(_c.c_int), _vp,
                                               _c.c_long, _i32p, _vp]),
     'dcahip_transpose': (_c.c_int, [_f32p, _c.c_long, _c.c_int, _c.c_int, _f32p, _c.c_long, _vp]),
+    'dcahip_hidden_small_chain': (_c.c_int, [_c.POINTER(SmallLayer), _c.c_int, _f32p, _c.c_long, _c.c_int, _c.c_int,
+                                             _c.c_float, _c.c_float, _c.c_int, _vp]),
     'dcahip_transpose_rows': (_c.c_int, [_f32p, _c.c_long, _i32p, _i64p, _c.c_int, _c.c_int, _f32p, _c.c_long, _vp]),
     'dcahip_heads_fused_loss': (_c.c_int, [_f32p, _c.c_long, _f32p, _c.c_long, _f32p, _c.c_long, _f32p,
                                            _f32p, _c.c_long, _f32p, _i32p, _i64p, _c.c_int, _c.c_int,

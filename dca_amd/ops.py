@@ -141,6 +141,17 @@ class HipOps:
                                                momentum, eps, int(act), p(Z), ldz, p(xhat), ldx, p(Hout), ldh, p(inv_std),
                                                hip.stream()), 'dense_bn_small')
 
+    def hidden_small_chain(self, layers, Hin, ldin, B, batchnorm, momentum, eps, act):
+        """layers: dicts with the fields of dcahip_small_layer (tensors or None); one launch for the whole list."""
+        arr = (hip.SmallLayer * len(layers))()
+        for q, d in zip(arr, layers):
+            for k in ('W', 'bias', 'beta', 'moving_mean', 'moving_var', 'Z', 'xhat', 'Hout', 'inv_std'):
+                setattr(q, k, hip.ptr(d.get(k)))
+            for k in ('ldw', 'K', 'H', 'ldz', 'ldx', 'ldh'):
+                setattr(q, k, int(d.get(k, 0)))
+        hip.check(self.L.dcahip_hidden_small_chain(arr, len(layers), hip.ptr(Hin), ldin, B, int(batchnorm), momentum, eps,
+                                                   int(act), hip.stream()), 'hidden_small_chain')
+
     def dense_bn_bwd_small(self, dH, ldd, Hact, ldh, xhat, ldx, inv_std, Hp, ldp, W, ldw, B, K, H, batchnorm, n_total, act,
                            gW, ldg, dbeta, dHp, lddp):
         p = hip.ptr

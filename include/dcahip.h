@@ -250,6 +250,21 @@ int dcahip_dense_bn_bwd_small(const float* dH, long ldd, const float* Hact, long
                               const float* Hp, long ldp, const float* W, long ldw,
                               int B, int K, int H, int batchnorm, float n_total, int act,
                               float* gW, long ldg, float* dbeta, float* dHp, long lddp, void* stream);
+/* The hidden stack behind the first layer's product in ONE launch (every layer <= 64 units, B <= dcahip_bn_fused_max_rows()):
+ * entry 0 with W == NULL normalises + activates its own Z (written by dcahip_sgemm), every entry with a kernel is
+ * Dense -> BatchNormalization -> activation on the previous entry's Hout (entry 0 with a kernel reads Hin).  Same
+ * formulas and outputs as dcahip_bn_relu_train_small / dcahip_dense_bn_small called one after the other
+ * (dca/network.py:124-135). */
+typedef struct dcahip_small_layer {
+    const float* W; long ldw;           /* kernel [K, H] or NULL */
+    const float* bias;                  /* [H] */
+    int K, H;
+    const float* beta; float* moving_mean; float* moving_var;
+    float* Z; long ldz;                 /* pre-activation: input when W == NULL, optional output otherwise */
+    float* xhat; long ldx; float* Hout; long ldh; float* inv_std;
+} dcahip_small_layer;
+int dcahip_hidden_small_chain(const dcahip_small_layer* layers, int n, const float* Hin, long ldin, int B,
+                              int batchnorm, float momentum, float eps, int act, void* stream);
 int dcahip_bn_relu_train_small(const float* Z, long ldz, int B, int H, const float* beta,
                                float* moving_mean, float* moving_var, float momentum, float eps,
                                int act, float* Hout, long ldh, float* xhat, long ldx,
