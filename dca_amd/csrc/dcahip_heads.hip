@@ -1495,10 +1495,15 @@ __global__ __launch_bounds__(256) void heads_fused_small_kernel(HeadsArgs2 p) {
     constexpr int ST_TILE = NP * ST_PLANE;
     constexpr int W_PIECE = 64 * 64;
     constexpr int W_FLOATS = NH * 3 * W_PIECE / 4;
-    constexpr int BIAS_FLOATS = (NH + 1) * 32;
+    constexpr int BIAS_FLOATS = CONST_DISP ? (NH + 1) * 32 : 0;       // conditional dispersion: biases straight from memory
     constexpr int NW = 4;
     static_assert(NW * kZU == 16, "one Z group per wave");
-    constexpr int LDS_FLOATS = W_FLOATS + ST_TILE + NW * kQCap + BIAS_FLOATS;
+    // a wave queues at most its 4 x 64 elements.  With 256 entries per queue the workgroup's LDS stays below a third
+    // of the CU's 160 KB: three workgroups per CU = 768 resident, the 625 gene tiles of G = 20 000 in ONE round
+    // (at two per CU the last 113 tiles ran after the first 512: 30 us instead of 17)
+    constexpr int QCAP = kZU * 64;
+    constexpr int LDS_FLOATS = W_FLOATS + ST_TILE + NW * QCAP + BIAS_FLOATS;
+    static_assert(LDS_FLOATS * 4 + NW * 8 <= 42 * 1280, "three workgroups per CU (LDS is allocated in 1280-byte granules)");
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     __shared__ double lred[NW];
 
@@ -1520,8 +1525,8 @@ __global__ __launch_bounds__(256) void heads_fused_small_kernel(HeadsArgs2 p) {
 
     unsigned char* const Wimg = reinterpret_cast<unsigned char*>(lds);
     float* const St = lds + W_FLOATS;
-    unsigned* const Q = reinterpret_cast<unsigned*>(lds + W_FLOATS + ST_TILE) + wave * kQCap;
-    float* const Bs = lds + W_FLOATS + ST_TILE + NW * kQCap;
+    unsigned* const Q = reinterpret_cast<unsigned*>(lds + W_FLOATS + ST_TILE) + wave * QCAP;
+    float* const Bs = lds + W_FLOATS + ST_TILE + NW * QCAP;
 
     // ---- requests that do not depend on the weights, in flight during the weight prologue: storage rows, size
     // factors, the counts of this wave's Z group, the decoder rows (both operand orientations) of the product waves
@@ -1536,7 +1541,9 @@ __global__ __launch_bounds__(256) void heads_fused_small_kernel(HeadsArgs2 p) {
         yv[j] = ycol[(unsigned long long)(unsigned)sr * (unsigned)p.ldy];
     }
     float hx[4][8], htx[2][2][8];
+    float bias_h = 0.f;
     if (wave < NH) {
+        bias_h = p.bh[(long)wave * p.plane + (gvalid ? gene : p.G - 1)];
         const float* hp = p.H + (long)rl * p.ldh;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
@@ -1588,12 +1595,7 @@ __global__ __launch_bounds__(256) void heads_fused_small_kernel(HeadsArgs2 p) {
             *reinterpret_cast<u32x2*>(Wimg + (h * 3 + 1) * W_PIECE + off) = u32x2{a1, b1};
             *reinterpret_cast<u32x2*>(Wimg + (h * 3 + 2) * W_PIECE + off) = u32x2{a2, b2};
         }
-        if (tid < 32) {
-            const bool gv = g0 + tid < p.G;
-#pragma unroll
-            for (int h = 0; h < NH; ++h) Bs[h * 32 + tid] = gv ? p.bh[(long)h * p.plane + g0 + tid] : 0.f;
-            Bs[NH * 32 + tid] = (CONST_DISP && gv) ? p.theta_w[g0 + tid] : 0.f;
-        }
+        if (CONST_DISP && tid < 32) Bs[NH * 32 + tid] = (g0 + tid < p.G) ? p.theta_w[g0 + tid] : 0.f;
     }
     __syncthreads();
 
@@ -1637,7 +1639,7 @@ __global__ __launch_bounds__(256) void heads_fused_small_kernel(HeadsArgs2 p) {
             u32x4 bf[3] = {w_tr(h, 0, ks), w_tr(h, 1, ks), w_tr(h, 2, ks)};
             MFMA_X3(af, bf, acc)
         }
-        const float bias = Bs[h * 32 + l31];
+        const float bias = gvalid ? bias_h : 0.f;
 #pragma unroll
         for (int e = 0; e < 16; ++e) St[h * ST_PLANE + l31 * kLdS + rowmap(e, hi)] = acc[e] + bias;
     }
