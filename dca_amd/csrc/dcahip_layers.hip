@@ -326,10 +326,16 @@ __global__ __launch_bounds__(256) void bn_relu_small_kernel(BnApplyArgs a) {
     const bool cv = c < a.H;
     float z[RPT];
     float s = 0.f;
+    const int ccl = cv ? c : a.H - 1;
+    const float mm_in = a.mm[ccl], mv_in = a.mv[ccl], beta_in = a.beta ? a.beta[ccl] : 0.f;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {                  // unconditional loads (clamped): all in flight at once
+        const int i = ty + 4 * k;
+        z[k] = a.Z[(long)(i < a.B ? i : a.B - 1) * a.ldz + ccl];
+    }
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
-        const int i = ty + 4 * k;
-        z[k] = (cv && i < a.B) ? a.Z[(long)i * a.ldz + c] : 0.f;
+        z[k] = (cv && ty + 4 * k < a.B) ? z[k] : 0.f;
         s += z[k];
     }
     const float mean = wg_rowlane_sum(s, sm) / (float)a.B;
@@ -344,11 +350,11 @@ __global__ __launch_bounds__(256) void bn_relu_small_kernel(BnApplyArgs a) {
     const float var = (float)((double)m2 / (double)a.B);             // biased variance
     const float inv = 1.f / sqrtf(var + a.eps);
     if (ty == 0) {
-        a.mm[c] = a.mm[c] - (a.mm[c] - mean) * (1.f - a.momentum);
-        a.mv[c] = a.mv[c] - (a.mv[c] - var) * (1.f - a.momentum);
+        a.mm[c] = mm_in - (mm_in - mean) * (1.f - a.momentum);
+        a.mv[c] = mv_in - (mv_in - var) * (1.f - a.momentum);
         if (a.inv_std) a.inv_std[c] = inv;
     }
-    const float beta = a.beta ? a.beta[c] : 0.f;
+    const float beta = beta_in;
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         const int i = ty + 4 * k;
@@ -366,21 +372,31 @@ __global__ __launch_bounds__(256) void bn_bwd_small_kernel(BnBwdArgs a) {
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + tx;
     const bool cv = c < a.H;
-    float dy[RPT], xh[RPT];
+    float dy[RPT], xh[RPT], ha[RPT];
     float s1 = 0.f, s2 = 0.f;
+    const int ccl = cv ? c : a.H - 1;
+    const float inv_in = a.inv_std[ccl];
+    // every load first (unconditional, clamped addresses), then the arithmetic: see dense_bn_bwd_small_kernel
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         const int i = ty + 4 * k;
-        const bool ok = cv && i < a.B;
-        dy[k] = ok ? a.dH[(long)i * a.ldd + c] * act_grad(a.act, a.Hact[(long)i * a.ldh + c]) : 0.f;
-        xh[k] = ok ? a.xhat[(long)i * a.ldx + c] : 0.f;
+        const int ic = i < a.B ? i : a.B - 1;
+        dy[k] = a.dH[(long)ic * a.ldd + ccl];
+        ha[k] = a.Hact[(long)ic * a.ldh + ccl];
+        xh[k] = a.xhat[(long)ic * a.ldx + ccl];
+    }
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const bool ok = cv && ty + 4 * k < a.B;
+        dy[k] = ok ? dy[k] * act_grad(a.act, ha[k]) : 0.f;
+        xh[k] = ok ? xh[k] : 0.f;
         s1 += dy[k]; s2 += dy[k] * xh[k];
     }
     const float t1 = wg_rowlane_sum(s1, sm);
     const float t2 = wg_rowlane_sum(s2, sm);
     if (!cv) return;
     if (ty == 0 && a.dbeta) a.dbeta[c] = t1;
-    const float m1 = t1 / a.n_total, m2 = t2 / a.n_total, inv = a.inv_std[c];
+    const float m1 = t1 / a.n_total, m2 = t2 / a.n_total, inv = inv_in;
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         const int i = ty + 4 * k;
@@ -659,17 +675,23 @@ __global__ __launch_bounds__(256) void dense_bn_bwd_small_kernel(DenseSmallBwdAr
     {
         const int c = tx;
         const bool cv = c < a.H;
-        float dy[RPT], xh[RPT];
+        float dy[RPT], xh[RPT], ha[RPT];
         float s1 = 0.f, s2 = 0.f;
+        // every load first (unconditional, clamped addresses): the activation derivative below may branch, and a branch
+        // between two loads costs a memory round trip per row
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
             const int i = ty + 4 * k;
-            const bool ok = cv && i < a.B;
-            const int ic = i < a.B ? i : a.B - 1, ccl = cv ? c : a.H - 1;      // unconditional loads (clamped), masked below
-            const float dh_v = a.dH[(long)ic * a.ldd + ccl], ha_v = a.Hact[(long)ic * a.ldh + ccl];
-            const float xh_v = a.batchnorm ? a.xhat[(long)ic * a.ldx + ccl] : 0.f;
-            dy[k] = ok ? dh_v * act_grad(a.act, ha_v) : 0.f;
-            xh[k] = ok ? xh_v : 0.f;
+            const int ic = i < a.B ? i : a.B - 1, ccl = cv ? c : a.H - 1;
+            dy[k] = a.dH[(long)ic * a.ldd + ccl];
+            ha[k] = a.Hact[(long)ic * a.ldh + ccl];
+            xh[k] = a.batchnorm ? a.xhat[(long)ic * a.ldx + ccl] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const bool ok = cv && ty + 4 * k < a.B;
+            dy[k] = ok ? dy[k] * act_grad(a.act, ha[k]) : 0.f;
+            xh[k] = ok ? xh[k] : 0.f;
             s1 += dy[k]; s2 += dy[k] * xh[k];
         }
         float m1 = 0.f, m2 = 0.f, inv = 1.f;
