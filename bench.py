@@ -251,7 +251,7 @@ def main():
     eng.reserve(max(B, 1024) if W == 1 else B)           # validation runs in chunks of up to 1024 rows
     eng.clip = 5.0
     eng.set_lr(1e-3)
-    total_steps = args.warmup + args.steps
+    total_steps = args.warmup + 8 + args.steps          # + one untimed replay of the (up to 8-step) graph
     # shuffled row order: as many reshuffles of the shard as the run needs
     gen = torch.Generator(device='cpu'); gen.manual_seed(1234 + rank)
     need = total_steps * B
@@ -285,6 +285,9 @@ def main():
         torch.cuda.synchronize()
     del sa, sb, sc
 
+    # steps per graph launch: the fit loop replays 8 consecutive steps per launch (dca_amd/train.py::_StepRunner); here the
+    # largest divisor of --steps up to 8, so that exactly --steps steps are timed
+    steps_per_graph = max(k for k in range(1, 9) if args.steps % k == 0) if use_graph else 1
     graph = None
     for i in range(args.warmup):
         if use_graph and i == 1:
@@ -293,27 +296,29 @@ def main():
                 s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(s):
                     with torch.cuda.graph(graph, stream=s):
-                        eng.train_step(B, B * W, counts, B)
+                        for _ in range(steps_per_graph):
+                            eng.train_step(B, B * W, counts, B)
                 torch.cuda.current_stream().wait_stream(s)
             except Exception as e:                       # capture refused: time the eager step instead
                 print('bench: hipGraph capture failed (%s); running eager' % e, file=sys.stderr)
                 graph, use_graph = None, False
                 torch.cuda.synchronize()
-        if graph is not None:
-            graph.replay()
-        else:
-            eng.train_step(B, B * W, counts, B)
+        eng.train_step(B, B * W, counts, B)
     if use_graph and graph is None:
         use_graph = False
+    if graph is not None:
+        graph.replay()                                   # untimed: first replay of the graph (steps_per_graph more warmup steps)
+    total_steps = args.warmup + (steps_per_graph if graph is not None else 0) + args.steps
     prof = None
     if not use_graph:
         prof = EventProfiler(); eng.prof = prof
     barrier()
     t_start = time.perf_counter()
-    for i in range(args.steps):
-        if graph is not None:
+    if graph is not None:
+        for i in range(args.steps // steps_per_graph):
             graph.replay()
-        else:
+    else:
+        for i in range(args.steps):
             eng.train_step(B, B * W, counts, B)
     barrier()
     el = time.perf_counter() - t_start
@@ -362,7 +367,7 @@ def main():
             if m and m['shape']['B'] == B and m['shape']['G'] == G and m['shape']['hL'] == hidden[-1]:
                 roof['traffic'] = m['traffic_bytes']
                 roof['traffic_source'] = ('rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same kernel and shape '
-                                          '(profiles/pmc_traffic.json, profiles/r01_pmc/): bytes per launch; '
+                                          '(profiles/pmc_traffic.json, profiles/r02x_pmc_traffic/): bytes per launch; '
                                           'algorithmic HBM bytes %.0f' % m['algorithmic_hbm_bytes'])
             break
 
@@ -384,7 +389,7 @@ def main():
                                       'BASELINE configs[2]' if (args.cells, G, hidden) == (68579, 20000, (64, 32, 64))
                                       else 'not a BASELINE shape: ad-hoc run', n_train_global, W),
                        'batch_per_gpu': B, 'global_batch': B * W, 'hidden': list(hidden),
-                       'parallelism': 'dp%d' % W, 'launch': 'hipGraph replay' if use_graph else 'eager',
+                       'parallelism': 'dp%d' % W, 'launch': ('hipGraph replay, %d steps per graph' % steps_per_graph) if use_graph else 'eager',
                        'optimizer': 'RMSprop+clipvalue', 'params': int(eng.lay.P),
                        'arithmetic': 'fp32 results: matrix products as three-way bf16 splits, six products, fp32 accumulation '
                                      '(fp32-dot-product accuracy, tests/test_heads_fused_gpu.py::test_x3_products_are_fp32_accurate); '
