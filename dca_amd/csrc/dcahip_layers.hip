@@ -148,13 +148,20 @@ __device__ __forceinline__ void merge_entries_wg(const float* entries, const flo
                                                  double& n_out, double& mean_out, double& m2_out) {
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     double n = 0.0, sw = 0.0;
-    if (c < H)
-#pragma unroll 4
-        for (int e = ty; e < E; e += 4) {
-            const double ne = entry_count(counts, e, E, Bfallback);
+    const int cc = c < H ? c : H - 1;
+    // batches of 4 entries per thread: the loads of a batch are unconditional (clamped) and in flight together
+    for (int e0 = ty; e0 < E; e0 += 16) {
+        float me[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) me[u] = entries[((long)(e0 + 4 * u < E ? e0 + 4 * u : E - 1) * 2 + 0) * H + cc];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + 4 * u;
+            const double ne = (e < E && c < H) ? entry_count(counts, e, E, Bfallback) : 0.0;
             n += ne;
-            sw += ne * (double)entries[((long)e * 2 + 0) * H + c];
+            sw += ne * (double)me[u];
         }
+    }
     __syncthreads();
     sm[ty * 64 + tx] = n; sm[256 + ty * 64 + tx] = sw;
     __syncthreads();
@@ -162,14 +169,21 @@ __device__ __forceinline__ void merge_entries_wg(const float* entries, const flo
     sw = (sm[256 + tx] + sm[320 + tx]) + (sm[384 + tx] + sm[448 + tx]);
     const double mean = n > 0.0 ? sw / n : 0.0;
     double q = 0.0;
-    if (c < H)
-#pragma unroll 4
-        for (int e = ty; e < E; e += 4) {
-            const double ne = entry_count(counts, e, E, Bfallback);
-            if (ne <= 0.0) continue;
-            const double d = (double)entries[((long)e * 2 + 0) * H + c] - mean;
-            q += (double)entries[((long)e * 2 + 1) * H + c] + ne * d * d;
+    for (int e0 = ty; e0 < E; e0 += 16) {
+        float me[4], qe[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long eo = (long)(e0 + 4 * u < E ? e0 + 4 * u : E - 1) * 2;
+            me[u] = entries[(eo + 0) * H + cc]; qe[u] = entries[(eo + 1) * H + cc];
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + 4 * u;
+            const double ne = (e < E && c < H) ? entry_count(counts, e, E, Bfallback) : 0.0;
+            const double d = (double)me[u] - mean;
+            q += ne > 0.0 ? (double)qe[u] + ne * d * d : 0.0;
+        }
+    }
     __syncthreads();
     sm[ty * 64 + tx] = q;
     __syncthreads();
@@ -232,12 +246,20 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(BnApplyArgs a) {
         const int c = c0 + tx;
         if (c >= a.H) continue;
         const float mean = s_mean[c], inv = s_inv[c], beta = a.beta ? a.beta[c] : 0.f;
-        for (int i = r0 + ty; i < r1; i += 4) {
-            const float xh = (a.Z[(long)i * a.ldz + c] - mean) * inv;
-            if (a.xhat) a.xhat[(long)i * a.ldx + c] = xh;
-            float y = xh + beta;
-            y = act_fwd(a.relu, y);
-            a.Hout[(long)i * a.ldh + c] = y;
+        float z[kApplyRows / 4];
+#pragma unroll
+        for (int u = 0; u < kApplyRows / 4; ++u) {           // loads first: the activation may branch
+            const int i = r0 + ty + 4 * u;
+            z[u] = a.Z[(long)(i < r1 ? i : r1 - 1) * a.ldz + c];
+        }
+#pragma unroll
+        for (int u = 0; u < kApplyRows / 4; ++u) {
+            const int i = r0 + ty + 4 * u;
+            if (i < r1) {
+                const float xh = (z[u] - mean) * inv;
+                if (a.xhat) a.xhat[(long)i * a.ldx + c] = xh;
+                a.Hout[(long)i * a.ldh + c] = act_fwd(a.relu, xh + beta);
+            }
         }
     }
 }
@@ -256,11 +278,19 @@ __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(const float* dH, long 
         const int c = c0 + tx;
         float s1 = 0.f, s2 = 0.f;
         if (c < H)
-#pragma unroll 8
-        for (int i = r0 + ty; i < r1; i += 4) {
-            const float dy = dH[(long)i * ldd + c] * act_grad(act, Hact[(long)i * ldh + c]);
-            s1 += dy; s2 += dy * xhat[(long)i * ldx + c];
-        }
+            for (int i0 = r0 + ty; i0 < r1; i0 += 32) {      // 8 rows per batch: all 24 loads in flight, then the arithmetic
+                float d[8], h[8], x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = i0 + 4 * u < r1 ? i0 + 4 * u : r1 - 1;
+                    d[u] = dH[(long)i * ldd + c]; h[u] = Hact[(long)i * ldh + c]; x[u] = xhat[(long)i * ldx + c];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float dy = i0 + 4 * u < r1 ? d[u] * act_grad(act, h[u]) : 0.f;
+                    s1 += dy; s2 += dy * x[u];
+                }
+            }
         const float t1 = wg_rowlane_sum(s1, sm);
         const float t2 = wg_rowlane_sum(s2, sm);
         if (c < H && ty == 0) {
@@ -304,9 +334,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
         const int c = c0 + tx;
         if (c >= a.H) continue;
         const float m1 = s1[c], m2 = s2[c], inv = a.inv_std[c];
-        for (int i = r0 + ty; i < r1; i += 4) {
-            const float dy = a.dH[(long)i * a.ldd + c] * act_grad(a.act, a.Hact[(long)i * a.ldh + c]);
-            a.dZ[(long)i * a.ldz + c] = inv * (dy - m1 - a.xhat[(long)i * a.ldx + c] * m2);
+        float d[kApplyRows / 4], h[kApplyRows / 4], x[kApplyRows / 4];
+#pragma unroll
+        for (int u = 0; u < kApplyRows / 4; ++u) {           // loads first: the activation derivative may branch
+            const int i = r0 + ty + 4 * u < r1 ? r0 + ty + 4 * u : r1 - 1;
+            d[u] = a.dH[(long)i * a.ldd + c]; h[u] = a.Hact[(long)i * a.ldh + c]; x[u] = a.xhat[(long)i * a.ldx + c];
+        }
+#pragma unroll
+        for (int u = 0; u < kApplyRows / 4; ++u) {
+            const int i = r0 + ty + 4 * u;
+            if (i < r1) a.dZ[(long)i * a.ldz + c] = inv * (d[u] * act_grad(a.act, h[u]) - m1 - x[u] * m2);
         }
     }
 }

@@ -300,6 +300,129 @@ def test_transpose_rows(ops, R, C, gather):
     assert (out[C:] == 7.0).all() and (out[:, R:] == 7.0).all()
 
 
+# ------------------------------------------------------------------------------- small-batch layer kernels
+def _np_layer_fwd(Hp, W, b, beta, mm, mv, batchnorm, mom=0.99, eps=1e-3):
+    Z = Hp @ W + b if W is not None else Hp
+    if not batchnorm:
+        return Z, None, np.maximum(Z, 0), None, mm, mv
+    mean, var = Z.mean(0), Z.var(0)
+    inv = 1.0 / np.sqrt(var + eps)
+    xh = (Z - mean) * inv
+    return Z, xh, np.maximum(xh + beta, 0), inv, mm - (mm - mean) * (1 - mom), mv - (mv - var) * (1 - mom)
+
+
+@pytest.mark.parametrize('batchnorm', [True, False])
+@pytest.mark.parametrize('B,hs', [(32, (64, 32, 64)), (17, (50, 7, 64)), (64, (64, 64)), (5, (3, 2)), (40, (20, 33, 9, 64)), (1, (4, 4))])
+def test_small_batch_layer_kernels_vs_numpy(ops, B, hs, batchnorm):
+    """dcahip_hidden_small_chain (the stack behind the first product in one launch), dcahip_bn_relu_train_small +
+    dcahip_dense_bn_small (the same, one launch per layer) and the two backward kernels against the numpy formulas of
+    Dense -> BatchNormalization(center, no scale, eps 1e-3, momentum 0.99) -> relu (dca/network.py:124-135)."""
+    rng = np.random.RandomState(B + sum(hs))
+    L = len(hs)
+    ld = [h + (-h) % 4 for h in hs]
+    Z0 = rng.normal(size=(B, hs[0]))
+    W = [None] + [rng.normal(size=(hs[i - 1], hs[i])) * 0.3 for i in range(1, L)]
+    b = [np.zeros(hs[0])] + [rng.normal(size=hs[i]) * 0.1 for i in range(1, L)]
+    beta = [rng.normal(size=h) * 0.1 for h in hs]
+    mm0 = [rng.normal(size=h) * 0.1 for h in hs]
+    mv0 = [rng.uniform(0.5, 1.5, size=h) for h in hs]
+    # numpy reference, layer after layer
+    ref = []
+    cur = Z0
+    for i in range(L):
+        Zi, xh, Hi, inv, mm1, mv1 = _np_layer_fwd(cur, W[i], b[i], beta[i], mm0[i], mv0[i], batchnorm)
+        ref.append(dict(Z=Zi, xh=xh, H=Hi, inv=inv, mm=mm1, mv=mv1))
+        cur = Hi
+    f32 = dict(dtype=torch.float32, device='cuda')
+
+    def buffers():
+        d = dict(Z=[torch.zeros(B, ld[i], **f32) for i in range(L)], XH=[torch.zeros(B, ld[i], **f32) for i in range(L)],
+                 H=[torch.zeros(B, ld[i], **f32) for i in range(L)], inv=[torch.zeros(hs[i], **f32) for i in range(L)],
+                 mm=[dev(mm0[i].astype(np.float32)) for i in range(L)], mv=[dev(mv0[i].astype(np.float32)) for i in range(L)])
+        d['Z'][0][:, :hs[0]] = dev(Z0.astype(np.float32))
+        return d
+    Wd = [None] + [dev(np.ascontiguousarray(W[i]).astype(np.float32)) for i in range(1, L)]
+    bd = [None] + [dev(b[i].astype(np.float32)) for i in range(1, L)]
+    betad = [dev(beta[i].astype(np.float32)) for i in range(L)]
+
+    def check(d, what):
+        for i in range(L):
+            tol = dict(rtol=2e-5, atol=2e-5)
+            np.testing.assert_allclose(d['H'][i][:, :hs[i]].cpu().numpy(), ref[i]['H'], err_msg='%s H%d' % (what, i), **tol)
+            if i > 0:
+                np.testing.assert_allclose(d['Z'][i][:, :hs[i]].cpu().numpy(), ref[i]['Z'], err_msg='%s Z%d' % (what, i), **tol)
+            if batchnorm:
+                if B > 1:
+                    np.testing.assert_allclose(d['XH'][i][:, :hs[i]].cpu().numpy(), ref[i]['xh'], err_msg='%s xhat%d' % (what, i), rtol=1e-4, atol=1e-4)
+                    np.testing.assert_allclose(d['inv'][i].cpu().numpy(), ref[i]['inv'], rtol=1e-4, err_msg='%s inv%d' % (what, i))
+                np.testing.assert_allclose(d['mm'][i].cpu().numpy(), ref[i]['mm'], rtol=1e-5, atol=1e-6, err_msg='%s mm%d' % (what, i))
+                np.testing.assert_allclose(d['mv'][i].cpu().numpy(), ref[i]['mv'], rtol=1e-5, atol=1e-6, err_msg='%s mv%d' % (what, i))
+            assert (d['H'][i][:, hs[i]:] == 0).all()            # padding columns untouched
+
+    # (a) the whole stack in one launch
+    d = buffers()
+    entries = []
+    for i in range(L):
+        e = dict(H=hs[i], beta=betad[i], moving_mean=d['mm'][i], moving_var=d['mv'][i], Z=d['Z'][i], ldz=ld[i], xhat=d['XH'][i],
+                 ldx=ld[i], Hout=d['H'][i], ldh=ld[i], inv_std=d['inv'][i])
+        if i > 0:
+            e.update(W=Wd[i], ldw=hs[i], bias=bd[i], K=hs[i - 1])
+        entries.append(e)
+    ops.hidden_small_chain(entries, None, 0, B, batchnorm, 0.99, 1e-3, 1)
+    torch.cuda.synchronize()
+    check(d, 'chain')
+    # (b) one launch per layer
+    d2 = buffers()
+    if batchnorm:
+        ops.bn_relu_train_small(d2['Z'][0], ld[0], B, hs[0], betad[0], d2['mm'][0], d2['mv'][0], 0.99, 1e-3, 1, d2['H'][0], ld[0],
+                                d2['XH'][0], ld[0], d2['inv'][0])
+    else:
+        ops.relu_fwd(d2['Z'][0], ld[0], B, hs[0], d2['H'][0], ld[0], 1)
+    for i in range(1, L):
+        ops.dense_bn_small(d2['H'][i - 1], ld[i - 1], Wd[i], hs[i], bd[i], B, hs[i - 1], hs[i], batchnorm, betad[i], d2['mm'][i],
+                           d2['mv'][i], 0.99, 1e-3, 1, d2['Z'][i], ld[i], d2['XH'][i], ld[i], d2['H'][i], ld[i], d2['inv'][i])
+    torch.cuda.synchronize()
+    check(d2, 'per layer')
+    # ---- backward of the last layer (whole-layer kernel) and of layer 0 (batch-norm only)
+    if B == 1 and batchnorm:
+        return              # one row: xhat = 0, inv_std = eps^-1/2 -- the backward amplifies rounding, nothing to compare
+    i = L - 1
+    dH = rng.normal(size=(B, hs[i]))
+    Hi, xh, inv = ref[i]['H'], ref[i]['xh'], ref[i]['inv']
+    dy = dH * (Hi > 0)
+    if batchnorm:
+        s1, s2 = dy.sum(0), (dy * xh).sum(0)
+        dZ = inv * (dy - s1 / B - xh * s2 / B)
+    else:
+        s1, dZ = None, dy
+    Hp = ref[i - 1]['H']
+    gW_ref, gb_ref, dHp_ref = Hp.T @ dZ, dZ.sum(0), dZ @ W[i].T
+    dHd = torch.zeros(B, ld[i], **f32); dHd[:, :hs[i]] = dev(dH.astype(np.float32))
+    gW = torch.zeros(hs[i - 1] + 1, hs[i], **f32); dbeta = torch.zeros(hs[i], **f32)
+    dHp = torch.zeros(B, ld[i - 1], **f32)
+    ops.dense_bn_bwd_small(dHd, ld[i], d['H'][i], ld[i], d['XH'][i] if batchnorm else None, ld[i], d['inv'][i], d['H'][i - 1], ld[i - 1],
+                           Wd[i], hs[i], B, hs[i - 1], hs[i], batchnorm, float(B), 1, gW, hs[i], dbeta if batchnorm else None,
+                           dHp, ld[i - 1])
+    torch.cuda.synchronize()
+    sc = np.abs(gW_ref).max() + 1e-6
+    np.testing.assert_allclose(gW[:hs[i - 1]].cpu().numpy(), gW_ref, rtol=1e-3, atol=2e-5 * sc)
+    # (with batch norm the bias gradient is a sum that cancels exactly: the tolerance is relative to the summed magnitudes)
+    np.testing.assert_allclose(gW[hs[i - 1]].cpu().numpy(), gb_ref, rtol=1e-3, atol=2e-6 * (np.abs(dZ).sum(0).max() + 1e-6))
+    np.testing.assert_allclose(dHp[:, :hs[i - 1]].cpu().numpy(), dHp_ref, rtol=1e-3, atol=2e-5 * (np.abs(dHp_ref).max() + 1e-6))
+    if batchnorm:
+        np.testing.assert_allclose(dbeta.cpu().numpy(), s1, rtol=1e-4, atol=1e-5)
+        dH0 = rng.normal(size=(B, hs[0]))
+        dy0 = dH0 * (ref[0]['H'] > 0)
+        t1, t2 = dy0.sum(0), (dy0 * ref[0]['xh']).sum(0)
+        dZ0_ref = ref[0]['inv'] * (dy0 - t1 / B - ref[0]['xh'] * t2 / B)
+        dH0d = torch.zeros(B, ld[0], **f32); dH0d[:, :hs[0]] = dev(dH0.astype(np.float32))
+        dZ0 = torch.zeros(B, ld[0], **f32); db0 = torch.zeros(hs[0], **f32)
+        ops.bn_bwd_small(dH0d, ld[0], d['H'][0], ld[0], d['XH'][0], ld[0], d['inv'][0], float(B), B, hs[0], dZ0, ld[0], db0)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(dZ0[:, :hs[0]].cpu().numpy(), dZ0_ref, rtol=1e-3, atol=2e-5 * (np.abs(dZ0_ref).max() + 1e-6))
+        np.testing.assert_allclose(db0.cpu().numpy(), t1, rtol=1e-4, atol=1e-5)
+
+
 # ------------------------------------------------------------------------------- batch norm
 @pytest.mark.parametrize('B,H', [(32, 64), (25, 32), (300, 64), (1000, 130), (8, 1)])
 def test_bn_forward_backward(ops, B, H):
