@@ -10,7 +10,7 @@ import random
 import numpy as np
 
 from ._anndata import is_anndata
-from .io import read_dataset, normalize, filter_genes_mask
+from .io import read_dataset, normalize, filter_genes_mask, resident_counts
 from .train import train
 from .network import AE_types
 
@@ -56,11 +56,15 @@ def dca(adata,
 
     # counts -> AnnData with .raw and the train/test column (api.py:156-160); copy=True works on a private copy
     work = read_dataset(adata, transpose=False, test_split=False, copy=copy, check_counts=check_counts)
-    keep_gene, _ = filter_genes_mask(work.X, min_counts=1)
-    assert keep_gene.all(), 'Please remove all-zero genes before using DCA.'            # api.py:163-164
+    # api.py:163-164.  With a GPU the counts are uploaded here, once (normalize() and train() use the resident copy), and
+    # the per-gene totals are the device's exact integer sums instead of a pass over the host matrix
+    resident = resident_counts(work)
+    gene_totals = resident[1] if resident is not None else filter_genes_mask(work.X, min_counts=1)[1]
+    assert (np.asarray(gene_totals) >= 1).all(), 'Please remove all-zero genes before using DCA.'
     # cell / gene indices must survive untouched, so no count filtering inside normalize (api.py:166-170)
     work = normalize(work, filter_min_counts=False, size_factors=normalize_per_cell,
-                     normalize_input=scale, logtrans_input=log1p)
+                     normalize_input=scale, logtrans_input=log1p,
+                     _resident=resident[0] if resident is not None else None)
 
     net = _make_network(ae_type, work.n_vars, random_state,
                         dict(network_kwds, hidden_size=hidden_size, hidden_dropout=hidden_dropout,

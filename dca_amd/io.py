@@ -172,8 +172,17 @@ def _device_prep_available():
         return False
 
 
+def resident_counts(adata):
+    """With a GPU present: the raw counts of ``adata`` uploaded once ([n, r4(G)] device tensor) together with their exact
+    per-gene totals -- (Y, gene_totals) for ``normalize(..., _resident=Y)``; None when the host path is in use."""
+    if not _device_prep_available():
+        return None
+    from . import prep
+    return prep.resident_counts(adata.X)
+
+
 def normalize(adata, filter_min_counts=True, size_factors=True, normalize_input=True,
-              logtrans_input=True, device='auto'):
+              logtrans_input=True, device='auto', _resident=None):
     """dca/io.py:88-111.  With a GPU present the arithmetic runs on the device (K-PREP,
     dca_amd/prep.py): one upload of the raw counts, the training tensors stay in HBM and are
     handed to ``train`` through ``adata._dca_device``; the AnnData receives exactly what this
@@ -182,7 +191,7 @@ def normalize(adata, filter_min_counts=True, size_factors=True, normalize_input=
     if device is True or (device == 'auto' and _device_prep_available()):
         from . import prep
         adata, dd = prep.normalize_device(adata, filter_min_counts, size_factors, normalize_input,
-                                          logtrans_input)
+                                          logtrans_input, Y=_resident)
         adata._dca_device = dd
         return adata
     if filter_min_counts:

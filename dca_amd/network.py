@@ -174,9 +174,11 @@ class Autoencoder():
             want.add('mean')
         return want
 
-    def _run_predict(self, adata, want, chunk=4096):
+    def _run_predict(self, adata, want, chunk=None):
         """One inference pass over all cells; returns host arrays for the requested outputs."""
         eng = self.engine
+        if chunk is None:       # rows per device -> host chunk: 2 page-locked staging buffers of this many rows per output
+            chunk = int(os.environ.get('DCA_AMD_PREDICT_CHUNK', '1024'))
         n = adata.n_obs
         X = adata.X
         sf = np.asarray(adata.obs['size_factors'].values, dtype=np.float32)

@@ -27,7 +27,8 @@ def timed(name, fn):
         torch.cuda.synchronize(); marks[name] = marks.get(name, 0.0) + time.perf_counter() - s
         return r
     return w
-A.normalize = timed('normalize (K-PREP incl. upload + X download)', orig_norm)
+A.resident_counts = timed('upload of the counts + per-gene totals', A.resident_counts)
+A.normalize = timed('normalize (K-PREP + X download + .raw copy)', orig_norm)
 A.train = timed('train', orig_train)
 s = time.perf_counter()
 net = dca(ad, ae_type='zinb-conddisp', epochs=epochs, batch_size=batch, early_stop=0, reduce_lr=0,
