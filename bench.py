@@ -36,6 +36,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32 MFMA peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (the headline 5 PF figure includes 2:1 sparsity)
 
 
 def parse():
@@ -363,6 +364,14 @@ def main():
                     'unit': e['unit'], 'frac': e['frac'], 'traffic': None,
                     'traffic_source': None,
                     'timing': 'HIP events around each launch, ' + ('isolated eager steps after the graph-replayed timed region' if use_graph else 'inside the timed region')}
+            if e['bound'] == 'mfma':
+                # the two honest denominators: `peak` prices the algorithmic fp32 flops against the fp32-MFMA peak (what an
+                # fp32 result costs on this chip's matrix pipe); the kernel computes them as six bf16 products per fp32
+                # product on the bf16 pipe, whose bound for the SAME result is the dense bf16 peak / 6
+                roof['peak_bf16_pipe_over_6'] = MFMA_BF16_PEAK_TFLOPS / 6.0
+                roof['frac_of_bf16_pipe_over_6'] = e['achieved'] / (MFMA_BF16_PEAK_TFLOPS / 6.0)
+                roof['note'] = ('K-HEADS is bound by the SUM of its matrix and vector instruction cycles per SIMD '
+                                '(DESIGN.md 4.1): MfmaUtil 29 %, VALUBusy 52 % (profiles/r02x_sq_counters_per_kernel.csv)')
             m = pmc.get(e['kernel'])
             if m and m['shape']['B'] == B and m['shape']['G'] == G and m['shape']['hL'] == hidden[-1]:
                 roof['traffic'] = m['traffic_bytes']
