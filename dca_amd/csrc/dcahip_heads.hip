@@ -50,7 +50,8 @@ constexpr int kTG = 32;        // genes per wave tile
 constexpr int kTR = 32;        // batch rows per tile
 constexpr int kLdS = 33;       // odd LDS row stride: both operand orientations conflict-free
 constexpr int kWG = 2;         // gene tiles per workgroup
-constexpr int kMaxGrid = 2048; // = dcahip_zinb_max_partials()
+constexpr int kMaxGrid = 2048;      // grid cap of the persistent kernels
+constexpr int kMaxSmallGrid = 8192; // = dcahip_zinb_max_partials(): loss partials of the four-wave kernel (one per workgroup)
 constexpr int kCUs = 256;
 constexpr int kZU = 4;        // staged rows per Z group (two groups per loop iteration)
 constexpr int kQCap = 320;     // non-zero queue entries per wave (< 64 left over + 4 x 64 pushed)
@@ -1442,9 +1443,12 @@ bool make_heads_plan(int B, int hL, int G, long plane, int flags, HeadsPlan* out
     p.nitems = p.S * p.ngb;
     p.grid = p.nitems;
     p.npart = p.ntg;
-    p.small = !f32 && p.NT == 1 && p.ntg <= kMaxGrid && use_small_kernel();
-    if (p.small) {                                   // S = 1, one partial per gene tile
-        p.grid = p.ntg;
+    p.small = !f32 && p.NT < kWR2 && (long)p.ntg * p.NT <= kMaxSmallGrid && use_small_kernel();
+    if (p.small) {                                   // one workgroup per (gene tile, row tile): S = NT weight-gradient partials
+        p.S = p.NT;
+        p.nitems = p.NT * p.ntg;
+        p.grid = p.nitems;
+        p.npart = p.ntg;
     } else if (!f32) {                               // persistent: as many workgroups as are resident, a multiple of S
         const int res = x3_resident(p.WR) / p.S * p.S;
         if (p.grid > res) p.grid = res;
@@ -1471,8 +1475,8 @@ void launch_fused(const HeadsPlan& pl, const HeadsArgs& a, hipStream_t s) {
 }
 
 // =====================================================================================================
-// K-HEADS for ONE row tile (B <= 32 -- the reference's default batch size, dca/api.py:33): one gene tile per
-// workgroup, FOUR waves working on it together.  With a lone wave per tile (the persistent kernel above at NT = 1) the
+// K-HEADS for batches below 256 rows (B <= 32, ONE row tile, is the reference's default batch size, dca/api.py:33):
+// one (gene tile, row tile) pair per workgroup, FOUR waves working on it together.  With a lone wave per tile (the persistent kernel above at NT = 1) the
 // 625 tiles of G = 20 000 leave three quarters of the SIMDs idle and every phase is one wave's dependent chain:
 // measured 41 us, of which 10 launch + weight prologue, 13 the likelihood pass, 18 the three products and their stores
 // (tools/_dbg experiment builds).  Here
@@ -1511,13 +1515,16 @@ __global__ __launch_bounds__(256) void heads_fused_small_kernel(HeadsArgs2 p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
     const long long cur = p.cursor ? *p.cursor : 0;
-    const int gb = blockIdx.x;
+    // workgroup = (gene tile gb, row tile t); the row tiles of a gene tile are neighbours (they share its weights in L2)
+    const int t = p.NT > 1 ? (int)(blockIdx.x % p.NT) : 0;
+    const int gb = p.NT > 1 ? (int)(blockIdx.x / p.NT) : (int)blockIdx.x;
+    const int row0 = t * kTR;
     const int gt = p.tile_order ? p.tile_order[gb] : gb;
     const int g0 = gt * kTG;
-    float* const dh_out = p.ws_dh + (long)gb * (kTR * KT);
+    float* const dh_out = p.ws_dh + ((long)t * p.npart + gb) * (kTR * KT);
     if (g0 >= p.G) {                         // padding entry of the tile order: an all-zero partial, no loss
         for (int i = tid; i < kTR * KT; i += 256) dh_out[i] = 0.f;
-        if (tid == 0) p.partials[gb] = 0.0;
+        if (tid == 0) p.partials[blockIdx.x] = 0.0;
         return;
     }
     const int gene = g0 + l31;
@@ -1530,7 +1537,7 @@ __global__ __launch_bounds__(256) void heads_fused_small_kernel(HeadsArgs2 p) {
 
     // ---- requests that do not depend on the weights, in flight during the weight prologue: storage rows, size
     // factors, the counts of this wave's Z group, the decoder rows (both operand orientations) of the product waves
-    const int rl = l31 < p.B ? l31 : p.B - 1;
+    const int rl = row0 + l31 < p.B ? row0 + l31 : p.B - 1;
     const int srow_l = p.perm ? p.perm[cur + rl] : (int)(cur + rl);
     const float sf_l = p.sf[srow_l];
     const float* const ycol = p.y + (gvalid ? gene : p.G - 1);
@@ -1558,7 +1565,7 @@ __global__ __launch_bounds__(256) void heads_fused_small_kernel(HeadsArgs2 p) {
             for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {        // hidden unit l31 + 32 ib, rows in the order of the MFMA row map
-                    const int row = rowmap(8 * ks + j, hi), i = l31 + 32 * ib;
+                    const int row = row0 + rowmap(8 * ks + j, hi), i = l31 + 32 * ib;
                     htx[ks][ib][j] = p.H[(long)(row < p.B ? row : p.B - 1) * p.ldh + (i < p.hL ? i : p.hL - 1)];
                 }
     }
@@ -1633,7 +1640,7 @@ __global__ __launch_bounds__(256) void heads_fused_small_kernel(HeadsArgs2 p) {
         for (int ks = 0; ks < 4; ++ks) {
             float x[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) x[j] = (l31 < p.B && 32 * hi + 8 * ks + j < p.hL) ? hx[ks][j] : 0.f;
+            for (int j = 0; j < 8; ++j) x[j] = (row0 + l31 < p.B && 32 * hi + 8 * ks + j < p.hL) ? hx[ks][j] : 0.f;
             u32x4 af[3];
             split8(x, af);
             u32x4 bf[3] = {w_tr(h, 0, ks), w_tr(h, 1, ks), w_tr(h, 2, ks)};
@@ -1664,7 +1671,7 @@ __global__ __launch_bounds__(256) void heads_fused_small_kernel(HeadsArgs2 p) {
 #pragma unroll
         for (int j = 0; j < kZU; ++j) {
             const int row = rowmap(wave * kZU + j, hi);
-            const bool valid = (row < p.B) && gvalid;
+            const bool valid = (row0 + row < p.B) && gvalid;
             const float yj = yv[j];
             const bool nz = valid && (HAS_PI ? !(yj < kZeroThresh) : (yj != 0.f));
             const float sc = valid ? p.inv_n : 0.f;
@@ -1771,9 +1778,13 @@ __global__ __launch_bounds__(256) void heads_fused_small_kernel(HeadsArgs2 p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) thsum += St[TH_P * ST_PLANE + l31 * kLdS + rowmap(e, hi)];
             const float tv = thsum + __shfl_xor(thsum, 32, 64);
-            if (gvalid && hi == 0) {
-                const float ex = expf(p.theta_w[gene]);
-                p.g_theta[gene] = (ex >= 1e-3f && ex <= 1e4f) ? tv * ex : 0.f;
+            if (p.NT == 1) {
+                if (gvalid && hi == 0) {
+                    const float ex = expf(p.theta_w[gene]);
+                    p.g_theta[gene] = (ex >= 1e-3f && ex <= 1e4f) ? tv * ex : 0.f;
+                }
+            } else if (gene < p.plane && hi == 0) {      // several row tiles: the raw sum, chained by the dW reduce
+                p.ws_dw[(long)t * p.dw_stride + (long)(p.hL + 1) * p.ldws + gene] = tv;
             }
         }
     } else if (wave < NH) {
@@ -1800,23 +1811,26 @@ __global__ __launch_bounds__(256) void heads_fused_small_kernel(HeadsArgs2 p) {
                 float x[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
-                    x[j] = (rowmap(8 * ks + j, hi) < p.B && l31 + 32 * ib < p.hL) ? htx[ks][ib][j] : 0.f;
+                    x[j] = (row0 + rowmap(8 * ks + j, hi) < p.B && l31 + 32 * ib < p.hL) ? htx[ks][ib][j] : 0.f;
                 u32x4 af[3];
                 split8(x, af);
                 MFMA_BWD(af, bf, dW[ib])
             }
         }
         const bool cw = gene < p.plane;
+        // one row tile: straight to the gradient buffer; several: row tile t's partial, summed by the dW reduce launch
+        float* const out = p.NT == 1 ? p.gW : p.ws_dw + (long)t * p.dw_stride;
+        const long ldo = p.NT == 1 ? p.ldg : p.ldws;
 #pragma unroll
         for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int i = ib * 32 + rowmap(e, hi);
                 const float v = dW[ib][e];
-                if (cw && i < p.hL) p.gW[(long)i * p.ldg + (long)h * p.plane + gene] = v;
+                if (cw && i < p.hL) out[(long)i * ldo + (long)h * p.plane + gene] = v;
             }
         const float bv = bsum + __shfl_xor(bsum, 32, 64);
-        if (cw && hi == 0) p.gW[(long)p.hL * p.ldg + (long)h * p.plane + gene] = bv;
+        if (cw && hi == 0) out[(long)p.hL * ldo + (long)h * p.plane + gene] = bv;
     }
 
     // ---- loss: wave -> workgroup (wave order) -> one partial per tile
@@ -1824,7 +1838,7 @@ __global__ __launch_bounds__(256) void heads_fused_small_kernel(HeadsArgs2 p) {
     for (int off = 32; off > 0; off >>= 1) dacc += __shfl_down(dacc, off, 64);
     if (lane == 0) lred[wave] = dacc;
     __syncthreads();
-    if (tid == 0) p.partials[gb] = ((lred[0] + lred[1]) + lred[2]) + lred[3];
+    if (tid == 0) p.partials[blockIdx.x] = ((lred[0] + lred[1]) + lred[2]) + lred[3];
 }
 
 // C [32, 32] = A [32, K] B [K, 32] with the operand split and the six bf16 products of K-HEADS, one wave
@@ -1866,10 +1880,20 @@ extern "C" long dcahip_heads_fused_workspace_bytes(int B, int hL, int G, long pl
     long smax = kMaxGrid / p.ngb;
     if (smax > p.NT) smax = p.NT;
     if (smax < 1) smax = 1;
+    if (!use_f32_mfma()) {                           // the four-wave kernel keeps one weight-gradient partial per row tile (< 8)
+        const long nts = p.NT < kWR2 ? p.NT : kWR2 - 1;
+        if (smax < nts) smax = nts;
+    }
     long dh = p.dh_bytes;
     if (!use_f32_mfma()) {                           // smaller batches: fewer row tiles, possibly more (single-wave) workgroups
-        const long a = (long)p.NT * kCUs, b = 7L * 3 * kCUs > kMaxGrid ? 7L * 3 * kCUs : (long)kMaxGrid;
-        dh = (a > b ? a : b) * kTR * (p.HLB * 32) * (long)sizeof(float);
+        // partials (32 x 64 floats each) of every plan a batch of at most B rows can get: persistent 8-wave workgroups
+        // (row tiles x resident workgroups), persistent single-wave workgroups (< 8 row tiles, three per CU), the
+        // four-wave kernel (< 8 row tiles x one partial per gene tile)
+        const long nts = p.NT < kWR2 ? p.NT : kWR2 - 1;
+        const long a = (long)p.NT * kCUs, b = nts * 3 * kCUs, c = nts * p.ntg <= kMaxSmallGrid ? nts * p.ntg : (long)kMaxSmallGrid;
+        long m = a > b ? a : b;
+        if (c > m) m = c;
+        dh = m * kTR * (p.HLB * 32) * (long)sizeof(float);
         if (dh < p.dh_bytes) dh = p.dh_bytes;
     }
     return smax * p.dw_stride * (long)sizeof(float) + dh + p.hs_bytes;

@@ -319,7 +319,9 @@ int launch_nll_simple(const NllArgs& a, bool vec, dim3 grid, hipStream_t s) {
 }  // namespace
 
 extern "C" int dcahip_version(void) { return DCAHIP_VERSION; }
-extern "C" int dcahip_zinb_max_partials(void) { return kMaxPartials; }
+// size of the caller's loss-partial buffer: this file's kernels write at most kMaxPartials (their grid cap), the small-batch
+// K-HEADS kernel one per (gene tile, row tile) workgroup, up to 8192 (dcahip_heads.hip kMaxSmallGrid)
+extern "C" int dcahip_zinb_max_partials(void) { return 8192; }
 
 extern "C" int dcahip_zinb_nll(const float* a_mean, const float* a_disp, const float* a_pi, long lda,
                                const float* theta_w, const float* y, long ldy, const float* sf,
