@@ -57,3 +57,32 @@ def test_checkpoint_resume_is_bit_exact_on_the_gpu(tmp_path, ae_type, optimizer)
     if best == 4:
         for k in p5:
             np.testing.assert_array_equal(z[k], p5[k])
+
+
+def test_all_zero_gene_is_refused_before_anything_is_touched():
+    """api.py:163-164 ('Please remove all-zero genes before using DCA.') with the per-gene totals taken from the counts
+    resident in HBM (io.resident_counts): same assertion, and the caller's AnnData is still the raw counts."""
+    from dca_amd.api import dca
+    n, G = 200, 60
+    Y = synth_counts(n, G, 1).astype(np.float32)
+    Y[:, 17] = 0
+    ad = AnnData(Y.copy(), obs=pd.DataFrame(index=['c%d' % i for i in range(n)]),
+                 var=pd.DataFrame(index=['g%d' % i for i in range(G)]))
+    with pytest.raises(AssertionError, match='all-zero genes'):
+        dca(ad, epochs=1, verbose=False)
+    np.testing.assert_array_equal(ad.X, Y)
+
+
+def test_staged_upload_and_download_are_exact():
+    """prep._upload / _download of a matrix large enough for the page-locked staging path (>= 4 Mi elements; rows not a
+    multiple of the chunk, columns not a multiple of 4): bit-identical round trip, padding columns zero."""
+    import torch
+    from dca_amd import prep
+    n, G = 4500, 1003
+    X = np.random.RandomState(0).standard_normal((n, G)).astype(np.float32)
+    d = prep._upload(X, torch.device('cuda'))
+    assert tuple(d.shape) == (n, 1004) and float(d[:, G:].abs().max()) == 0.0
+    np.testing.assert_array_equal(d[:, :G].cpu().numpy(), X)
+    np.testing.assert_array_equal(prep._download(d, n, G), X)
+    Y, totals = prep.resident_counts(np.abs(np.round(X * 3)))
+    np.testing.assert_array_equal(totals, np.abs(np.round(X * 3)).sum(axis=0, dtype=np.float64))
