@@ -130,7 +130,7 @@ constexpr int kNzCap = 64 + 256;      // entries per wave: < 64 left over + up t
 struct NzEntry { float am, ad, ap, y, sf; unsigned dof; };
 
 template <bool HAS_PI, bool CONST_DISP, bool GRAD>
-__global__ __launch_bounds__(256) void zinb_nll_compact_kernel(NllArgs a) {
+__global__ __launch_bounds__(256, 4) void zinb_nll_compact_kernel(NllArgs a) {     // 4 waves per SIMD: 128 registers
     constexpr int V = 4;
     __shared__ NzEntry queue[4][kNzCap];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -171,8 +171,13 @@ __global__ __launch_bounds__(256) void zinb_nll_compact_kernel(NllArgs a) {
         const int g = (qv ? q : 0) * V;
         float vd[V] = {0.f, 0.f, 0.f, 0.f};
         if (CONST_DISP && qv) ldv<V>(a.theta_w + g, vd);
+        // storage row of the NEXT iteration requested one iteration ahead: perm -> (size factor, counts) is a chain of
+        // two memory round trips per row otherwise
+        long srow_n = a.perm ? (long)a.perm[cur + (blockIdx.y < a.B ? blockIdx.y : 0)] : (long)(cur + blockIdx.y);
         for (int row = blockIdx.y; row < a.B; row += gridDim.y) {
-            const long srow = a.perm ? (long)a.perm[cur + row] : (long)(cur + row);
+            const long srow = srow_n;
+            const int rown = row + gridDim.y < a.B ? row + gridDim.y : row;
+            srow_n = a.perm ? (long)a.perm[cur + rown] : (long)(cur + rown);
             const float sf = a.sf[srow];
             const long ao = (long)row * a.lda + g;
             const long dof = (long)row * a.ldd + g;
