@@ -307,7 +307,7 @@ class Engine:
         self.ws_heads = None
         self._pending = None        # in-flight all-reduce of the heads bucket (data parallel)
         self.W0T = None             # transposed first-layer kernel (throughput batches)
-        self.WhT = self.HT = self.XT = None     # wide networks: transposed head weights / last activations / minibatch
+        self.WhT = self.HT = self.XT = self.dZT = None     # wide networks: transposed head weights / last activations / minibatch / dZ0
         self.opt_kind = 'rmsprop'   # train.py:54-57 picks the Keras optimizer by name
         self.slot2 = None
         self.m_sched = None         # Nadam: running product of the momentum schedule
@@ -595,7 +595,7 @@ class Engine:
                 need = max(need, ops.sgemm_workspace_bytes(0, 1, b, lay.hL, nc))
         nb = ops.heads_fused_workspace_bytes(B, lay.hidden[-1], lay.G_out, lay.Gp, self.flags) if self.use_fused else 0
         self.ws_heads = torch.zeros(nb // 4, **f32) if nb > 0 else None
-        self.W0T = self.WhT = self.HT = self.XT = None
+        self.W0T = self.WhT = self.HT = self.XT = self.dZT = None
         if hasattr(ops, 'transpose') and B >= 256:
             self.W0T = torch.zeros(lay.hidden[0], _r4(lay.G_in), **f32)
             for b in cand:
@@ -610,12 +610,13 @@ class Engine:
                 self.HT = torch.zeros(hin, self.ldb_t, **f32)
                 if lay.hidden[0] >= 128:
                     self.XT = torch.zeros(lay.G_in, self.ldb_t, **f32)
+                    self.dZT = torch.zeros(lay.hidden[0], self.ldb_t, **f32)
                 for b in cand:
                     for _c0, nc, _h0 in self._head_blocks():
                         need = max(need, ops.sgemm_workspace_bytes(0, 1, b, nc, lay.hL))
                         need = max(need, ops.sgemm_workspace_bytes(0, 0, lay.hL, nc, b, True))
                     if self.XT is not None:
-                        need = max(need, ops.sgemm_workspace_bytes(0, 0, lay.G_in, lay.hidden[0], b, True))
+                        need = max(need, ops.sgemm_workspace_bytes(0, 1, lay.G_in, lay.hidden[0], b))
         self.ws = torch.zeros(max(need // 4, 4), **f32)
 
     # ------------------------------------------------------------------ forward pieces
@@ -960,9 +961,12 @@ class Engine:
                         ops.sgemm(1, 0, Kp, h, B, self.Xb, self.ldx, self.dZ[0], self.ldh[0], gW, h,
                                   colsum_row=True, ws=self.ws)
                     elif self.XT is not None and B >= 256:
+                        # X^T dZ with BOTH operands contiguous along the batch (the fastest operand path of K-GEMM): the
+                        # gathered minibatch and the (small) dZ transposed; the bias gradient = row sums of dZ^T
                         ops.transpose(self.X, self.ldx, B, Kp, self.XT, self.ldb_t, perm=self.perm, cursor=self.cursor)
-                        ops.sgemm(0, 0, Kp, h, B, self.XT, self.ldb_t, self.dZ[0], self.ldh[0], gW, h,
-                                  colsum_row=True, ws=self.ws)
+                        ops.transpose(self.dZ[0], self.ldh[0], B, h, self.dZT, self.ldb_t)
+                        ops.sgemm(0, 1, Kp, h, B, self.XT, self.ldb_t, self.dZT, self.ldb_t, gW, h, ws=self.ws)
+                        ops.row_sums_strided(self.dZT, self.ldb_t, h, B, lay.view(g, 'b0'), 1)
                     else:
                         ops.sgemm(1, 0, Kp, h, B, self.X, self.ldx, self.dZ[0], self.ldh[0], gW, h,
                                   perm=self.perm, cursor=self.cursor, colsum_row=True, ws=self.ws)
