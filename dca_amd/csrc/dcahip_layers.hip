@@ -904,6 +904,46 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
     }
 }
 
+// the same through 64 x 64 tiles with 16-byte accesses on both sides (aligned operands, leading dimensions multiples of 4)
+__global__ __launch_bounds__(256) void transpose64_kernel(const float* __restrict__ src, long lds_, int R, int C,
+                                                          float* __restrict__ dst, long ldd,
+                                                          const int* __restrict__ perm, const long long* __restrict__ cursor) {
+    __shared__ float tile[64][65];
+    const int tq = threadIdx.x & 15, tr = threadIdx.x >> 4;           // 16 quads across, 16 rows per pass
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const long long cur = (perm && cursor) ? *cursor : 0;
+    float4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                                     // all four loads in flight (clamped addresses)
+        const int r = r0 + tr + 16 * k, c = c0 + 4 * tq;
+        const int rc = r < R ? r : R - 1;
+        const long sr = perm ? (long)perm[cur + rc] : (long)rc;
+        // c is a multiple of 4 and the leading dimension too: the quad at c < C lies inside the row's storage (its tail may
+        // be padding, which lands in tile columns that are never written out)
+        v[k] = *reinterpret_cast<const float4*>(src + sr * lds_ + (c < C ? c : 0));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = tr + 16 * k, c = 4 * tq;
+        tile[r][c] = v[k].x; tile[r][c + 1] = v[k].y; tile[r][c + 2] = v[k].z; tile[r][c + 3] = v[k].w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = tr + 16 * k, r = 4 * tq;                        // output row c0 + c, source rows r0 + r .. + 3
+        if (c0 + c < C) {
+            const float4 o = make_float4(tile[r][c], tile[r + 1][c], tile[r + 2][c], tile[r + 3][c]);
+            float* d = dst + (long)(c0 + c) * ldd + r0 + r;
+            if (r0 + r + 4 <= R) *reinterpret_cast<float4*>(d) = o;
+            else {
+                if (r0 + r < R) d[0] = o.x;
+                if (r0 + r + 1 < R) d[1] = o.y;
+                if (r0 + r + 2 < R) d[2] = o.z;
+            }
+        }
+    }
+}
+
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -911,8 +951,12 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 extern "C" int dcahip_transpose_rows(const float* src, long ld_src, const int* perm, const long long* cursor, int R, int C,
                                      float* dst, long ld_dst, void* stream) {
     if (!src || !dst || R <= 0 || C <= 0 || ld_src < C || ld_dst < R) return DCAHIP_EINVAL;
-    hipLaunchKernelGGL(transpose_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), src, ld_src, R, C, dst, ld_dst, perm, cursor);
+    if (R >= 64 && C >= 64 && al16(src) && al16(dst) && ld_src % 4 == 0 && ld_dst % 4 == 0)
+        hipLaunchKernelGGL(transpose64_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), src, ld_src, R, C, dst, ld_dst, perm, cursor);
+    else
+        hipLaunchKernelGGL(transpose_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), src, ld_src, R, C, dst, ld_dst, perm, cursor);
     return (int)hipGetLastError();
 }
 

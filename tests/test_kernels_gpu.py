@@ -281,7 +281,7 @@ def test_sgemm_vs_numpy(ops, ta, tb, M, N, K, gather, bias, colsum, split):
     assert (out[Mo:, :] == 123.0).all() and (out[:, N:] == 123.0).all()
 
 
-@pytest.mark.parametrize('R,C,gather', [(1, 1, False), (37, 203, True), (300, 64, False), (2048, 1000, True)])
+@pytest.mark.parametrize('R,C,gather', [(1, 1, False), (37, 203, True), (300, 64, False), (2048, 1000, True), (130, 203, True), (67, 64, False)])
 def test_transpose_rows(ops, R, C, gather):
     rng = np.random.RandomState(R + C)
     n_store = R + 7 if gather else R
