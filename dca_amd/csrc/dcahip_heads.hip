@@ -1305,12 +1305,27 @@ __global__ __launch_bounds__(256) void heads_reduce_dw_kernel(const float* ws, i
                                                               float* gW, long ldg,
                                                               const float* theta_w, float* g_theta,
                                                               int G) {
-    const long total = (long)(hL + 1) * ncols;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const long i = idx / ncols, c = idx - i * ncols;
-        float v = 0.f;
-        for (int s = 0; s < S; ++s) v += ws[(long)s * stride + i * ldws + c];
-        gW[i * ldg + c] = v;
+    if ((ncols & 3) == 0 && (ldws & 3) == 0 && (ldg & 3) == 0 && (stride & 3) == 0 &&
+        ((reinterpret_cast<uintptr_t>(ws) | reinterpret_cast<uintptr_t>(gW)) & 15) == 0) {
+        // 16 bytes per lane (the plane width is a multiple of 4); partial s is added in order s = 0, 1, ..
+        const long nq = ncols >> 2, totalq = (long)(hL + 1) * nq;
+        for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < totalq; idx += (long)gridDim.x * 256) {
+            const long i = idx / nq, c = (idx - i * nq) << 2;
+            float4 v = *reinterpret_cast<const float4*>(ws + i * ldws + c);
+            for (int s = 1; s < S; ++s) {
+                const float4 x = *reinterpret_cast<const float4*>(ws + (long)s * stride + i * ldws + c);
+                v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+            }
+            *reinterpret_cast<float4*>(gW + i * ldg + c) = v;
+        }
+    } else {
+        const long total = (long)(hL + 1) * ncols;
+        for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+            const long i = idx / ncols, c = idx - i * ncols;
+            float v = 0.f;
+            for (int s = 0; s < S; ++s) v += ws[(long)s * stride + i * ldws + c];
+            gW[i * ldg + c] = v;
+        }
     }
     if (g_theta) {
         for (long c = (long)blockIdx.x * 256 + threadIdx.x; c < G; c += (long)gridDim.x * 256) {
