@@ -21,7 +21,7 @@ SOURCES = ['dcahip_zinb.hip', 'dcahip_gemm.hip', 'dcahip_layers.hip', 'dcahip_he
 HEADERS = ['zinb_math.hpp']
 ARCH = 'gfx950'
 HOST_LIB = os.path.join(CSRC, 'libdcahost.so')
-HOST_SOURCES = ['dcahost_tsv.cpp']
+HOST_SOURCES = ['dcahost_tsv.cpp', 'dcahost_read.cpp']
 
 
 def _hipcc():

@@ -19,6 +19,12 @@ _SIGNATURES = {
     'dcahost_format_f32': (ctypes.c_long, [ctypes.c_void_p, ctypes.c_long, ctypes.c_char_p, ctypes.c_long]),
     'dcahost_format_f64': (ctypes.c_long, [ctypes.c_void_p, ctypes.c_long, ctypes.c_char_p, ctypes.c_long]),
     'dcahost_parallel_copy': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_int]),
+    'dcahost_tsv_open': (ctypes.c_int, [ctypes.c_char_p, ctypes.c_char, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p),
+                                        ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long),
+                                        ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long)]),
+    'dcahost_tsv_read_f32': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_char_p, ctypes.c_long,
+                                            ctypes.c_char_p, ctypes.c_long]),
+    'dcahost_tsv_close': (None, [ctypes.c_void_p]),
 }
 
 
@@ -91,3 +97,30 @@ def parallel_copy(dst, src, threads=0):
     rc = lib().dcahost_parallel_copy(dst.ctypes.data, src.ctypes.data, dst.nbytes, threads)
     if rc != 0:
         raise RuntimeError('dcahost_parallel_copy failed (%d)' % rc)
+
+
+def read_tsv(path, sep='\t', threads=0):
+    """Numeric text matrix with a header line and a name column -> (float32 [n, g] array, row names, column names), parsed
+    on several host threads; None when the file holds something the native reader leaves to pandas (quoted fields,
+    ragged lines, text in a numeric column) or cannot be opened."""
+    L = lib()
+    h = ctypes.c_void_p()
+    n, g, rb, cb = ctypes.c_long(), ctypes.c_long(), ctypes.c_long(), ctypes.c_long()
+    rc = L.dcahost_tsv_open(os.fsencode(path), sep.encode('ascii'), int(threads), ctypes.byref(h), ctypes.byref(n),
+                            ctypes.byref(g), ctypes.byref(rb), ctypes.byref(cb))
+    if rc != 0:
+        return None
+    try:
+        out = np.empty((n.value, g.value), dtype=np.float32)
+        rbuf = ctypes.create_string_buffer(rb.value + 2)
+        cbuf = ctypes.create_string_buffer(cb.value + 2)
+        rc = L.dcahost_tsv_read_f32(h, out.ctypes.data, g.value, rbuf, rb.value + 2, cbuf, cb.value + 2)
+        if rc != 0:
+            return None
+        rows = rbuf.value.decode('utf-8').split('\n') if n.value else []
+        cols = cbuf.value.decode('utf-8').split('\n')
+        if len(rows) != n.value or len(cols) != g.value:
+            return None
+        return out, rows, cols
+    finally:
+        L.dcahost_tsv_close(h)

@@ -116,10 +116,37 @@ def scale(adata):
 def read_text(filename, first_column_names=True):
     """Stand-in for sc.read(path, first_column_names=True) on TSV/CSV (io.py:59)."""
     sep = ',' if filename.endswith('.csv') else '\t'
+    if first_column_names and os.environ.get('DCA_AMD_NATIVE_READ', '1') != '0':
+        native = _read_text_native(filename, sep)
+        if native is not None:
+            return native
     df = pd.read_csv(filename, sep=sep, index_col=0 if first_column_names else None)
     return AnnData(df.values.astype(np.float32),
                    obs=pd.DataFrame(index=df.index.astype(str)),
                    var=pd.DataFrame(index=df.columns.astype(str)))
+
+
+def _read_text_native(filename, sep):
+    """The plain numeric matrices DCA is fed, parsed on all host cores (include/dcahost.h dcahost_tsv_*; pandas reads
+    them on one).  Returns None -- the caller then takes the pandas route -- for anything whose pandas semantics the
+    native reader does not reproduce: quoted fields, ragged or non-numeric lines, duplicated or empty column labels."""
+    import io as _pyio
+    try:
+        from . import hostlib
+        got = hostlib.read_tsv(filename, sep)
+    except Exception:
+        return None
+    if got is None:
+        return None
+    X, rows, cols = got
+    if len(set(cols)) != len(cols) or any(c == '' for c in cols):
+        return None             # pandas renames these ('x.1', 'Unnamed: 3')
+    # the name column goes through pandas' own type inference ('007' is the integer 7 to read_csv, an empty name NaN)
+    idx = pd.read_csv(_pyio.StringIO('\n'.join(rows) + '\n'), sep=sep, header=None, usecols=[0], skip_blank_lines=False,
+                      dtype=None)[0] if rows else pd.Series([], dtype=object)
+    if len(idx) != len(rows):
+        return None
+    return AnnData(X, obs=pd.DataFrame(index=pd.Index(idx.values).astype(str)), var=pd.DataFrame(index=pd.Index(cols).astype(str)))
 
 
 def read_dataset(adata, transpose=False, test_split=False, copy=False, check_counts=True):

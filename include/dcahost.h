@@ -26,6 +26,7 @@ extern "C" {
 #define DCAHOST_OK 0
 #define DCAHOST_EINVAL (-1)
 #define DCAHOST_EIO (-2)
+#define DCAHOST_EUNSUPPORTED (-3)   /* the reader meets something it leaves to pandas (quotes, ragged lines, text) */
 
 /* Matrix element (r, c) of the OUTPUT is data[r * row_stride + c * col_stride] (strides in
  * elements), so transpose=True of the reference is row_stride = 1, col_stride = ld of the stored
@@ -50,6 +51,21 @@ long dcahost_format_f64(const double* v, long n, char* out, long cap);
 /* memcpy on nthreads threads (<= 0: one per hardware thread, at most 32), page-aligned shares: moves the result
  * matrices of predict() from the pinned staging buffers into the caller's arrays (dca/network.py:188-211, 395-405). */
 int dcahost_parallel_copy(void* dst, const void* src, long nbytes, int nthreads);
+
+/* The count matrix of `dca <input> <outdir>` read natively (dca/io.py:59: sc.read(filename, first_column_names=True),
+ * restated as pandas.read_csv(sep, index_col=0).values.astype(float32)): one header line of column names (with or
+ * without a label for the name column), then one name + ncols numbers per line; '\n' or '\r\n' line ends, blank
+ * lines skipped, empty field / NA spellings = NaN.  The file is mapped and parsed by a pool of threads (nthreads <= 0:
+ * one per hardware thread, at most 64, at least 4 MB of text each).
+ *   dcahost_tsv_open  : maps and indexes the file; shape and the byte sizes the name buffers need.
+ *   dcahost_tsv_read_f32 : values -> out[row * ld + col]; row / column names '\n'-joined, NUL-terminated.
+ *   dcahost_tsv_close : unmaps.
+ * DCAHOST_EUNSUPPORTED: quoted fields, ragged lines or a field that is not a number -- the caller falls back to pandas. */
+int dcahost_tsv_open(const char* path, char sep, int nthreads, void** handle, long* nrows, long* ncols,
+                     long* rowname_bytes, long* colname_bytes);
+int dcahost_tsv_read_f32(void* handle, float* out, long ld, char* rownames, long rowname_cap,
+                         char* colnames, long colname_cap);
+void dcahost_tsv_close(void* handle);
 
 #ifdef __cplusplus
 }
