@@ -1444,7 +1444,11 @@ bool make_heads_plan(int B, int hL, int G, long plane, int flags, HeadsPlan* out
     p.ntg = (G + kTG - 1) / kTG;
     p.ngb = (p.ntg + wg_tiles - 1) / wg_tiles;
     if (p.ngb > kMaxGrid) return false;
-    p.WR = f32 ? (p.NT >= 4 ? 4 : 1) : (p.NT >= kWR2 ? kWR2 : 1);
+    // the 8-wave persistent kernel from 5 row tiles on (waves beyond the batch idle): measured against the four-wave kernel
+    // at G = 20 000: B = 128 0.088 / 0.086 ms (kept on the four-wave kernel), 160: 0.100 / 0.104, 192: 0.103 / 0.121,
+    // 224: 0.107 / 0.142 (profiles/r02z_heads_kernel_switch.txt)
+    static const int wr8_min_nt = [] { const char* e = getenv("DCA_HEADS_WR8_MIN_NT"); return e ? atoi(e) : 5; }();
+    p.WR = f32 ? (p.NT >= 4 ? 4 : 1) : (p.NT >= wr8_min_nt ? kWR2 : 1);
     const int smax = (p.NT + p.WR - 1) / p.WR;
     double best = 1e300;
     p.S = 1;
@@ -1458,7 +1462,7 @@ bool make_heads_plan(int B, int hL, int G, long plane, int flags, HeadsPlan* out
     p.nitems = p.S * p.ngb;
     p.grid = p.nitems;
     p.npart = p.ntg;
-    p.small = !f32 && p.NT < kWR2 && (long)p.ntg * p.NT <= kMaxSmallGrid && use_small_kernel();
+    p.small = !f32 && p.WR == 1 && (long)p.ntg * p.NT <= kMaxSmallGrid && use_small_kernel();
     if (p.small) {                                   // one workgroup per (gene tile, row tile): S = NT weight-gradient partials
         p.S = p.NT;
         p.nitems = p.NT * p.ntg;
