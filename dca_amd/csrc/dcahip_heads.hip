@@ -1300,16 +1300,22 @@ __global__ __launch_bounds__(64 * WR) void heads_fused_x3_kernel(HeadsArgs2 p) {
 
 // gW[i, col] = sum_s ws[s][i][col], i = 0..hL (row hL = bias gradient), then the
 // ConstantDispersionLayer chain (dca/layers.py:17-21) on the per-gene theta sums.
-__global__ __launch_bounds__(256) void heads_reduce_dw_kernel(const float* ws, int S, long stride,
-                                                              int hL, long ldws, long ncols,
-                                                              float* gW, long ldg,
-                                                              const float* theta_w, float* g_theta,
-                                                              int G) {
+struct ReduceDwArgs {
+    const float* ws; int S; long stride; int hL; long ldws, ncols; float* gW; long ldg;
+    const float* theta_w; float* g_theta; int G;
+};
+
+// bid / nblk: this workgroup's index among the nblk that share the reduction (the stand-alone kernel: blockIdx / gridDim;
+// the combined launch below: the workgroups behind those of the dH reduction)
+__device__ __forceinline__ void reduce_dw_body(const ReduceDwArgs& q, int bid, int nblk) {
+    const float* ws = q.ws; const int S = q.S; const long stride = q.stride; const int hL = q.hL;
+    const long ldws = q.ldws, ncols = q.ncols; float* gW = q.gW; const long ldg = q.ldg;
+    const float* theta_w = q.theta_w; float* g_theta = q.g_theta; const int G = q.G;
     if ((ncols & 3) == 0 && (ldws & 3) == 0 && (ldg & 3) == 0 && (stride & 3) == 0 &&
         ((reinterpret_cast<uintptr_t>(ws) | reinterpret_cast<uintptr_t>(gW)) & 15) == 0) {
         // 16 bytes per lane (the plane width is a multiple of 4); partial s is added in order s = 0, 1, ..
         const long nq = ncols >> 2, totalq = (long)(hL + 1) * nq;
-        for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < totalq; idx += (long)gridDim.x * 256) {
+        for (long idx = (long)bid * 256 + threadIdx.x; idx < totalq; idx += (long)nblk * 256) {
             const long i = idx / nq, c = (idx - i * nq) << 2;
             float4 v = *reinterpret_cast<const float4*>(ws + i * ldws + c);
             for (int s = 1; s < S; ++s) {
@@ -1320,7 +1326,7 @@ __global__ __launch_bounds__(256) void heads_reduce_dw_kernel(const float* ws, i
         }
     } else {
         const long total = (long)(hL + 1) * ncols;
-        for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        for (long idx = (long)bid * 256 + threadIdx.x; idx < total; idx += (long)nblk * 256) {
             const long i = idx / ncols, c = idx - i * ncols;
             float v = 0.f;
             for (int s = 0; s < S; ++s) v += ws[(long)s * stride + i * ldws + c];
@@ -1328,7 +1334,7 @@ __global__ __launch_bounds__(256) void heads_reduce_dw_kernel(const float* ws, i
         }
     }
     if (g_theta) {
-        for (long c = (long)blockIdx.x * 256 + threadIdx.x; c < G; c += (long)gridDim.x * 256) {
+        for (long c = (long)bid * 256 + threadIdx.x; c < G; c += (long)nblk * 256) {
             float v = 0.f;
             for (int s = 0; s < S; ++s) v += ws[(long)s * stride + (long)(hL + 1) * ldws + c];
             const float e = expf(theta_w[c]);
@@ -1337,19 +1343,26 @@ __global__ __launch_bounds__(256) void heads_reduce_dw_kernel(const float* ws, i
     }
 }
 
+__global__ __launch_bounds__(256) void heads_reduce_dw_kernel(ReduceDwArgs q) { reduce_dw_body(q, blockIdx.x, gridDim.x); }
+
 // dH[row, i] = sum over gene tiles of ws[row tile][gt][row % 32][i]; GL threads split the gene tiles of
 // one output quad, combined in fixed order through LDS.
+struct ReduceDhArgs {
+    const float* ws; int ntg, B, Bpad, KT, hL; float* dH; long lddh;
+    const double* loss_partials; int n_partials; double loss_scale; float* loss_out;
+};
+
 template <int GL>
-__global__ __launch_bounds__(256) void heads_reduce_dh_kernel(const float* ws, int ntg, int B, int Bpad,
-                                                              int KT, int hL, float* dH, long lddh,
-                                                              const double* loss_partials, int n_partials,
-                                                              double loss_scale, float* loss_out) {
+__device__ __forceinline__ void reduce_dh_body(const ReduceDhArgs& q, int bid) {
+    const float* ws = q.ws; const int ntg = q.ntg, B = q.B, KT = q.KT, hL = q.hL; float* dH = q.dH; const long lddh = q.lddh;
+    const double* loss_partials = q.loss_partials; const int n_partials = q.n_partials; const double loss_scale = q.loss_scale;
+    float* loss_out = q.loss_out;
     constexpr int OUT = 256 / GL;
     __shared__ float4 red[256];
     const int o = threadIdx.x % OUT, gl = threadIdx.x / OUT;
     const int q4 = KT / 4;
     const long nq = (long)B * q4;
-    const long quad = (long)blockIdx.x * OUT + o;
+    const long quad = (long)bid * OUT + o;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (quad < nq) {
         const long tq = (long)kTR * q4;                      // quads of one (row tile, gene tile) partial
@@ -1386,7 +1399,7 @@ __global__ __launch_bounds__(256) void heads_reduce_dh_kernel(const float* ws, i
     }
     // optionally the work of dcahip_loss_finalize on this launch (block 0): batch loss = scale * sum of the workgroup
     // partials, nan -> inf (dca/loss.py:146-148)
-    if (loss_out && blockIdx.x == 0) {
+    if (loss_out && bid == 0) {
         __shared__ double lsum[256];
         double a = 0.0;
         for (int i = threadIdx.x; i < n_partials; i += 256) a += loss_partials[i];
@@ -1402,6 +1415,17 @@ __global__ __launch_bounds__(256) void heads_reduce_dh_kernel(const float* ws, i
             *loss_out = lf;
         }
     }
+}
+
+template <int GL>
+__global__ __launch_bounds__(256) void heads_reduce_dh_kernel(ReduceDhArgs q) { reduce_dh_body<GL>(q, blockIdx.x); }
+
+// Both reductions of a launch with several batch splits in ONE kernel: the first n_dh workgroups reduce the input-gradient
+// partials, the others the weight-gradient partials -- they run side by side instead of one after the other.
+template <int GL>
+__global__ __launch_bounds__(256) void heads_reduce_both_kernel(ReduceDhArgs qh, ReduceDwArgs qw, int n_dh) {
+    if ((int)blockIdx.x < n_dh) reduce_dh_body<GL>(qh, blockIdx.x);
+    else reduce_dw_body(qw, blockIdx.x - n_dh, gridDim.x - n_dh);
 }
 
 struct HeadsPlan {
@@ -2023,28 +2047,27 @@ extern "C" int dcahip_heads_fused_loss(const float* H, long ldh, const float* Wh
     int rc = (int)hipGetLastError();
     if (rc != 0) return rc;
     if (n_partials_out) *n_partials_out = pl.grid;
-    if (!direct_dw) {
-        const long total = (long)(hL + 1) * pl.ldws;
-        long gr = (total + 255) / 256;
-        if (gr > 2048) gr = 2048;
-        hipLaunchKernelGGL(heads_reduce_dw_kernel, dim3((int)gr), dim3(256), 0, s, ws_dw, pl.S,
-                           pl.dw_stride, hL, pl.ldws, pl.ldws, gW, ldg, cdisp ? theta_w : nullptr,
-                           cdisp ? g_theta : nullptr, G);
-        rc = (int)hipGetLastError();
-        if (rc != 0) return rc;
-    }
     {
         const int KT = pl.HLB * 32;
         const long nq = (long)B * (KT / 4);
-        if (nq <= 1024 && pl.npart >= 256) {             // one or two row tiles: many partials per output, few outputs
-            hipLaunchKernelGGL(heads_reduce_dh_kernel<64>, dim3((int)((nq + 3) / 4)), dim3(256), 0, s,
-                               ws_dh, pl.npart, B, pl.NT * kTR, KT, hL, dH, lddh, loss_partials, pl.grid, (double)inv_n, loss_out);
-        } else if (nq >= 64L * 512) {
-            hipLaunchKernelGGL(heads_reduce_dh_kernel<4>, dim3((int)((nq + 63) / 64)), dim3(256), 0, s,
-                               ws_dh, pl.npart, B, pl.NT * kTR, KT, hL, dH, lddh, loss_partials, pl.grid, (double)inv_n, loss_out);
+        const ReduceDhArgs qh{ws_dh, pl.npart, B, pl.NT * kTR, KT, hL, dH, lddh, loss_partials, pl.grid, (double)inv_n, loss_out};
+        const long total = (long)(hL + 1) * pl.ldws;
+        long gr = (total / 4 + 255) / 256;                  // the weight-gradient reduction moves 16 bytes per lane
+        if (gr > 2048) gr = 2048;
+        if (gr < 1) gr = 1;
+        const ReduceDwArgs qw{ws_dw, pl.S, pl.dw_stride, hL, pl.ldws, pl.ldws, gW, ldg, cdisp ? theta_w : nullptr,
+                              cdisp ? g_theta : nullptr, G};
+        const int gl = (nq <= 1024 && pl.npart >= 256) ? 64 : (nq >= 64L * 512 ? 4 : 16);
+        const int n_dh = (int)((nq + 256 / gl - 1) / (256 / gl));
+        if (!direct_dw) {
+            const dim3 grid(n_dh + (int)gr);
+            if (gl == 64) hipLaunchKernelGGL(heads_reduce_both_kernel<64>, grid, dim3(256), 0, s, qh, qw, n_dh);
+            else if (gl == 4) hipLaunchKernelGGL(heads_reduce_both_kernel<4>, grid, dim3(256), 0, s, qh, qw, n_dh);
+            else hipLaunchKernelGGL(heads_reduce_both_kernel<16>, grid, dim3(256), 0, s, qh, qw, n_dh);
         } else {
-            hipLaunchKernelGGL(heads_reduce_dh_kernel<16>, dim3((int)((nq + 15) / 16)), dim3(256), 0, s,
-                               ws_dh, pl.npart, B, pl.NT * kTR, KT, hL, dH, lddh, loss_partials, pl.grid, (double)inv_n, loss_out);
+            if (gl == 64) hipLaunchKernelGGL(heads_reduce_dh_kernel<64>, dim3(n_dh), dim3(256), 0, s, qh);
+            else if (gl == 4) hipLaunchKernelGGL(heads_reduce_dh_kernel<4>, dim3(n_dh), dim3(256), 0, s, qh);
+            else hipLaunchKernelGGL(heads_reduce_dh_kernel<16>, dim3(n_dh), dim3(256), 0, s, qh);
         }
         rc = (int)hipGetLastError();
     }
