@@ -2,7 +2,6 @@
 (dca/__main__.py:23-24, dca/train.py:105-176).  python tools/bench_cli.py [cells] [genes] [epochs]
 Phases are timed by wrapping the functions the CLI calls (no change to them)."""
 import os, sys, time, shutil, tempfile
-import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
@@ -27,8 +26,6 @@ def timed(name, fn):
 dio.read_text = timed('read the text matrix', dio.read_text)
 dio.normalize = timed('normalize (upload, K-PREP, download)', dio.normalize)
 T.train = timed('train', T.train)
-for cls in set(NW.AE_types.values()):
-    pass
 NW.Autoencoder.predict = timed('predict', NW.Autoencoder.predict)
 NW.write_text_matrix = timed('write the result files', NW.write_text_matrix)
 from dca_amd.__main__ import main
