@@ -245,10 +245,11 @@ def main():
     counts = prep.cell_counts(pops, Y, n_store, G)
     med = (comm.all_gather(counts).flatten() if W > 1 else counts).median()
     sf = counts / med
-    X = prep.transform(pops, Y, n_store, G, sf, True, True, comm if W > 1 else None)
+    X, norm = prep.transform(pops, Y, n_store, G, sf, True, True, comm if W > 1 else None, return_norm=True)
     eng = Engine('zinb-conddisp', G, G, hidden, True, 0.0, comm=comm)
     eng.init_params(0)
-    eng.attach_device_data(X, Y, sf)
+    # norm: how X was made from Y -> the engine keeps the counts as bytes and runs the first layer on the non-zero ones
+    eng.attach_device_data(X, Y, sf, norm=norm)
     eng.reserve(max(B, 1024) if W == 1 else B)           # validation runs in chunks of up to 1024 rows
     eng.clip = 5.0
     eng.set_lr(1e-3)

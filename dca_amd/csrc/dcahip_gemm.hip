@@ -585,16 +585,18 @@ Plan make_plan(int M, int N, int K, int split_k) {
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-// DCA_GEMM_F32MFMA=1: the exact-fp32 MFMA kernel (A/B runs and the yardstick of the accuracy test)
-inline bool use_f32_mfma() {
-    static const bool v = [] { const char* e = getenv("DCA_GEMM_F32MFMA"); return e && e[0] == '1'; }();
-    return v;
-}
-
-inline bool force_x3() {            // DCA_GEMM_X3=1: split-bf16 kernel for every layout (A/B runs)
-    static const bool v = [] { const char* e = getenv("DCA_GEMM_X3"); return e && e[0] == '1'; }();
-    return v;
-}
+// A/B builds only (hipcc -DDCA_GEMM_F32MFMA / -DDCA_GEMM_X3): the exact-fp32 MFMA kernel / the split-bf16 kernel for every
+// layout.  The shipped library has no run-time switches: the choice is a pure function of layout and shape.
+#ifdef DCA_GEMM_F32MFMA
+constexpr bool use_f32_mfma() { return true; }
+#else
+constexpr bool use_f32_mfma() { return false; }
+#endif
+#ifdef DCA_GEMM_X3
+constexpr bool force_x3() { return true; }
+#else
+constexpr bool force_x3() { return false; }
+#endif
 
 template <int BM, int BN, int WGM, int WGN>
 int launch_cfg(const GemmArgs& a, int ta, int tb, bool vec, int grid, hipStream_t s, bool exact) {

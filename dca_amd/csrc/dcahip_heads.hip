@@ -37,7 +37,6 @@
 //   * deterministic: fixed summation orders everywhere (no atomics).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 #include <type_traits>
 #include "dcahip.h"
 #include "zinb_math.hpp"
@@ -57,38 +56,11 @@ constexpr int kZU = 4;        // staged rows per Z group (two groups per loop it
 constexpr int kQCap = 320;     // non-zero queue entries per wave (< 64 left over + 4 x 64 pushed)
 constexpr int kLdH = 65;       // row stride of the H tile parked in the staging buffer
 
-#ifdef DCA_EXP_NOMFMA
-#define MFMA(a, b, c) (c)
-#else
-#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0)
-#endif
-
 #ifdef DCA_HEADS_TIMING
 #define TSTAMP(i) { const long long now_ = __builtin_readcyclecounter(); tacc[i] += now_ - tlast; tlast = now_; }
 #else
 #define TSTAMP(i)
 #endif
-
-struct HeadsArgs {
-    long long* timing;                // debug builds only: per-wave phase cycle sums
-    const float* H;  long ldh;
-    const float* Wh; long ldw;
-    const float* bh;
-    const float* theta_w;
-    const float* y;  long ldy;
-    const float* sf;
-    const int* perm;
-    const long long* cursor;
-    float* ws_dw;  long dw_stride;   // [S][(hL + 2)][ldws]
-    float* ws_dh;                     // [NT][ntg][32][KT]: the partials of one row tile are contiguous
-    int ntg;
-    const int* tile_order;            // gene tiles in the order workgroups take them (kWG consecutive entries each), or NULL
-    double* partials;
-    long plane, ldws;
-    int B, hL, G;
-    int S, NT;
-    float ridge, inv_n;
-};
 
 __device__ __forceinline__ int rowmap(int e, int hi) { return (e & 3) + 8 * (e >> 2) + 4 * hi; }
 
@@ -96,513 +68,6 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// FULLK: hL == 32 * HLB exactly and H rows densely packed (ldh == hL; the default 64-wide decoder): no k /
-// hidden-unit guards at all and a compile-time row stride (H loads are one base + immediate offsets), which
-// also keeps dozens of loop-invariant clamped offsets, address pairs and predicates out of the register file.
-template <bool HAS_PI, bool CONST_DISP, int HLB, int WR, bool FULLK>
-__global__ __launch_bounds__(64 * kWG * WR) void heads_fused_kernel(HeadsArgs p) {
-    constexpr int NH = 1 + (CONST_DISP ? 0 : 1) + (HAS_PI ? 1 : 0);
-    constexpr int PI_H = NH - 1;                 // plane of the pi head (when present)
-    constexpr int KT = HLB * 32;                 // padded hidden width
-    constexpr int KH = HLB * 16;                 // k per half-wave in the forward
-    constexpr int WS_TILE = NH * KT * kLdS;      // floats of one gene tile's weights
-    constexpr int ST_PLANE = kTG * kLdS;
-    constexpr int NP = NH + (CONST_DISP ? 1 : 0);  // staging planes (+ d nll / d theta for const-disp)
-    constexpr int TH_P = NH;                        // that extra plane
-    constexpr int ST_WAVE = NP * ST_PLANE > kTR * kLdH ? NP * ST_PLANE : kTR * kLdH;
-    constexpr int NTHREADS = 64 * kWG * WR;
-    constexpr int NRED = NH * HLB * 16 + NH + 1; // registers a wave hands over in the dW reduce
-    constexpr int LDS_FLOATS = kWG * WS_TILE + kWG * WR * (ST_WAVE + kQCap);
-    static_assert(WR == 1 || (kWG * WR / 2) * NRED * 64 <= LDS_FLOATS, "dW reduce scratch");
-    static_assert(kTR * kLdH <= ST_WAVE, "H tile must fit the staging buffer");
-    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
-    __shared__ double lred[kWG * WR];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: tile indices live in SGPRs
-#ifdef DCA_HEADS_TIMING
-    const long long t_entry = __builtin_readcyclecounter();
-    long long t_loop0 = t_entry, t_loop1 = t_entry;
-#endif
-    const int l31 = lane & 31, hi = lane >> 5;
-    const int g = wave / WR, r = wave % WR;
-    const int s = blockIdx.x % p.S, gb = blockIdx.x / p.S;
-    // which gene tiles share a workgroup is free (every result is per gene tile): the caller can pair tiles of
-    // similar non-zero load, a workgroup lasts as long as its slower tile
-    const int gt = p.tile_order ? p.tile_order[gb * kWG + g] : gb * kWG + g;
-    const int g0 = gt * kTG;
-    const int gene = g0 + l31;
-    const bool tile_ok = g0 < p.G;
-    const bool gvalid = gene < p.G;
-    const long long cur = p.cursor ? *p.cursor : 0;
-
-    float* Ws = lds;
-    float* Wsg = Ws + g * WS_TILE;
-    float* St = lds + kWG * WS_TILE + wave * ST_WAVE;
-    unsigned* Q = reinterpret_cast<unsigned*>(lds + kWG * WS_TILE + kWG * WR * ST_WAVE) + wave * kQCap;
-
-    // ---- head weights of this workgroup's genes -> LDS, [tile][head][k][33]
-    {
-        constexpr int NT4 = kWG * NH * KT * (kTG / 4);
-        for (int idx = tid; idx < NT4; idx += NTHREADS) {
-            const int c4 = idx & 7;
-            int rest = idx >> 3;
-            const int k = rest % KT; rest /= KT;
-            const int h = rest % NH;
-            const int gg = rest / NH;
-            const int gtile = p.tile_order ? p.tile_order[gb * kWG + gg] : gb * kWG + gg;
-            const int gcol = gtile * kTG + c4 * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (k < p.hL && gcol < p.plane)
-                v = *reinterpret_cast<const float4*>(p.Wh + (long)k * p.ldw + (long)h * p.plane + gcol);
-            float* d = Ws + ((gg * NH + h) * KT + k) * kLdS + c4 * 4;
-            d[0] = gcol + 0 < p.G ? v.x : 0.f;
-            d[1] = gcol + 1 < p.G ? v.y : 0.f;
-            d[2] = gcol + 2 < p.G ? v.z : 0.f;
-            d[3] = gcol + 3 < p.G ? v.w : 0.f;
-        }
-    }
-    __syncthreads();
-
-    f32x16 dW[NH][HLB];
-#pragma unroll
-    for (int h = 0; h < NH; ++h)
-#pragma unroll
-        for (int ib = 0; ib < HLB; ++ib)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) dW[h][ib][e] = 0.f;
-    float bsum[NH];
-#pragma unroll
-    for (int h = 0; h < NH; ++h) bsum[h] = 0.f;
-    float thsum = 0.f;
-    double dacc = 0.0;
-
-    if (tile_ok) {
-        float bias[NH];
-#pragma unroll
-        for (int h = 0; h < NH; ++h) bias[h] = gvalid ? p.bh[(long)h * p.plane + gene] : 0.f;
-        const float thw = (CONST_DISP && gvalid) ? p.theta_w[gene] : 0.f;
-
-        const int hl4 = (p.hL + 3) & ~3;
-        const long LDH = FULLK ? (long)KT : p.ldh;
-        const int gene_c = gvalid ? gene : p.G - 1;         // clamped: loads stay unconditional
-        // count loads: storage row (non-negative) x row stride as ONE 32 x 32 -> 64-bit multiply-add instead of
-        // the sign-extended 64 x 64 product (three quarter-rate multiplies per load); the plan checks ldy < 2^32
-        const float* const ycol = p.y + gene_c;
-        const unsigned ldy_u = (unsigned)p.ldy;
-        // Software pipeline across tiles: the row indices (perm), size factors, H rows and the
-        // first count groups of tile t+1 are requested while tile t is in its Z / Bk phases.
-        const int tstep = p.S * WR;
-        int t = s * WR + r;
-        const long dh_tstride = (long)p.ntg * (kTR * KT);
-        float* const dh_base = p.ws_dh + (long)gt * (kTR * KT) + l31;
-        int srow_l = 0;
-        float sf_l = 1.f;
-        float4 hv[KH / 4];
-        float yA[kZU], yB[kZU];
-        auto row_clamped = [&](int tt) { const int rl = tt * kTR + l31; return rl < p.B ? rl : p.B - 1; };
-        auto load_srow = [&](int tt) { const int rlc = row_clamped(tt); return p.perm ? p.perm[cur + rlc] : (int)(cur + rlc); };
-        // FULLK: H through a buffer resource ([B x KT] floats): every load is (per-lane offset fixed for the whole
-        // kernel) + (wave-uniform tile offset in an SGPR) + immediate, and rows beyond B read as 0 in hardware --
-        // no clamps, no selects, no 64-bit address pairs in the register file
-        const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(p.H), 0, FULLK ? p.B * KT * 4 : 0, 0x00020000);
-        const int hv_lane = (l31 * KT + hi * KH) * 4;            // bytes: row l31 of a tile, this lane half's k range
-        const int hd_lane = (4 * hi * KT + l31) * 4;             // bytes: row 4 hi of a tile, hidden unit l31
-        auto load_hv = [&](int tt) {
-            if (FULLK) {
-                const int so = tt * (kTR * KT * 4);
-#pragma unroll
-                for (int c = 0; c < KH / 4; ++c) {
-                    const auto w = __builtin_amdgcn_raw_buffer_load_b128(hrs, hv_lane + 16 * c, so, 0);
-                    static_assert(sizeof(w) == 16, "128-bit buffer load");
-                    hv[c] = __builtin_bit_cast(float4, w);
-                }
-                return;
-            }
-            const float* hp = p.H + (long)row_clamped(tt) * LDH;
-#pragma unroll
-            for (int c = 0; c < KH / 4; ++c) {
-                const int k = hi * KH + 4 * c;
-                const int kc = (FULLK || k < hl4) ? k : hl4 - 4;
-                hv[c] = *reinterpret_cast<const float4*>(hp + kc);
-            }
-        };
-        if (t < p.NT) {
-            srow_l = load_srow(t);
-            sf_l = p.sf[srow_l];
-            load_hv(t);
-#pragma unroll
-            for (int j = 0; j < kZU; ++j) {
-                const int sr = __shfl(srow_l, rowmap(j, hi), 64);
-                yA[j] = ycol[(unsigned long long)(unsigned)sr * ldy_u];
-            }
-        }
-#ifdef DCA_HEADS_TIMING
-        long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        long long tlast = __builtin_readcyclecounter();
-        t_loop0 = tlast;
-#endif
-        // Two waves share a SIMD (wave w and w + 4 of the workgroup) and one of them runs ~15 % ahead of the other
-        // (issue arbitration by priority, then age); the workgroup then waits for the slower half at the end.
-        // Alternating the priority per tile, in anti-phase between the halves, treats them alike.
-        int tile_no = wave >> 2;
-        for (; t < p.NT; t += tstep) {
-            if (kWG * WR == 8) { if ((tile_no++) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
-            TSTAMP(0)
-            const int row0 = t * kTR;
-            const bool rv = row0 + l31 < p.B;
-            const int tn = t + tstep < p.NT ? t + tstep : t;     // next tile (or a harmless re-read)
-            // ---- this tile's rows of H -> the (still unused) staging tile, [row][k] with an odd
-            // row stride: the forward's A operands are then plain conflict-free ds_reads
-#pragma unroll
-            for (int c = 0; c < KH / 4; ++c) {
-                const int k = hi * KH + 4 * c;
-                float* d = St + l31 * kLdH + k;
-                d[0] = (FULLK || (rv && k + 0 < p.hL)) ? hv[c].x : 0.f;      // FULLK: rows beyond B were loaded as 0
-                d[1] = (FULLK || (rv && k + 1 < p.hL)) ? hv[c].y : 0.f;
-                d[2] = (FULLK || (rv && k + 2 < p.hL)) ? hv[c].z : 0.f;
-                d[3] = (FULLK || (rv && k + 3 < p.hL)) ? hv[c].w : 0.f;
-            }
-            wave_sync();
-            TSTAMP(1)
-            // ---- F: pre-activations.  Lane half hi covers k in [hi*KH, hi*KH+KH): the MFMA's
-            // k order is free as long as A and B agree.
-            f32x16 acc[NH];
-#pragma unroll
-            for (int h = 0; h < NH; ++h)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[h][e] = 0.f;    // bias joins at the staging store
-#pragma unroll
-            for (int kk = 0; kk < KH; ++kk) {
-                const float a = St[l31 * kLdH + hi * KH + kk];
-#pragma unroll
-                for (int h = 0; h < NH; ++h) {
-                    const float b = Wsg[(h * KT + hi * KH + kk) * kLdS + l31];
-                    acc[h] = MFMA(a, b, acc[h]);
-                }
-            }
-            wave_sync();
-            TSTAMP(2)
-            // ---- stage [gene][row] (row stride 1, gene stride 33)
-#pragma unroll
-            for (int h = 0; h < NH; ++h)
-#pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    St[h * ST_PLANE + l31 * kLdS + rowmap(e, hi)] = acc[h][e] + bias[h];
-            const int srow_n = load_srow(tn);       // in flight during the Z loop
-            wave_sync();
-            TSTAMP(3)
-
-            // ---- Z: element-wise likelihood and gradient.  16 staged rows = 4 groups of 4; the
-            // counts of group g+1 are in flight while group g is evaluated (two named buffers,
-            // no register rotation: a rotation would have to wait for the load it just issued).
-            // The last request already belongs to the next tile.
-            // Counts are ~93 % zeros: the dense pass evaluates the y = 0 formulas for every
-            // element and queues the positions of the non-zero ones; the queue is drained 64
-            // entries at a time by the NB branch (lgamma / digamma differences), which therefore
-            // runs ~2x per tile instead of 16x with 5 % of its lanes alive.
-            float lacc = 0.f;
-            int qn = 0;
-            auto z_dense = [&](auto fullv, int grp, const float (&yv)[kZU]) {
-                constexpr bool FULLV = decltype(fullv)::value;      // interior tile: every row and gene of it exists
-                // (1) all staged inputs of the group first: the kZU element chains below are then
-                // independent (no LDS store between their loads) and interleave
-                float i_am[kZU], i_ad[kZU], i_ap[kZU];
-#pragma unroll
-                for (int j = 0; j < kZU; ++j) {
-                    const int row = rowmap(grp * kZU + j, hi);
-                    const int idx = l31 * kLdS + row;
-                    i_am[j] = St[idx];
-                    i_ad[j] = CONST_DISP ? thw : St[ST_PLANE + idx];
-                    i_ap[j] = HAS_PI ? St[PI_H * ST_PLANE + idx] : 0.f;
-                }
-                // (2) arithmetic
-                float o_m[kZU], o_d[kZU], o_p[kZU];
-                bool o_nz[kZU];
-#pragma unroll
-                for (int j = 0; j < kZU; ++j) {
-                    const int row = rowmap(grp * kZU + j, hi);
-                    const bool valid = FULLV || ((row0 + row < p.B) && gvalid);
-                    const float yj = yv[j];
-#if defined(DCA_EXP_NOZ)
-                    const bool nz = false;
-                    lacc += valid ? yj : 0.f;
-                    o_m[j] = i_am[j] * i_sf[j]; o_d[j] = i_ad[j]; o_p[j] = i_ap[j];
-                    o_nz[j] = nz;
-#else
-#if defined(DCA_EXP_NOSPARSE)
-                    const bool nz = false;
-#else
-                    const bool nz = valid && (HAS_PI ? !(yj < kZeroThresh) : (yj != 0.f));
-#endif
-                    if (HAS_PI) {
-                        // the y = 0 formulas for every element (the non-zero ones are redone by the sparse pass)
-                        float gmv, gdv, gpv;
-                        const float nll = zinb_zero_elem<CONST_DISP>(i_am[j], i_ad[j], i_ap[j], __shfl(sf_l, row, 64), p.ridge, gmv, gdv, gpv);
-                        const float sc = valid ? p.inv_n : 0.f;      // pre-activations of padding are finite
-                        lacc += (valid && !nz) ? nll : 0.f;
-                        o_m[j] = gmv * sc;
-                        o_d[j] = gdv * sc;
-                        o_p[j] = gpv * sc;
-                    } else {
-                        float gmv, gdv;
-                        const float nll = nb_zero_elem<CONST_DISP>(i_am[j], i_ad[j], __shfl(sf_l, row, 64), gmv, gdv);
-                        const float sc = valid ? p.inv_n : 0.f;
-                        lacc += (valid && !nz) ? nll : 0.f;
-                        o_m[j] = gmv * sc;
-                        o_d[j] = gdv * sc;
-                        o_p[j] = 0.f;
-                    }
-                    o_nz[j] = nz;
-#endif
-                }
-                // (3) results / queue
-#pragma unroll
-                for (int j = 0; j < kZU; ++j) {
-                    const int row = rowmap(grp * kZU + j, hi);
-                    const int idx = l31 * kLdS + row;
-                    const bool nz = o_nz[j];
-                    const unsigned long long m = __ballot(nz);
-                    const int slot = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                    if (nz) {
-                        // entry = staging index | count as uint16 (0xFFFF: not representable --
-                        // re-read from memory by the sparse pass)
-                        const float yj = yv[j];
-                        const unsigned y16 = (yj < 65535.f && yj == floorf(yj)) ? (unsigned)yj : 0xFFFFu;
-                        Q[slot] = (unsigned)idx | (y16 << 16);
-                    } else {                 // pre-activations of queued elements stay in place
-                        St[idx] = o_m[j];
-                        if (CONST_DISP) St[TH_P * ST_PLANE + idx] = o_d[j]; else St[ST_PLANE + idx] = o_d[j];
-                        if (HAS_PI) St[PI_H * ST_PLANE + idx] = o_p[j];
-                    }
-                    qn += __popcll(m);
-                }
-            };
-            auto z_sparse = [&](int q0, int cnt) {
-                const bool act = lane < cnt;
-                const unsigned e = Q[q0 + (act ? lane : 0)];
-                const int idx = e & 2047;
-                const int gq = (idx * 1986) >> 16;          // idx / 33 for idx < 1056
-                const int row = idx - gq * kLdS;
-                const float sfr = __shfl(sf_l, row, 64);
-                const int sr = __shfl(srow_l, row, 64);
-                const float am = St[idx];
-                const float ad = CONST_DISP ? __shfl(thw, gq, 64) : St[ST_PLANE + idx];
-                const float ap = HAS_PI ? St[PI_H * ST_PLANE + idx] : 0.f;
-                float yq = (float)(e >> 16);
-                if ((e >> 16) == 0xFFFFu) yq = p.y[(long)sr * p.ldy + g0 + gq];
-                float o1, o2, o3 = 0.f, nll;
-                if (HAS_PI) {
-                    nll = zinb_nz_elem<CONST_DISP>(am, ad, ap, sfr, yq, p.ridge, o1, o2, o3);
-                } else {
-                    float dmu = 0.f, dth = 0.f, dpi = 0.f;
-                    const Heads hd = head_acts<HAS_PI, CONST_DISP>(am, ad, ap, sfr);
-                    nll = nll_elem<HAS_PI, true, true>(hd, yq, p.ridge, dmu, dth, dpi);
-                    o1 = dmu * hd.gm; o2 = dth * hd.gd;
-                }
-                lacc += act ? nll : 0.f;
-                if (act) {
-                    St[idx] = o1 * p.inv_n;
-                    const float od = o2 * p.inv_n;
-                    if (CONST_DISP) St[TH_P * ST_PLANE + idx] = od; else St[ST_PLANE + idx] = od;
-                    if (HAS_PI) St[PI_H * ST_PLANE + idx] = o3 * p.inv_n;
-                }
-            };
-            auto z_flush = [&](bool last) {
-                while (qn >= 64 || (last && qn > 0)) {
-                    const int c = qn < 64 ? qn : 64;
-                    wave_sync();
-                    z_sparse(qn - c, c);
-                    qn -= c;
-                }
-            };
-            auto load_y = [&](int srow_src, int grp, float (&yv)[kZU]) {
-#pragma unroll
-                for (int j = 0; j < kZU; ++j) {
-                    const int sr = __shfl(srow_src, rowmap(grp * kZU + j, hi), 64);
-                    yv[j] = ycol[(unsigned long long)(unsigned)sr * ldy_u];
-                }
-            };
-            auto z_loop = [&](auto fullv) {
-#pragma unroll 1
-                for (int it = 0; it < 16 / (2 * kZU); ++it) {
-                    const bool last = it + 1 == 16 / (2 * kZU);
-                    load_y(srow_l, 2 * it + 1, yB);
-                    z_dense(fullv, 2 * it, yA);
-                    z_flush(false);
-                    if (!last) load_y(srow_l, 2 * it + 2, yA);
-                    else load_y(srow_n, 0, yA);              // next tile's first group
-                    z_dense(fullv, 2 * it + 1, yB);
-                    z_flush(last);
-                }
-            };
-            // wave-uniform: all but the last row tile / gene tile take the path without validity selects
-            if (row0 + kTR <= p.B && g0 + kTG <= p.G) z_loop(std::true_type{}); else z_loop(std::false_type{});
-            dacc += (double)lacc;
-            // next tile: size factors; this tile: A operands of the weight-gradient
-            // product (H rows, lanes along the hidden units) -- all in flight during the dH MFMAs
-            const float sf_n = p.sf[srow_n];
-            wave_sync();
-            TSTAMP(4)
-
-            // ---- Bk (1): dH[row, i] = sum_genes D[row, gene] W[i, gene] (this gene tile's share;
-            // D read transposed from the staging tile)
-            {
-                f32x16 dHa[HLB];
-#pragma unroll
-                for (int jb = 0; jb < HLB; ++jb)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) dHa[jb][e] = 0.f;
-#pragma unroll
-                for (int h = 0; h < NH; ++h)
-#pragma unroll
-                    for (int kk = 0; kk < 16; ++kk) {
-                        const int gl = 16 * hi + kk;
-                        const float a = St[h * ST_PLANE + gl * kLdS + l31];
-#pragma unroll
-                        for (int jb = 0; jb < HLB; ++jb) {
-                            const float b = Wsg[(h * KT + jb * 32 + l31) * kLdS + gl];
-                            dHa[jb] = MFMA(a, b, dHa[jb]);
-                        }
-                    }
-                TSTAMP(7)                              // timing build: MFMA part of the dH phase ends here
-                float* dst = dh_base + (long)t * dh_tstride;
-#pragma unroll
-                for (int jb = 0; jb < HLB; ++jb)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) dst[rowmap(e, hi) * KT + jb * 32] = dHa[jb][e];
-            }
-            float Hd[HLB][16];
-            if (FULLK) {
-                const int so = row0 * (KT * 4);
-#pragma unroll
-                for (int ib = 0; ib < HLB; ++ib)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e)
-                        Hd[ib][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                            hrs, hd_lane + (rowmap(e, 0) * KT + ib * 32) * 4, so, 0));
-            } else {
-#pragma unroll
-                for (int ib = 0; ib < HLB; ++ib)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int row = row0 + rowmap(e, hi);
-                        const int i = ib * 32 + l31;
-                        const int rc = row < p.B ? row : p.B - 1;
-                        const int ic = i < hl4 ? i : hl4 - 1;
-                        Hd[ib][e] = p.H[(long)rc * LDH + ic];
-                    }
-            }
-            load_hv(tn);                           // next tile's H rows: in flight during the dW MFMAs
-            TSTAMP(5)
-            // ---- Bk (2): dW[i, gene] += sum_rows H[row, i] D[row, gene]; the staged D column
-            // of a lane IS its B operand (k slot = lane half), A = H rows of this tile
-#pragma unroll
-            for (int h = 0; h < NH; ++h)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const float b = St[h * ST_PLANE + l31 * kLdS + rowmap(e, hi)];
-                    bsum[h] += b;                    // bias gradient = column sum of D
-#pragma unroll
-                    for (int ib = 0; ib < HLB; ++ib) {
-                        // FULLK: no select -- rows beyond B were loaded as 0 (buffer bounds) and their staged D
-                        // is exactly 0 as well
-                        const bool ok = FULLK || ((row0 + rowmap(e, hi) < p.B) && (ib * 32 + l31 < p.hL));
-                        dW[h][ib] = MFMA(ok ? Hd[ib][e] : 0.f, b, dW[h][ib]);
-                    }
-                }
-            if (CONST_DISP) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) thsum += St[TH_P * ST_PLANE + l31 * kLdS + rowmap(e, hi)];
-            }
-            srow_l = srow_n;
-            sf_l = sf_n;
-            wave_sync();
-            TSTAMP(6)
-        }
-#ifdef DCA_HEADS_TIMING
-        t_loop1 = __builtin_readcyclecounter();
-        if (p.timing && lane == 0)
-            for (int i = 0; i < 8; ++i) p.timing[((long)blockIdx.x * (kWG * WR) + wave) * 10 + i] = tacc[i];
-#endif
-    }
-
-    // ---- loss: wave -> workgroup -> one partial per workgroup
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) dacc += __shfl_down(dacc, off, 64);
-    if (lane == 0) lred[wave] = dacc;
-    __syncthreads();                      // also: every wave is done with the LDS weights / staging
-    if (tid == 0) {
-        double v = 0.0;
-        for (int w = 0; w < kWG * WR; ++w) v += lred[w];
-        p.partials[blockIdx.x] = v;
-    }
-
-    // ---- dW / bias-gradient sums of the WR row slots of a gene tile: ordered tree through LDS
-    if (WR > 1) {
-        float* red = lds;
-#pragma unroll
-        for (int step = 1; step < WR; step *= 2) {
-            const int slot = g * (WR / 2) + r / (2 * step);
-            float* rs = red + (long)slot * NRED * 64 + lane;
-            if (r % (2 * step) == step) {
-                int n = 0;
-#pragma unroll
-                for (int h = 0; h < NH; ++h)
-#pragma unroll
-                    for (int ib = 0; ib < HLB; ++ib)
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) rs[(n++) * 64] = dW[h][ib][e];
-#pragma unroll
-                for (int h = 0; h < NH; ++h) rs[(n++) * 64] = bsum[h];
-                rs[(n++) * 64] = thsum;
-            }
-            __syncthreads();
-            if (r % (2 * step) == 0 && r + step < WR) {
-                int n = 0;
-#pragma unroll
-                for (int h = 0; h < NH; ++h)
-#pragma unroll
-                    for (int ib = 0; ib < HLB; ++ib)
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) dW[h][ib][e] += rs[(n++) * 64];
-#pragma unroll
-                for (int h = 0; h < NH; ++h) bsum[h] += rs[(n++) * 64];
-                thsum += rs[(n++) * 64];
-            }
-            __syncthreads();
-        }
-    }
-    if (r == 0 && tile_ok) {
-        float* out = p.ws_dw + (long)s * p.dw_stride;
-        const bool cw = gene < p.plane;
-#pragma unroll
-        for (int h = 0; h < NH; ++h) {
-#pragma unroll
-            for (int ib = 0; ib < HLB; ++ib)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int i = ib * 32 + rowmap(e, hi);
-                    if (cw && (FULLK || i < p.hL)) out[(long)i * p.ldws + (long)h * p.plane + gene] = dW[h][ib][e];
-                }
-            const float bv = bsum[h] + __shfl_xor(bsum[h], 32, 64);
-            if (cw && hi == 0) out[(long)p.hL * p.ldws + (long)h * p.plane + gene] = bv;
-        }
-        if (CONST_DISP) {
-            const float tv = thsum + __shfl_xor(thsum, 32, 64);
-            if (cw && hi == 0) out[(long)(p.hL + 1) * p.ldws + gene] = tv;
-        }
-    }
-#ifdef DCA_HEADS_TIMING
-    if (p.timing && lane == 0) {
-        long long* tp = p.timing + ((long)blockIdx.x * (kWG * WR) + wave) * 10;
-        tp[8] = t_loop0 - t_entry;                                   // prologue: weights -> LDS, first requests
-        tp[9] = (long long)__builtin_readcyclecounter() - t_loop1;   // epilogue: loss, dW tree, partial stores issued
-    }
-#endif
 }
 
 // =====================================================================================================
@@ -616,6 +81,7 @@ using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
 using s16x4 = __attribute__((ext_vector_type(4))) short;
 
 constexpr int kWR2 = 8;                 // row slots (waves) per workgroup, one gene tile per workgroup
+constexpr int kWr8MinNT = 5;            // the 8-wave persistent kernel from this many row tiles on (see make_heads_plan)
 constexpr int kHTile = 3 * 32 * 64;     // bf16 elements of one row tile of the split decoder output (3 pieces x 32 x 64)
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0)
@@ -661,6 +127,8 @@ struct HeadsArgs2 {
     const float* bh;
     const float* theta_w;
     const float* y;  long ldy;
+    const unsigned char* yc; long ldc;                  // compact counts (YC kernels): one byte per count, 255 = escape
+    const int* ovf_ptr; const int* ovf_col; const float* ovf_val;   // per-row overflow list behind the escapes
     const float* sf;
     const int* perm;
     const long long* cursor;
@@ -674,6 +142,15 @@ struct HeadsArgs2 {
     int S, NT;
     float ridge, inv_n;
 };
+
+// the count behind an escape byte of the compact store (counts >= 255: rare)
+__device__ __forceinline__ float escaped_count(const HeadsArgs2& p, long srow, int col) {
+    float v = 255.f;
+    if (p.ovf_ptr)
+        for (int i = p.ovf_ptr[srow], e = p.ovf_ptr[srow + 1]; i < e; ++i)
+            if (p.ovf_col[i] == col) { v = p.ovf_val[i]; break; }
+    return v;
+}
 
 // Decoder output -> bf16 pieces, once per launch (B x 64 elements: ~1 us).  One 32-row tile per block.
 __global__ __launch_bounds__(256) void heads_split_h_kernel(const float* H, long ldh, int B, int hL,
@@ -706,8 +183,9 @@ __global__ __launch_bounds__(256) void heads_split_h_kernel(const float* H, long
     }
 }
 
-template <bool HAS_PI, bool CONST_DISP, int WR>
+template <bool HAS_PI, bool CONST_DISP, int WR, bool YC>
 __global__ __launch_bounds__(64 * WR) void heads_fused_x3_kernel(HeadsArgs2 p) {
+    using YV = std::conditional_t<YC, unsigned, float>;        // a count as the kernel holds it: the byte code / the fp32 value
     constexpr int NH = 1 + (CONST_DISP ? 0 : 1) + (HAS_PI ? 1 : 0);
     constexpr int PI_H = NH - 1;
     constexpr int KT = 64;
@@ -830,7 +308,12 @@ __global__ __launch_bounds__(64 * WR) void heads_fused_x3_kernel(HeadsArgs2 p) {
         // more to the point -- no spill slot whose reload would wait for every global prefetch in flight
         const int gene_c = gvalid ? gene : p.G - 1;
         const float* const ycol = p.y + gene_c;
-        const unsigned ldy_u = (unsigned)p.ldy;
+        const unsigned char* const ycolc = p.yc + gene_c;
+        const unsigned ldy_u = YC ? (unsigned)p.ldc : (unsigned)p.ldy;
+        auto count_at = [&](int sr) -> YV {
+            if constexpr (YC) return (unsigned)ycolc[(unsigned long long)(unsigned)sr * ldy_u];
+            else return ycol[(unsigned long long)(unsigned)sr * ldy_u];
+        };
         const int tstep = p.S * WR;
         int t = s * WR + r;
         const long dh_tstride = (long)p.npart * (kTR * KT);
@@ -838,7 +321,7 @@ __global__ __launch_bounds__(64 * WR) void heads_fused_x3_kernel(HeadsArgs2 p) {
         const int dh_lane = (4 * hi * KT + l31) * 4;
         int srow_l = 0;
         float sf_l = 1.f;
-        float yA[kZU], yB[kZU];
+        YV yA[kZU], yB[kZU];
         auto row_clamped = [&](int tt) { const int rl = tt * kTR + l31; return rl < p.B ? rl : p.B - 1; };
         auto load_srow = [&](int tt) { const int rlc = row_clamped(tt); return p.perm ? p.perm[cur + rlc] : (int)(cur + rlc); };
         // split decoder output through buffer resources: (per-lane offset fixed for the whole kernel) + (tile offset
@@ -934,7 +417,7 @@ __global__ __launch_bounds__(64 * WR) void heads_fused_x3_kernel(HeadsArgs2 p) {
 #pragma unroll
             for (int j = 0; j < kZU; ++j) {
                 const int sr = __shfl(srow_l, rowmap(j, hi), 64);
-                yA[j] = ycol[(unsigned long long)(unsigned)sr * ldy_u];
+                yA[j] = count_at(sr);
             }
         }
 #ifdef DCA_HEADS_TIMING
@@ -992,7 +475,7 @@ __global__ __launch_bounds__(64 * WR) void heads_fused_x3_kernel(HeadsArgs2 p) {
             // ---- Z: element-wise likelihood and gradient (dense y = 0 pass + compacted non-zero pass)
             float lacc = 0.f;
             int qn = 0;
-            auto z_dense = [&](auto fullv, int grp, const float (&yv)[kZU]) {
+            auto z_dense = [&](auto fullv, int grp, const YV (&yv)[kZU]) {
                 constexpr bool FULLV = decltype(fullv)::value;
                 float i_am[kZU], i_ad[kZU], i_ap[kZU];
 #pragma unroll
@@ -1009,8 +492,10 @@ __global__ __launch_bounds__(64 * WR) void heads_fused_x3_kernel(HeadsArgs2 p) {
                 for (int j = 0; j < kZU; ++j) {
                     const int row = rowmap(grp * kZU + j, hi);
                     const bool valid = FULLV || ((row0 + row < p.B) && gvalid);
-                    const float yj = yv[j];
-                    const bool nz = valid && (HAS_PI ? !(yj < kZeroThresh) : (yj != 0.f));
+                    const YV yj = yv[j];
+                    bool nz;
+                    if constexpr (YC) nz = valid && yj != 0u;
+                    else nz = valid && (HAS_PI ? !(yj < kZeroThresh) : (yj != 0.f));
                     if (HAS_PI) {
                         float gmv, gdv, gpv;
                         const float nll = zinb_zero_elem<CONST_DISP>(i_am[j], i_ad[j], i_ap[j], __shfl(sf_l, row, 64), p.ridge, gmv, gdv, gpv);
@@ -1038,8 +523,10 @@ __global__ __launch_bounds__(64 * WR) void heads_fused_x3_kernel(HeadsArgs2 p) {
                     const unsigned long long m = __ballot(nz);
                     const int slot = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
                     if (nz) {
-                        const float yj = yv[j];
-                        const unsigned y16 = (yj < 65535.f && yj == floorf(yj)) ? (unsigned)yj : 0xFFFFu;
+                        const YV yj = yv[j];
+                        unsigned y16;
+                        if constexpr (YC) y16 = yj == 255u ? 0xFFFFu : yj;
+                        else y16 = (yj < 65535.f && yj == floorf(yj)) ? (unsigned)yj : 0xFFFFu;
                         Q[slot] = (unsigned)idx | (y16 << 16);
                     } else {
                         St[idx] = o_m[j];
@@ -1061,7 +548,7 @@ __global__ __launch_bounds__(64 * WR) void heads_fused_x3_kernel(HeadsArgs2 p) {
                 const float ad = CONST_DISP ? Bs[NH * 32 + gq] : St[ST_PLANE + idx];
                 const float ap = HAS_PI ? St[PI_H * ST_PLANE + idx] : 0.f;
                 float yq = (float)(e >> 16);
-                if ((e >> 16) == 0xFFFFu) yq = p.y[(long)sr * p.ldy + g0 + gq];
+                if ((e >> 16) == 0xFFFFu) yq = YC ? escaped_count(p, sr, g0 + gq) : p.y[(long)sr * p.ldy + g0 + gq];
                 float o1, o2, o3 = 0.f, nll;
                 if (HAS_PI) {
                     nll = zinb_nz_elem<CONST_DISP>(am, ad, ap, sfr, yq, p.ridge, o1, o2, o3);
@@ -1087,11 +574,11 @@ __global__ __launch_bounds__(64 * WR) void heads_fused_x3_kernel(HeadsArgs2 p) {
                     qn -= c;
                 }
             };
-            auto load_y = [&](int srow_src, int grp, float (&yv)[kZU]) {
+            auto load_y = [&](int srow_src, int grp, YV (&yv)[kZU]) {
 #pragma unroll
                 for (int j = 0; j < kZU; ++j) {
                     const int sr = __shfl(srow_src, rowmap(grp * kZU + j, hi), 64);
-                    yv[j] = ycol[(unsigned long long)(unsigned)sr * ldy_u];
+                    yv[j] = count_at(sr);
                 }
             };
             auto z_loop = [&](auto fullv) {
@@ -1441,18 +928,6 @@ inline int x3_resident(int WR) { return WR == 1 ? 3 * kCUs : kCUs; }
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-// DCA_HEADS_F32MFMA=1: the first implementation (fp32 MFMA, two gene tiles per workgroup), for A/B runs only
-inline bool use_f32_mfma() {
-    static const bool v = [] { const char* e = getenv("DCA_HEADS_F32MFMA"); return e && e[0] == '1'; }();
-    return v;
-}
-
-// DCA_HEADS_SMALL=0: batches of one row tile through the persistent kernel (single-wave workgroups), for A/B runs
-inline bool use_small_kernel() {
-    static const bool v = [] { const char* e = getenv("DCA_HEADS_SMALL"); return !(e && e[0] == '0'); }();
-    return v;
-}
-
 // a pure function of the shape: row slots per workgroup, batch splits, workspace layout
 bool make_heads_plan(int B, int hL, int G, long plane, int flags, HeadsPlan* out) {
     if (flags & (DCAHIP_NLL_POISSON | DCAHIP_NLL_MSE)) return false;     // NB / ZINB family only
@@ -1460,8 +935,7 @@ bool make_heads_plan(int B, int hL, int G, long plane, int flags, HeadsPlan* out
     if (B > (1 << 22)) return false;                 // H is addressed through a 32-bit buffer resource (B x 64 floats)
     const bool has_pi = flags & DCAHIP_NLL_HAS_PI, cdisp = flags & DCAHIP_NLL_CONST_DISP;
     const int NH = 1 + (cdisp ? 0 : 1) + (has_pi ? 1 : 0);
-    const bool f32 = use_f32_mfma();
-    const int wg_tiles = f32 ? kWG : 1;              // gene tiles per workgroup
+    const int wg_tiles = 1;                          // gene tiles per workgroup
     HeadsPlan p;
     p.HLB = 2;
     p.NT = (B + kTR - 1) / kTR;
@@ -1471,8 +945,7 @@ bool make_heads_plan(int B, int hL, int G, long plane, int flags, HeadsPlan* out
     // the 8-wave persistent kernel from 5 row tiles on (waves beyond the batch idle): measured against the four-wave kernel
     // at G = 20 000: B = 128 0.088 / 0.086 ms (kept on the four-wave kernel), 160: 0.100 / 0.104, 192: 0.103 / 0.121,
     // 224: 0.107 / 0.142 (profiles/r02z_heads_kernel_switch.txt)
-    static const int wr8_min_nt = [] { const char* e = getenv("DCA_HEADS_WR8_MIN_NT"); return e ? atoi(e) : 5; }();
-    p.WR = f32 ? (p.NT >= 4 ? 4 : 1) : (p.NT >= wr8_min_nt ? kWR2 : 1);
+    p.WR = p.NT >= kWr8MinNT ? kWR2 : 1;
     const int smax = (p.NT + p.WR - 1) / p.WR;
     double best = 1e300;
     p.S = 1;
@@ -1486,13 +959,13 @@ bool make_heads_plan(int B, int hL, int G, long plane, int flags, HeadsPlan* out
     p.nitems = p.S * p.ngb;
     p.grid = p.nitems;
     p.npart = p.ntg;
-    p.small = !f32 && p.WR == 1 && (long)p.ntg * p.NT <= kMaxSmallGrid && use_small_kernel();
+    p.small = p.WR == 1 && (long)p.ntg * p.NT <= kMaxSmallGrid;
     if (p.small) {                                   // one workgroup per (gene tile, row tile): S = NT weight-gradient partials
         p.S = p.NT;
         p.nitems = p.NT * p.ntg;
         p.grid = p.nitems;
         p.npart = p.ntg;
-    } else if (!f32) {                               // persistent: as many workgroups as are resident, a multiple of S
+    } else {                                         // persistent: as many workgroups as are resident, a multiple of S
         const int res = x3_resident(p.WR) / p.S * p.S;
         if (p.grid > res) p.grid = res;
         p.npart = p.grid / p.S;
@@ -1501,21 +974,12 @@ bool make_heads_plan(int B, int hL, int G, long plane, int flags, HeadsPlan* out
     p.dw_stride = (long)(hL + 2) * p.ldws;
     p.dw_bytes = (long)p.S * p.dw_stride * (long)sizeof(float);
     p.dh_bytes = (long)p.npart * p.NT * kTR * (p.HLB * 32) * (long)sizeof(float);
-    p.hs_bytes = f32 ? 0 : 2L * p.NT * kHTile * 2;   // split decoder output, both layouts
+    p.hs_bytes = 2L * p.NT * kHTile * 2;             // split decoder output, both layouts
     *out = p;
     return true;
 }
 
 long long* g_timing = nullptr;
-
-template <bool P, bool C>
-void launch_fused(const HeadsPlan& pl, const HeadsArgs& a, hipStream_t s) {
-    const bool full = a.hL == 32 * pl.HLB && a.ldh == 32 * pl.HLB;
-#define DCA_LF(WRV, FK) hipLaunchKernelGGL((heads_fused_kernel<P, C, 2, WRV, FK>), dim3(pl.grid), dim3(64 * kWG * WRV), 0, s, a)
-    if (pl.WR == 4) { if (full) DCA_LF(4, true); else DCA_LF(4, false); }
-    else            { if (full) DCA_LF(1, true); else DCA_LF(1, false); }
-#undef DCA_LF
-}
 
 // =====================================================================================================
 // K-HEADS for batches below 256 rows (B <= 32, ONE row tile, is the reference's default batch size, dca/api.py:33):
@@ -1531,8 +995,9 @@ void launch_fused(const HeadsPlan& pl, const HeadsArgs& a, hipStream_t s) {
 // those of the persistent kernel (same products, same six-term order; the loss partial of the tile is the sum of its
 // four waves' in wave order).
 // =====================================================================================================
-template <bool HAS_PI, bool CONST_DISP>
+template <bool HAS_PI, bool CONST_DISP, bool YC>
 __global__ __launch_bounds__(256) void heads_fused_small_kernel(HeadsArgs2 p) {
+    using YV = std::conditional_t<YC, unsigned, float>;
     constexpr int NH = 1 + (CONST_DISP ? 0 : 1) + (HAS_PI ? 1 : 0);
     constexpr int PI_H = NH - 1;
     constexpr int KT = 64;
@@ -1584,11 +1049,13 @@ __global__ __launch_bounds__(256) void heads_fused_small_kernel(HeadsArgs2 p) {
     const int srow_l = p.perm ? p.perm[cur + rl] : (int)(cur + rl);
     const float sf_l = p.sf[srow_l];
     const float* const ycol = p.y + (gvalid ? gene : p.G - 1);
-    float yv[kZU];
+    const unsigned char* const ycolc = p.yc + (gvalid ? gene : p.G - 1);
+    YV yv[kZU];
 #pragma unroll
     for (int j = 0; j < kZU; ++j) {
         const int sr = __shfl(srow_l, rowmap(wave * kZU + j, hi), 64);
-        yv[j] = ycol[(unsigned long long)(unsigned)sr * (unsigned)p.ldy];
+        if constexpr (YC) yv[j] = (unsigned)ycolc[(unsigned long long)(unsigned)sr * (unsigned)p.ldc];
+        else yv[j] = ycol[(unsigned long long)(unsigned)sr * (unsigned)p.ldy];
     }
     float hx[4][8], htx[2][2][8];
     float bias_h = 0.f;
@@ -1715,8 +1182,10 @@ __global__ __launch_bounds__(256) void heads_fused_small_kernel(HeadsArgs2 p) {
         for (int j = 0; j < kZU; ++j) {
             const int row = rowmap(wave * kZU + j, hi);
             const bool valid = (row0 + row < p.B) && gvalid;
-            const float yj = yv[j];
-            const bool nz = valid && (HAS_PI ? !(yj < kZeroThresh) : (yj != 0.f));
+            const YV yj = yv[j];
+            bool nz;
+            if constexpr (YC) nz = valid && yj != 0u;
+            else nz = valid && (HAS_PI ? !(yj < kZeroThresh) : (yj != 0.f));
             const float sc = valid ? p.inv_n : 0.f;
             if (HAS_PI) {
                 float gmv, gdv, gpv;
@@ -1738,8 +1207,10 @@ __global__ __launch_bounds__(256) void heads_fused_small_kernel(HeadsArgs2 p) {
             const unsigned long long m = __ballot(nz);
             const int slot = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
             if (nz) {
-                const float yj = yv[j];
-                const unsigned y16 = (yj < 65535.f && yj == floorf(yj)) ? (unsigned)yj : 0xFFFFu;
+                const YV yj = yv[j];
+                unsigned y16;
+                if constexpr (YC) y16 = yj == 255u ? 0xFFFFu : yj;
+                else y16 = (yj < 65535.f && yj == floorf(yj)) ? (unsigned)yj : 0xFFFFu;
                 Q[slot] = (unsigned)idx | (y16 << 16);
             } else {
                 St[idx] = o_m[j];
@@ -1764,7 +1235,7 @@ __global__ __launch_bounds__(256) void heads_fused_small_kernel(HeadsArgs2 p) {
             const float ad = CONST_DISP ? Bs[NH * 32 + gq] : St[ST_PLANE + idx];
             const float ap = HAS_PI ? St[PI_H * ST_PLANE + idx] : 0.f;
             float yq = (float)(e >> 16);
-            if ((e >> 16) == 0xFFFFu) yq = p.y[(long)sr * p.ldy + g0 + gq];
+            if ((e >> 16) == 0xFFFFu) yq = YC ? escaped_count(p, sr, g0 + gq) : p.y[(long)sr * p.ldy + g0 + gq];
             float o1, o2, o3 = 0.f, nll;
             if (HAS_PI) {
                 nll = zinb_nz_elem<CONST_DISP>(am, ad, ap, sfr, yq, p.ridge, o1, o2, o3);
@@ -1907,39 +1378,29 @@ __global__ __launch_bounds__(64) void x3_product_kernel(const float* A, const fl
     for (int e = 0; e < 16; ++e) C[rowmap(e, hi) * 32 + l31] = acc[e];
 }
 
-template <bool P, bool C>
+template <bool P, bool C, bool YC>
 void launch_fused_x3(const HeadsPlan& pl, const HeadsArgs2& a, hipStream_t s) {
-    if (pl.small) hipLaunchKernelGGL((heads_fused_small_kernel<P, C>), dim3(pl.grid), dim3(256), 0, s, a);
-    else if (pl.WR == kWR2) hipLaunchKernelGGL((heads_fused_x3_kernel<P, C, kWR2>), dim3(pl.grid), dim3(64 * kWR2), 0, s, a);
-    else hipLaunchKernelGGL((heads_fused_x3_kernel<P, C, 1>), dim3(pl.grid), dim3(64), 0, s, a);
+    if (pl.small) hipLaunchKernelGGL((heads_fused_small_kernel<P, C, YC>), dim3(pl.grid), dim3(256), 0, s, a);
+    else if (pl.WR == kWR2) hipLaunchKernelGGL((heads_fused_x3_kernel<P, C, kWR2, YC>), dim3(pl.grid), dim3(64 * kWR2), 0, s, a);
+    else hipLaunchKernelGGL((heads_fused_x3_kernel<P, C, 1, YC>), dim3(pl.grid), dim3(64), 0, s, a);
 }
 
 }  // namespace
 
-// sufficient for every batch of at most B rows (the plan of a smaller batch may split more)
+// sufficient for every batch of at most B rows: the maximum over the plans of all of them (a smaller batch may
+// split more and keep more partials); a plan depends on B only through its row-tile count
 extern "C" long dcahip_heads_fused_workspace_bytes(int B, int hL, int G, long plane, int flags) {
     HeadsPlan p;
     if (!make_heads_plan(B, hL, G, plane, flags, &p)) return 0;
-    long smax = kMaxGrid / p.ngb;
-    if (smax > p.NT) smax = p.NT;
-    if (smax < 1) smax = 1;
-    if (!use_f32_mfma()) {                           // the four-wave kernel keeps one weight-gradient partial per row tile (< 8)
-        const long nts = p.NT < kWR2 ? p.NT : kWR2 - 1;
-        if (smax < nts) smax = nts;
+    long need = 0;
+    for (int nt = 1; nt <= p.NT; ++nt) {
+        HeadsPlan q;
+        const int b = nt * kTR < B ? nt * kTR : B;
+        if (!make_heads_plan(b, hL, G, plane, flags, &q)) continue;
+        const long n = q.dw_bytes + q.dh_bytes + q.hs_bytes;
+        if (n > need) need = n;
     }
-    long dh = p.dh_bytes;
-    if (!use_f32_mfma()) {                           // smaller batches: fewer row tiles, possibly more (single-wave) workgroups
-        // partials (32 x 64 floats each) of every plan a batch of at most B rows can get: persistent 8-wave workgroups
-        // (row tiles x resident workgroups), persistent single-wave workgroups (< 8 row tiles, three per CU), the
-        // four-wave kernel (< 8 row tiles x one partial per gene tile)
-        const long nts = p.NT < kWR2 ? p.NT : kWR2 - 1;
-        const long a = (long)p.NT * kCUs, b = nts * 3 * kCUs, c = nts * p.ntg <= kMaxSmallGrid ? nts * p.ntg : (long)kMaxSmallGrid;
-        long m = a > b ? a : b;
-        if (c > m) m = c;
-        dh = m * kTR * (p.HLB * 32) * (long)sizeof(float);
-        if (dh < p.dh_bytes) dh = p.dh_bytes;
-    }
-    return smax * p.dw_stride * (long)sizeof(float) + dh + p.hs_bytes;
+    return need;
 }
 
 extern "C" int dcahip_x3_product_32x32(const float* A, const float* B, float* C, int K, void* stream) {
@@ -1972,6 +1433,17 @@ extern "C" int dcahip_heads_fused_loss(const float* H, long ldh, const float* Wh
                                        float* dH, long lddh, double* loss_partials, int* n_partials_out,
                                        void* workspace, long workspace_bytes, const int* tile_order,
                                        float* loss_out, void* stream);
+
+extern "C" int dcahip_heads_fused_compact(const float* H, long ldh, const float* Wh, long ldw,
+                                          const float* bh, long plane, const float* theta_w,
+                                          const float* y, long ldy,
+                                          const unsigned char* yc, long ldc, const int* ovf_ptr, const int* ovf_col,
+                                          const float* ovf_val, const float* sf, const int* perm,
+                                          const long long* cursor, int B, int hL, int G, float ridge,
+                                          float inv_n, int flags, float* gW, long ldg, float* g_theta,
+                                          float* dH, long lddh, double* loss_partials, int* n_partials_out,
+                                          void* workspace, long workspace_bytes, const int* tile_order,
+                                          float* loss_out, void* stream);
 
 extern "C" int dcahip_heads_fused(const float* H, long ldh, const float* Wh, long ldw,
                                   const float* bh, long plane, const float* theta_w,
@@ -2006,29 +1478,37 @@ extern "C" int dcahip_heads_fused_loss(const float* H, long ldh, const float* Wh
                                        float* dH, long lddh, double* loss_partials, int* n_partials_out,
                                        void* workspace, long workspace_bytes, const int* tile_order,
                                        float* loss_out, void* stream) {
+    return dcahip_heads_fused_compact(H, ldh, Wh, ldw, bh, plane, theta_w, y, ldy, nullptr, 0, nullptr, nullptr, nullptr,
+                                      sf, perm, cursor, B, hL, G, ridge, inv_n, flags, gW, ldg, g_theta, dH, lddh,
+                                      loss_partials, n_partials_out, workspace, workspace_bytes, tile_order, loss_out, stream);
+}
+
+extern "C" int dcahip_heads_fused_compact(const float* H, long ldh, const float* Wh, long ldw,
+                                          const float* bh, long plane, const float* theta_w,
+                                          const float* y, long ldy,
+                                          const unsigned char* yc, long ldc, const int* ovf_ptr, const int* ovf_col,
+                                          const float* ovf_val, const float* sf, const int* perm,
+                                          const long long* cursor, int B, int hL, int G, float ridge,
+                                          float inv_n, int flags, float* gW, long ldg, float* g_theta,
+                                          float* dH, long lddh, double* loss_partials, int* n_partials_out,
+                                          void* workspace, long workspace_bytes, const int* tile_order,
+                                          float* loss_out, void* stream) {
     const bool has_pi = flags & DCAHIP_NLL_HAS_PI, cdisp = flags & DCAHIP_NLL_CONST_DISP;
     HeadsPlan pl;
     if (!make_heads_plan(B, hL, G, plane, flags, &pl)) return DCAHIP_EINVAL;
-    if (!H || !Wh || !bh || !y || !sf || !gW || !dH || !loss_partials || !workspace) return DCAHIP_EINVAL;
+    if (!H || !Wh || !bh || (!y && !yc) || !sf || !gW || !dH || !loss_partials || !workspace) return DCAHIP_EINVAL;
     if (cdisp && (!theta_w || !g_theta)) return DCAHIP_EINVAL;
     if (workspace_bytes < pl.dw_bytes + pl.dh_bytes + pl.hs_bytes) return DCAHIP_EINVAL;
     if (!al16(H) || !al16(Wh) || !al16(workspace) || (ldh & 3) || (ldw & 3) || ldh < ((hL + 3) & ~3))
         return DCAHIP_EINVAL;
     const int NH = 1 + (cdisp ? 0 : 1) + (has_pi ? 1 : 0);
     if (ldw < (long)NH * plane || ldg < (long)NH * plane) return DCAHIP_EINVAL;
-    if (ldy < G || ldy > 0xffffffffL) return DCAHIP_EINVAL;
+    if (yc ? (ldc < G || ldc > 0xffffffffL) : (ldy < G || ldy > 0xffffffffL)) return DCAHIP_EINVAL;
     float* ws_dh = static_cast<float*>(workspace);
     float* ws_dw = ws_dh + pl.dh_bytes / sizeof(float);
     hipStream_t s = static_cast<hipStream_t>(stream);
     bool direct_dw = false;
-    if (use_f32_mfma()) {
-        HeadsArgs a{g_timing, H, ldh, Wh, ldw, bh, theta_w, y, ldy, sf, perm, cursor, ws_dw, pl.dw_stride, ws_dh, pl.ntg,
-                    tile_order, loss_partials, plane, pl.ldws, B, hL, G, pl.S, pl.NT, ridge, inv_n};
-        if (has_pi && cdisp) launch_fused<true, true>(pl, a, s);
-        else if (has_pi) launch_fused<true, false>(pl, a, s);
-        else if (cdisp) launch_fused<false, true>(pl, a, s);
-        else launch_fused<false, false>(pl, a, s);
-    } else {
+    {
         unsigned short* HA = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(workspace) + pl.dh_bytes + pl.dw_bytes);
         unsigned short* HT = HA + (long)pl.NT * kHTile;
         if (pl.WR != 1) {                    // single-wave workgroups (batches below 256 rows) split H themselves
@@ -2037,12 +1517,20 @@ extern "C" int dcahip_heads_fused_loss(const float* H, long ldh, const float* Wh
             if (rc0 != 0) return rc0;
         }
         direct_dw = pl.S == 1;
-        HeadsArgs2 a{g_timing, HA, HT, H, ldh, gW, ldg, g_theta, Wh, ldw, bh, theta_w, y, ldy, sf, perm, cursor, ws_dw, pl.dw_stride, ws_dh,
+        HeadsArgs2 a{g_timing, HA, HT, H, ldh, gW, ldg, g_theta, Wh, ldw, bh, theta_w, y, ldy, yc, ldc, ovf_ptr, ovf_col, ovf_val,
+                     sf, perm, cursor, ws_dw, pl.dw_stride, ws_dh,
                      pl.npart, pl.nitems, tile_order, loss_partials, plane, pl.ldws, B, hL, G, pl.S, pl.NT, ridge, inv_n};
-        if (has_pi && cdisp) launch_fused_x3<true, true>(pl, a, s);
-        else if (has_pi) launch_fused_x3<true, false>(pl, a, s);
-        else if (cdisp) launch_fused_x3<false, true>(pl, a, s);
-        else launch_fused_x3<false, false>(pl, a, s);
+        if (yc) {
+            if (has_pi && cdisp) launch_fused_x3<true, true, true>(pl, a, s);
+            else if (has_pi) launch_fused_x3<true, false, true>(pl, a, s);
+            else if (cdisp) launch_fused_x3<false, true, true>(pl, a, s);
+            else launch_fused_x3<false, false, true>(pl, a, s);
+        } else {
+            if (has_pi && cdisp) launch_fused_x3<true, true, false>(pl, a, s);
+            else if (has_pi) launch_fused_x3<true, false, false>(pl, a, s);
+            else if (cdisp) launch_fused_x3<false, true, false>(pl, a, s);
+            else launch_fused_x3<false, false, false>(pl, a, s);
+        }
     }
     int rc = (int)hipGetLastError();
     if (rc != 0) return rc;

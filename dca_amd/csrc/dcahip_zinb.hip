@@ -306,7 +306,11 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 template <bool HAS_PI, bool CONST_DISP, bool GRAD>
 int launch_nll(const NllArgs& a, bool vec, dim3 grid, hipStream_t s) {
     // the compacted kernel addresses gradient elements with 32 bits
-    static const bool plain = [] { const char* e = getenv("DCA_ZINB_PLAIN"); return e && e[0] == '1'; }();
+#ifdef DCA_ZINB_PLAIN          // A/B builds only: K-ZINB without the non-zero compaction
+    constexpr bool plain = true;
+#else
+    constexpr bool plain = false;
+#endif
     const bool fits = !GRAD || (long)a.B * a.ldd < (1L << 32);
     if (vec && fits && !plain) hipLaunchKernelGGL((zinb_nll_compact_kernel<HAS_PI, CONST_DISP, GRAD>), grid, dim3(256), 0, s, a);
     else if (vec) hipLaunchKernelGGL((zinb_nll_kernel<HAS_PI, CONST_DISP, GRAD, 4>), grid, dim3(256), 0, s, a);

@@ -330,6 +330,12 @@ class Engine:
         self.drop_iter = torch.zeros(1, dtype=torch.int64, device=self.dev)
         self.row0 = 0               # this rank's first row inside the global batch
         self.Xb = None
+        # compact counts (dca_amd/compact.py): K-HEADS reads its targets from the byte store (cc); with the input
+        # normalisation known (cc_in) the first Dense layer works on the non-zero counts only (K-SPARSE)
+        self.cc = self.cc_in = None
+        self.ws_enc0 = self.ws_enc0f = None
+        self.sparse_fwd_min = int(os.environ.get('DCA_AMD_SPARSE_FWD_MIN', '512'))    # batch rows from which the sparse
+        self.sparse_dw_min = int(os.environ.get('DCA_AMD_SPARSE_DW_MIN', '1'))        # forward / weight gradient are used
 
     def _t(self, name):
         return self.prof.section(name) if self.prof is not None else _NULL
@@ -517,14 +523,55 @@ class Engine:
         sfv = np.ones(n, np.float32) if sf is None else np.asarray(sf, dtype=np.float32).reshape(-1)
         self.sf = torch.as_tensor(sfv).to(self.dev)
         self._set_tile_order()
+        self.attach_compact()               # K-HEADS reads the byte store; the input normalisation of a host X is unknown
 
-    def attach_device_data(self, X, Y, sf):
-        """Uses tensors that already live on the device (synthetic generators, bench)."""
+    def attach_device_data(self, X, Y, sf, norm=None, compact=None):
+        """Uses tensors that already live on the device (K-PREP, synthetic generators, bench).
+        norm: how X was made from Y -- dict(fac=[n] or None, do_log=bool, mean=[G] or None, std=[G] or None) with
+        x = (f(y / fac) - mean) / std (dca/io.py:99-109); with it (and counts that fit the compact store) the first
+        layer takes the sparse kernels.  compact: a CompactCounts of Y built earlier (else built here)."""
         lay = self.lay
         assert X.shape[1] == _r4(lay.G_in) and (Y is None or Y.shape[1] == lay.Gp)
         self.n, self.ldx, self.ldy = X.shape[0], X.shape[1], lay.Gp
         self.X, self.Y, self.sf = X, Y, sf
         self._set_tile_order()
+        self.attach_compact(compact, norm)
+
+    def attach_compact(self, compact=None, norm=None):
+        """Compact byte store of the resident counts (built here unless given) for K-HEADS and -- when the input
+        normalisation is known and input genes = output genes -- the sparse first layer."""
+        self.cc = self.cc_in = None
+        ops, lay = self.ops, self.lay
+        if self.Y is None or not hasattr(ops, 'counts_compact') or os.environ.get('DCA_AMD_COMPACT', '1') == '0':
+            return
+        if compact is None:
+            from . import compact as _compact
+            compact = _compact.build(ops, self.Y, self.Y.shape[0], lay.G_out)
+        if compact is None:
+            return                          # not a count matrix (check_counts=False on arbitrary data): fp32 path
+        self.cc = compact
+        if norm is not None and lay.G_in == lay.G_out and ops.enc0_sparse_supported(lay.hidden[0]) \
+                and os.environ.get('DCA_AMD_SPARSE_ENC0', '1') != '0':
+            self.cc_in = compact.with_input(norm.get('fac'), norm.get('do_log', False), norm.get('mean'), norm.get('std'))
+        self._sparse_workspaces()
+
+    def _sparse_workspaces(self):
+        if self.cc_in is None or self.Bmax <= 0:
+            return
+        lay, ops = self.lay, self.ops
+        need = ops.enc0_dw_sparse_workspace_bytes(self.Bmax, lay.G_in, lay.hidden[0])
+        if self.ws_enc0 is None or self.ws_enc0.numel() * 4 < need:
+            self.ws_enc0 = torch.zeros(need // 4 + 4, dtype=torch.float32, device=self.dev)
+        if self.ws_enc0f is None:
+            self.ws_enc0f = torch.zeros(ops.enc0_fwd_sparse_workspace_bytes(lay.hidden[0]) // 4 + 4,
+                                        dtype=torch.float32, device=self.dev)
+
+    def _sparse_fwd(self, B, training):
+        return (self.cc_in is not None and self.ws_enc0f is not None and B >= self.sparse_fwd_min
+                and not (training and self.in_drop > 0.0))
+
+    def _sparse_dw(self, B):
+        return (self.cc_in is not None and self.ws_enc0 is not None and B >= self.sparse_dw_min and self.in_drop == 0.0)
 
     def _set_tile_order(self):
         """K-HEADS: which 32-gene tiles share a workgroup.  A workgroup lasts as long as its slower tile and the
@@ -618,6 +665,7 @@ class Engine:
                     if self.XT is not None:
                         need = max(need, ops.sgemm_workspace_bytes(0, 1, lay.G_in, lay.hidden[0], b))
         self.ws = torch.zeros(max(need // 4, 4), **f32)
+        self._sparse_workspaces()
 
     # ------------------------------------------------------------------ forward pieces
     def _hidden_forward(self, B, rows_from, training, counts=None):
@@ -629,7 +677,14 @@ class Engine:
         for i, h in enumerate(lay.hidden):
             Wi = lay.view(w, 'W%d' % i); bi = lay.view(w, 'b%d' % i)
             if i == 0:
-                if training and self.in_drop > 0.0:
+                if self._sparse_fwd(B, training):
+                    # K-SPARSE: the product over the non-zero counts of the batch rows (x = (log1p(y / fac) - mean) / std)
+                    gather = rows_from[0] == 'perm'
+                    with self._t('gemm_enc0_fwd'):
+                        ops.enc0_fwd_sparse(self.cc_in, self.perm if gather else None, self.cursor if gather else None,
+                                            0 if gather else rows_from[1], B, K, h, Wi, h, bi, self.Z[0], self.ldh[0],
+                                            self.ws_enc0f)
+                elif training and self.in_drop > 0.0:
                     assert rows_from[0] == 'perm'
                     if self.Xb is None or self.Xb.shape[0] < self.Bmax:
                         self.Xb = torch.zeros(self.Bmax, self.ldx, dtype=torch.float32, device=self.dev)
@@ -873,6 +928,9 @@ class Engine:
         ops.step_end(g[lay.P:], float(Bg), self.hist, rows_per_slot or max(self.Bmax, 1), self.acc,
                      self.cursor, B)
 
+    def _heads_compact(self):
+        return {'compact': self.cc} if self.cc is not None else {}
+
     def _launch_heads_bucket(self):
         """Data parallel: all-reduce of g[Wh .. P] (head weights, biases, log-dispersion, batch
         loss) starts now, asynchronously."""
@@ -908,7 +966,7 @@ class Engine:
                                     self.ridge, inv_n, self.flags, lay.view(g, 'Wh'), lay.NH,
                                     lay.view(g, 'theta_w') if lay.const_disp else None,
                                     self.dH[-1], self.ldh[-1], self.partials, self.ws_heads,
-                                    tile_order=self.tile_order, loss_out=g[lay.P:])
+                                    tile_order=self.tile_order, loss_out=g[lay.P:], **self._heads_compact())
         else:
             self._heads_backward_unfused(B, KL, inv_n)
         self._launch_heads_bucket()
@@ -957,7 +1015,10 @@ class Engine:
             gW = lay.view(g, 'W%d' % i)
             if i == 0:
                 with self._t('gemm_enc0_dW'):
-                    if self.in_drop > 0.0:
+                    if self._sparse_dw(B):
+                        ops.enc0_dw_sparse(self.cc_in, self.perm, self.cursor, 0, B, Kp, h, self.dZ[0], self.ldh[0], gW, h,
+                                           self.ws_enc0)
+                    elif self.in_drop > 0.0:
                         ops.sgemm(1, 0, Kp, h, B, self.Xb, self.ldx, self.dZ[0], self.ldh[0], gW, h,
                                   colsum_row=True, ws=self.ws)
                     elif self.XT is not None and B >= 256:

@@ -132,6 +132,22 @@ _SIGNATURES = {
     'dcahip_prep_scale': (_c.c_int, [_f32p, _c.c_long, _c.c_int, _c.c_int, _f32p, _f32p, _vp]),
     'dcahip_rmsprop_clip': (_c.c_int, [_f32p, _f32p, _f32p, _c.c_long, _f32p, _c.c_float,
                                        _c.c_float, _c.c_float, _vp]),
+    'dcahip_counts_compact_ld': (_c.c_long, [_c.c_int]),
+    'dcahip_counts_compact': (_c.c_int, [_f32p, _c.c_long, _c.c_int, _c.c_int, _vp, _c.c_long, _i32p, _vp]),
+    'dcahip_enc0_sparse_supported': (_c.c_int, [_c.c_int]),
+    'dcahip_enc0_dw_sparse_workspace_bytes': (_c.c_long, [_c.c_int, _c.c_int, _c.c_int]),
+    'dcahip_enc0_dw_sparse': (_c.c_int, [_vp, _c.c_long, _i32p, _i32p, _f32p, _f32p, _c.c_int, _f32p, _f32p, _i32p, _i64p,
+                                         _c.c_long, _c.c_int, _c.c_int, _c.c_int, _f32p, _c.c_long, _f32p, _c.c_long,
+                                         _vp, _c.c_long, _vp]),
+    'dcahip_enc0_fwd_sparse_workspace_bytes': (_c.c_long, [_c.c_int]),
+    'dcahip_enc0_fwd_sparse': (_c.c_int, [_vp, _c.c_long, _i32p, _i32p, _f32p, _f32p, _c.c_int, _f32p, _f32p, _i32p, _i64p,
+                                          _c.c_long, _c.c_int, _c.c_int, _c.c_int, _f32p, _c.c_long, _f32p, _f32p, _c.c_long,
+                                          _vp, _c.c_long, _vp]),
+    'dcahip_heads_fused_compact': (_c.c_int, [_f32p, _c.c_long, _f32p, _c.c_long, _f32p, _c.c_long, _f32p,
+                                              _f32p, _c.c_long, _vp, _c.c_long, _i32p, _i32p, _f32p, _f32p, _i32p, _i64p,
+                                              _c.c_int, _c.c_int, _c.c_int, _c.c_float, _c.c_float, _c.c_int, _f32p,
+                                              _c.c_long, _f32p, _f32p, _c.c_long, _f64p, _c.POINTER(_c.c_int), _vp,
+                                              _c.c_long, _i32p, _f32p, _vp]),
 }
 
 _lib = None

@@ -184,7 +184,9 @@ class Autoencoder():
         sf = np.asarray(adata.obs['size_factors'].values, dtype=np.float32)
         dd = getattr(adata, '_dca_device', None)
         if dd is not None and dd.n == n and dd.G == lay_G(eng) and dd.X.device == eng.dev and dd.matches(X):
-            eng.attach_device_data(dd.X, dd.Y, dd.sf)      # K-PREP's tensors are still in HBM and still ARE adata.X
+            # K-PREP's tensors are still in HBM and still ARE adata.X
+            eng.attach_device_data(dd.X, dd.Y, dd.sf, norm=dd.norm, compact=dd.compact)
+            dd.compact = eng.cc
         else:
             eng.load_data(X, None, sf)
         chunk = min(chunk, n)

@@ -56,16 +56,56 @@ class HipOps:
         return int(self.L.dcahip_heads_tile_order_len(G))
 
     def heads_fused(self, H, ldh, Wh, ldw, bh, plane, theta_w, Y, ldy, sf, perm, cursor, B, hL, G,
-                    ridge, inv_n, flags, gW, ldg, g_theta, dH, lddh, partials, ws, tile_order=None, loss_out=None):
-        """loss_out (a device float): the call also finishes the batch loss there (no loss_finalize launch needed)."""
+                    ridge, inv_n, flags, gW, ldg, g_theta, dH, lddh, partials, ws, tile_order=None, loss_out=None,
+                    compact=None):
+        """loss_out (a device float): the call also finishes the batch loss there (no loss_finalize launch needed).
+        compact (dca_amd.compact.CompactCounts): the counts are read from the byte store instead of Y."""
         n = ctypes.c_int(0)
         p = hip.ptr
-        hip.check(self.L.dcahip_heads_fused_loss(p(H), ldh, p(Wh), ldw, p(bh), plane, p(theta_w), p(Y), ldy,
-                                                 p(sf), p(perm), p(cursor), B, hL, G, ridge, inv_n, flags,
-                                                 p(gW), ldg, p(g_theta), p(dH), lddh, p(partials),
-                                                 ctypes.byref(n), p(ws), ws.numel() * ws.element_size(),
-                                                 p(tile_order), p(loss_out), hip.stream()), 'heads_fused')
+        c = compact
+        hip.check(self.L.dcahip_heads_fused_compact(p(H), ldh, p(Wh), ldw, p(bh), plane, p(theta_w), p(Y), ldy,
+                                                    p(c.Yc) if c is not None else None, c.ldc if c is not None else 0,
+                                                    p(c.ovf_ptr) if c is not None else None,
+                                                    p(c.ovf_col) if c is not None else None,
+                                                    p(c.ovf_val) if c is not None else None,
+                                                    p(sf), p(perm), p(cursor), B, hL, G, ridge, inv_n, flags,
+                                                    p(gW), ldg, p(g_theta), p(dH), lddh, p(partials),
+                                                    ctypes.byref(n), p(ws), ws.numel() * ws.element_size(),
+                                                    p(tile_order), p(loss_out), hip.stream()), 'heads_fused')
         return n.value
+
+    # ------------------------------------------------------------------ compact counts, sparse first layer
+    def counts_compact_ld(self, G):
+        return int(self.L.dcahip_counts_compact_ld(G))
+
+    def counts_compact(self, Y, ldy, n, G, Yc, ldc, status):
+        hip.check(self.L.dcahip_counts_compact(hip.ptr(Y), ldy, n, G, hip.ptr(Yc), ldc, hip.ptr(status), hip.stream()),
+                  'counts_compact')
+
+    def enc0_sparse_supported(self, H1):
+        return bool(self.L.dcahip_enc0_sparse_supported(int(H1)))
+
+    def enc0_dw_sparse_workspace_bytes(self, B, G, H1):
+        return int(self.L.dcahip_enc0_dw_sparse_workspace_bytes(B, G, H1))
+
+    def enc0_fwd_sparse_workspace_bytes(self, H1):
+        return int(self.L.dcahip_enc0_fwd_sparse_workspace_bytes(H1))
+
+    def enc0_dw_sparse(self, c, perm, cursor, row_base, B, G, H1, dZ, ldz, gW, ldg, ws):
+        """gW [G + 1, ldg] = [X^T dZ ; colsum dZ] with X described by the compact counts c (its normalisation fields)."""
+        p = hip.ptr
+        hip.check(self.L.dcahip_enc0_dw_sparse(p(c.Yc), c.ldc, p(c.ovf_ptr), p(c.ovf_col), p(c.ovf_val), p(c.fac),
+                                               int(c.do_log), p(c.mean), p(c.std), p(perm), p(cursor), int(row_base),
+                                               B, G, H1, p(dZ), ldz, p(gW), ldg, p(ws), ws.numel() * ws.element_size(),
+                                               hip.stream()), 'enc0_dw_sparse')
+
+    def enc0_fwd_sparse(self, c, perm, cursor, row_base, B, G, H1, W, ldw, bias, Z, ldz, ws):
+        """Z [B, ldz] = X W + bias; ws: zero-initialised once, private to this call site."""
+        p = hip.ptr
+        hip.check(self.L.dcahip_enc0_fwd_sparse(p(c.Yc), c.ldc, p(c.ovf_ptr), p(c.ovf_col), p(c.ovf_val), p(c.fac),
+                                                int(c.do_log), p(c.mean), p(c.std), p(perm), p(cursor), int(row_base),
+                                                B, G, H1, p(W), ldw, p(bias), p(Z), ldz, p(ws),
+                                                ws.numel() * ws.element_size(), hip.stream()), 'enc0_fwd_sparse')
 
     # ------------------------------------------------------------------ gemm
     def sgemm_workspace_bytes(self, ta, tb, M, N, K, colsum_row=False, split_k=0):

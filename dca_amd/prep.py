@@ -21,8 +21,12 @@ class DeviceData:
     """Preprocessed tensors resident on the device: X [n, ldx] (network input), Y [n, ldy]
     (raw counts, the loss target), sf [n]."""
 
-    def __init__(self, X, Y, sf, n, G, host_x=None):
+    def __init__(self, X, Y, sf, n, G, host_x=None, norm=None):
         self.X, self.Y, self.sf, self.n, self.G = X, Y, sf, n, G
+        # how X was made from Y (fac, do_log, mean, std: dca/io.py:99-109) -- lets the engine run the first layer on the
+        # non-zero counts (Engine.attach_device_data); the compact byte store of Y is built once and kept here
+        self.norm = norm
+        self.compact = None
         # what adata.X held when these tensors were made: train() / predict() use the resident tensors only while the
         # host matrix still is that matrix (the reference always feeds the CURRENT adata.X, network.py:188-211)
         self.host_mark = fingerprint(host_x) if host_x is not None else None
@@ -132,9 +136,10 @@ def cell_counts(ops, Y, n, G):
     return out
 
 
-def transform(ops, Y, n, G, fac, logtrans_input, normalize_input, comm=None):
+def transform(ops, Y, n, G, fac, logtrans_input, normalize_input, comm=None, return_norm=False):
     """X = scale(log1p(Y / fac)) on the device (each step optional).  With a communicator the
-    per-gene statistics are those of all ranks' shards (data-parallel preprocessing)."""
+    per-gene statistics are those of all ranks' shards (data-parallel preprocessing).
+    return_norm: also the description of the transform, (X, dict(fac, do_log, mean, std))."""
     dev = Y.device
     ld = Y.shape[1]
     X = torch.zeros(n, ld, dtype=torch.float32, device=dev)
@@ -142,6 +147,7 @@ def transform(ops, Y, n, G, fac, logtrans_input, normalize_input, comm=None):
     Gp = _r4(G)
     part = torch.zeros(R * 2 * Gp, dtype=torch.float64, device=dev)
     ops.prep_col_pass(Y, ld, n, G, fac, logtrans_input, X, ld, part)
+    mean = std = None
     if normalize_input:
         mean = torch.zeros(Gp, dtype=torch.float32, device=dev)
         std = torch.ones(Gp, dtype=torch.float32, device=dev)
@@ -155,6 +161,8 @@ def transform(ops, Y, n, G, fac, logtrans_input, normalize_input, comm=None):
         else:
             ops.prep_col_finish(part, R, G, n_total, None, mean, std)
         ops.prep_scale(X, ld, n, G, mean, std)
+    if return_norm:
+        return X, dict(fac=fac, do_log=bool(logtrans_input), mean=mean, std=std)
     return X
 
 
@@ -228,9 +236,9 @@ def normalize_device(adata, filter_min_counts=True, size_factors=True, normalize
         sf_d = torch.ones(n, dtype=torch.float32, device=dev)
 
     if fac_d is not None or logtrans_input or normalize_input:
-        X = transform(ops, Y, n, G, fac_d, logtrans_input, normalize_input)
+        X, norm = transform(ops, Y, n, G, fac_d, logtrans_input, normalize_input, return_norm=True)
     else:
-        X = Y
+        X, norm = Y, dict(fac=None, do_log=False, mean=None, std=None)
     if to_host:
         adata.X = _download(X, n, G)
-    return adata, DeviceData(X, Y, sf_d, n, G, host_x=adata.X if to_host else None)
+    return adata, DeviceData(X, Y, sf_d, n, G, host_x=adata.X if to_host else None, norm=norm)

@@ -267,7 +267,8 @@ def train(adata, network, output_dir=None, optimizer='RMSprop', learning_rate=No
     if comm.world == 1 and dd is not None and not output_subset and use_raw_as_output and \
             dd.n == n and dd.G == X.shape[1] == eng.lay.G_in == eng.lay.G_out and \
             dd.X.device == eng.dev and dd.matches(X):
-        eng.attach_device_data(dd.X, dd.Y, dd.sf)      # K-PREP left the tensors in HBM
+        eng.attach_device_data(dd.X, dd.Y, dd.sf, norm=dd.norm, compact=dd.compact)      # K-PREP left the tensors in HBM
+        dd.compact = eng.cc
     elif comm.world == 1:
         eng.load_data(X, Y, sf)
     else:

@@ -11,7 +11,8 @@
  * Conventions
  *   - every pointer is a DEVICE pointer to row-major fp32 unless stated; the caller
  *     (host code / PyTorch as allocator) owns every buffer, the library allocates nothing
- *     and keeps no global state;
+ *     and keeps no global state (no environment variables either: every choice of kernel is a pure function of the
+ *     arguments; A/B variants exist only as -D builds of the sources);
  *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), re-entrant
  *     across streams and capturable into a hipGraph (no host synchronisation inside);
  *   - return value: 0 on success, otherwise the hipError_t of the failed launch or
@@ -417,6 +418,69 @@ int dcahip_l1l2_apply(const dcahip_reg_desc* d, const float* w, float* g, float*
 int dcahip_dropout_apply(const float* x, long ldx, const int* perm, const long long* cursor, int B, int h,
                          float rate, unsigned long long seed, const long long* step, int layer, long row0,
                          float* out, long ldo, void* stream);
+
+/*
+ * K-SPARSE: compact count storage and the first Dense layer on the non-zero counts only.
+ *
+ * The reference turns the ~93 %-zero count matrix into a DENSE fp32 input X = scale(log1p(counts / size factor))
+ * (dca/io.py:88-111; scanpy normalize_per_cell, log1p, scale) and feeds it to the first Dense layer
+ * (dca/network.py:124-126); TensorFlow's autodiff forms the weight gradient X^T dZ from the same dense matrix.
+ * With x[c, g] = (L[c, g] - mean[g]) / std[g], L = log1p(y / fac[c]) (0 where y = 0; each step optional) both
+ * products need the non-zero counts only (formulas in dca_amd/csrc/dcahip_sparse.hip).
+ *
+ * Compact counts: Yc [n, ldc] bytes, ldc = dcahip_counts_compact_ld(G) (G rounded up to 16, pad columns 0); a count
+ * 0 .. 254 is stored as is, 255 is an escape whose value is looked up in a per-row overflow list: entries
+ * ovf_ptr[r] .. ovf_ptr[r + 1] - 1 of (ovf_col, ovf_val), sorted by column (all three may be NULL when no count
+ * reaches 255).  dcahip_counts_compact writes Yc from the fp32 counts and ADDS to status[0] the number of values that
+ * are not counts (negative, fractional, not finite: stored as 0 -- the caller must not use the compact store then)
+ * and to status[1] the number of escapes (the caller builds the overflow list from Y >= 255).
+ * K-HEADS takes the same store through dcahip_heads_fused_compact.
+ */
+long dcahip_counts_compact_ld(int G);
+int dcahip_counts_compact(const float* Y, long ldy, int n, int G, unsigned char* Yc, long ldc, int* status,
+                          void* stream);
+/* K-HEADS (dcahip_heads_fused_loss) reading the counts from the compact store: yc != NULL selects it (y / ldy are then
+ * unused and may be NULL / 0), yc == NULL is dcahip_heads_fused_loss.  4 x fewer count bytes per launch. */
+int dcahip_heads_fused_compact(const float* H, long ldh, const float* Wh, long ldw, const float* bh,
+                               long plane, const float* theta_w,
+                               const float* y, long ldy,
+                               const unsigned char* yc, long ldc, const int* ovf_ptr, const int* ovf_col,
+                               const float* ovf_val, const float* sf,
+                               const int* perm, const long long* cursor,
+                               int B, int hL, int G, float ridge, float inv_n, int flags,
+                               float* gW, long ldg, float* g_theta, float* dH, long lddh,
+                               double* loss_partials, int* n_partials_out,
+                               void* workspace, long workspace_bytes, const int* tile_order,
+                               float* loss_out, void* stream);
+/* First-layer widths the sparse kernels take (16, 32, 64, 128, 256). */
+int dcahip_enc0_sparse_supported(int H1);
+/*
+ * Weight (+ bias) gradient of the first Dense layer from the compact counts:
+ *   gW [G + 1, ldg]: rows g < G = sum_c x[c, g] dZ[c, :], row G = column sums of dZ (what dcahip_sgemm(ta = 1,
+ *   colsum_row = 1) writes from the dense X).  Batch row c = storage row perm[*cursor + row_base + c] (perm NULL:
+ *   *cursor + row_base + c) of Yc / fac.  fac NULL: no size-factor division; do_log 0: no log1p; mean NULL: 0;
+ *   stdv NULL: 1.  dZ [B, ldz] 16-byte aligned, ldz % 4 == 0.  Deterministic (fixed summation order).
+ *   workspace >= dcahip_enc0_dw_sparse_workspace_bytes(B, G, H1), 16-byte aligned.
+ * Replaces the autodiff of dca/network.py:124-126 w.r.t. the first kernel on the input of dca/io.py:88-111.
+ */
+long dcahip_enc0_dw_sparse_workspace_bytes(int B, int G, int H1);
+int dcahip_enc0_dw_sparse(const unsigned char* Yc, long ldc, const int* ovf_ptr, const int* ovf_col,
+                          const float* ovf_val, const float* fac, int do_log, const float* mean,
+                          const float* stdv, const int* perm, const long long* cursor, long row_base,
+                          int B, int G, int H1, const float* dZ, long ldz, float* gW, long ldg,
+                          void* workspace, long workspace_bytes, void* stream);
+/*
+ * Forward of the first Dense layer from the compact counts: Z [B, ldz] = X W + bias with X as above, W [G, ldw].
+ * workspace >= dcahip_enc0_fwd_sparse_workspace_bytes(H1) bytes, 16-byte aligned, ZERO before the first call (it
+ * holds the arrival counter of the bias-correction reduction; every call leaves it at zero).
+ * Replaces Dense(hidden_size[0]) of dca/network.py:124-126 on the input of dca/io.py:88-111.
+ */
+long dcahip_enc0_fwd_sparse_workspace_bytes(int H1);
+int dcahip_enc0_fwd_sparse(const unsigned char* Yc, long ldc, const int* ovf_ptr, const int* ovf_col,
+                           const float* ovf_val, const float* fac, int do_log, const float* mean,
+                           const float* stdv, const int* perm, const long long* cursor, long row_base,
+                           int B, int G, int H1, const float* W, long ldw, const float* bias,
+                           float* Z, long ldz, void* workspace, long workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }
