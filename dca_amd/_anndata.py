@@ -134,7 +134,12 @@ class MiniAnnData:
             # selecting everything: a view-like object sharing the matrices, as anndata's own (lazy) views do -- dca()
             # takes adata[adata.obs.dca_split == 'train'] of a dataset without a test split (api.py:203), and copying
             # two 5.5 GB matrices there cost more than the GPU training
-            out = MiniAnnData(self._X, self.obs, self.var, dict(self.obsm), dict(self.uns), self._raw)
+            # (read-only, like a view that has not been written to: a write through the subset must not reach the parent)
+            Xv = self._X
+            if isinstance(Xv, np.ndarray):
+                Xv = Xv.view()
+                Xv.setflags(write=False)
+            out = MiniAnnData(Xv, self.obs, self.var, dict(self.obsm), dict(self.uns), self._raw)
             dd = getattr(self, '_dca_device', None)
             if dd is not None:
                 out._dca_device = dd

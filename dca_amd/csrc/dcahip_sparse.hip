@@ -92,124 +92,144 @@ __global__ __launch_bounds__(256) void counts_compact_kernel(const float* Y, lon
 }
 
 // ------------------------------------------------------------------------------------------------- weight gradient
+// lut [n, 8]: lut[r][k] = f(k / fac[r]) for the counts k = 0 .. 7 that make up ~99 % of the non-zero entries (f = log1p
+// or the identity): one table row per cell, made once per dataset; larger counts (and escapes) take the formula.
+constexpr int kLut = 8;
+
+__global__ __launch_bounds__(256) void enc0_lut_kernel(const float* fac, int do_log, int n, float* lut) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)n * kLut) return;
+    const int r = (int)(idx / kLut), k = (int)(idx - (long)r * kLut);
+    float x = (float)k;
+    if (fac) x = __fdiv_rn(x, fac[r]);
+    if (do_log) x = log1pf(x);
+    lut[idx] = x;
+}
+
 struct DwArgs {
     Compact c;
     const float* fac; int do_log;
+    const float* lut;               // [n, 8]
     const int* perm; const long long* cursor; long row_base;
     int B, G;
     const float* dZ; long ldz;
     float* P; long Gs;              // [NS][Gs][H1] partial sums over the non-zero counts
     float* Sp;                      // [NS][H1] partial column sums of dZ
-    int RS;                         // batch rows per split (multiple of 256)
+    int RS;                         // batch rows per split (multiple of the row block)
 };
 
-constexpr int kDwCap = 256;         // queue entries per wave = rows per group
+// rows of dZ a workgroup keeps in LDS at a time: 64 KB of them
+constexpr int dw_row_block(int H1) { return H1 <= 64 ? 256 : (H1 == 128 ? 128 : 64); }
+constexpr int kDwWaves = 16;        // waves per workgroup: 256 genes
 
 template <int H1>
-__global__ __launch_bounds__(256) void enc0_dw_kernel(DwArgs a) {
+__global__ __launch_bounds__(64 * kDwWaves) void enc0_dw_kernel(DwArgs a) {
     constexpr int LPE = H1 / 4;             // lanes per queue entry (4 columns each)
     constexpr int EPI = 64 / LPE;           // entries per iteration
+    constexpr int RB = dw_row_block(H1);
+    constexpr int NCH = RB / 64;
+    constexpr int NW = kDwWaves;
+    constexpr int LS = kLut + 1;            // odd row stride of the table: rows x codes spread over the banks
     static_assert(LPE >= 1 && LPE <= 64 && (64 % LPE) == 0, "first-layer width");
-    __shared__ unsigned q[4][kDwCap];
-    __shared__ uint2 qe[4][64];
-    __shared__ float rfac[4][kDwCap];
-    __shared__ int srows[4][kDwCap];
-    __shared__ float csum[4][H1];
+    __shared__ __attribute__((aligned(16))) float dzs[RB * H1];
+    __shared__ float luts[RB * LS];
+    __shared__ float rfac[RB];
+    __shared__ int srows[RB];
+    __shared__ uint2 qe[NW][RB + 2 * EPI];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nsg = (a.G + 63) >> 6;
     const int split = blockIdx.y;
     const int rb = split * a.RS;
     const int re = min(a.B, rb + a.RS);
     const long long cur = (a.cursor ? *a.cursor : 0) + a.row_base;
+    const int g0 = (blockIdx.x * NW + wave) * 16;
+    const bool wave_on = g0 < a.G;
 
-    if ((int)blockIdx.x == nsg) {
-        // column sums of this split's rows of dZ (the bias gradient; the mean[g] term of the weight gradient)
-        for (int j0 = 0; j0 < H1; j0 += 64) {
-            const int j = j0 + lane;
-            float s = 0.f;
-            if (j < H1)
-                for (int c = rb + wave; c < re; c += 4) s += a.dZ[(long)c * a.ldz + j];
-            if (j < H1) csum[wave][j] = s;
-        }
-        __syncthreads();
-        for (int j = tid; j < H1; j += 256)
-            a.Sp[(long)split * H1 + j] = ((csum[0][j] + csum[1][j]) + csum[2][j]) + csum[3][j];
-        return;
-    }
-    const int g0 = (blockIdx.x * 4 + wave) * 16;
-    if (g0 >= a.G) return;
-
-    unsigned* const Q = q[wave];
     uint2* const QE = qe[wave];
-    float* const RF = rfac[wave];
-    int* const SR = srows[wave];
     const int grp = lane / LPE, lidx = lane - grp * LPE;
-    const char* const dzb = reinterpret_cast<const char*>(a.dZ) + lidx * 16;
-    const unsigned ldzb = (unsigned)(a.ldz * 4);
+    const char* const dzl = reinterpret_cast<const char*>(dzs) + lidx * 16;
 
     float4 acc[16];
 #pragma unroll
     for (int b = 0; b < 16; ++b) acc[b] = make_float4(0.f, 0.f, 0.f, 0.f);
-
-    auto flush = [&](float4& ac, int qn, int rg0, int gcol) {
-        wave_sync();
-        for (int base = 0; base < qn; base += 64) {
-            const int n = min(64, qn - base);
-            const unsigned e = lane < n ? Q[base + lane] : 0u;
-            const unsigned code = e & 255u;
-            const int cl = (int)(e >> 8);
-            float val = (float)code;
-            if (code == 255u) val = escaped_count(a.c, SR[cl], gcol);
-            float x = a.fac ? __fdiv_rn(val, RF[cl]) : val;
-            if (a.do_log) x = log1pf(x);
-            QE[lane] = make_uint2(__float_as_uint(x), (unsigned)(rg0 + cl) * ldzb);
-            wave_sync();
-            const int nit = (n + EPI - 1) / EPI;
-#pragma unroll 4
-            for (int it = 0; it < nit; ++it) {
-                const uint2 en = QE[it * EPI + grp];
-                const float4 dz = *reinterpret_cast<const float4*>(dzb + en.y);
-                const float xv = __uint_as_float(en.x);
-                ac.x = fmaf(xv, dz.x, ac.x); ac.y = fmaf(xv, dz.y, ac.y);
-                ac.z = fmaf(xv, dz.z, ac.z); ac.w = fmaf(xv, dz.w, ac.w);
-            }
-            wave_sync();
-        }
-    };
+    float colsum = 0.f;                     // workgroup 0 of the split: thread j < H1 sums column j of dZ
 
 #pragma unroll 1
-    for (int rg0 = rb; rg0 < re; rg0 += kDwCap) {
-        const int nrow = min(kDwCap, re - rg0);
-        uint4 codes[4];
+    for (int rg0 = rb; rg0 < re; rg0 += RB) {
+        const int nrow = min(RB, re - rg0);
+        __syncthreads();                    // everyone is done with the previous block
+        // ---- the block's rows of dZ (zero beyond the batch), table rows, divisors, storage rows
+        for (int i = tid; i < RB * (H1 / 4); i += 64 * NW) {
+            const int r = i / (H1 / 4), c4 = i - r * (H1 / 4);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < nrow) v = *reinterpret_cast<const float4*>(a.dZ + (long)(rg0 + r) * a.ldz + 4 * c4);
+            *reinterpret_cast<float4*>(dzs + r * H1 + 4 * c4) = v;
+        }
+        for (int i = tid; i < RB; i += 64 * NW) {
+            const int rc = i < nrow ? i : nrow - 1;
+            const long sr = a.perm ? (long)a.perm[cur + rg0 + rc] : cur + rg0 + rc;
+            srows[i] = (int)sr;
+            rfac[i] = a.fac ? a.fac[sr] : 1.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+            for (int k = 0; k < kLut; ++k) luts[i * LS + k] = a.lut[sr * kLut + k];
+        }
+        // ---- this wave's counts: row i * 64 + lane of the block, 16 genes
+        uint4 codes[NCH];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
             const int cl = i * 64 + lane;
             const int clc = cl < nrow ? cl : nrow - 1;
             const long sr = a.perm ? (long)a.perm[cur + rg0 + clc] : cur + rg0 + clc;
-            uint4 v = *reinterpret_cast<const uint4*>(a.c.yc + sr * a.c.ldc + g0);
-            if (cl >= nrow) v = make_uint4(0u, 0u, 0u, 0u);
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (wave_on && cl < nrow) v = *reinterpret_cast<const uint4*>(a.c.yc + sr * a.c.ldc + g0);
             codes[i] = v;
-            SR[cl] = (int)sr;
-            RF[cl] = a.fac ? a.fac[sr] : 1.f;
         }
+        __syncthreads();
+        if (blockIdx.x == 0 && tid < H1)
+            for (int r = 0; r < nrow; ++r) colsum += dzs[r * H1 + tid];
+        if (!wave_on) continue;
 #pragma unroll
         for (int b = 0; b < 16; ++b) {
             const int d = b >> 2, sh = 8 * (b & 3);
             int qn = 0;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NCH; ++i) {
                 const unsigned dw = d == 0 ? codes[i].x : d == 1 ? codes[i].y : d == 2 ? codes[i].z : codes[i].w;
                 const unsigned code = (dw >> sh) & 255u;
+                const int cl = i * 64 + lane;
                 const bool nz = code != 0u;
+                float x = luts[cl * LS + (code < kLut ? code : 0u)];
+                if (code >= kLut) {                        // rare: a large count (or an escape): the formula itself
+                    float val = (float)code;
+                    if (code == 255u) val = escaped_count(a.c, srows[cl], g0 + b);
+                    x = a.fac ? __fdiv_rn(val, rfac[cl]) : val;
+                    if (a.do_log) x = log1pf(x);
+                }
                 const unsigned long long m = __ballot(nz);
-                if (nz) Q[qn + mbcnt64(m)] = code | ((unsigned)(i * 64 + lane) << 8);
+                if (nz) QE[qn + mbcnt64(m)] = make_uint2(__float_as_uint(x), (unsigned)(cl * H1 * 4));
                 qn += __popcll(m);
             }
-            if (qn > 0) flush(acc[b], qn, rg0, g0 + b);
+            if (qn == 0) continue;
+            // harmless entries up to the next multiple of two iterations
+            const int nit = ((qn + 2 * EPI - 1) / (2 * EPI)) * 2;
+            if (lane < nit * EPI - qn) QE[qn + lane] = make_uint2(0u, 0u);
+            wave_sync();
+            float4 ac = acc[b];
+            for (int it = 0; it < nit; it += 2) {
+                const uint2 e0 = QE[it * EPI + grp], e1 = QE[(it + 1) * EPI + grp];
+                const float4 d0 = *reinterpret_cast<const float4*>(dzl + e0.y);
+                const float4 d1 = *reinterpret_cast<const float4*>(dzl + e1.y);
+                const float x0 = __uint_as_float(e0.x), x1 = __uint_as_float(e1.x);
+                ac.x = fmaf(x0, d0.x, ac.x); ac.y = fmaf(x0, d0.y, ac.y); ac.z = fmaf(x0, d0.z, ac.z); ac.w = fmaf(x0, d0.w, ac.w);
+                ac.x = fmaf(x1, d1.x, ac.x); ac.y = fmaf(x1, d1.y, ac.y); ac.z = fmaf(x1, d1.z, ac.z); ac.w = fmaf(x1, d1.w, ac.w);
+            }
+            acc[b] = ac;
+            wave_sync();                                   // the queue is free for the next gene
         }
     }
+    if (blockIdx.x == 0 && tid < H1) a.Sp[(long)split * H1 + tid] = colsum;
+    if (!wave_on) return;
     // ---- the EPI groups hold partial sums over different entries: add them (fixed order), one row of P per gene
 #pragma unroll
     for (int b = 0; b < 16; ++b) {
@@ -365,14 +385,24 @@ __global__ __launch_bounds__(256) void enc0_fwd_kernel(FwArgs a) {
             if (a.stdv) x = __fdiv_rn(x, a.stdv[gene]);
             QE[lane] = make_uint2(__float_as_uint(x), (unsigned)gene * ldwb);
             wave_sync();
+            // every row of W the batch needs is requested before the first product (lanes beyond n hold x = 0, row 0):
+            // the gathers come from L2 and their latency, not their number, is what a wave waits for
+            constexpr int NIT = 64 / EPI, HALF = NIT > 8 ? 8 : NIT;
             const int nit = (n + EPI - 1) / EPI;
-#pragma unroll 4
-            for (int it = 0; it < nit; ++it) {
-                const uint2 en = QE[it * EPI + grp];
-                const float4 w = *reinterpret_cast<const float4*>(wb + en.y);
-                const float xv = __uint_as_float(en.x);
-                acc.x = fmaf(xv, w.x, acc.x); acc.y = fmaf(xv, w.y, acc.y);
-                acc.z = fmaf(xv, w.z, acc.z); acc.w = fmaf(xv, w.w, acc.w);
+#pragma unroll 1
+            for (int h0 = 0; h0 < nit; h0 += HALF) {
+                uint2 en[HALF];
+                float4 w[HALF];
+#pragma unroll
+                for (int it = 0; it < HALF; ++it) en[it] = QE[(h0 + it) * EPI + grp];
+#pragma unroll
+                for (int it = 0; it < HALF; ++it) w[it] = *reinterpret_cast<const float4*>(wb + en[it].y);
+#pragma unroll
+                for (int it = 0; it < HALF; ++it) {
+                    const float xv = __uint_as_float(en[it].x);
+                    acc.x = fmaf(xv, w[it].x, acc.x); acc.y = fmaf(xv, w[it].y, acc.y);
+                    acc.z = fmaf(xv, w[it].z, acc.z); acc.w = fmaf(xv, w[it].w, acc.w);
+                }
             }
             qn -= n;
             wave_sync();
@@ -417,14 +447,21 @@ __global__ __launch_bounds__(256) void enc0_fwd_kernel(FwArgs a) {
 
 inline bool width_ok(int H1) { return H1 == 16 || H1 == 32 || H1 == 64 || H1 == 128 || H1 == 256; }
 
-inline int dw_splits(int B) {
-    // rows per split: a multiple of the 256-row group, at most 16 splits; ~1024 rows per split at throughput batches
-    int ns = (B + 1023) / 1024;
-    if (ns < 1) ns = 1;
+// row splits: as many as keep the grid at (or just below) one workgroup per CU -- every workgroup resident, one round
+inline int dw_splits(int B, int G, int H1) {
+    const int RB = dw_row_block(H1);
+    const int groups = (G + 16 * kDwWaves - 1) / (16 * kDwWaves);
+    int ns = 256 / groups;
+    const int maxs = (B + RB - 1) / RB;
+    if (ns > maxs) ns = maxs;
     if (ns > 16) ns = 16;
+    if (ns < 1) ns = 1;
     return ns;
 }
-inline int dw_rows_per_split(int B, int ns) { return (((B + ns - 1) / ns) + kDwCap - 1) / kDwCap * kDwCap; }
+inline int dw_rows_per_split(int B, int ns, int H1) {
+    const int RB = dw_row_block(H1);
+    return (((B + ns - 1) / ns) + RB - 1) / RB * RB;
+}
 
 }  // namespace
 
@@ -444,36 +481,44 @@ extern "C" int dcahip_enc0_sparse_supported(int H1) { return width_ok(H1) ? 1 : 
 
 extern "C" long dcahip_enc0_dw_sparse_workspace_bytes(int B, int G, int H1) {
     if (!width_ok(H1) || B <= 0 || G <= 0) return 0;
-    const int ns = dw_splits(B);
-    const long Gs = ((long)G + 63) / 64 * 64;
+    const int ns = dw_splits(B, G, H1);
+    const long Gs = ((long)G + 255) / 256 * 256;
     return ((long)ns * Gs * H1 + (long)ns * H1) * 4;
 }
 
+extern "C" int dcahip_enc0_lut(const float* fac, int do_log, int n, float* lut, void* stream) {
+    if (n <= 0 || !lut) return DCAHIP_EINVAL;
+    hipLaunchKernelGGL(enc0_lut_kernel, dim3((unsigned)(((long)n * kLut + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       fac, do_log, n, lut);
+    return (int)hipGetLastError();
+}
+
 extern "C" int dcahip_enc0_dw_sparse(const unsigned char* Yc, long ldc, const int* ovf_ptr, const int* ovf_col,
-                                     const float* ovf_val, const float* fac, int do_log, const float* mean,
+                                     const float* ovf_val, const float* fac, int do_log, const float* lut, const float* mean,
                                      const float* stdv, const int* perm, const long long* cursor, long row_base,
                                      int B, int G, int H1, const float* dZ, long ldz, float* gW, long ldg,
                                      void* workspace, long workspace_bytes, void* stream) {
-    if (!width_ok(H1) || B <= 0 || G <= 0 || !Yc || (ldc & 15) || ldc < G || !dZ || (ldz & 3) || ldz < H1 || !gW ||
+    if (!width_ok(H1) || B <= 0 || G <= 0 || !Yc || !lut || (ldc & 15) || ldc < G || !dZ || (ldz & 3) || ldz < H1 || !gW ||
         ldg < H1 || (reinterpret_cast<uintptr_t>(dZ) & 15) || (reinterpret_cast<uintptr_t>(workspace) & 15) || !workspace)
         return DCAHIP_EINVAL;
     if (workspace_bytes < dcahip_enc0_dw_sparse_workspace_bytes(B, G, H1)) return DCAHIP_EINVAL;
-    const int ns = dw_splits(B);
-    const long Gs = ((long)G + 63) / 64 * 64;
+    const int ns = dw_splits(B, G, H1);
+    const long Gs = ((long)G + 255) / 256 * 256;
     DwArgs a;
     a.c = Compact{Yc, ldc, ovf_ptr, ovf_col, ovf_val};
-    a.fac = fac; a.do_log = do_log; a.perm = perm; a.cursor = cursor; a.row_base = row_base;
+    a.fac = fac; a.do_log = do_log; a.lut = lut; a.perm = perm; a.cursor = cursor; a.row_base = row_base;
     a.B = B; a.G = G; a.dZ = dZ; a.ldz = ldz;
     a.P = static_cast<float*>(workspace); a.Gs = Gs; a.Sp = a.P + (long)ns * Gs * H1;
-    a.RS = dw_rows_per_split(B, ns);
-    const dim3 grid((unsigned)((G + 63) / 64 + 1), (unsigned)ns);
+    a.RS = dw_rows_per_split(B, ns, H1);
+    const dim3 grid((unsigned)((G + 16 * kDwWaves - 1) / (16 * kDwWaves)), (unsigned)ns);
+    const dim3 block(64 * kDwWaves);
     hipStream_t s = (hipStream_t)stream;
     switch (H1) {
-        case 16: hipLaunchKernelGGL(enc0_dw_kernel<16>, grid, dim3(256), 0, s, a); break;
-        case 32: hipLaunchKernelGGL(enc0_dw_kernel<32>, grid, dim3(256), 0, s, a); break;
-        case 64: hipLaunchKernelGGL(enc0_dw_kernel<64>, grid, dim3(256), 0, s, a); break;
-        case 128: hipLaunchKernelGGL(enc0_dw_kernel<128>, grid, dim3(256), 0, s, a); break;
-        default: hipLaunchKernelGGL(enc0_dw_kernel<256>, grid, dim3(256), 0, s, a); break;
+        case 16: hipLaunchKernelGGL(enc0_dw_kernel<16>, grid, block, 0, s, a); break;
+        case 32: hipLaunchKernelGGL(enc0_dw_kernel<32>, grid, block, 0, s, a); break;
+        case 64: hipLaunchKernelGGL(enc0_dw_kernel<64>, grid, block, 0, s, a); break;
+        case 128: hipLaunchKernelGGL(enc0_dw_kernel<128>, grid, block, 0, s, a); break;
+        default: hipLaunchKernelGGL(enc0_dw_kernel<256>, grid, block, 0, s, a); break;
     }
     int rc = (int)hipGetLastError();
     if (rc) return rc;

@@ -68,7 +68,10 @@ inline bool parse_field(const char* p, const char* e, float* out) {
     while (p < e && (*p == ' ')) ++p;
     while (e > p && (e[-1] == ' ')) --e;
     if (p == e) { *out = std::numeric_limits<float>::quiet_NaN(); return true; }
-    if (*p == '+') ++p;                                       // from_chars rejects a leading plus, pandas accepts it
+    if (*p == '+') {                                          // from_chars rejects a leading plus, pandas accepts ONE in front of a number
+        ++p;
+        if (p == e || *p == '+' || *p == '-') return false;
+    }
     // the common case first: a short run of digits (counts)
     if (e - p <= 9) {
         unsigned v = 0;

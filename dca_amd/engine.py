@@ -552,7 +552,7 @@ class Engine:
         self.cc = compact
         if norm is not None and lay.G_in == lay.G_out and ops.enc0_sparse_supported(lay.hidden[0]) \
                 and os.environ.get('DCA_AMD_SPARSE_ENC0', '1') != '0':
-            self.cc_in = compact.with_input(norm.get('fac'), norm.get('do_log', False), norm.get('mean'), norm.get('std'))
+            self.cc_in = compact.with_input(norm.get('fac'), norm.get('do_log', False), norm.get('mean'), norm.get('std'), ops=ops)
         self._sparse_workspaces()
 
     def _sparse_workspaces(self):

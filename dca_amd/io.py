@@ -142,8 +142,11 @@ def _read_text_native(filename, sep):
     if len(set(cols)) != len(cols) or any(c == '' for c in cols):
         return None             # pandas renames these ('x.1', 'Unnamed: 3')
     # the name column goes through pandas' own type inference ('007' is the integer 7 to read_csv, an empty name NaN)
-    idx = pd.read_csv(_pyio.StringIO('\n'.join(rows) + '\n'), sep=sep, header=None, usecols=[0], skip_blank_lines=False,
-                      dtype=None)[0] if rows else pd.Series([], dtype=object)
+    try:
+        idx = pd.read_csv(_pyio.StringIO('\n'.join(rows) + '\n'), sep=sep, header=None, usecols=[0], skip_blank_lines=False,
+                          dtype=None)[0] if rows else pd.Series([], dtype=object)
+    except Exception:           # e.g. every name empty (EmptyDataError): pandas' own reader decides what the file means
+        return None
     if len(idx) != len(rows):
         return None
     return AnnData(X, obs=pd.DataFrame(index=pd.Index(idx.values).astype(str)), var=pd.DataFrame(index=pd.Index(cols).astype(str)))

@@ -50,14 +50,25 @@ _stage_cache = {}
 
 
 def _staging(want, cols, chunk, pinned):
-    """Two staging buffers [chunk, cols] per requested output, page-locked when a GPU is present; cached per shape."""
-    out = {}
-    for k in want:
-        key = (k, chunk, cols[k], pinned)
-        if key not in _stage_cache:
-            _stage_cache[key] = [torch.empty((chunk, cols[k]), dtype=torch.float32, pin_memory=pinned) for _ in range(2)]
-        out[k] = _stage_cache[key]
-    return out
+    """Two staging buffers [chunk, cols] per requested output, page-locked when a GPU is present.  ONE set is kept
+    between calls (locking pages costs about as much as copying them): a call with other shapes drops it first, and
+    DCA_AMD_KEEP_STAGING=0 releases the page-locked memory at the end of every predict()."""
+    keys = {k: (k, chunk, cols[k], pinned) for k in want}
+    if any(key not in _stage_cache for key in keys.values()) or len(_stage_cache) != len(keys):
+        _stage_cache.clear()
+        for key in keys.values():
+            _stage_cache[key] = [torch.empty((chunk, key[2]), dtype=torch.float32, pin_memory=pinned) for _ in range(2)]
+    return {k: _stage_cache[key] for k, key in keys.items()}
+
+
+def _host_copy(dst, src):
+    """dst[...] = src on the host-thread pool of libdcahost.so; numpy when that library cannot be loaded (no compiler
+    on the host): slower, same result."""
+    try:
+        from . import hostlib
+        hostlib.parallel_copy(dst, src)
+    except (OSError, RuntimeError, AttributeError):
+        dst[...] = src
 
 
 def lay_G(eng):
@@ -205,13 +216,12 @@ class Autoencoder():
         # thread alone is slower than the PCIe link and takes every first-touch page fault itself).
         stage = _staging(want, cols, chunk, pinned)
         events = [torch.cuda.Event() for _ in range(2)] if pinned else None
-        from . import hostlib
 
         def drain(slot, start, rows):
             if pinned:
                 events[slot].synchronize()
             for k in want:
-                hostlib.parallel_copy(outs[k][start:start + rows], stage[k][slot][:rows].numpy())
+                _host_copy(outs[k][start:start + rows], stage[k][slot][:rows].numpy())
 
         trace = os.environ.get('DCA_AMD_PREDICT_TRACE')
         import time as _time
@@ -236,6 +246,8 @@ class Autoencoder():
         if trace:
             print('dca: predict trace: %d cells, outputs %s: enqueue %.2f s, wait + host copies %.2f s, loop total %.2f s'
                   % (n, sorted(want), t_launch, t_drain, _time.perf_counter() - t_all))
+        if os.environ.get('DCA_AMD_KEEP_STAGING', '1') == '0':
+            _stage_cache.clear()
         return outs
 
     def predict(self, adata, mode='denoise', return_info=False, copy=False):

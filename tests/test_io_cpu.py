@@ -101,7 +101,10 @@ def test_identity_selection_shares_the_matrices_and_partial_selection_copies():
     ad = MiniAnnData(y, obs=pd.DataFrame({'dca_split': ['train'] * 30}, index=['c%d' % i for i in range(30)]))
     ad.raw = ad.copy()
     everything = ad[ad.obs.dca_split == 'train']
-    assert everything.X is ad.X and everything.raw.X is ad.raw.X
+    assert np.shares_memory(everything.X, ad.X) and everything.raw.X is ad.raw.X
+    with pytest.raises(ValueError):           # a view that has not been copied: writes must not reach the parent
+        everything.X[0, 0] = 5.0
+    ad.X[0, 0] = y[0, 0]                       # the parent itself stays writeable
     assert list(everything.obs.index) == list(ad.obs.index)
     part = ad[np.arange(30) % 2 == 0]
     assert part.X is not ad.X and part.shape == (15, 12)

@@ -272,8 +272,13 @@ def test_sgemm_vs_numpy(ops, ta, tb, M, N, K, gather, bias, colsum, split):
     torch.cuda.synchronize()
     out = C.cpu().numpy().astype(np.float64)
     err = np.abs(out[:M, :N] - ref)
-    tol = 2e-6 * absref + 1e-6
-    assert (err <= tol).all(), (err.max(), np.argwhere(err > tol)[:5])
+    # the shapes dcahip_sgemm runs as split-bf16 products (NT, and NN with N >= 128) are held to the contract
+    # include/dcahip.h states for them: 5e-7 of sum|ab| (+ the rounding of the bias add); the exact-fp32 MFMA kernel
+    # (an fmaf chain over K, TN and narrow NN) keeps its chain bound
+    x3 = (not ta) and (tb or N >= 128) and split >= 0
+    mag = absref + (np.abs(bvec.astype(np.float64)) if bias else 0.0)
+    tol = (5e-7 * mag + 1e-30) if x3 else (2e-6 * mag + 1e-6)
+    assert (err <= tol).all(), (err.max(), float((err / mag).max()), np.argwhere(err > tol)[:5])
     if colsum:
         cs = Bv.sum(axis=0)
         np.testing.assert_allclose(out[M, :N], cs, rtol=0, atol=2e-6 * np.abs(Bv).sum(axis=0).max() + 1e-6)

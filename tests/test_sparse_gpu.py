@@ -124,7 +124,7 @@ def test_sparse_first_layer_vs_numpy(ops, B, G, H1, gather, use_fac, do_log, sca
             np.abs(mean / std)[:, None] * np.abs(dZ.sum(0))[None, :]
 
     _, cc = build_compact(ops, Y)
-    cc = cc.with_input(dev(fac) if use_fac else None, do_log, dev(mean) if scale else None, dev(std) if scale else None)
+    cc = cc.with_input(dev(fac) if use_fac else None, do_log, dev(mean) if scale else None, dev(std) if scale else None, ops=ops)
     dperm = torch.as_tensor(perm).cuda() if perm is not None else None
     dcur = torch.tensor([cur if gather else 0], dtype=torch.int64, device='cuda')
     base = 0 if gather else cur
@@ -214,7 +214,12 @@ def test_step_with_compact_counts_matches_oracle(ops, ae_type, B):
     loss, g, _ = run_single_step(eng, rows)
     assert eng._sparse_fwd(B, True) and eng._sparse_dw(B)
     assert abs(loss - rl) < 1e-5 * abs(rl), (loss, rl)
-    assert_grads_close(g, rg)
+    # (the biases in front of batch normalisation have an identically zero gradient: column sums of dZ that cancel --
+    # the round-off left over depends on the order of the sum and is held to the absolute bound of the zero case)
+    zero_b = tuple('b%d' % i for i in range(len(hs)))
+    assert_grads_close(g, rg, skip=zero_b)
+    gscale = max(float(np.abs(np.asarray(v)).max()) for v in rg.values())
+    assert all(np.abs(g[k]).max() < 1e-5 * gscale for k in zero_b)
     # and the same step on the dense fp32 matrices: the two paths agree far inside the oracle tolerance
     eng2 = Engine(ae_type, G, G, hs, True, 0.0, ops=ops)
     eng2.set_params(p)
@@ -222,4 +227,4 @@ def test_step_with_compact_counts_matches_oracle(ops, ae_type, B):
     eng2.cc = None
     loss2, g2, _ = run_single_step(eng2, rows)
     assert abs(loss - loss2) < 2e-6 * abs(loss2)
-    assert_grads_close(g, {k: np.asarray(v, np.float64) for k, v in g2.items()}, rtol=5e-4, atol_scale=5e-6)
+    assert_grads_close(g, {k: np.asarray(v, np.float64) for k, v in g2.items()}, rtol=5e-4, atol_scale=5e-6, skip=zero_b)

@@ -16,7 +16,7 @@ Y = synth.generate_counts(n, G, device=dev)
 counts = prep.cell_counts(ops, Y, n, G)
 sf = counts / counts.median()
 X, norm = prep.transform(ops, Y, n, G, sf, True, True, return_norm=True)
-cc = compact.build(ops, Y, n, G).with_input(norm['fac'], norm['do_log'], norm['mean'], norm['std'])
+cc = compact.build(ops, Y, n, G).with_input(norm['fac'], norm['do_log'], norm['mean'], norm['std'], ops=ops)
 print('nonzero fraction %.4f  max count %d  escapes %s' % ((Y[:, :G] != 0).float().mean().item(), int(Y.max().item()),
                                                             0 if cc.ovf_col is None else cc.ovf_col.numel()))
 W0 = torch.randn(G + 1, h, device=dev) * 0.01
