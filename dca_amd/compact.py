@@ -17,16 +17,18 @@ class CompactCounts:
         self.Yc, self.ldc = Yc, int(ldc)
         self.ovf_ptr, self.ovf_col, self.ovf_val = ovf_ptr, ovf_col, ovf_val
         self.fac, self.do_log, self.mean, self.std = fac, bool(do_log), mean, std
-        self.lut = None         # [n, 8]: f(k / fac[r]) for the counts k = 0 .. 7 (dcahip_enc0_lut)
+        self.lutp = None        # [n, 64] x 8 bytes: f(k / fac[r]) for the counts k = 0 .. 63 as bf16 pieces (dcahip_enc0_lut)
 
     def with_input(self, fac, do_log, mean, std, ops=None):
-        """The same store with the description of the network input; with ops the per-row table of the common counts is
-        made as well (the sparse weight gradient needs it)."""
+        """The same store with the description of the network input; with ops the per-cell table of the common counts is
+        made as well (the first-layer weight gradient looks its operand up there)."""
         c = CompactCounts(self.Yc, self.ldc, self.ovf_ptr, self.ovf_col, self.ovf_val, fac, do_log, mean, std)
         if ops is not None:
             n = self.Yc.shape[0]
-            c.lut = torch.zeros(n, 8, dtype=torch.float32, device=self.Yc.device)
-            ops.enc0_lut(fac, do_log, n, c.lut)
+            if n * self.ldc >= 2 ** 32:
+                return None                 # the kernels address the store with 32-bit byte offsets
+            c.lutp = torch.zeros(n, 64, 2, dtype=torch.int32, device=self.Yc.device)
+            ops.enc0_lut(fac, do_log, n, c.lutp)
         return c
 
 

@@ -92,156 +92,259 @@ __global__ __launch_bounds__(256) void counts_compact_kernel(const float* Y, lon
 }
 
 // ------------------------------------------------------------------------------------------------- weight gradient
-// lut [n, 8]: lut[r][k] = f(k / fac[r]) for the counts k = 0 .. 7 that make up ~99 % of the non-zero entries (f = log1p
-// or the identity): one table row per cell, made once per dataset; larger counts (and escapes) take the formula.
-constexpr int kLut = 8;
+// dW0 = X^T dZ0 on the matrix pipe, X built on the fly from the byte store:
+//     sum_c x[c, g] dZ[c, :] = (sum_c L[c, g] dZ[c, :] - mean[g] colsum(dZ)) / std[g],   L = f(y / fac[c])
+// A wave owns a 32-gene tile and all H1 columns; K = the batch rows, 16 per step.  The A operand (32 genes x 16 rows
+// of L as three bf16 pieces) is LOOKED UP, not computed: 8 byte loads of counts per lane and step, each the index
+// into the cell's table of pre-split values lutp[cell][count] (counts 0 .. 15; larger ones take the formula -- a
+// wave-uniform branch that is rare on count data; stores with escapes, i.e. counts >= 255, keep the dense path).  The B operand (dZ as three bf16 pieces, laid out
+// for the MFMA by enc0_split_dz once per call) is shared by the workgroup's 8 waves through LDS, 128 rows at a time.
+// Six bf16 products per fp32 product, fp32 accumulation (the arithmetic of K-HEADS / K-GEMM); fixed order.
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x2v = __attribute__((ext_vector_type(2))) __bf16;
+using f32x2v = __attribute__((ext_vector_type(2))) float;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
-__global__ __launch_bounds__(256) void enc0_lut_kernel(const float* fac, int do_log, int n, float* lut) {
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0)
+// the six products of one K = 16 step, small terms first (index 0 = leading piece)
+#define MFMA_X3(A, Bf, ACC) { ACC = MFMA16(A[2], Bf[0], ACC); ACC = MFMA16(A[1], Bf[1], ACC); ACC = MFMA16(A[0], Bf[2], ACC); \
+                              ACC = MFMA16(A[1], Bf[0], ACC); ACC = MFMA16(A[0], Bf[1], ACC); ACC = MFMA16(A[0], Bf[0], ACC); }
+
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {           // v_cvt_pk_bf16_f32: a -> low half
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{a, b}, bf16x2v));
+}
+// x = p0 + p1 + p2 (bf16 each, round-to-nearest residuals), two values per call
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& p0, unsigned& p1, unsigned& p2) {
+    p0 = pk_bf16(x0, x1);
+    const float r0 = x0 - __uint_as_float(p0 << 16), r1 = x1 - __uint_as_float(p0 & 0xffff0000u);
+    p1 = pk_bf16(r0, r1);
+    const float q0 = r0 - __uint_as_float(p1 << 16), q1 = r1 - __uint_as_float(p1 & 0xffff0000u);
+    p2 = pk_bf16(q0, q1);
+}
+// one value -> table entry {p0 | p1 << 16, p2}
+__device__ __forceinline__ uint2 split_entry(float x) {
+    unsigned a, b, c;
+    split_pair(x, 0.f, a, b, c);
+    return make_uint2((a & 0xffffu) | (b << 16), c & 0xffffu);
+}
+__device__ __forceinline__ int rowmap(int e, int hi) { return (e & 3) + 8 * (e >> 2) + 4 * hi; }   // row of accumulator element e
+
+constexpr int kLut = 64;            // table entries per cell (counts 0 .. 63: all but ~1e-4 of the non-zero counts of scRNA-seq data)
+
+__global__ __launch_bounds__(256) void enc0_lut_kernel(const float* fac, int do_log, int n, uint2* lutp) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long)n * kLut) return;
     const int r = (int)(idx / kLut), k = (int)(idx - (long)r * kLut);
     float x = (float)k;
     if (fac) x = __fdiv_rn(x, fac[r]);
     if (do_log) x = log1pf(x);
-    lut[idx] = x;
+    lutp[idx] = split_entry(x);
+}
+
+constexpr int kKS = 16;             // batch rows per K step
+constexpr int kDwWaves = 8;         // waves (32-gene tiles) per workgroup: 256 genes
+constexpr int kDwRB = 64;           // batch rows a workgroup holds in LDS at a time (4 K steps)
+constexpr int kCodeLd = 272;        // row stride of the count tile in LDS (256 + 16: rows 8 apart sit 32 banks apart)
+constexpr int dz_step_elems(int H1) { return 3 * (H1 / 32) * 2 * 32 * 8; }   // bf16 elements of one K step of split dZ
+
+// dZ [B, ldz] -> DZP [ceil(B / 16)][piece][column tile][k half][32 columns][8 rows] bf16 (zero rows beyond B), the
+// column sums of each step's 16 rows -> Spp [steps][H1], and the storage row of every batch row -> srowb [B]
+template <int H1>
+__global__ __launch_bounds__(256) void enc0_split_dz_kernel(const float* dZ, long ldz, int B, const int* perm,
+                                                            const long long* cursor, long row_base,
+                                                            unsigned short* DZP, float* Spp, int* srowb) {
+    constexpr int NTL = H1 / 32;
+    __shared__ float part[8][H1];
+    const int ks = blockIdx.x, tid = threadIdx.x;
+    if (tid < kKS && ks * kKS + tid < B) {
+        const long long cur = (cursor ? *cursor : 0) + row_base;
+        const int r = ks * kKS + tid;
+        srowb[r] = perm ? perm[cur + r] : (int)(cur + r);
+    }
+    unsigned* out = reinterpret_cast<unsigned*>(DZP + (long)ks * dz_step_elems(H1));
+    for (int idx = tid; idx < 8 * H1; idx += 256) {
+        const int col = idx % H1, rp = idx / H1;            // row pair rp: rows 8 hi + 2 jp, + 1
+        const int hi = rp >> 2, jp = rp & 3;
+        const int r0 = ks * kKS + 8 * hi + 2 * jp;
+        const float x0 = r0 < B ? dZ[(long)r0 * ldz + col] : 0.f;
+        const float x1 = r0 + 1 < B ? dZ[(long)(r0 + 1) * ldz + col] : 0.f;
+        unsigned p[3];
+        split_pair(x0, x1, p[0], p[1], p[2]);
+        const int t = col >> 5, c = col & 31;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) out[((((q * NTL + t) * 2 + hi) * 32 + c) * 8 + 2 * jp) >> 1] = p[q];
+        part[rp][col] = x0 + x1;
+    }
+    __syncthreads();
+    for (int col = tid; col < H1; col += 256) {
+        float v = 0.f;
+#pragma unroll
+        for (int rp = 0; rp < 8; ++rp) v += part[rp][col];
+        Spp[(long)ks * H1 + col] = v;
+    }
 }
 
 struct DwArgs {
     Compact c;
     const float* fac; int do_log;
-    const float* lut;               // [n, 8]
-    const int* perm; const long long* cursor; long row_base;
+    const uint2* lutp;              // [n, kLut]
     int B, G;
-    const float* dZ; long ldz;
-    float* P; long Gs;              // [NS][Gs][H1] partial sums over the non-zero counts
-    float* Sp;                      // [NS][H1] partial column sums of dZ
+    const unsigned short* DZP; const float* Spp; const int* srowb;
+    float* P; long Gs;              // [NS][Gs][H1] partial sums over the batch rows of a split
+    float* Sp;                      // [NS][H1] column sums of dZ per split
     int RS;                         // batch rows per split (multiple of the row block)
 };
 
-// rows of dZ a workgroup keeps in LDS at a time: 64 KB of them
-constexpr int dw_row_block(int H1) { return H1 <= 64 ? 256 : (H1 == 128 ? 128 : 64); }
-constexpr int kDwWaves = 16;        // waves per workgroup: 256 genes
-
 template <int H1>
 __global__ __launch_bounds__(64 * kDwWaves) void enc0_dw_kernel(DwArgs a) {
-    constexpr int LPE = H1 / 4;             // lanes per queue entry (4 columns each)
-    constexpr int EPI = 64 / LPE;           // entries per iteration
-    constexpr int RB = dw_row_block(H1);
-    constexpr int NCH = RB / 64;
-    constexpr int NW = kDwWaves;
-    constexpr int LS = kLut + 1;            // odd row stride of the table: rows x codes spread over the banks
-    static_assert(LPE >= 1 && LPE <= 64 && (64 % LPE) == 0, "first-layer width");
-    __shared__ __attribute__((aligned(16))) float dzs[RB * H1];
-    __shared__ float luts[RB * LS];
+    constexpr int NTL = H1 / 32;
+    constexpr int RB = kDwRB;
+    constexpr int NKS = RB / kKS;
+    constexpr int KSE = dz_step_elems(H1);
+    constexpr int NT = 64 * kDwWaves;
+    constexpr int DZ_UNITS = NKS * KSE * 2 / 16;         // 16-byte units of the block's split dZ
+    constexpr int DZ_PER = (DZ_UNITS + NT - 1) / NT;
+    constexpr int LUT_PER = RB * (kLut / 2) / NT;        // 16-byte units of the table rows per thread
+    static_assert(RB * 16 == 2 * NT && RB * (kLut / 2) == LUT_PER * NT && NT % (kLut / 2) == 0, "tile units per thread");
+    __shared__ __attribute__((aligned(16))) unsigned short dzp[NKS * KSE];
+    __shared__ __attribute__((aligned(16))) uint2 lutl[RB * kLut];
+    __shared__ __attribute__((aligned(16))) unsigned char codes[RB * kCodeLd];
     __shared__ float rfac[RB];
-    __shared__ int srows[RB];
-    __shared__ uint2 qe[NW][RB + 2 * EPI];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
     const int split = blockIdx.y;
     const int rb = split * a.RS;
     const int re = min(a.B, rb + a.RS);
-    const long long cur = (a.cursor ? *a.cursor : 0) + a.row_base;
-    const int g0 = (blockIdx.x * NW + wave) * 16;
+    const int gbase = blockIdx.x * (32 * kDwWaves);
+    const int g0 = gbase + wave * 32;
     const bool wave_on = g0 < a.G;
+    const int gene = g0 + l31;
+    const int nks_total = (a.B + kKS - 1) / kKS;
 
-    uint2* const QE = qe[wave];
-    const int grp = lane / LPE, lidx = lane - grp * LPE;
-    const char* const dzl = reinterpret_cast<const char*>(dzs) + lidx * 16;
-
-    float4 acc[16];
+    f32x16 acc[NTL];
 #pragma unroll
-    for (int b = 0; b < 16; ++b) acc[b] = make_float4(0.f, 0.f, 0.f, 0.f);
-    float colsum = 0.f;                     // workgroup 0 of the split: thread j < H1 sums column j of dZ
+    for (int t = 0; t < NTL; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 
+    // ---- the loader: every thread moves fixed pieces of a block -- two 16-byte units of the count tile (rows tid / 16
+    // and 32 + tid / 16), one of the table rows (row tid / 8), DZ_PER of the split dZ, and (tid < RB) one row's divisor.
+    // The pieces of block i + 1 are requested before block i is computed and written to LDS after it.
+    const int crow = tid >> 4, cseg = tid & 15;
+    constexpr int LROWS = NT / (kLut / 2);               // table rows one pass of the workgroup covers
+    const int lrow = tid / (kLut / 2), lseg = tid % (kLut / 2);
+    const bool cseg_ok = gbase + cseg * 16 < a.c.ldc;
+    auto srow_of = [&](int rg0, int row) __attribute__((always_inline)) {               // storage row of the block's row (clamped inside the split)
+        const int r = rg0 + row;
+        return a.srowb[r < re ? r : re - 1];
+    };
+    int sr_c0, sr_c1, sr_l[LUT_PER], sr_t;               // storage rows of this thread's pieces of the NEXT block to request
+    u32x4 r_c0, r_c1, r_l[LUT_PER], r_dz[DZ_PER];
+    float r_fac = 1.f;
+    auto load_rows = [&](int rg0) __attribute__((always_inline)) {
+        sr_c0 = srow_of(rg0, crow); sr_c1 = srow_of(rg0, 32 + crow);
+#pragma unroll
+        for (int i = 0; i < LUT_PER; ++i) sr_l[i] = srow_of(rg0, lrow + i * LROWS);
+        sr_t = srow_of(rg0, tid < RB ? tid : 0);
+    };
+    auto request = [&](int rg0) __attribute__((always_inline)) {
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        r_c0 = (cseg_ok && rg0 + crow < re) ? *reinterpret_cast<const u32x4*>(a.c.yc + (long)sr_c0 * a.c.ldc + gbase + cseg * 16) : z;
+        r_c1 = (cseg_ok && rg0 + 32 + crow < re) ? *reinterpret_cast<const u32x4*>(a.c.yc + (long)sr_c1 * a.c.ldc + gbase + cseg * 16) : z;
+#pragma unroll
+        for (int i = 0; i < LUT_PER; ++i) r_l[i] = *reinterpret_cast<const u32x4*>(a.lutp + (long)sr_l[i] * kLut + lseg * 2);
+        const int ks0 = rg0 / kKS;
+        const u32x4* src = reinterpret_cast<const u32x4*>(a.DZP + (long)ks0 * KSE);
+#pragma unroll
+        for (int i = 0; i < DZ_PER; ++i) {
+            const int u = tid + i * NT;
+            const int k = u / (KSE * 2 / 16);
+            r_dz[i] = (u < DZ_UNITS && ks0 + k < nks_total) ? src[u] : z;
+        }
+        r_fac = a.fac ? a.fac[sr_t] : 1.f;
+    };
+    auto deposit = [&]() __attribute__((always_inline)) {
+        *reinterpret_cast<u32x4*>(codes + crow * kCodeLd + cseg * 16) = r_c0;
+        *reinterpret_cast<u32x4*>(codes + (32 + crow) * kCodeLd + cseg * 16) = r_c1;
+#pragma unroll
+        for (int i = 0; i < LUT_PER; ++i) *reinterpret_cast<u32x4*>(lutl + (lrow + i * LROWS) * kLut + lseg * 2) = r_l[i];
+#pragma unroll
+        for (int i = 0; i < DZ_PER; ++i) {
+            const int u = tid + i * NT;
+            if (u < DZ_UNITS) reinterpret_cast<u32x4*>(dzp)[u] = r_dz[i];
+        }
+        if (tid < RB) rfac[tid] = r_fac;
+    };
+
+    if (rb < re) { load_rows(rb); request(rb); if (rb + RB < re) load_rows(rb + RB); }
 #pragma unroll 1
     for (int rg0 = rb; rg0 < re; rg0 += RB) {
         const int nrow = min(RB, re - rg0);
         __syncthreads();                    // everyone is done with the previous block
-        // ---- the block's rows of dZ (zero beyond the batch), table rows, divisors, storage rows
-        for (int i = tid; i < RB * (H1 / 4); i += 64 * NW) {
-            const int r = i / (H1 / 4), c4 = i - r * (H1 / 4);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < nrow) v = *reinterpret_cast<const float4*>(a.dZ + (long)(rg0 + r) * a.ldz + 4 * c4);
-            *reinterpret_cast<float4*>(dzs + r * H1 + 4 * c4) = v;
-        }
-        for (int i = tid; i < RB; i += 64 * NW) {
-            const int rc = i < nrow ? i : nrow - 1;
-            const long sr = a.perm ? (long)a.perm[cur + rg0 + rc] : cur + rg0 + rc;
-            srows[i] = (int)sr;
-            rfac[i] = a.fac ? a.fac[sr] : 1.f;
-#pragma unroll
-            for (int k = 0; k < kLut; ++k) luts[i * LS + k] = a.lut[sr * kLut + k];
-        }
-        // ---- this wave's counts: row i * 64 + lane of the block, 16 genes
-        uint4 codes[NCH];
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int cl = i * 64 + lane;
-            const int clc = cl < nrow ? cl : nrow - 1;
-            const long sr = a.perm ? (long)a.perm[cur + rg0 + clc] : cur + rg0 + clc;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (wave_on && cl < nrow) v = *reinterpret_cast<const uint4*>(a.c.yc + sr * a.c.ldc + g0);
-            codes[i] = v;
-        }
+        deposit();
         __syncthreads();
-        if (blockIdx.x == 0 && tid < H1)
-            for (int r = 0; r < nrow; ++r) colsum += dzs[r * H1 + tid];
+        if (rg0 + RB < re) { request(rg0 + RB); if (rg0 + 2 * RB < re) load_rows(rg0 + 2 * RB); }
         if (!wave_on) continue;
 #pragma unroll
-        for (int b = 0; b < 16; ++b) {
-            const int d = b >> 2, sh = 8 * (b & 3);
-            int qn = 0;
+        for (int ks = 0; ks < NKS; ++ks) {
+            if (ks * kKS >= nrow) break;
+            const int rl0 = ks * kKS + 8 * hi;           // this lane's 8 rows of the step
+            const unsigned char* cp = codes + rl0 * kCodeLd + wave * 32 + l31;
+            unsigned code[8];
 #pragma unroll
-            for (int i = 0; i < NCH; ++i) {
-                const unsigned dw = d == 0 ? codes[i].x : d == 1 ? codes[i].y : d == 2 ? codes[i].z : codes[i].w;
-                const unsigned code = (dw >> sh) & 255u;
-                const int cl = i * 64 + lane;
-                const bool nz = code != 0u;
-                float x = luts[cl * LS + (code < kLut ? code : 0u)];
-                if (code >= kLut) {                        // rare: a large count (or an escape): the formula itself
-                    float val = (float)code;
-                    if (code == 255u) val = escaped_count(a.c, srows[cl], g0 + b);
-                    x = a.fac ? __fdiv_rn(val, rfac[cl]) : val;
-                    if (a.do_log) x = log1pf(x);
+            for (int j = 0; j < 8; ++j) code[j] = cp[j * kCodeLd];
+            unsigned lo[8], hx[8];
+            const uint2* lp = lutl + rl0 * kLut;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned idx = code[j] < (unsigned)(kLut - 1) ? code[j] : (unsigned)(kLut - 1);
+                const uint2 e = lp[j * kLut + idx];
+                lo[j] = e.x; hx[j] = e.y;
+            }
+            const unsigned any = (code[0] | code[1] | code[2]) | (code[3] | code[4] | code[5]) | (code[6] | code[7]);
+            if (__ballot(any >= (unsigned)kLut)) {       // rare: counts beyond the table take the formula itself
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (__ballot(code[j] >= (unsigned)kLut)) {
+                        float x = a.fac ? __fdiv_rn((float)code[j], rfac[rl0 + j]) : (float)code[j];
+                        if (a.do_log) x = log1pf(x);
+                        const uint2 e = split_entry(x);
+                        if (code[j] >= (unsigned)kLut) { lo[j] = e.x; hx[j] = e.y; }
+                    }
                 }
-                const unsigned long long m = __ballot(nz);
-                if (nz) QE[qn + mbcnt64(m)] = make_uint2(__float_as_uint(x), (unsigned)(cl * H1 * 4));
-                qn += __popcll(m);
             }
-            if (qn == 0) continue;
-            // harmless entries up to the next multiple of two iterations
-            const int nit = ((qn + 2 * EPI - 1) / (2 * EPI)) * 2;
-            if (lane < nit * EPI - qn) QE[qn + lane] = make_uint2(0u, 0u);
-            wave_sync();
-            float4 ac = acc[b];
-            for (int it = 0; it < nit; it += 2) {
-                const uint2 e0 = QE[it * EPI + grp], e1 = QE[(it + 1) * EPI + grp];
-                const float4 d0 = *reinterpret_cast<const float4*>(dzl + e0.y);
-                const float4 d1 = *reinterpret_cast<const float4*>(dzl + e1.y);
-                const float x0 = __uint_as_float(e0.x), x1 = __uint_as_float(e1.x);
-                ac.x = fmaf(x0, d0.x, ac.x); ac.y = fmaf(x0, d0.y, ac.y); ac.z = fmaf(x0, d0.z, ac.z); ac.w = fmaf(x0, d0.w, ac.w);
-                ac.x = fmaf(x1, d1.x, ac.x); ac.y = fmaf(x1, d1.y, ac.y); ac.z = fmaf(x1, d1.z, ac.z); ac.w = fmaf(x1, d1.w, ac.w);
+            u32x4 A[3];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                A[0][jj] = __builtin_amdgcn_perm(lo[2 * jj + 1], lo[2 * jj], 0x05040100u);
+                A[1][jj] = __builtin_amdgcn_perm(lo[2 * jj + 1], lo[2 * jj], 0x07060302u);
+                A[2][jj] = __builtin_amdgcn_perm(hx[2 * jj + 1], hx[2 * jj], 0x05040100u);
             }
-            acc[b] = ac;
-            wave_sync();                                   // the queue is free for the next gene
+            const unsigned short* bstep = dzp + ks * KSE + (hi * 32 + l31) * 8;
+#pragma unroll
+            for (int t = 0; t < NTL; ++t) {
+                u32x4 Bf[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    Bf[q] = *reinterpret_cast<const u32x4*>(bstep + ((q * NTL + t) * 2) * 32 * 8);
+                MFMA_X3(A, Bf, acc[t])
+            }
         }
     }
-    if (blockIdx.x == 0 && tid < H1) a.Sp[(long)split * H1 + tid] = colsum;
+    if (blockIdx.x == 0 && tid < H1) {                   // column sums of this split's rows: its K steps in order
+        float s = 0.f;
+        for (int ks = rb / kKS; ks * kKS < re; ++ks) s += a.Spp[(long)ks * H1 + tid];
+        a.Sp[(long)split * H1 + tid] = s;
+    }
     if (!wave_on) return;
-    // ---- the EPI groups hold partial sums over different entries: add them (fixed order), one row of P per gene
 #pragma unroll
-    for (int b = 0; b < 16; ++b) {
-        float4 v = acc[b];
+    for (int t = 0; t < NTL; ++t)
 #pragma unroll
-        for (int off = LPE; off < 64; off <<= 1) {
-            v.x += __shfl_xor(v.x, off, 64); v.y += __shfl_xor(v.y, off, 64);
-            v.z += __shfl_xor(v.z, off, 64); v.w += __shfl_xor(v.w, off, 64);
-        }
-        if (lane < LPE)
-            *reinterpret_cast<float4*>(a.P + ((long)split * a.Gs + g0 + b) * H1 + 4 * lane) = v;
-    }
+        for (int e = 0; e < 16; ++e)
+            a.P[((long)split * a.Gs + g0 + rowmap(e, hi)) * H1 + 32 * t + l31] = acc[t][e];
 }
 
 struct DwFinishArgs {
@@ -447,21 +550,22 @@ __global__ __launch_bounds__(256) void enc0_fwd_kernel(FwArgs a) {
 
 inline bool width_ok(int H1) { return H1 == 16 || H1 == 32 || H1 == 64 || H1 == 128 || H1 == 256; }
 
-// row splits: as many as keep the grid at (or just below) one workgroup per CU -- every workgroup resident, one round
+inline bool dw_width_ok(int H1) { return H1 == 32 || H1 == 64 || H1 == 128; }
+
+// row splits: as many workgroups as are resident at once (or just below): one round
 inline int dw_splits(int B, int G, int H1) {
-    const int RB = dw_row_block(H1);
-    const int groups = (G + 16 * kDwWaves - 1) / (16 * kDwWaves);
-    int ns = 256 / groups;
-    const int maxs = (B + RB - 1) / RB;
+    const int groups = (G + 32 * kDwWaves - 1) / (32 * kDwWaves);
+    int ns = 256 / groups;                               // one 8-wave workgroup per CU (registers)
+    const int maxs = (B + kDwRB - 1) / kDwRB;
     if (ns > maxs) ns = maxs;
     if (ns > 16) ns = 16;
     if (ns < 1) ns = 1;
     return ns;
 }
 inline int dw_rows_per_split(int B, int ns, int H1) {
-    const int RB = dw_row_block(H1);
-    return (((B + ns - 1) / ns) + RB - 1) / RB * RB;
+    return (((B + ns - 1) / ns) + kDwRB - 1) / kDwRB * kDwRB;
 }
+inline long r16(long x) { return (x + 15) / 16 * 16; }
 
 }  // namespace
 
@@ -477,48 +581,60 @@ extern "C" int dcahip_counts_compact(const float* Y, long ldy, int n, int G, uns
     return (int)hipGetLastError();
 }
 
-extern "C" int dcahip_enc0_sparse_supported(int H1) { return width_ok(H1) ? 1 : 0; }
+extern "C" int dcahip_enc0_sparse_supported(int H1) { return dw_width_ok(H1) ? 1 : 0; }
 
-extern "C" long dcahip_enc0_dw_sparse_workspace_bytes(int B, int G, int H1) {
-    if (!width_ok(H1) || B <= 0 || G <= 0) return 0;
-    const int ns = dw_splits(B, G, H1);
-    const long Gs = ((long)G + 255) / 256 * 256;
-    return ((long)ns * Gs * H1 + (long)ns * H1) * 4;
-}
-
-extern "C" int dcahip_enc0_lut(const float* fac, int do_log, int n, float* lut, void* stream) {
-    if (n <= 0 || !lut) return DCAHIP_EINVAL;
+extern "C" int dcahip_enc0_lut(const float* fac, int do_log, int n, void* lutp, void* stream) {
+    if (n <= 0 || !lutp) return DCAHIP_EINVAL;
     hipLaunchKernelGGL(enc0_lut_kernel, dim3((unsigned)(((long)n * kLut + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       fac, do_log, n, lut);
+                       fac, do_log, n, static_cast<uint2*>(lutp));
     return (int)hipGetLastError();
 }
 
+// workspace: P [NS][Gs][H1] | Sp [NS][H1] | Spp [steps][H1] | DZP [steps][...] bf16
+extern "C" long dcahip_enc0_dw_sparse_workspace_bytes(int B, int G, int H1) {
+    if (!dw_width_ok(H1) || B <= 0 || G <= 0) return 0;
+    const int ns = dw_splits(B, G, H1);
+    const long Gs = ((long)G + 255) / 256 * 256;
+    const long steps = (B + kKS - 1) / kKS;
+    return r16(((long)ns * Gs * H1 + (long)ns * H1) * 4) + r16(steps * H1 * 4) + r16(steps * (long)dz_step_elems(H1) * 2) + r16((long)B * 4);
+}
+
 extern "C" int dcahip_enc0_dw_sparse(const unsigned char* Yc, long ldc, const int* ovf_ptr, const int* ovf_col,
-                                     const float* ovf_val, const float* fac, int do_log, const float* lut, const float* mean,
+                                     const float* ovf_val, const float* fac, int do_log, const void* lutp, const float* mean,
                                      const float* stdv, const int* perm, const long long* cursor, long row_base,
                                      int B, int G, int H1, const float* dZ, long ldz, float* gW, long ldg,
                                      void* workspace, long workspace_bytes, void* stream) {
-    if (!width_ok(H1) || B <= 0 || G <= 0 || !Yc || !lut || (ldc & 15) || ldc < G || !dZ || (ldz & 3) || ldz < H1 || !gW ||
-        ldg < H1 || (reinterpret_cast<uintptr_t>(dZ) & 15) || (reinterpret_cast<uintptr_t>(workspace) & 15) || !workspace)
+    if (!dw_width_ok(H1) || B <= 0 || G <= 0 || !Yc || !lutp || (ldc & 15) || ldc < G || !dZ || ldz < H1 || !gW ||
+        ldg < H1 || (reinterpret_cast<uintptr_t>(workspace) & 15) || !workspace)
         return DCAHIP_EINVAL;
     if (workspace_bytes < dcahip_enc0_dw_sparse_workspace_bytes(B, G, H1)) return DCAHIP_EINVAL;
     const int ns = dw_splits(B, G, H1);
     const long Gs = ((long)G + 255) / 256 * 256;
+    const long steps = (B + kKS - 1) / kKS;
+    char* wsb = static_cast<char*>(workspace);
     DwArgs a;
     a.c = Compact{Yc, ldc, ovf_ptr, ovf_col, ovf_val};
-    a.fac = fac; a.do_log = do_log; a.lut = lut; a.perm = perm; a.cursor = cursor; a.row_base = row_base;
-    a.B = B; a.G = G; a.dZ = dZ; a.ldz = ldz;
-    a.P = static_cast<float*>(workspace); a.Gs = Gs; a.Sp = a.P + (long)ns * Gs * H1;
+    a.fac = fac; a.do_log = do_log; a.lutp = static_cast<const uint2*>(lutp);
+    a.B = B; a.G = G;
+    a.P = reinterpret_cast<float*>(wsb); a.Gs = Gs; a.Sp = a.P + (long)ns * Gs * H1;
+    float* Spp = reinterpret_cast<float*>(wsb + r16(((long)ns * Gs * H1 + (long)ns * H1) * 4));
+    unsigned short* DZP = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(Spp) + r16(steps * H1 * 4));
+    int* srowb = reinterpret_cast<int*>(reinterpret_cast<char*>(DZP) + r16(steps * (long)dz_step_elems(H1) * 2));
+    a.DZP = DZP; a.Spp = Spp; a.srowb = srowb;
     a.RS = dw_rows_per_split(B, ns, H1);
-    const dim3 grid((unsigned)((G + 16 * kDwWaves - 1) / (16 * kDwWaves)), (unsigned)ns);
+    const dim3 grid((unsigned)((G + 32 * kDwWaves - 1) / (32 * kDwWaves)), (unsigned)ns);
     const dim3 block(64 * kDwWaves);
     hipStream_t s = (hipStream_t)stream;
     switch (H1) {
-        case 16: hipLaunchKernelGGL(enc0_dw_kernel<16>, grid, block, 0, s, a); break;
-        case 32: hipLaunchKernelGGL(enc0_dw_kernel<32>, grid, block, 0, s, a); break;
-        case 64: hipLaunchKernelGGL(enc0_dw_kernel<64>, grid, block, 0, s, a); break;
-        case 128: hipLaunchKernelGGL(enc0_dw_kernel<128>, grid, block, 0, s, a); break;
-        default: hipLaunchKernelGGL(enc0_dw_kernel<256>, grid, block, 0, s, a); break;
+        case 32:
+            hipLaunchKernelGGL(enc0_split_dz_kernel<32>, dim3((unsigned)steps), dim3(256), 0, s, dZ, ldz, B, perm, cursor, row_base, DZP, Spp, srowb);
+            hipLaunchKernelGGL(enc0_dw_kernel<32>, grid, block, 0, s, a); break;
+        case 64:
+            hipLaunchKernelGGL(enc0_split_dz_kernel<64>, dim3((unsigned)steps), dim3(256), 0, s, dZ, ldz, B, perm, cursor, row_base, DZP, Spp, srowb);
+            hipLaunchKernelGGL(enc0_dw_kernel<64>, grid, block, 0, s, a); break;
+        default:
+            hipLaunchKernelGGL(enc0_split_dz_kernel<128>, dim3((unsigned)steps), dim3(256), 0, s, dZ, ldz, B, perm, cursor, row_base, DZP, Spp, srowb);
+            hipLaunchKernelGGL(enc0_dw_kernel<128>, grid, block, 0, s, a); break;
     }
     int rc = (int)hipGetLastError();
     if (rc) return rc;

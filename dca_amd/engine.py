@@ -334,8 +334,13 @@ class Engine:
         # normalisation known (cc_in) the first Dense layer works on the non-zero counts only (K-SPARSE)
         self.cc = self.cc_in = None
         self.ws_enc0 = self.ws_enc0f = None
-        self.sparse_fwd_min = int(os.environ.get('DCA_AMD_SPARSE_FWD_MIN', '512'))    # batch rows from which the sparse
-        self.sparse_dw_min = int(os.environ.get('DCA_AMD_SPARSE_DW_MIN', '1'))        # forward / weight gradient are used
+        # batch rows from which the byte-store kernels replace the dense first-layer GEMMs -- measured on the MI355X at
+        # the benchmark shape (profiles/r03*_enc0_*): the weight gradient on the matrix pipe from the byte store ties the
+        # dense TN GEMM at 4096 rows on the 68 579-cell matrix (0.149-0.154 vs 0.157 ms) and wins on a cache-resident one
+        # (0.112 vs 0.150); the sparse forward (gathers of W0 rows from L2) loses to the dense NT GEMM at every batch
+        # (0.160 vs 0.107 ms at 4096 rows) and stays off
+        self.sparse_fwd_min = int(os.environ.get('DCA_AMD_SPARSE_FWD_MIN', str(1 << 30)))
+        self.sparse_dw_min = int(os.environ.get('DCA_AMD_SPARSE_DW_MIN', '512'))
 
     def _t(self, name):
         return self.prof.section(name) if self.prof is not None else _NULL
@@ -550,8 +555,9 @@ class Engine:
         if compact is None:
             return                          # not a count matrix (check_counts=False on arbitrary data): fp32 path
         self.cc = compact
+        # (stores with escapes -- counts >= 255 -- keep the dense first layer: the operand tables stop at the byte code)
         if norm is not None and lay.G_in == lay.G_out and ops.enc0_sparse_supported(lay.hidden[0]) \
-                and os.environ.get('DCA_AMD_SPARSE_ENC0', '1') != '0':
+                and compact.ovf_ptr is None and os.environ.get('DCA_AMD_SPARSE_ENC0', '1') != '0':
             self.cc_in = compact.with_input(norm.get('fac'), norm.get('do_log', False), norm.get('mean'), norm.get('std'), ops=ops)
         self._sparse_workspaces()
 

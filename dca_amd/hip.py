@@ -136,7 +136,7 @@ _SIGNATURES = {
     'dcahip_counts_compact': (_c.c_int, [_f32p, _c.c_long, _c.c_int, _c.c_int, _vp, _c.c_long, _i32p, _vp]),
     'dcahip_enc0_sparse_supported': (_c.c_int, [_c.c_int]),
     'dcahip_enc0_dw_sparse_workspace_bytes': (_c.c_long, [_c.c_int, _c.c_int, _c.c_int]),
-    'dcahip_enc0_lut': (_c.c_int, [_f32p, _c.c_int, _c.c_int, _f32p, _vp]),
+    'dcahip_enc0_lut': (_c.c_int, [_f32p, _c.c_int, _c.c_int, _vp, _vp]),
     'dcahip_enc0_dw_sparse': (_c.c_int, [_vp, _c.c_long, _i32p, _i32p, _f32p, _f32p, _c.c_int, _f32p, _f32p, _f32p, _i32p, _i64p,
                                          _c.c_long, _c.c_int, _c.c_int, _c.c_int, _f32p, _c.c_long, _f32p, _c.c_long,
                                          _vp, _c.c_long, _vp]),

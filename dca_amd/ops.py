@@ -82,8 +82,8 @@ class HipOps:
         hip.check(self.L.dcahip_counts_compact(hip.ptr(Y), ldy, n, G, hip.ptr(Yc), ldc, hip.ptr(status), hip.stream()),
                   'counts_compact')
 
-    def enc0_lut(self, fac, do_log, n, lut):
-        hip.check(self.L.dcahip_enc0_lut(hip.ptr(fac), int(do_log), n, hip.ptr(lut), hip.stream()), 'enc0_lut')
+    def enc0_lut(self, fac, do_log, n, lutp):
+        hip.check(self.L.dcahip_enc0_lut(hip.ptr(fac), int(do_log), n, hip.ptr(lutp), hip.stream()), 'enc0_lut')
 
     def enc0_sparse_supported(self, H1):
         return bool(self.L.dcahip_enc0_sparse_supported(int(H1)))
@@ -98,7 +98,7 @@ class HipOps:
         """gW [G + 1, ldg] = [X^T dZ ; colsum dZ] with X described by the compact counts c (its normalisation fields)."""
         p = hip.ptr
         hip.check(self.L.dcahip_enc0_dw_sparse(p(c.Yc), c.ldc, p(c.ovf_ptr), p(c.ovf_col), p(c.ovf_val), p(c.fac),
-                                               int(c.do_log), p(c.lut), p(c.mean), p(c.std), p(perm), p(cursor), int(row_base),
+                                               int(c.do_log), p(c.lutp), p(c.mean), p(c.std), p(perm), p(cursor), int(row_base),
                                                B, G, H1, p(dZ), ldz, p(gW), ldg, p(ws), ws.numel() * ws.element_size(),
                                                hip.stream()), 'enc0_dw_sparse')
 

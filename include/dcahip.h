@@ -452,24 +452,25 @@ int dcahip_heads_fused_compact(const float* H, long ldh, const float* Wh, long l
                                double* loss_partials, int* n_partials_out,
                                void* workspace, long workspace_bytes, const int* tile_order,
                                float* loss_out, void* stream);
-/* First-layer widths the sparse kernels take (16, 32, 64, 128, 256). */
+/* First-layer widths the kernels below take (32, 64, 128). */
 int dcahip_enc0_sparse_supported(int H1);
 /*
  * Weight (+ bias) gradient of the first Dense layer from the compact counts:
  *   gW [G + 1, ldg]: rows g < G = sum_c x[c, g] dZ[c, :], row G = column sums of dZ (what dcahip_sgemm(ta = 1,
  *   colsum_row = 1) writes from the dense X).  Batch row c = storage row perm[*cursor + row_base + c] (perm NULL:
  *   *cursor + row_base + c) of Yc / fac.  fac NULL: no size-factor division; do_log 0: no log1p; mean NULL: 0;
- *   stdv NULL: 1.  lut = dcahip_enc0_lut(fac, do_log) of the same store.  dZ [B, ldz] 16-byte aligned, ldz % 4 == 0.
- *   Deterministic (fixed summation order).
+ *   stdv NULL: 1.  lutp = dcahip_enc0_lut(fac, do_log) of the same cells.  n_cells * ldc must stay below 2^32.
+ *   Arithmetic: X^T dZ on the matrix pipe, six bf16 products per fp32 product as dcahip_sgemm; deterministic.
  *   workspace >= dcahip_enc0_dw_sparse_workspace_bytes(B, G, H1), 16-byte aligned.
  * Replaces the autodiff of dca/network.py:124-126 w.r.t. the first kernel on the input of dca/io.py:88-111.
  */
-/* lut [n, 8]: lut[r][k] = f(k / fac[r]) (f = log1p if do_log, fac NULL: 1) for the counts k = 0 .. 7 -- made once per
- * dataset, so that the sparse kernels look the common counts up instead of dividing and taking logarithms. */
-int dcahip_enc0_lut(const float* fac, int do_log, int n, float* lut, void* stream);
+/* lutp [n, 64] entries of 8 bytes: entry k of cell r = f(k / fac[r]) (f = log1p if do_log, fac NULL: 1) split into the
+ * three bf16 pieces the matrix products use ({p0 | p1 << 16, p2}) -- made once per dataset, so that the weight gradient
+ * LOOKS UP its operand instead of dividing, taking logarithms and splitting (counts beyond 63 take the formula). */
+int dcahip_enc0_lut(const float* fac, int do_log, int n, void* lutp, void* stream);
 long dcahip_enc0_dw_sparse_workspace_bytes(int B, int G, int H1);
 int dcahip_enc0_dw_sparse(const unsigned char* Yc, long ldc, const int* ovf_ptr, const int* ovf_col,
-                          const float* ovf_val, const float* fac, int do_log, const float* lut, const float* mean,
+                          const float* ovf_val, const float* fac, int do_log, const void* lutp, const float* mean,
                           const float* stdv, const int* perm, const long long* cursor, long row_base,
                           int B, int G, int H1, const float* dZ, long ldz, float* gW, long ldg,
                           void* workspace, long workspace_bytes, void* stream);
