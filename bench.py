@@ -42,7 +42,7 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (the headline 5 PF figure
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--steps', type=int, default=0, help='timed steps; default: three epochs of the workload')
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--cells', type=int, default=68579)
     ap.add_argument('--genes', type=int, default=20000)
@@ -132,7 +132,7 @@ def graph_kernel_nodes(graph):
         return None
 
 
-def capture_step(eng, b, counts, k=1):
+def capture_step(eng, b, counts, k=1, rows_per_slot=None):
     """k consecutive training steps in one hipGraph (the device cursor advances inside the graph)."""
     try:
         g = torch.cuda.CUDAGraph(keep_graph=True)
@@ -142,7 +142,7 @@ def capture_step(eng, b, counts, k=1):
     with torch.cuda.stream(st):
         with torch.cuda.graph(g, stream=st):
             for _ in range(k):
-                eng.train_step(b, b, counts, b)
+                eng.train_step(b, b, counts, rows_per_slot or b)
     torch.cuda.current_stream().wait_stream(st)
     return g
 
@@ -153,22 +153,120 @@ def _mark(msg):
         print('bench: ' + msg, file=sys.stderr, flush=True)
 
 
-def after_measurements(eng, args, B, n_train, n_val, G, dev):
-    """Same process, same resident matrix, after the timed region (one GPU): the reference-default batch 32 and
-    the end-to-end epoch (all train rows incl. the last partial batch + the validation pass)."""
-    out = {}
-    gen = torch.Generator(device='cpu'); gen.manual_seed(99)
-    # captured steps hold the addresses of eng.perm / eng.hist: ONE buffer each for everything below, refilled in place
-    b32, k32 = 32, 400
-    eng.perm = torch.zeros(max(n_train, (k32 + 8) * b32), dtype=torch.int32, device=dev)
-    eng.hist = torch.zeros(max(n_train // b32, k32) + 16, dtype=torch.float32, device=dev)
+class EpochRunner:
+    """Training steps in the order of the fit loop (dca_amd/train.py::fit_engine / dca/train.py:91-98): every epoch visits
+    the train rows in a fresh shuffled order, full batches first, the partial one last; on one GPU up to 8 consecutive
+    full steps are replayed per hipGraph launch (as train.py::_StepRunner does), the partial batch as its own graph.
+    Step k of a run is step k % steps_per_epoch of epoch k // steps_per_epoch; the device cursor walks through the
+    concatenated shuffles, so a captured graph serves every epoch."""
 
-    def new_order(count):
-        eng.perm[:count].copy_(torch.randperm(n_train, generator=gen, dtype=torch.int32)[:count])
+    def __init__(self, eng, n_train, B, dev, max_epochs, seed=1234, use_graph=True):
+        self.eng, self.n, self.B, self.dev, self.use_graph = eng, n_train, B, dev, use_graph
+        self.seq = [B] * (n_train // B) + ([n_train % B] if n_train % B else [])
+        self.spe = len(self.seq)
+        self.gen = torch.Generator(device='cpu'); self.gen.manual_seed(seed)
+        self.max_epochs = max_epochs
+        eng.perm = torch.zeros(max_epochs * n_train, dtype=torch.int32, device=dev)     # graphs hold this address
+        eng.hist = torch.zeros(max_epochs * self.spe + 16, dtype=torch.float32, device=dev)
+        self.graphs = {}
+        self.k = 0
+
+    def new_run(self, epochs):
+        """Fresh shuffles for `epochs` epochs, cursor and accumulators at zero."""
+        assert epochs <= self.max_epochs
+        for e in range(epochs):
+            self.eng.perm[e * self.n:(e + 1) * self.n].copy_(torch.randperm(self.n, generator=self.gen, dtype=torch.int32))
+        self.eng.cursor.zero_(); self.eng.acc.zero_()
+        self.k = 0
+
+    def _graph(self, b, k):
+        if (b, k) not in self.graphs:
+            self.graphs[(b, k)] = capture_step(self.eng, b, [b], k, rows_per_slot=self.B)
+        return self.graphs[(b, k)]
+
+    def capture_all(self):
+        """Every graph an epoch needs (capturing runs nothing: no step is consumed)."""
+        if not self.use_graph:
+            return
+        full = self.n // self.B
+        for k in {min(8, full), full % 8} - {0}:
+            self._graph(self.B, k)
+        if self.n % self.B:
+            self._graph(self.n % self.B, 1)
+
+    def plan(self, steps, start=None):
+        """[(batch, consecutive steps)] launches of the next `steps` steps."""
+        k0 = self.k if start is None else start
+        out = []
+        while steps > 0:
+            pos = k0 % self.spe
+            b = self.seq[pos]
+            k = min(steps, 8, (self.n // self.B) - pos) if b == self.B else 1    # consecutive full steps left in this epoch
+            out.append((b, k))
+            k0 += k; steps -= k
+        return out
+
+    def run(self, steps, capture_only=False):
+        """The next `steps` steps of the sequence; returns the number of cells they held.  capture_only: only make
+        sure every graph the steps need exists (nothing runs, no step is consumed)."""
+        cells = 0
+        for b, k in self.plan(steps):
+            if capture_only:
+                if self.use_graph:
+                    self._graph(b, k)
+                continue
+            if self.use_graph:
+                self._graph(b, k).replay()
+            else:
+                for _ in range(k):
+                    self.eng.train_step(b, b, [b], self.B)
+            self.k += k; cells += b * k
+        return cells
+
+    def launches_per_epoch(self):
+        full = self.n // self.B
+        return (full + 7) // 8 + (1 if self.n % self.B else 0)
+
+
+def after_measurements(eng, args, B, n_train, n_val, G, dev, runner):
+    """Same process, same resident matrix, after the timed region (one GPU): three individually timed epochs with the
+    validation pass (SURVEY 8d's end-to-end figure), then the reference-default batch 32."""
+    out = {}
+    _mark('epoch timing')
+    times = []
+    runner.new_run(4)
+    for ep in range(4):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        runner.run(runner.spe)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        if n_val:
+            eng.eval_loss_sum(n_train, n_train + n_val, 1.0 / (float(n_val) * G))
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        if ep > 0:
+            times.append((t1 - t0, t2 - t1))
+        if ep < 3:
+            eng.acc.zero_()
+    tr = [t[0] for t in times]; va = [t[1] for t in times]
+    acc = eng.acc.cpu().numpy()
+    out['epoch'] = {'train_s': {'min': min(tr), 'median': float(np.median(tr)), 'max': max(tr)},
+                    'validation_s': {'min': min(va), 'median': float(np.median(va)), 'max': max(va)},
+                    'train_cells': n_train, 'validation_cells': n_val,
+                    'cells_per_s_train_only': {'min': n_train / max(tr), 'median': n_train / float(np.median(tr)), 'max': n_train / min(tr)},
+                    'cells_per_s_incl_validation': n_train / (float(np.median(tr)) + float(np.median(va))),
+                    'timed_epochs': len(times), 'val_loss_last': float(acc[1]), 'loss_last': float(acc[0]) / n_train,
+                    'steps_per_epoch': runner.spe, 'last_batch': n_train % B,
+                    'graph_launches_per_epoch': runner.launches_per_epoch()}
+    # ---- batch 32 (dca/train.py:37 default): hipGraph replay, 400 timed steps
+    gen = torch.Generator(device='cpu'); gen.manual_seed(99)
+    b32, k32 = 32, 400
+    eng.perm = torch.zeros((k32 + 16) * b32, dtype=torch.int32, device=dev)
+    eng.hist = torch.zeros(k32 + 32, dtype=torch.float32, device=dev)
+
+    def new_order():
+        eng.perm.copy_(torch.randperm(n_train, generator=gen, dtype=torch.int32)[:eng.perm.numel()])
         eng.cursor.zero_(); eng.acc.zero_()
 
-    # ---- batch 32 (dca/train.py:37 default): hipGraph replay, 400 timed steps
-    new_order((k32 + 8) * b32)
+    new_order()
     _mark('batch-32 eager step')
     eng.train_step(b32, b32, [b32], b32)
     _mark('batch-32 capture')
@@ -178,7 +276,7 @@ def after_measurements(eng, args, B, n_train, n_val, G, dev):
         ks = 8                               # steps per graph launch, as the fit loop replays them (dca_amd/train.py)
         g32k = capture_step(eng, b32, [b32], ks)
         g32k.replay()
-        new_order((k32 + 8) * b32)
+        new_order()
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(k32 // ks):
             g32k.replay()
@@ -187,33 +285,6 @@ def after_measurements(eng, args, B, n_train, n_val, G, dev):
                           'steps': k32, 'launch': 'hipGraph replay, %d steps per graph' % ks}
     except Exception as e:
         out['batch32'] = {'error': str(e)}
-    _mark('epoch timing')
-    # ---- one epoch at the bench batch: train rows in shuffled order, last partial batch included, then validation
-    steps_full, b_last = n_train // B, n_train % B
-    new_order(n_train)
-    eng.train_step(B, B, [B], B)
-    gB = capture_step(eng, B, [B])
-    times = []
-    for ep in range(4):
-        new_order(n_train)
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        for _ in range(steps_full):
-            gB.replay()
-        if b_last:
-            eng.train_step(b_last, b_last, [b_last], B)
-        torch.cuda.synchronize(); t1 = time.perf_counter()
-        if n_val:
-            eng.eval_loss_sum(n_train, n_train + n_val, 1.0 / (float(n_val) * G))
-        torch.cuda.synchronize(); t2 = time.perf_counter()
-        if ep > 0:
-            times.append((t1 - t0, t2 - t1))
-    tr = float(np.median([t[0] for t in times])); va = float(np.median([t[1] for t in times]))
-    acc = eng.acc.cpu().numpy()
-    out['epoch'] = {'train_s': tr, 'validation_s': va, 'train_cells': n_train, 'validation_cells': n_val,
-                    'cells_per_s_train_only': n_train / tr, 'cells_per_s_incl_validation': n_train / (tr + va),
-                    'timed_epochs': len(times), 'val_loss_last': float(acc[1]), 'loss_last': float(acc[0]) / n_train,
-                    'steps_per_epoch': steps_full + (1 if b_last else 0), 'last_batch': b_last,
-                    'train_s_each': [round(t[0], 6) for t in times]}
     return out
 
 
@@ -253,23 +324,10 @@ def main():
     eng.reserve(max(B, 1024) if W == 1 else B)           # validation runs in chunks of up to 1024 rows
     eng.clip = 5.0
     eng.set_lr(1e-3)
-    total_steps = args.warmup + 8 + args.steps          # + one untimed replay of the (up to 8-step) graph
-    # shuffled row order: as many reshuffles of the shard as the run needs
-    gen = torch.Generator(device='cpu'); gen.manual_seed(1234 + rank)
-    need = total_steps * B
-    perms = []
-    while sum(p.numel() for p in perms) < need:
-        perms.append(torch.randperm(n_local, generator=gen, dtype=torch.int32) if n_local >= B
-                     else torch.randint(0, n_local, (B,), generator=gen, dtype=torch.int32))
-    eng.perm = torch.cat(perms)[:need].to(dev)
-    eng.hist = torch.zeros(total_steps + 1, dtype=torch.float32, device=dev)
-    eng.cursor.zero_(); eng.acc.zero_()
     counts = [B] * W
-    # one GPU: the step is replayed as a hipGraph at every batch size -- ~40 launches per 1.8 ms step leave the host
-    # little slack (a busy host starves the GPU: one eager run in ~10 measured 2.66 ms/step with unchanged kernel
-    # times); replay is GPU-paced (1.784 ms/step, run-to-run identical).  N > 1 stays eager (collectives).
-    use_graph = (args.graph == 'on') or (args.graph == 'auto' and W == 1)
-    use_graph = use_graph and W == 1
+    # one GPU: the steps are replayed as hipGraphs -- ~30 launches per 1.3 ms step leave the host little slack (a busy
+    # host starves the GPU); replay is GPU-paced.  N > 1 stays eager (collectives).
+    use_graph = ((args.graph == 'on') or (args.graph == 'auto' and W == 1)) and W == 1
 
     def barrier():
         if W > 1:
@@ -277,8 +335,7 @@ def main():
         torch.cuda.synchronize()
 
     # clock spin-up (not a training step): the first kernels of a process that starts right after another GPU
-    # process has exited were measured up to 2.5x slow (bench_heads: 3.5-3.9 ms instead of 1.32); ~0.2 s of
-    # throw-away GEMMs on scratch buffers before the W warm-up steps
+    # process has exited were measured up to 2.5x slow; ~0.2 s of throw-away GEMMs on scratch buffers first
     sa = torch.randn(2048, 2048, device=dev); sb = torch.randn(2048, 2048, device=dev); sc = torch.empty(2048, 2048, device=dev)
     t_spin = time.perf_counter()
     while time.perf_counter() - t_spin < 0.2:
@@ -287,63 +344,91 @@ def main():
         torch.cuda.synchronize()
     del sa, sb, sc
 
-    # steps per graph launch: the fit loop replays 8 consecutive steps per launch (dca_amd/train.py::_StepRunner); here the
-    # largest divisor of --steps up to 8, so that exactly --steps steps are timed
-    steps_per_graph = max(k for k in range(1, 9) if args.steps % k == 0) if use_graph else 1
-    graph = None
-    for i in range(args.warmup):
-        if use_graph and i == 1:
-            try:
-                graph = torch.cuda.CUDAGraph()
-                s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(s):
-                    with torch.cuda.graph(graph, stream=s):
-                        for _ in range(steps_per_graph):
-                            eng.train_step(B, B * W, counts, B)
-                torch.cuda.current_stream().wait_stream(s)
-            except Exception as e:                       # capture refused: time the eager step instead
-                print('bench: hipGraph capture failed (%s); running eager' % e, file=sys.stderr)
-                graph, use_graph = None, False
-                torch.cuda.synchronize()
-        eng.train_step(B, B * W, counts, B)
-    if use_graph and graph is None:
-        use_graph = False
-    if graph is not None:
-        graph.replay()                                   # untimed: first replay of the graph (steps_per_graph more warmup steps)
-    total_steps = args.warmup + (steps_per_graph if graph is not None else 0) + args.steps
     prof = None
-    if not use_graph:
-        prof = EventProfiler(); eng.prof = prof
-    barrier()
-    t_start = time.perf_counter()
-    if graph is not None:
-        for i in range(args.steps // steps_per_graph):
-            graph.replay()
+    comm_ms = None
+    if W == 1:
+        # ---- one GPU: the K timed steps are K consecutive steps of the FIT LOOP's sequence -- epoch after epoch over the
+        # train rows in shuffled order, full batches then the partial one -- after W eager warm-up steps and one
+        # untimed epoch through the graphs.  The default K is three epochs: `value` is then the >= 3-epoch figure.
+        spe_guess = (n_local + B - 1) // B
+        K = args.steps if args.steps > 0 else 3 * spe_guess
+        runner = EpochRunner(eng, n_local, B, dev, max_epochs=(args.warmup + K) // spe_guess + 6, use_graph=use_graph)
+        runner.new_run(runner.max_epochs)
+        runner.use_graph = False
+        runner.run(args.warmup)                            # eager warm-up steps (kernels' first launches, allocator)
+        runner.use_graph = use_graph
+        try:
+            runner.capture_all()
+        except Exception as e:                             # capture refused: time the eager steps instead
+            print('bench: hipGraph capture failed (%s); running eager' % e, file=sys.stderr)
+            runner.use_graph = use_graph = False
+            torch.cuda.synchronize()
+        runner.run(runner.spe - (runner.k % runner.spe))   # untimed: to the end of the epoch, first replay of every graph
+        runner.run(runner.spe)                             # untimed: one whole epoch through the graphs
+        runner.run(K, capture_only=True)                   # (a K that ends inside an epoch needs a shorter graph)
+        if not use_graph:
+            prof = EventProfiler(); eng.prof = prof
+        barrier()
+        t_start = time.perf_counter()
+        cells_timed = runner.run(K)
+        barrier()
+        el = time.perf_counter() - t_start
+        total_steps = runner.k
+        steps_timed = K
+        launch_desc = ('hipGraph replay, up to 8 consecutive steps per graph launch, the partial last batch of an epoch as '
+                       'its own graph (%d launches per %d-step epoch)' % (runner.launches_per_epoch(), runner.spe)) \
+            if use_graph else 'eager'
     else:
-        for i in range(args.steps):
+        # ---- N GPUs: weak scaling, every rank takes B rows of its shard per step, eager (collectives)
+        runner = None
+        K = args.steps if args.steps > 0 else 48
+        total_steps = args.warmup + K
+        gen = torch.Generator(device='cpu'); gen.manual_seed(1234 + rank)
+        need = total_steps * B
+        perms = []
+        while sum(p.numel() for p in perms) < need:
+            perms.append(torch.randperm(n_local, generator=gen, dtype=torch.int32) if n_local >= B
+                         else torch.randint(0, n_local, (B,), generator=gen, dtype=torch.int32))
+        eng.perm = torch.cat(perms)[:need].to(dev)
+        eng.hist = torch.zeros(total_steps + 1, dtype=torch.float32, device=dev)
+        eng.cursor.zero_(); eng.acc.zero_()
+        for i in range(args.warmup):
             eng.train_step(B, B * W, counts, B)
-    barrier()
-    el = time.perf_counter() - t_start
+        prof = EventProfiler(); eng.prof = prof
+        comm.timer = {}
+        barrier()
+        t_start = time.perf_counter()
+        for i in range(K):
+            eng.train_step(B, B * W, counts, B)
+        barrier()
+        el = time.perf_counter() - t_start
+        # exposed communication: what the compute stream spent inside (or waiting for) each exchange, per step
+        comm_ms = {k: {'calls_per_step': v[0] / K, 'ms_per_step': v[1] / K} for k, v in comm.timer_summary().items()}
+        comm.timer = None
+        cells_timed = K * B * W
+        steps_timed = K
+        launch_desc = 'eager'
     elt = torch.tensor([el], dtype=torch.float64, device=dev)
     if W > 1:
         torch.distributed.all_reduce(elt, op=torch.distributed.ReduceOp.MAX)
     el = float(elt.item())
     eng.prof = None
-    losses = eng.hist[:total_steps].cpu().numpy()
+    loss_last = float(eng.g[eng.lay.P].item())
+    loss_first = float(eng.hist[0].item())
 
     # ---- per-kernel timing (HIP events on the launch stream)
     ksum = prof.summary() if prof is not None else {}
     if use_graph:
-        # graph replay hides individual launches: time the dominant kernels in isolation
+        # graph replay hides individual launches: time the dominant kernels in isolation (eager full-batch steps)
         eng.prof = EventProfiler()
         eng.cursor.zero_()
-        for i in range(min(args.steps, 20)):
+        for i in range(min(steps_timed, 20, n_local // B)):
             eng.train_step(B, B * W, counts, B)
         ksum = eng.prof.summary(); eng.prof = None
     kernels = []
     for name, st in ksum.items():
         bound, work = kernel_model(name, B, G, hidden)
-        ent = {'kernel': name, 'mean_ms': st['mean_ms'], 'share_of_step': st['total_ms'] / st['count'] / (1e3 * el / args.steps)}
+        ent = {'kernel': name, 'mean_ms': st['mean_ms'], 'share_of_step': st['total_ms'] / st['count'] / (1e3 * el / steps_timed)}
         if work:
             if bound == 'hbm':
                 ent.update(bound='hbm', achieved=work / (st['mean_ms'] * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit='GB/s')
@@ -384,14 +469,14 @@ def main():
     extra = {}
     _mark('timed region and kernel timing done')
     if W == 1:
-        extra = after_measurements(eng, args, B, n_local, n_val, G, dev)
+        extra = after_measurements(eng, args, B, n_local, n_val, G, dev, runner)
     _mark('after-measurements done')
 
     if rank == 0:
         out = {
             'metric': 'cells/sec training (ZINB AE, 68k x 20k)',
-            'value': args.steps * B * W / el, 'unit': 'cells/s', 'n_gpus': W, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': 1e3 * el / args.steps, 'higher_is_better': True,
+            'value': cells_timed / el, 'unit': 'cells/s', 'n_gpus': W, 'steps': steps_timed,
+            'warmup': args.warmup, 'ms_per_step': 1e3 * el / steps_timed, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'zinb-conddisp autoencoder %s on synthetic %d x %d counts '
                                    '(%s); train rows %d sharded over %d GPU(s)'
@@ -399,13 +484,18 @@ def main():
                                       'BASELINE configs[2]' if (args.cells, G, hidden) == (68579, 20000, (64, 32, 64))
                                       else 'not a BASELINE shape: ad-hoc run', n_train_global, W),
                        'batch_per_gpu': B, 'global_batch': B * W, 'hidden': list(hidden),
-                       'parallelism': 'dp%d' % W, 'launch': ('hipGraph replay, %d steps per graph' % steps_per_graph) if use_graph else 'eager',
+                       'parallelism': 'dp%d' % W, 'launch': launch_desc,
+                       'timed_region': ('%d consecutive steps of the fit loop (epochs of %d full batches of %d cells + one of %d), '
+                                        '%d cells; ms_per_step averages over full and partial batches'
+                                        % (steps_timed, n_local // B, B, n_local % B, cells_timed)) if W == 1 else
+                                       ('%d steps of %d cells per GPU' % (steps_timed, B)),
+                       'exposed_comm_ms_per_step': comm_ms,
                        'optimizer': 'RMSprop+clipvalue', 'params': int(eng.lay.P),
                        'arithmetic': 'fp32 results: matrix products as three-way bf16 splits, six products, fp32 accumulation '
                                      '(fp32-dot-product accuracy, tests/test_heads_fused_gpu.py::test_x3_products_are_fp32_accurate); '
                                      'likelihood in fp32',
                        **extra},
-            'loss_first': float(losses[0]), 'loss_last': float(losses[total_steps - 1]),
+            'loss_first': loss_first, 'loss_last': loss_last,
             'roofline': roof, 'kernels': kernels,
         }
         if not args.no_cpu_baseline and W == 1:

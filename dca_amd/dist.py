@@ -28,21 +28,83 @@ class TorchDistComm:
         self.bulk = dist.new_group(ranks=list(range(dist.get_world_size())) if group is None else None) \
             if group is None else group
 
+    # every exchange can be timed: with .timer = {} the communicator brackets each call (and each wait for an
+    # asynchronous one) with events on the compute stream -- what the stream spends there is the EXPOSED communication
+    # time of the step (bench.py --gpus N reports it per category)
+    timer = None
+
+    class _Span:
+        def __init__(self, comm, name, t):
+            self.comm, self.name, self.cuda = comm, name, t.is_cuda
+
+        def __enter__(self):
+            if self.comm.timer is None:
+                return self
+            if self.cuda:
+                self.s = torch.cuda.Event(enable_timing=True); self.e = torch.cuda.Event(enable_timing=True)
+                self.s.record()
+            else:
+                import time
+                self.t0 = time.perf_counter()
+            return self
+
+        def __exit__(self, *a):
+            if self.comm.timer is None:
+                return False
+            if self.cuda:
+                self.e.record()
+                self.comm.timer.setdefault(self.name, []).append((self.s, self.e))
+            else:
+                import time
+                self.comm.timer.setdefault(self.name, []).append(time.perf_counter() - self.t0)
+            return False
+
+    def timer_summary(self):
+        """{category: (calls, total ms)} of the spans recorded since .timer was set."""
+        out = {}
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        for k, lst in (self.timer or {}).items():
+            ms = [x * 1e3 if isinstance(x, float) else x[0].elapsed_time(x[1]) for x in lst]
+            out[k] = (len(ms), float(sum(ms)))
+        return out
+
     def all_reduce_sum(self, t):
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        with self._Span(self, 'all_reduce_%s' % ('small' if t.numel() <= 4096 else 'bucket'), t):
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
     def all_reduce_sum_async(self, t):
         """Starts the all-reduce on the communication stream and returns a handle; wait() makes
         the current stream wait for it.  Lets the head-gradient bucket (75 % of the bytes, ready
         first) travel over xGMI while the hidden stack's backward still computes."""
+        self._async_probe = t
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.bulk, async_op=True)
+
+    def wait(self, work):
+        with self._Span(self, 'wait_async_bucket', self._async_probe):
+            work.wait()
 
     def all_gather(self, t):
         flat = t.contiguous().view(-1)
         out = torch.empty(self.world * flat.numel(), dtype=t.dtype, device=t.device)
-        dist.all_gather_into_tensor(out, flat, group=self.group)
+        with self._Span(self, 'all_gather_small' if flat.numel() <= 4096 else 'all_gather', t):
+            dist.all_gather_into_tensor(out, flat, group=self.group)
         return out.view((self.world,) + tuple(t.shape))
+
+    def reduce_scatter_sum(self, inp, out):
+        """out [len / world] = this rank's shard of the element-wise sum of inp over the ranks."""
+        with self._Span(self, 'reduce_scatter', inp):
+            dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, group=self.group)
+        return out
+
+    def all_gather_into(self, out, shard):
+        """out = concatenation of every rank's shard (shard may be a slice of out)."""
+        src = shard.clone() if shard.data_ptr() >= out.data_ptr() and \
+            shard.data_ptr() < out.data_ptr() + out.numel() * out.element_size() else shard
+        with self._Span(self, 'all_gather_params', out):
+            dist.all_gather_into_tensor(out, src, group=self.group)
+        return out
 
 
 def init_from_env(backend=None):

@@ -115,6 +115,9 @@ class SingleProcess:
     def all_reduce_sum_async(self, t):
         return None
 
+    def wait(self, work):
+        pass
+
 
 def _truncated_normal(rng, stddev, shape):
     """TF truncated_normal: values beyond two standard deviations are redrawn."""
@@ -281,9 +284,17 @@ class Engine:
         self.flags = (1 if self.has_pi else 0) | (2 if lay.const_disp else 0) | AE_LOSS_FLAG.get(ae_type, 0)
         self.center = lay.center
         f32 = dict(dtype=torch.float32, device=self.dev)
-        self.w = torch.zeros(lay.total, **f32)
-        self.g = torch.zeros(lay.total, **f32)
-        self.ms = torch.zeros(lay.total, **f32)
+        # flat buffers, padded so that every rank's shard of the sharded-optimizer exchange (below) starts 16-byte aligned
+        pad = 4 * self.comm.world
+        self.flat_len = (lay.total + pad - 1) // pad * pad
+        self.w = torch.zeros(self.flat_len, **f32)
+        self.g = torch.zeros(self.flat_len, **f32)
+        self.ms = torch.zeros(self.flat_len, **f32)
+        # data parallel, RMSprop: reduce-scatter of the gradient -> every rank clips and updates ITS shard of the
+        # parameters (and keeps only that shard of the RMSprop slots current) -> all-gather of the parameters, instead of
+        # all-reducing the whole gradient and updating everything everywhere.  Same bytes on the wire
+        # (2 (N-1)/N P either way), 1/N of the optimizer traffic per rank; DCA_AMD_DP_SHARDED_OPT=1 switches it on.
+        self.sharded_opt = self.comm.world > 1 and os.environ.get('DCA_AMD_DP_SHARDED_OPT', '0') == '1'
         self.mm = [torch.zeros(h, **f32) for h in lay.hidden] if batchnorm else []
         self.mv = [torch.ones(h, **f32) for h in lay.hidden] if batchnorm else []
         self.lr = torch.full((1,), 1e-3, **f32)
@@ -475,7 +486,11 @@ class Engine:
         extra = {} if self.slot2 is None else {'slot2': self.slot2.cpu().numpy()}
         if self.m_sched is not None:
             extra['m_sched'] = self.m_sched.cpu().numpy()
-        np.savez(path, w=self.w.cpu().numpy(), ms=self.ms.cpu().numpy(), opt_iter=self.opt_iter.cpu().numpy(),
+        if self.sharded_opt and self.comm.world > 1:      # every rank holds one shard of the slots: collect them
+            sh = self.flat_len // self.comm.world
+            self.ms.copy_(self.comm.all_gather(self.ms[self.comm.rank * sh:(self.comm.rank + 1) * sh]).reshape(-1))
+        T = self.lay.total
+        np.savez(path, w=self.w[:T].cpu().numpy(), ms=self.ms[:T].cpu().numpy(), opt_iter=self.opt_iter.cpu().numpy(),
                  drop_iter=self.drop_iter.cpu().numpy(), **extra,
                  **{'mm%d' % i: t.cpu().numpy() for i, t in enumerate(self.mm)},
                  **{'mv%d' % i: t.cpu().numpy() for i, t in enumerate(self.mv)},
@@ -484,9 +499,10 @@ class Engine:
     def load_state(self, path):
         import json
         with np.load(path) as z:
-            assert z['w'].shape[0] == self.w.shape[0], 'checkpoint belongs to a different network'
-            self.w.copy_(torch.as_tensor(z['w']))
-            self.ms.copy_(torch.as_tensor(z['ms']))
+            T = self.lay.total
+            assert z['w'].shape[0] == T, 'checkpoint belongs to a different network'
+            self.w[:T].copy_(torch.as_tensor(z['w']))
+            self.ms[:T].copy_(torch.as_tensor(z['ms']))
             if 'opt_iter' in z.files:
                 self.opt_iter.copy_(torch.as_tensor(z['opt_iter']))
             if self.m_sched is not None and 'm_sched' in z.files:
@@ -494,7 +510,7 @@ class Engine:
             if 'drop_iter' in z.files:
                 self.drop_iter.copy_(torch.as_tensor(z['drop_iter']))
             if self.slot2 is not None and 'slot2' in z.files:
-                self.slot2.copy_(torch.as_tensor(z['slot2']))
+                self.slot2[:z['slot2'].shape[0]].copy_(torch.as_tensor(z['slot2']))
             for i in range(len(self.mm)):
                 self.mm[i].copy_(torch.as_tensor(z['mm%d' % i]))
                 self.mv[i].copy_(torch.as_tensor(z['mv%d' % i]))
@@ -904,12 +920,27 @@ class Engine:
             self._forward_backward(B, Bg, inv_n)
         else:
             self._empty_step()
+        if comm.world > 1 and self._use_sharded_opt():
+            # reduce-scatter -> this rank's shard of clip + RMSprop -> all-gather of the updated parameters
+            sh = self.flat_len // comm.world
+            lo = comm.rank * sh
+            comm.all_reduce_sum(g[lay.P:lay.P + 1])                  # the batch loss (its slot sits in the last shard)
+            gs = comm.reduce_scatter_sum(g, self._g_shard(sh))
+            n_upd = max(0, min(sh, lay.P - lo))                       # parameters of the shard (the tail is padding / loss)
+            if n_upd > 0:
+                with self._t('rmsprop_clip'):
+                    ops.rmsprop_clip(w[lo:lo + sh], gs, self.ms[lo:lo + sh], n_upd, self.lr, RMS_RHO, RMS_EPS, self.clip)
+            comm.all_gather_into(w, w[lo:lo + sh])
+            if self.has_dropout:
+                ops.counter_add(self.drop_iter, 1)
+            ops.step_end(g[lay.P:], float(Bg), self.hist, rows_per_slot or max(self.Bmax, 1), self.acc, self.cursor, B)
+            return
         if comm.world > 1:
             # bucket 2: hidden layers; bucket 1 (heads + loss) has been travelling since the heads'
             # backward finished (_launch_heads_bucket)
             comm.all_reduce_sum(g[:lay.seg['Wh'][0]])
             if self._pending is not None:
-                self._pending.wait()
+                comm.wait(self._pending)
                 self._pending = None
         if self.reg is not None:           # after the exchange: every rank adds the same terms once
             ops.l1l2_apply(self.reg, w, g, g[lay.P:], self.reg_ws)
@@ -937,10 +968,18 @@ class Engine:
     def _heads_compact(self):
         return {'compact': self.cc} if self.cc is not None else {}
 
+    def _use_sharded_opt(self):
+        return self.sharded_opt and self.opt_kind == 'rmsprop' and self.reg is None
+
+    def _g_shard(self, sh):
+        if getattr(self, '_gshard', None) is None or self._gshard.numel() != sh:
+            self._gshard = torch.zeros(sh, dtype=torch.float32, device=self.dev)
+        return self._gshard
+
     def _launch_heads_bucket(self):
         """Data parallel: all-reduce of g[Wh .. P] (head weights, biases, log-dispersion, batch
         loss) starts now, asynchronously."""
-        if self.comm.world > 1:
+        if self.comm.world > 1 and not self._use_sharded_opt():
             lay = self.lay
             self._pending = self.comm.all_reduce_sum_async(self.g[lay.seg['Wh'][0]:lay.P + 1])
 

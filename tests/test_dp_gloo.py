@@ -60,6 +60,8 @@ def _run(rank, world, port, cfg, q):
         n, G, hs, ae, bn, B, epochs, seed = cfg[:8]
         optimizer = cfg[8] if len(cfg) > 8 else None
         drop = cfg[9] if len(cfg) > 9 else {}
+        if len(cfg) > 10 and cfg[10]:
+            os.environ['DCA_AMD_DP_SHARDED_OPT'] = '1'
         X, Y, sf, p = make_problem(n, G, hs, ae, bn, seed=3)
         n_train = int(n * 0.9)
         n_val = n - n_train
@@ -93,12 +95,19 @@ def _free_port():
                                          # 4 ranks, 18 train rows = shards of 5, 5, 4, 4 at 4 rows per rank and step: in the last
                                          # step of every epoch ranks 2 and 3 are EMPTY (they still join every collective);
                                          # 2 validation rows = shards 1, 1, 0, 0
-                                         ('zinb-conddisp', True, 20, 16, 4), ('nb', True, 23, 8, 4)])
+                                         ('zinb-conddisp', True, 20, 16, 4), ('nb', True, 23, 8, 4),
+                                         # 8 ranks (the target node): 36 train rows = shards 5, 5, 5, 5, 4, 4, 4, 4 at 2 rows per
+                                         # rank and step: FOUR empty ranks in the last step of every epoch; 5 validation rows =
+                                         # shards 1, 1, 1, 1, 1, 0, 0, 0
+                                         ('zinb-conddisp', True, 41, 16, 8)])
 def test_two_rank_dp_equals_single_process_and_oracle(ae, bn, n, B, W):
     G, hs, epochs, seed = 14, (6, 3, 6), 3, 17
     if W == 4 and n == 20:
         shards = [ddist.shard(int(n * 0.9), W, r)[1] for r in range(W)]
         assert shards == [5, 5, 4, 4] and B // W == 4           # => two empty ranks in the last step
+    if W == 8:
+        assert [ddist.shard(int(n * 0.9), W, r)[1] for r in range(W)] == [5, 5, 5, 5, 4, 4, 4, 4] and B // W == 2
+        assert [ddist.shard(n - int(n * 0.9), W, r)[1] for r in range(W)] == [1, 1, 1, 1, 1, 0, 0, 0]
     cfg = (n, G, hs, ae, bn, B, epochs, seed)
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
@@ -106,7 +115,7 @@ def test_two_rank_dp_equals_single_process_and_oracle(ae, bn, n, B, W):
     procs = [ctx.Process(target=_run, args=(r, W, port, cfg, q)) for r in range(W)]
     for pr in procs:
         pr.start()
-    hist_dp, p_dp = q.get(timeout=120)
+    hist_dp, p_dp = q.get(timeout=240)
     for pr in procs:
         pr.join(timeout=60)
         assert pr.exitcode == 0
@@ -137,6 +146,36 @@ def test_two_rank_dp_equals_single_process_and_oracle(ae, bn, n, B, W):
                batch_size=B, shuffle_rng=FixedOrders(orders), reduce_lr=1, early_stop=0)
     np.testing.assert_allclose(hist_dp['loss'], rh['loss'], rtol=1e-4)
     np.testing.assert_allclose(hist_dp['val_loss'], rh['val_loss'], rtol=1e-4)
+
+
+def _dp_fit(cfg, W):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_run, args=(r, W, port, cfg, q)) for r in range(W)]
+    for pr in procs:
+        pr.start()
+    out = q.get(timeout=240)
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    return out
+
+
+@pytest.mark.parametrize('ae,bn,n,B,W', [('zinb-conddisp', True, 60, 16, 2), ('nb', True, 23, 8, 4), ('zinb', True, 41, 16, 8)])
+def test_sharded_optimizer_equals_the_all_reduce_path(ae, bn, n, B, W):
+    """reduce-scatter -> per-rank clip + RMSprop on its shard -> all-gather of the parameters (DCA_AMD_DP_SHARDED_OPT=1,
+    SURVEY 5) against the default two-bucket all-reduce: the same fit, uneven shards and empty ranks included.  With
+    two ranks the sums are the same sums; with more, gloo's reduction order may differ between the two collectives."""
+    G, hs, epochs, seed = 14, (6, 3, 6), 3, 17
+    base = (n, G, hs, ae, bn, B, epochs, seed, None, {})
+    h0, p0 = _dp_fit(base + (False,), W)
+    h1, p1 = _dp_fit(base + (True,), W)
+    tol = 0 if W == 2 else 2e-5
+    np.testing.assert_allclose(h1['loss'], h0['loss'], rtol=tol)
+    np.testing.assert_allclose(h1['val_loss'], h0['val_loss'], rtol=tol)
+    for k in p0:
+        np.testing.assert_allclose(p1[k], p0[k], rtol=0, atol=0 if W == 2 else 2e-3, err_msg=k)
 
 
 def test_two_rank_dp_gradients_are_summed_once():

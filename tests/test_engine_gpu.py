@@ -367,3 +367,49 @@ def test_prelu_step_matches_oracle(ops, batchnorm):
     want = oracle_net(ae, p, hs, batchnorm, activation='PReLU').predict(X[:32], sf[:32])
     np.testing.assert_allclose(out['mean'].cpu().numpy()[:, :G], want['mean'], rtol=3e-4)
     np.testing.assert_allclose(out['latent'].cpu().numpy(), want['latent'], rtol=3e-4, atol=1e-5)
+
+
+def test_c3_first_steps_match_oracle(ops):
+    """BASELINE configs[2] at the reference-default batch, where the driver can see it: the first 64 training steps
+    (batch 32) of the 68 579 x 20 000 zinb-conddisp problem and the validation loss on 512 held-out cells, against the
+    fp64 oracle's numbers in tests/golden/c3_steps_oracle.npz (generator beside it: the whole matrix is generated there,
+    because size factors and per-gene statistics depend on every cell; the fixture stores the 2 560 cells the steps
+    touch).  Per step 1e-5, on the mean of the step losses and on val_loss 1e-4 -- north_star's per-epoch bound."""
+    import os
+    from dca_amd.engine import Engine
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'c3_steps_oracle.npz'))
+    nrows, G, steps, B, n_val = (int(v) for v in z['shape'])
+    hs = (64, 32, 64)
+    Gp = (G + 3) // 4 * 4
+    Yh = np.zeros((nrows, Gp), np.float32)
+    Yh[z['nz_row'].astype(np.int64), z['nz_col'].astype(np.int64)] = z['nz_val']
+    Y = torch.as_tensor(Yh).cuda()
+    sf = torch.as_tensor(z['sf']).cuda()
+    mean = torch.zeros(Gp, device='cuda'); mean[:G] = torch.as_tensor(z['gene_mean']).cuda()
+    std = torch.ones(Gp, device='cuda'); std[:G] = torch.as_tensor(z['gene_std']).cuda()
+    # X with K-PREP's own kernels from the fixture's statistics of ALL 68 579 cells (dca/io.py:99-109)
+    X = torch.zeros(nrows, Gp, device='cuda')
+    part = torch.zeros(ops.prep_chunks(nrows) * 2 * Gp, dtype=torch.float64, device='cuda')
+    ops.prep_col_pass(Y, Gp, nrows, G, sf, True, X, Gp, part)
+    ops.prep_scale(X, Gp, nrows, G, mean, std)
+    p = N.init_params('zinb-conddisp', G, hs, batchnorm=True, seed=0, dtype=np.float64)
+    eng = Engine('zinb-conddisp', G, G, hs, True, 0.0, ops=ops)
+    eng.set_params({k: np.asarray(v, np.float32) for k, v in p.items()})
+    eng.attach_device_data(X, Y, sf, norm=dict(fac=sf, do_log=True, mean=mean, std=std))
+    assert eng.cc is not None                            # K-HEADS reads the byte store
+    eng.reserve(max(B, 512))
+    eng.perm = torch.arange(steps * B, dtype=torch.int32, device='cuda')     # the fixture stores the cells in visiting order
+    eng.hist = torch.zeros(steps + 4, dtype=torch.float32, device='cuda')
+    eng.cursor.zero_(); eng.acc.zero_()
+    eng.set_lr(1e-3)
+    for _ in range(steps):
+        eng.train_step(B, rows_per_slot=B)
+    eng.eval_loss_sum(steps * B, steps * B + n_val, 1.0 / (float(n_val) * G))
+    torch.cuda.synchronize()
+    got = eng.hist[:steps].cpu().numpy().astype(np.float64)
+    want = z['step_loss']
+    rel = np.abs(got / want - 1)
+    assert rel.max() < 1e-5, (int(rel.argmax()), float(rel.max()))
+    assert abs(got.mean() / want.mean() - 1) < 1e-4
+    val = float(eng.acc[1].item())
+    assert abs(val / float(z['val_loss']) - 1) < 1e-4, (val, float(z['val_loss']))

@@ -219,3 +219,30 @@ def test_threaded_likelihood_equals_the_single_call():
         b = Z.rows_in_parallel(Z.nb_loss_and_grads, (am, None if tw_ is not None else ad, y, sf), 5, n_total=nt, theta_w=tw_)
         for u, v in zip(a, b):
             np.testing.assert_allclose(np.asarray(u), np.asarray(v), rtol=1e-12, atol=1e-18)
+
+
+def test_c3_steps_fixture_is_what_the_oracle_computes():
+    """tests/golden/c3_steps_oracle.npz cannot go stale silently: the first two of its 64 step losses are re-derived
+    here from the stored cells, statistics and the committed generator's own functions (fp64 oracle)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), 'golden'))
+    import make_c3_steps_golden as M
+    from oracle import net_np as N
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'c3_steps_oracle.npz'))
+    nrows, G, steps, B, n_val = (int(v) for v in z['shape'])
+    assert (nrows, G, steps, B, n_val) == (M.STEPS * M.BATCH + M.N_VAL, M.N_GENES, M.STEPS, M.BATCH, M.N_VAL)
+    take = 2 * B
+    sel = z['nz_row'] < take
+    Y = np.zeros((take, G), np.uint8)
+    Y[z['nz_row'][sel].astype(np.int64), z['nz_col'][sel].astype(np.int64)] = z['nz_val'][sel]
+    X = M.kprep_input(Y, z['sf'][:take], z['gene_mean'], z['gene_std']).astype(np.float64)
+    p = N.init_params('zinb-conddisp', G, M.HIDDEN, batchnorm=True, seed=M.INIT_SEED, dtype=np.float64)
+    p = {k: np.asarray(v, np.float32).astype(np.float64) for k, v in p.items()}
+    net = N.OracleAE('zinb-conddisp', p, M.HIDDEN, True, 0.0)
+    ms = {}
+    for st in range(2):
+        b = slice(st * B, (st + 1) * B)
+        loss, g = net.loss_and_grads(X[b], Y[b].astype(np.float64), z['sf'][b].astype(np.float64))
+        N.rmsprop_step(net.p, g, ms, float(np.float32(M.LR)), clip=M.CLIP)
+        assert abs(loss / z['step_loss'][st] - 1) < 1e-12, (st, loss, z['step_loss'][st])

@@ -220,7 +220,7 @@ def test_step_with_compact_counts_matches_oracle(ops, ae_type, B):
     Gp = (G + 3) // 4 * 4
     Xd = torch.zeros(n, Gp, device='cuda'); Xd[:, :G] = dev(X)
     Yd = torch.zeros(n, Gp, device='cuda'); Yd[:, :G] = dev(Y)
-    eng.sparse_fwd_min = 1
+    eng.sparse_fwd_min = eng.sparse_dw_min = 1           # both byte-store kernels at every batch size
     norm = dict(fac=dev(sf), do_log=True, mean=dev(mean), std=dev(std))
     eng.attach_device_data(Xd, Yd, dev(sf), norm=norm)
     assert eng.cc is not None and eng.cc_in is not None
