@@ -944,6 +944,768 @@ __global__ __launch_bounds__(256) void transpose64_kernel(const float* __restric
     }
 }
 
+// =====================================================================================================
+// K-STACK: the hidden stack behind the first layer's product at throughput batches, ONE launch per direction.
+// With one launch per operation the 64-32-64 stack of the benchmark network costs 22 launches of ~5 us each per step
+// (launch floor + one memory round trip: the whole activation set at 4096 rows is 2.6 MB) -- 10 % of the step.  Here a
+// workgroup owns a block of batch rows for the whole pass and keeps its tiles in LDS; the only thing workgroups
+// exchange are the batch-norm statistics (forward: one (mean, M2) pair per workgroup and layer; backward: the two sums
+// of dcahip_bn_bwd_sums) and, at the end of the backward pass, the weight-gradient partials -- through grid-wide
+// barriers (an arrival counter polled with agent-scope loads, release before / acquire after: the forms
+// MI355X_MICROARCH.md lists as valid).  Every workgroup must be resident at once: at most 256 of them, launched on an
+// otherwise idle device (the stream order of the training step guarantees it); every spin is bounded.
+// Same formulas, same merge (merge_entries_wg) and same summation structure as the per-operation kernels above.
+// =====================================================================================================
+constexpr int kStackMaxLayers = 8;
+constexpr int kStackRows = 64;          // most rows a workgroup owns
+constexpr int kStackMaxWG = 256;
+constexpr int kStackLd = 68;            // LDS row stride (floats): 16-byte aligned rows, rows 4 banks apart
+
+struct StackBwdLayer {                  // = dcahip_stack_bwd_layer (include/dcahip.h)
+    const float* W; long ldw; int K, H;
+    const float* Hact; long ldh; const float* xhat; long ldx; const float* inv_std;
+    const float* Hprev; long ldp;
+    float* gW; long ldg; float* dbeta;
+    float* dHin; long lddh;             // gradient w.r.t. this layer's output (read at the start of a launch; written for the layer below)
+};
+
+struct StackFwdArgs {
+    SmallLayer l[kStackMaxLayers];
+    int n, B, act, nwg, first, last;
+    float momentum, eps;
+    float* part;                        // [n][nwg][2][64]
+    unsigned* sync;                     // [0] arrivals, [1] exits, [2] error flag
+};
+
+struct StackBwdArgs {
+    StackBwdLayer l[kStackMaxLayers];
+    int n, B, act, nwg, first, last;
+    float n_total;
+    float* dZ0; long ldz0;              // OUT: gradient w.r.t. the first layer's pre-activation
+    float* part;                        // [n][nwg][2][64]
+    float* gwp;                         // [n][nwg][65][64] weight (+ bias) gradient partials
+    unsigned* sync;
+};
+
+__device__ __forceinline__ void grid_barrier(unsigned* sync, unsigned target) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1u << 22)) {                      // never hang the device: flag the error and go on
+                __hip_atomic_store(sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+}
+
+// the last workgroup to leave puts the counters back to zero for the next launch
+__device__ __forceinline__ void grid_exit(unsigned* sync, unsigned nwg) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = __hip_atomic_fetch_add(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == nwg - 1) {
+            __hip_atomic_store(sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// merge_entries_wg for K-STACK: the same two-pass fp64 merge of the workgroups' (mean, M2) pairs (counts from the row
+// partition), with ALL of a thread's loads of a pass in flight at once -- the entries were written by other CUs and
+// come from their L2 slices: a dependent load per entry costs a fabric round trip each
+__device__ __forceinline__ void stack_merge(const float* entries, int E, int H, int c, int B, double* sm /*[2][256]*/,
+                                            double& n_out, double& mean_out, double& m2_out) {
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int cc = c < H ? c : H - 1;
+    double n = 0.0, sw = 0.0;
+    for (int e0 = ty; e0 < E; e0 += 64) {
+        float me[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) me[u] = entries[((long)(e0 + 4 * u < E ? e0 + 4 * u : E - 1) * 2 + 0) * H + cc];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int e = e0 + 4 * u;
+            const double ne = (e < E && c < H) ? entry_count(nullptr, e, E, B) : 0.0;
+            n += ne; sw += ne * (double)me[u];
+        }
+    }
+    __syncthreads();
+    sm[ty * 64 + tx] = n; sm[256 + ty * 64 + tx] = sw;
+    __syncthreads();
+    n = (sm[tx] + sm[64 + tx]) + (sm[128 + tx] + sm[192 + tx]);
+    sw = (sm[256 + tx] + sm[320 + tx]) + (sm[384 + tx] + sm[448 + tx]);
+    const double mean = n > 0.0 ? sw / n : 0.0;
+    double q = 0.0;
+    for (int e0 = ty; e0 < E; e0 += 64) {
+        float me[16], qe[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const long eo = (long)(e0 + 4 * u < E ? e0 + 4 * u : E - 1) * 2;
+            me[u] = entries[(eo + 0) * H + cc]; qe[u] = entries[(eo + 1) * H + cc];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int e = e0 + 4 * u;
+            const double ne = (e < E && c < H) ? entry_count(nullptr, e, E, B) : 0.0;
+            const double d = (double)me[u] - mean;
+            q += ne > 0.0 ? (double)qe[u] + ne * d * d : 0.0;
+        }
+    }
+    __syncthreads();
+    sm[ty * 64 + tx] = q;
+    __syncthreads();
+    n_out = n; mean_out = mean;
+    m2_out = (sm[tx] + sm[64 + tx]) + (sm[128 + tx] + sm[192 + tx]);
+}
+
+// Steps of the forward pass: 0 = partial statistics of the first layer's pre-activation; 1 + i = layer i: merge the
+// statistics, normalise + activate the block's rows, next layer's pre-activation of the block and ITS partial statistics.
+// A launch runs steps [first, last]: all of them (cooperative: a grid barrier between steps) or one per launch (the
+// kernel boundary is the barrier; the block's tile is re-read from memory at the start of the step).
+__global__ __launch_bounds__(256) void hidden_stack_fwd_kernel(StackFwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float zt[kStackRows * kStackLd];     // pre-activations of the current layer
+    __shared__ __attribute__((aligned(16))) float ht[kStackRows * kStackLd];     // its activations (the next layer's input)
+    __shared__ __attribute__((aligned(16))) float wl[64 * kStackLd];             // the next layer's kernel
+    __shared__ float smf[256];
+    __shared__ double smd[512];
+    const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+    const int wg = blockIdx.x, nwg = a.nwg;
+    const int cr = chunk_rows(a.B, nwg);
+    const int r0 = wg * cr;
+    const int nrows = max(0, min(a.B, r0 + cr) - r0);
+    const int c = tx;
+    unsigned nbar = 0;
+    auto block_stats = [&](int i) {                       // (mean, M2) of the block's rows of layer i, from zt
+        const int H = a.l[i].H;
+        float sv = 0.f;
+        if (c < H) for (int r = ty; r < nrows; r += 4) sv += zt[r * kStackLd + c];
+        const float tot = wg_rowlane_sum(sv, smf);
+        const float bmean = nrows > 0 ? tot / (float)nrows : 0.f;
+        float q = 0.f;
+        if (c < H) for (int r = ty; r < nrows; r += 4) { const float d = zt[r * kStackLd + c] - bmean; q += d * d; }
+        const float bm2 = wg_rowlane_sum(q, smf);
+        float* part = a.part + (long)i * nwg * 2 * 64;
+        if (c < H && ty == 0) {
+            part[((long)wg * 2 + 0) * H + c] = bmean;
+            part[((long)wg * 2 + 1) * H + c] = bm2;
+        }
+    };
+    {   // the block's rows of the pre-activation the first step of this launch works on
+        const SmallLayer& L = a.l[a.first > 0 ? a.first - 1 : 0];
+        for (int r = ty; r < nrows; r += 4)
+            if (tx < L.H) zt[r * kStackLd + tx] = L.Z[(long)(r0 + r) * L.ldz + tx];
+        __syncthreads();
+    }
+    bool fresh = false;                                   // statistics written by THIS launch: a grid barrier before their merge
+    if (a.first == 0) { block_stats(0); fresh = true; }
+    for (int step = max(a.first, 1); step <= a.last; ++step) {
+        const int i = step - 1;
+        const SmallLayer& L = a.l[i];
+        const int H = L.H;
+        if (fresh) grid_barrier(a.sync, (unsigned)nwg * (++nbar));
+        // ---- statistics of the whole batch: every workgroup merges the same entries in the same order
+        const float* part = a.part + (long)i * nwg * 2 * 64;
+        double n_, m_, m2_;
+        stack_merge(part, nwg, H, c, a.B, smd, n_, m_, m2_);
+        const float mean = (float)m_;
+        const float var = (float)(m2_ / n_);
+        const float inv = 1.f / sqrtf(var + a.eps);
+        if (wg == 0 && ty == 0 && c < H) {
+            L.mm[c] = L.mm[c] - (L.mm[c] - mean) * (1.f - a.momentum);
+            L.mv[c] = L.mv[c] - (L.mv[c] - var) * (1.f - a.momentum);
+            if (L.inv_std) L.inv_std[c] = inv;
+        }
+        // ---- normalise + activation of the block's rows
+        if (c < H) {
+            const float beta = L.beta ? L.beta[c] : 0.f;
+            for (int r = ty; r < nrows; r += 4) {
+                const float xh = (zt[r * kStackLd + c] - mean) * inv;
+                const float h = act_fwd(a.act, xh + beta);
+                if (L.xhat) L.xhat[(long)(r0 + r) * L.ldx + c] = xh;
+                L.Hout[(long)(r0 + r) * L.ldh + c] = h;
+                ht[r * kStackLd + c] = h;
+            }
+        }
+        if (i + 1 == a.n) break;
+        // ---- the next layer's pre-activations of the block's rows: zt = ht W + b
+        const SmallLayer& N = a.l[i + 1];
+        const int K = H, HN = N.H;
+        for (int idx = tid; idx < ((K + 3) & ~3) * 64; idx += 256) {
+            const int k = idx >> 6, cc = idx & 63;
+            wl[k * kStackLd + cc] = (k < K && cc < HN) ? N.W[(long)k * N.ldw + cc] : 0.f;
+        }
+        for (int idx = tid; idx < kStackRows * 4; idx += 256) {         // zero the k padding of ht (K < 64 rounded up to 4)
+            const int r = idx >> 2, kk = (K & ~3) + (idx & 3);
+            if (kk >= K && kk < ((K + 3) & ~3)) ht[r * kStackLd + kk] = 0.f;
+        }
+        __syncthreads();
+        float acc[kStackRows / 4];
+#pragma unroll
+        for (int j = 0; j < kStackRows / 4; ++j) acc[j] = 0.f;
+        const int K4 = (K + 3) & ~3;
+        for (int k = 0; k < K4; k += 4) {
+            const float w0 = wl[(k + 0) * kStackLd + c], w1 = wl[(k + 1) * kStackLd + c];
+            const float w2 = wl[(k + 2) * kStackLd + c], w3 = wl[(k + 3) * kStackLd + c];
+#pragma unroll
+            for (int j = 0; j < kStackRows / 4; ++j) {
+                const int r = ty + 4 * j;
+                if (r < nrows) {
+                    const float4 h4 = *reinterpret_cast<const float4*>(ht + r * kStackLd + k);
+                    acc[j] = fmaf(h4.w, w3, fmaf(h4.z, w2, fmaf(h4.y, w1, fmaf(h4.x, w0, acc[j]))));
+                }
+            }
+        }
+        __syncthreads();                                  // every read of zt / ht of this layer is done
+        if (c < HN) {
+            const float b = N.bias ? N.bias[c] : 0.f;
+#pragma unroll
+            for (int j = 0; j < kStackRows / 4; ++j) {
+                const int r = ty + 4 * j;
+                if (r < nrows) {
+                    const float z = acc[j] + b;
+                    zt[r * kStackLd + c] = z;
+                    if (N.Z) N.Z[(long)(r0 + r) * N.ldz + c] = z;
+                }
+            }
+        }
+        __syncthreads();
+        block_stats(i + 1);
+        fresh = true;
+    }
+    if (nbar) grid_exit(a.sync, (unsigned)nwg);
+}
+
+// Steps of the backward pass (n layers): 0 = dy and the two batch sums of the last layer; 1 + j = layer i = n - 1 - j:
+// merge the sums, dZ, d beta, the block's weight-gradient partial, the gradient w.r.t. the layer's input and, for the
+// layer below, dy and ITS sums; n + 1 = add the weight-gradient partials of the blocks.
+__global__ __launch_bounds__(256) void hidden_stack_bwd_kernel(StackBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float dyt[kStackRows * kStackLd];    // dH -> dy -> dZ of the current layer
+    __shared__ __attribute__((aligned(16))) float xt[kStackRows * kStackLd];     // xhat of the block's rows
+    __shared__ __attribute__((aligned(16))) float ht[kStackRows * kStackLd];     // the layer's input activations
+    __shared__ __attribute__((aligned(16))) float wl[64 * kStackLd];             // the layer's kernel
+    __shared__ float smf[256];
+    const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+    const int wg = blockIdx.x, nwg = a.nwg;
+    const int cr = chunk_rows(a.B, nwg);
+    const int r0 = wg * cr;
+    const int nrows = max(0, min(a.B, r0 + cr) - r0);
+    const int c = tx;
+    unsigned nbar = 0;
+    // dy = dH act'(h) of layer i into dyt (+ xhat into xt); with_sums: the block's share of the two batch sums -> part
+    auto prep = [&](int i, bool load_dh, bool with_sums) {
+        const StackBwdLayer& L = a.l[i];
+        const int H = L.H;
+        if (load_dh) {
+            for (int r = ty; r < kStackRows; r += 4)
+                dyt[r * kStackLd + tx] = (r < nrows && tx < H) ? L.dHin[(long)(r0 + r) * L.lddh + tx] : 0.f;
+        }
+        float s1 = 0.f, s2 = 0.f;
+        if (c < H)
+            for (int r = ty; r < nrows; r += 4) {
+                const float h = L.Hact[(long)(r0 + r) * L.ldh + c];
+                const float xh = L.xhat[(long)(r0 + r) * L.ldx + c];
+                const float dy = dyt[r * kStackLd + c] * act_grad(a.act, h);
+                dyt[r * kStackLd + c] = dy;
+                xt[r * kStackLd + c] = xh;
+                s1 += dy; s2 += dy * xh;
+            }
+        if (!with_sums) { __syncthreads(); return; }
+        const float t1 = wg_rowlane_sum(s1, smf);
+        const float t2 = wg_rowlane_sum(s2, smf);
+        float* part = a.part + (long)i * nwg * 2 * 64;
+        if (c < H && ty == 0) {
+            part[((long)wg * 2 + 0) * H + c] = t1;
+            part[((long)wg * 2 + 1) * H + c] = t2;
+        }
+    };
+    bool fresh = false, have_tile = false;
+    if (a.first == 0) { prep(a.n - 1, true, true); fresh = true; have_tile = true; }
+    for (int step = max(a.first, 1); step <= min(a.last, a.n); ++step) {
+        const int i = a.n - step;
+        const StackBwdLayer& L = a.l[i];
+        const int H = L.H;
+        if (!have_tile) { prep(i, true, false); have_tile = true; }
+        if (fresh) grid_barrier(a.sync, (unsigned)nwg * (++nbar));
+        const float* part = a.part + (long)i * nwg * 2 * 64;
+        float v1 = 0.f, v2 = 0.f;
+        {
+            const int cc = c < H ? c : H - 1;
+            for (int e0 = ty; e0 < nwg; e0 += 64) {           // 16 entries per thread and batch: 32 loads in flight
+                float p1[16], p2[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const long eo = (long)(e0 + 4 * u < nwg ? e0 + 4 * u : nwg - 1) * 2;
+                    p1[u] = part[(eo + 0) * H + cc]; p2[u] = part[(eo + 1) * H + cc];
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (e0 + 4 * u < nwg && c < H) { v1 += p1[u]; v2 += p2[u]; }
+            }
+        }
+        v1 = wg_rowlane_sum(v1, smf);
+        v2 = wg_rowlane_sum(v2, smf);
+        if (wg == 0 && ty == 0 && c < H && L.dbeta) L.dbeta[c] = v1;
+        if (c < H) {
+            const float m1 = v1 / a.n_total, m2 = v2 / a.n_total, inv = L.inv_std[c];
+            for (int r = ty; r < nrows; r += 4) {
+                const float dz = inv * (dyt[r * kStackLd + c] - m1 - xt[r * kStackLd + c] * m2);
+                dyt[r * kStackLd + c] = dz;
+                if (i == 0) a.dZ0[(long)(r0 + r) * a.ldz0 + c] = dz;
+            }
+        }
+        if (i == 0) { fresh = true; break; }
+        // ---- this layer's kernel and input activations -> LDS
+        const int K = L.K;
+        for (int idx = tid; idx < K * 64; idx += 256) {
+            const int k = idx >> 6, cc = idx & 63;
+            wl[k * kStackLd + cc] = cc < H ? L.W[(long)k * L.ldw + cc] : 0.f;
+        }
+        for (int idx = tid; idx < kStackRows * 64; idx += 256) {
+            const int r = idx >> 6, k = idx & 63;
+            ht[r * kStackLd + k] = (r < nrows && k < K) ? L.Hprev[(long)(r0 + r) * L.ldp + k] : 0.f;
+        }
+        __syncthreads();
+        // ---- weight-gradient partial of the block: gW[k][c] = sum_r Hprev[r][k] dz[r][c], k in [16 ty, 16 ty + 16)
+        float* gw = a.gwp + ((long)i * nwg + wg) * 65 * 64;
+        {
+            float acc[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+            float bs = 0.f;
+            for (int r = 0; r < nrows; ++r) {
+                const float d = dyt[r * kStackLd + c];
+                bs += d;
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const float4 h4 = *reinterpret_cast<const float4*>(ht + r * kStackLd + 16 * ty + 4 * q4);
+                    acc[4 * q4 + 0] = fmaf(h4.x, d, acc[4 * q4 + 0]); acc[4 * q4 + 1] = fmaf(h4.y, d, acc[4 * q4 + 1]);
+                    acc[4 * q4 + 2] = fmaf(h4.z, d, acc[4 * q4 + 2]); acc[4 * q4 + 3] = fmaf(h4.w, d, acc[4 * q4 + 3]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int k = 16 * ty + j;
+                if (k < K) gw[(long)k * 64 + c] = acc[j];
+            }
+            if (ty == 0) gw[(long)K * 64 + c] = bs;            // bias gradient = column sums of dZ
+        }
+        // ---- gradient w.r.t. the layer's input, block rows: dHp[r][k] = sum_c dz[r][c] W[k][c]; thread: k = tx, rows ty + 4 j
+        {
+            float acc[kStackRows / 4];
+#pragma unroll
+            for (int j = 0; j < kStackRows / 4; ++j) acc[j] = 0.f;
+            for (int c4 = 0; c4 < 64; c4 += 4) {
+                const float4 w4 = *reinterpret_cast<const float4*>(wl + tx * kStackLd + c4);
+#pragma unroll
+                for (int j = 0; j < kStackRows / 4; ++j) {
+                    const int r = ty + 4 * j;
+                    if (r < nrows) {
+                        const float4 d4 = *reinterpret_cast<const float4*>(dyt + r * kStackLd + c4);
+                        acc[j] = fmaf(d4.w, w4.w, fmaf(d4.z, w4.z, fmaf(d4.y, w4.y, fmaf(d4.x, w4.x, acc[j]))));
+                    }
+                }
+            }
+            __syncthreads();                              // every read of dyt of this layer is done
+            const StackBwdLayer& P = a.l[i - 1];
+#pragma unroll
+            for (int j = 0; j < kStackRows / 4; ++j) {
+                const int r = ty + 4 * j;
+                const float v = (r < nrows && tx < K) ? acc[j] : 0.f;
+                dyt[r * kStackLd + tx] = v;
+                if (r < nrows && tx < K && P.dHin) P.dHin[(long)(r0 + r) * P.lddh + tx] = v;     // for a later launch
+            }
+        }
+        __syncthreads();
+        prep(i - 1, false, true);                         // the layer below: dy and its sums, from the tile just made
+        fresh = true;
+    }
+    if (a.last > a.n) {
+        // ---- weight gradients: element e of the layers' [K + 1, H] blocks is the sum of the blocks' partials in order
+        // (thread = element e0 + tid % 32, slice tid / 32 of the blocks: its share of the partials in flight at once, the
+        // 8 slices added in order through LDS)
+        if (fresh) grid_barrier(a.sync, (unsigned)nwg * (++nbar));
+        for (int i = 1; i < a.n; ++i) {
+            const StackBwdLayer& L = a.l[i];
+            const int total = (L.K + 1) * L.H;
+            const float* gw = a.gwp + (long)i * nwg * 65 * 64;
+            const int el = tid & 31, sl = tid >> 5;
+            const int per = (nwg + 7) / 8;                    // blocks per slice
+            for (int e0 = wg * 32; e0 < total; e0 += nwg * 32) {
+                const int e = e0 + el;
+                const int ec = e < total ? e : total - 1;
+                const int k = ec / L.H, cc = ec - k * L.H;
+                const float* src = gw + (long)k * 64 + cc;
+                float v = 0.f;
+                for (int b0 = sl * per; b0 < min(nwg, (sl + 1) * per); b0 += 16) {
+                    float pv[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) pv[u] = src[(long)min(b0 + u, nwg - 1) * 65 * 64];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) if (b0 + u < min(nwg, (sl + 1) * per)) v += pv[u];
+                }
+                __syncthreads();
+                smf[tid] = v;
+                __syncthreads();
+                if (tid < 32 && e < total) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int q8 = 0; q8 < 8; ++q8) t += smf[q8 * 32 + tid];
+                    L.gW[(long)k * L.ldg + cc] = t;
+                }
+            }
+        }
+    }
+    if (nbar) grid_exit(a.sync, (unsigned)nwg);
+}
+
+// ---- K-STACK, one step per launch: the same steps with every global read of a step issued UP FRONT (the block's tile,
+// the other blocks' partial statistics, the layer's kernel: all independent of each other), so a launch waits for ONE
+// memory round trip instead of one per phase -- at these sizes a step is nothing but latency.
+constexpr int kStepRows = 32;           // rows per workgroup: 8 per row lane
+
+struct StepFwdArgs {
+    SmallLayer cur, nxt;                // layer i and layer i + 1 (nxt.W == NULL: none)
+    int B, act, nwg, stats_only;
+    float momentum, eps;
+    const float* part_in;               // [nwg][2][H] (mean, M2) of layer i (unused with stats_only)
+    float* part_out;                    // [nwg][2][H'] of layer i + 1 (stats_only: of layer i)
+};
+
+__global__ __launch_bounds__(256) void stack_fwd_step_kernel(StepFwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float ht[kStepRows * kStackLd];
+    __shared__ __attribute__((aligned(16))) float wl[64 * kStackLd];
+    __shared__ float smf[256];
+    __shared__ double smd[1024];
+    const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+    const int wg = blockIdx.x, E = a.nwg;
+    const int cr = chunk_rows(a.B, E);
+    const int r0 = wg * cr;
+    const int nrows = max(0, min(a.B, r0 + cr) - r0);
+    const int c = tx;
+    const SmallLayer& L = a.cur;
+    const int H = L.H, cc = c < H ? c : H - 1;
+    // ---- every read of the step, up front
+    float z[kStepRows / 4];
+#pragma unroll
+    for (int j = 0; j < kStepRows / 4; ++j) {
+        const int r = ty + 4 * j;
+        z[j] = L.Z[(long)(r0 + (r < nrows ? r : (nrows > 0 ? nrows - 1 : 0))) * L.ldz + cc];
+    }
+    float out_z[kStepRows / 4];
+    int Hs = H;                                            // width of the layer whose block statistics this launch writes
+    if (!a.stats_only) {
+        float pm[32], pq[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            const long eo = (long)(ty + 4 * u < E ? ty + 4 * u : E - 1) * 2;
+            pm[u] = a.part_in[(eo + 0) * H + cc]; pq[u] = a.part_in[(eo + 1) * H + cc];
+        }
+        const SmallLayer& N = a.nxt;
+        const int K = H, HN = N.W ? N.H : 0;
+        float4 wv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                      // the next layer's kernel [K, HN]: float t of row k = (tid + 256 q) / 16
+            const int idx = tid + 256 * q, k = idx >> 4, c4 = (idx & 15) * 4;
+            wv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (N.W && k < K) {
+                const float* src = N.W + (long)k * N.ldw + c4;
+                if (c4 + 3 < HN && (N.ldw & 3) == 0 && (reinterpret_cast<uintptr_t>(N.W) & 15) == 0) wv[q] = *reinterpret_cast<const float4*>(src);
+                else {
+                    if (c4 + 0 < HN) wv[q].x = src[0];
+                    if (c4 + 1 < HN) wv[q].y = src[1];
+                    if (c4 + 2 < HN) wv[q].z = src[2];
+                    if (c4 + 3 < HN) wv[q].w = src[3];
+                }
+            }
+        }
+        const float beta = L.beta ? L.beta[cc] : 0.f;
+        const float nbias = (N.W && N.bias && c < HN) ? N.bias[c] : 0.f;
+        // ---- statistics of the whole batch (one pass, fp64: N, sum n m, sum (M2 + n m^2)), every block the same order
+        double n = 0.0, sw = 0.0, sq = 0.0;
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            const int e = ty + 4 * u;
+            const double ne = (e < E && c < H) ? entry_count(nullptr, e, E, a.B) : 0.0;
+            n += ne; sw += ne * (double)pm[u]; sq += ne > 0.0 ? (double)pq[u] + ne * (double)pm[u] * (double)pm[u] : 0.0;
+        }
+        for (int e0 = ty + 128; e0 < E; e0 += 128) {       // (more than 128 blocks: further batches)
+#pragma unroll 4
+            for (int u = 0; u < 32; ++u) {
+                const int e = e0 + 4 * u;
+                if (e < E && c < H) {
+                    const double ne = entry_count(nullptr, e, E, a.B);
+                    const double me = (double)a.part_in[((long)e * 2 + 0) * H + cc], qe = (double)a.part_in[((long)e * 2 + 1) * H + cc];
+                    n += ne; sw += ne * me; sq += qe + ne * me * me;
+                }
+            }
+        }
+        smd[ty * 64 + tx] = n; smd[256 + ty * 64 + tx] = sw; smd[512 + ty * 64 + tx] = sq;
+        __syncthreads();
+        n = (smd[tx] + smd[64 + tx]) + (smd[128 + tx] + smd[192 + tx]);
+        sw = (smd[256 + tx] + smd[320 + tx]) + (smd[384 + tx] + smd[448 + tx]);
+        sq = (smd[512 + tx] + smd[576 + tx]) + (smd[640 + tx] + smd[704 + tx]);
+        const double meand = n > 0.0 ? sw / n : 0.0;
+        const float mean = (float)meand;
+        double m2 = sq - n * meand * meand;
+        if (m2 < 0.0) m2 = 0.0;
+        const float var = n > 0.0 ? (float)(m2 / n) : 0.f;
+        const float inv = 1.f / sqrtf(var + a.eps);
+        if (wg == 0 && ty == 0 && c < H) {
+            L.mm[c] = L.mm[c] - (L.mm[c] - mean) * (1.f - a.momentum);
+            L.mv[c] = L.mv[c] - (L.mv[c] - var) * (1.f - a.momentum);
+            if (L.inv_std) L.inv_std[c] = inv;
+        }
+        // ---- normalise + activation; kernel and activations -> LDS
+#pragma unroll
+        for (int j = 0; j < kStepRows / 4; ++j) {
+            const int r = ty + 4 * j;
+            float h = 0.f;
+            if (r < nrows && c < H) {
+                const float xh = (z[j] - mean) * inv;
+                h = act_fwd(a.act, xh + beta);
+                if (L.xhat) L.xhat[(long)(r0 + r) * L.ldx + c] = xh;
+                L.Hout[(long)(r0 + r) * L.ldh + c] = h;
+            }
+            ht[r * kStackLd + c] = h;                      // zero beyond the layer's width / the block's rows
+        }
+        if (!N.W) return;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = tid + 256 * q, k = idx >> 4, c4 = (idx & 15) * 4;
+            *reinterpret_cast<float4*>(wl + k * kStackLd + c4) = wv[q];
+        }
+        __syncthreads();
+        float acc[kStepRows / 4];
+#pragma unroll
+        for (int j = 0; j < kStepRows / 4; ++j) acc[j] = 0.f;
+        const int K4 = (K + 3) & ~3;
+        for (int k = 0; k < K4; k += 4) {
+            const float w0 = wl[(k + 0) * kStackLd + c], w1 = wl[(k + 1) * kStackLd + c];
+            const float w2 = wl[(k + 2) * kStackLd + c], w3 = wl[(k + 3) * kStackLd + c];
+#pragma unroll
+            for (int j = 0; j < kStepRows / 4; ++j) {
+                const float4 h4 = *reinterpret_cast<const float4*>(ht + (ty + 4 * j) * kStackLd + k);
+                acc[j] = fmaf(h4.w, w3, fmaf(h4.z, w2, fmaf(h4.y, w1, fmaf(h4.x, w0, acc[j]))));
+            }
+        }
+        Hs = HN;
+#pragma unroll
+        for (int j = 0; j < kStepRows / 4; ++j) {
+            const int r = ty + 4 * j;
+            out_z[j] = acc[j] + nbias;
+            if (r < nrows && c < HN && N.Z) N.Z[(long)(r0 + r) * N.ldz + c] = out_z[j];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < kStepRows / 4; ++j) out_z[j] = z[j];
+    }
+    // ---- (mean, M2) of the block's rows of the layer just made
+    float sv = 0.f;
+#pragma unroll
+    for (int j = 0; j < kStepRows / 4; ++j) if (ty + 4 * j < nrows && c < Hs) sv += out_z[j];
+    const float tot = wg_rowlane_sum(sv, smf);
+    const float bmean = nrows > 0 ? tot / (float)nrows : 0.f;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < kStepRows / 4; ++j) if (ty + 4 * j < nrows && c < Hs) { const float d = out_z[j] - bmean; q += d * d; }
+    const float bm2 = wg_rowlane_sum(q, smf);
+    if (c < Hs && ty == 0) {
+        a.part_out[((long)wg * 2 + 0) * Hs + c] = bmean;
+        a.part_out[((long)wg * 2 + 1) * Hs + c] = bm2;
+    }
+}
+
+struct StepBwdArgs {
+    StackBwdLayer cur, low;             // layer i and the layer below (low.Hact == NULL: none, i == 0)
+    int B, act, nwg, sums_only;
+    float n_total;
+    float* dZ0; long ldz0;
+    const float* part_in;               // [nwg][2][H] sums of layer i (unused with sums_only)
+    float* part_out;                    // sums of the layer below (sums_only: of layer i)
+    float* gwp;                         // [nwg][65][64] weight-gradient partials of layer i
+};
+
+__global__ __launch_bounds__(256) void stack_bwd_step_kernel(StepBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float dyt[kStepRows * kStackLd];
+    __shared__ __attribute__((aligned(16))) float ht[kStepRows * kStackLd];
+    __shared__ __attribute__((aligned(16))) float wl[64 * kStackLd];
+    __shared__ float smf[256];
+    const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+    const int wg = blockIdx.x, E = a.nwg;
+    const int cr = chunk_rows(a.B, E);
+    const int r0 = wg * cr;
+    const int nrows = max(0, min(a.B, r0 + cr) - r0);
+    const int c = tx;
+    const StackBwdLayer& L = a.cur;
+    const int H = L.H, cc = c < H ? c : H - 1;
+    // ---- every read of the step, up front
+    float dh[kStepRows / 4], hv[kStepRows / 4], xv[kStepRows / 4];
+#pragma unroll
+    for (int j = 0; j < kStepRows / 4; ++j) {
+        const int r = ty + 4 * j;
+        const long row = r0 + (r < nrows ? r : (nrows > 0 ? nrows - 1 : 0));
+        dh[j] = L.dHin[row * L.lddh + cc]; hv[j] = L.Hact[row * L.ldh + cc]; xv[j] = L.xhat[row * L.ldx + cc];
+    }
+    float dy[kStepRows / 4];
+    if (a.sums_only) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < kStepRows / 4; ++j) {
+            const float d = (ty + 4 * j < nrows && c < H) ? dh[j] * act_grad(a.act, hv[j]) : 0.f;
+            s1 += d; s2 += d * xv[j];
+        }
+        const float t1 = wg_rowlane_sum(s1, smf), t2 = wg_rowlane_sum(s2, smf);
+        if (c < H && ty == 0) { a.part_out[((long)wg * 2 + 0) * H + c] = t1; a.part_out[((long)wg * 2 + 1) * H + c] = t2; }
+        return;
+    }
+    float p1[16], p2[16];                                  // the first 64 blocks' sums (the rest in further batches below)
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const long eo = (long)(ty + 4 * u < E ? ty + 4 * u : E - 1) * 2;
+        p1[u] = a.part_in[(eo + 0) * H + cc]; p2[u] = a.part_in[(eo + 1) * H + cc];
+    }
+    const bool has_low = a.low.Hact != nullptr;
+    const int K = has_low ? L.K : 0;
+    float4 wv[4];
+    float hp[kStepRows / 4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                          // this layer's kernel [K, H]
+        const int idx = tid + 256 * q, k = idx >> 4, c4 = (idx & 15) * 4;
+        wv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (has_low && k < K) {
+            const float* src = L.W + (long)k * L.ldw + c4;
+            if (c4 + 3 < H && (L.ldw & 3) == 0 && (reinterpret_cast<uintptr_t>(L.W) & 15) == 0) wv[q] = *reinterpret_cast<const float4*>(src);
+            else {
+                if (c4 + 0 < H) wv[q].x = src[0];
+                if (c4 + 1 < H) wv[q].y = src[1];
+                if (c4 + 2 < H) wv[q].z = src[2];
+                if (c4 + 3 < H) wv[q].w = src[3];
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kStepRows / 4; ++j) {              // the layer's input activations (= the layer below's output) and its xhat
+        const int r = ty + 4 * j;
+        const long row = r0 + (r < nrows ? r : (nrows > 0 ? nrows - 1 : 0));
+        const int kc = tx < K ? tx : (K > 0 ? K - 1 : 0);
+        hp[j] = has_low ? L.Hprev[row * L.ldp + kc] : 0.f;
+    }
+    const float inv = L.inv_std[cc];
+    // ---- the two batch sums, every block the same order
+    float v1 = 0.f, v2 = 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) if (ty + 4 * u < E && c < H) { v1 += p1[u]; v2 += p2[u]; }
+#pragma unroll 1
+    for (int e0 = ty + 64; e0 < E; e0 += 64) {
+        float q1[16], q2[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const long eo = (long)(e0 + 4 * u < E ? e0 + 4 * u : E - 1) * 2;
+            q1[u] = a.part_in[(eo + 0) * H + cc]; q2[u] = a.part_in[(eo + 1) * H + cc];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) if (e0 + 4 * u < E && c < H) { v1 += q1[u]; v2 += q2[u]; }
+    }
+    v1 = wg_rowlane_sum(v1, smf);
+    v2 = wg_rowlane_sum(v2, smf);
+    if (wg == 0 && ty == 0 && c < H && L.dbeta) L.dbeta[c] = v1;
+    const float m1 = v1 / a.n_total, m2 = v2 / a.n_total;
+#pragma unroll
+    for (int j = 0; j < kStepRows / 4; ++j) {
+        const int r = ty + 4 * j;
+        float dz = 0.f;
+        if (r < nrows && c < H) {
+            dz = inv * (dh[j] * act_grad(a.act, hv[j]) - m1 - xv[j] * m2);
+            if (!has_low) a.dZ0[(long)(r0 + r) * a.ldz0 + c] = dz;
+        }
+        dyt[r * kStackLd + c] = dz;
+        ht[r * kStackLd + tx] = (r < nrows && tx < K) ? hp[j] : 0.f;
+    }
+    if (!has_low) return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int idx = tid + 256 * q, k = idx >> 4, c4 = (idx & 15) * 4;
+        *reinterpret_cast<float4*>(wl + k * kStackLd + c4) = wv[q];
+    }
+    __syncthreads();
+    // (the layer below's output and xhat of the block's rows, column k = tx: requested now, used after the two products)
+    float lh[kStepRows / 4], lx[kStepRows / 4];
+#pragma unroll
+    for (int j = 0; j < kStepRows / 4; ++j) {
+        const int r = ty + 4 * j;
+        const long row = r0 + (r < nrows ? r : (nrows > 0 ? nrows - 1 : 0));
+        const int kc = tx < K ? tx : (K > 0 ? K - 1 : 0);
+        lh[j] = a.low.Hact[row * a.low.ldh + kc];
+        lx[j] = a.low.xhat[row * a.low.ldx + kc];
+    }
+    // ---- weight-gradient partial of the block: gW[k][c] = sum_r Hprev[r][k] dz[r][c], k in [16 ty, 16 ty + 16)
+    float* gw = a.gwp + (long)wg * 65 * 64;
+    {
+        float acc[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+        float bs = 0.f;
+#pragma unroll 2
+        for (int r = 0; r < nrows; ++r) {
+            const float d = dyt[r * kStackLd + c];
+            bs += d;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const float4 h4 = *reinterpret_cast<const float4*>(ht + r * kStackLd + 16 * ty + 4 * q4);
+                acc[4 * q4 + 0] = fmaf(h4.x, d, acc[4 * q4 + 0]); acc[4 * q4 + 1] = fmaf(h4.y, d, acc[4 * q4 + 1]);
+                acc[4 * q4 + 2] = fmaf(h4.z, d, acc[4 * q4 + 2]); acc[4 * q4 + 3] = fmaf(h4.w, d, acc[4 * q4 + 3]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int k = 16 * ty + j;
+            if (k < K) gw[(long)k * 64 + c] = acc[j];
+        }
+        if (ty == 0) gw[(long)K * 64 + c] = bs;
+    }
+    // ---- gradient w.r.t. the layer's input: dHp[r][k] = sum_c dz[r][c] W[k][c]; thread: k = tx, rows ty + 4 j
+    float acc[kStepRows / 4];
+#pragma unroll
+    for (int j = 0; j < kStepRows / 4; ++j) acc[j] = 0.f;
+#pragma unroll 2
+    for (int c4 = 0; c4 < 64; c4 += 4) {
+        const float4 w4 = *reinterpret_cast<const float4*>(wl + tx * kStackLd + c4);
+#pragma unroll
+        for (int j = 0; j < kStepRows / 4; ++j) {
+            const float4 d4 = *reinterpret_cast<const float4*>(dyt + (ty + 4 * j) * kStackLd + c4);
+            acc[j] = fmaf(d4.w, w4.w, fmaf(d4.z, w4.z, fmaf(d4.y, w4.y, fmaf(d4.x, w4.x, acc[j]))));
+        }
+    }
+    // the layer below (k = its column): dH handed on through memory, dy and its block sums
+    const StackBwdLayer& P = a.low;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < kStepRows / 4; ++j) {
+        const int r = ty + 4 * j;
+        if (r < nrows && tx < K) {
+            P.dHin[(long)(r0 + r) * P.lddh + tx] = acc[j];
+            const float d = acc[j] * act_grad(a.act, lh[j]);
+            s1 += d; s2 += d * lx[j];
+        }
+    }
+    const float t1 = wg_rowlane_sum(s1, smf), t2 = wg_rowlane_sum(s2, smf);
+    if (tx < K && ty == 0) { a.part_out[((long)wg * 2 + 0) * K + tx] = t1; a.part_out[((long)wg * 2 + 1) * K + tx] = t2; }
+}
+
+inline int stack_workgroups(int B, int rows) {
+    int n = (B + rows - 1) / rows;
+    return n < 1 ? 1 : n;
+}
+constexpr int kStackMaxPhaseWG = 1024;      // workgroups of a one-step launch (no residency requirement)
+
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -1321,5 +2083,96 @@ extern "C" int dcahip_rmsprop_clip_end(float* w, const float* g, float* ms, long
     hipLaunchKernelGGL(rmsprop_clip_kernel, dim3((int)grid), dim3(256), 0,
                        static_cast<hipStream_t>(stream), w, g, ms, n, lr, rho, eps, clip,
                        StepEnd{loss, weight, hist, rows_per_slot, acc, cursor, advance, 1});
+    return (int)hipGetLastError();
+}
+
+// ---- K-STACK entry points
+extern "C" int dcahip_hidden_stack_max_rows(void) { return kStackMaxWG * kStackRows; }
+
+extern "C" long dcahip_hidden_stack_workspace_bytes(int n_layers, int B) {
+    if (n_layers < 1 || n_layers > kStackMaxLayers || B <= 0 || B > kStackMaxWG * kStackRows) return 0;
+    const long nwg = stack_workgroups(B, 16);        // the finest row partition a caller may ask for
+    return 256 + ((long)n_layers * nwg * 2 * 64 + (long)n_layers * nwg * 65 * 64) * (long)sizeof(float);
+}
+
+static int stack_plan(int n, int B, int rows_per_wg, int first, int last, int nsteps, int* nwg_out) {
+    if (rows_per_wg < 16 || rows_per_wg > kStackRows || first < 0 || last < first || last >= nsteps) return DCAHIP_EINVAL;
+    const int nwg = stack_workgroups(B, rows_per_wg);
+    if (nwg > kStackMaxPhaseWG) return DCAHIP_EINVAL;
+    if (last > first && nwg > kStackMaxWG) return DCAHIP_EINVAL;      // several steps per launch: every workgroup resident
+    *nwg_out = nwg;
+    return 0;
+}
+
+extern "C" int dcahip_hidden_stack_fwd(const dcahip_small_layer* layers, int n, int B, float momentum, float eps, int act,
+                                       int rows_per_wg, int first_step, int last_step,
+                                       void* workspace, long workspace_bytes, void* stream) {
+    if (!layers || n < 1 || n > kStackMaxLayers || B <= 0 || B > kStackMaxWG * kStackRows || !workspace) return DCAHIP_EINVAL;
+    if (workspace_bytes < dcahip_hidden_stack_workspace_bytes(n, B) || !al16(workspace)) return DCAHIP_EINVAL;
+    StackFwdArgs a{};
+    if (stack_plan(n, B, rows_per_wg, first_step, last_step, n + 1, &a.nwg)) return DCAHIP_EINVAL;
+    for (int i = 0; i < n; ++i) {
+        const dcahip_small_layer& q = layers[i];
+        if (q.H <= 0 || q.H > 64 || !q.Hout || !q.moving_mean || !q.moving_var) return DCAHIP_EINVAL;
+        if (i == 0 ? !q.Z : (!q.W || q.K != layers[i - 1].H)) return DCAHIP_EINVAL;
+        if (i > 0 && !q.Z && !(first_step == 0 && last_step == n)) return DCAHIP_EINVAL;   // one step per launch: Z hands over
+        a.l[i] = SmallLayer{q.W, q.ldw, q.bias, q.K, q.H, q.beta, q.moving_mean, q.moving_var, q.Z, q.ldz, q.xhat, q.ldx,
+                            q.Hout, q.ldh, q.inv_std};
+    }
+    a.n = n; a.B = B; a.act = act; a.first = first_step; a.last = last_step; a.momentum = momentum; a.eps = eps;
+    a.sync = static_cast<unsigned*>(workspace);
+    a.part = reinterpret_cast<float*>(static_cast<char*>(workspace) + 256);
+    if (first_step == last_step && rows_per_wg == kStepRows) {
+        // one step per launch at the step kernels' row partition: every read of the step up front
+        StepFwdArgs q{};
+        const int i = first_step == 0 ? 0 : first_step - 1;
+        q.cur = a.l[i];
+        if (first_step > 0 && i + 1 < n) q.nxt = a.l[i + 1];
+        q.B = B; q.act = act; q.nwg = a.nwg; q.stats_only = first_step == 0; q.momentum = momentum; q.eps = eps;
+        q.part_in = a.part + (long)i * a.nwg * 2 * 64;
+        q.part_out = a.part + (long)(first_step == 0 ? 0 : i + 1) * a.nwg * 2 * 64;
+        hipLaunchKernelGGL(stack_fwd_step_kernel, dim3(a.nwg), dim3(256), 0, static_cast<hipStream_t>(stream), q);
+        return (int)hipGetLastError();
+    }
+    hipLaunchKernelGGL(hidden_stack_fwd_kernel, dim3(a.nwg), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dcahip_hidden_stack_bwd(const dcahip_stack_bwd_layer* layers, int n, int B, float n_total, int act,
+                                       float* dZ0, long ldz0, int rows_per_wg, int first_step, int last_step,
+                                       void* workspace, long workspace_bytes, void* stream) {
+    if (!layers || n < 1 || n > kStackMaxLayers || B <= 0 || B > kStackMaxWG * kStackRows || !workspace || !dZ0)
+        return DCAHIP_EINVAL;
+    if (workspace_bytes < dcahip_hidden_stack_workspace_bytes(n, B) || !al16(workspace)) return DCAHIP_EINVAL;
+    StackBwdArgs a{};
+    if (stack_plan(n, B, rows_per_wg, first_step, last_step, n + 2, &a.nwg)) return DCAHIP_EINVAL;
+    const bool one_launch = first_step == 0 && last_step == n + 1;
+    for (int i = 0; i < n; ++i) {
+        const dcahip_stack_bwd_layer& q = layers[i];
+        if (q.H <= 0 || q.H > 64 || !q.Hact || !q.xhat || !q.inv_std) return DCAHIP_EINVAL;
+        if (i > 0 && (!q.W || !q.Hprev || !q.gW || q.K != layers[i - 1].H || q.K > 64)) return DCAHIP_EINVAL;
+        if (!q.dH && (i == n - 1 || !one_launch)) return DCAHIP_EINVAL;
+        a.l[i] = StackBwdLayer{q.W, q.ldw, q.K, q.H, q.Hact, q.ldh, q.xhat, q.ldx, q.inv_std, q.Hprev, q.ldp, q.gW, q.ldg,
+                               q.dbeta, q.dH, q.lddh};
+    }
+    a.n = n; a.B = B; a.act = act; a.first = first_step; a.last = last_step; a.n_total = n_total;
+    a.dZ0 = dZ0; a.ldz0 = ldz0;
+    a.sync = static_cast<unsigned*>(workspace);
+    a.part = reinterpret_cast<float*>(static_cast<char*>(workspace) + 256);
+    a.gwp = a.part + (long)n * a.nwg * 2 * 64;
+    if (first_step == last_step && first_step <= n && rows_per_wg == kStepRows) {
+        StepBwdArgs q{};
+        const int i = first_step == 0 ? n - 1 : n - first_step;
+        q.cur = a.l[i];
+        if (first_step > 0 && i > 0) q.low = a.l[i - 1];
+        q.B = B; q.act = act; q.nwg = a.nwg; q.sums_only = first_step == 0; q.n_total = n_total;
+        q.dZ0 = dZ0; q.ldz0 = ldz0;
+        q.part_in = a.part + (long)i * a.nwg * 2 * 64;
+        q.part_out = a.part + (long)(first_step == 0 ? i : (i > 0 ? i - 1 : 0)) * a.nwg * 2 * 64;
+        q.gwp = a.gwp + (long)i * a.nwg * 65 * 64;
+        hipLaunchKernelGGL(stack_bwd_step_kernel, dim3(a.nwg), dim3(256), 0, static_cast<hipStream_t>(stream), q);
+        return (int)hipGetLastError();
+    }
+    hipLaunchKernelGGL(hidden_stack_bwd_kernel, dim3(a.nwg), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return (int)hipGetLastError();
 }

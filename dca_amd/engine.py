@@ -345,6 +345,11 @@ class Engine:
         # normalisation known (cc_in) the first Dense layer works on the non-zero counts only (K-SPARSE)
         self.cc = self.cc_in = None
         self.ws_enc0 = self.ws_enc0f = None
+        self.ws_stack = None
+        # K-STACK at throughput batches: 'steps' = one launch per batch-wide dependency (9 launches instead of 22 for
+        # the 64-32-64 stack), 'coop' = one cooperative launch per direction with grid barriers, 'off' = one launch per
+        # operation.  Measured on the MI355X at 4096 rows (profiles/r03_stack_*): see DESIGN.md.
+        self.stack_mode = os.environ.get('DCA_AMD_STACK', 'steps')
         # batch rows from which the byte-store kernels replace the dense first-layer GEMMs -- measured on the MI355X at
         # the benchmark shape (profiles/r03*_enc0_*): the weight gradient on the matrix pipe from the byte store ties the
         # dense TN GEMM at 4096 rows on the 68 579-cell matrix (0.149-0.154 vs 0.157 ms) and wins on a cache-resident one
@@ -687,6 +692,10 @@ class Engine:
                     if self.XT is not None:
                         need = max(need, ops.sgemm_workspace_bytes(0, 1, lay.G_in, lay.hidden[0], b))
         self.ws = torch.zeros(max(need // 4, 4), **f32)
+        self.ws_stack = None
+        if hasattr(ops, 'hidden_stack_fwd') and max(lay.hidden) <= 64 and len(lay.hidden) <= 8:
+            nb = ops.hidden_stack_workspace_bytes(len(lay.hidden), min(B, ops.hidden_stack_max_rows))
+            self.ws_stack = torch.zeros(nb // 4 + 4, **f32) if nb > 0 else None
         self._sparse_workspaces()
 
     # ------------------------------------------------------------------ forward pieces
@@ -746,6 +755,20 @@ class Engine:
             else:
                 ops.sgemm(0, 0, B, h, K, self.Hcur[i - 1], self.ldh[i - 1], Wi, h, self.Z[i],
                           self.ldh[i], bias=bi, ws=self.ws)
+            if training and i == 0 and self._stack_coop(B):
+                # throughput batches: batch norm + activation of this layer and the whole stack behind it in ONE cooperative
+                # launch (K-STACK: workgroups own row blocks, exchange the batch statistics through grid barriers)
+                entries = [self._chain_entry(j) for j in range(len(lay.hidden))]
+                if self.stack_mode == 'coop' and B <= 256 * 64:
+                    ops.hidden_stack_fwd(entries, B, BN_MOMENTUM, BN_EPS, self.act, self.ws_stack, rows_per_wg=64)
+                else:           # one step per launch: the kernel boundary is the barrier, small row blocks fill the chip
+                    for st in range(len(entries) + 1):
+                        ops.hidden_stack_fwd(entries, B, BN_MOMENTUM, BN_EPS, self.act, self.ws_stack,
+                                             rows_per_wg=self._stack_rows(B), steps=(st, st))
+                for j, hj in enumerate(lay.hidden):
+                    self.Hcur[j] = self.H[j]
+                    K = hj
+                break
             if training and i == 0 and self._stack_small(B):
                 # small batches, every layer at most 64 units: batch norm + activation of this layer and the whole stack
                 # behind it (Dense -> BatchNormalization -> activation per layer) in ONE launch
@@ -799,6 +822,22 @@ class Engine:
         return (self.lay.batchnorm and 2 <= L <= 4 and hasattr(self.ops, 'hidden_small_chain') and self._bn_small(B)
                 and all(self._layer_small(B, i) for i in range(1, L)) and self.lay.hidden[0] <= 64
                 and os.environ.get('DCA_AMD_SMALL_CHAIN', '1') != '0')
+
+    def _stack_coop(self, B):
+        """The hidden stack in one cooperative launch per direction (K-STACK): one GPU, batch norm on, every layer at
+        most 64 units, no dropout / PReLU, batches beyond the single-workgroup kernels."""
+        lay = self.lay
+        return (self.comm.world == 1 and lay.batchnorm and not self.prelu and not self.has_dropout
+                and hasattr(self.ops, 'hidden_stack_fwd') and self.ws_stack is not None
+                and 1 <= len(lay.hidden) <= 8 and max(lay.hidden) <= 64 and not self._bn_small(B)
+                and B <= self.ops.hidden_stack_max_rows and self.stack_mode != 'off')
+
+    def _stack_rows(self, B):
+        """Rows per workgroup of the one-step launches."""
+        r = 32              # the partition of the step kernels (all reads of a step up front); coarser beyond 32 768 rows
+        while (B + r - 1) // r > 1024:
+            r *= 2
+        return r
 
     def _chain_entry(self, j):
         lay, w = self.lay, self.w
@@ -1017,45 +1056,64 @@ class Engine:
         self._launch_heads_bucket()
         # ---- backward: hidden stack
         L = len(lay.hidden)
-        for i in reversed(range(L)):
-            h = lay.hidden[i]
-            if self.drop[i] > 0.0:      # gradient through the dropout of this layer's output: same mask
-                ops.dropout_apply(self.dH[i], self.ldh[i], None, None, B, h, self.drop[i], self.drop_seed,
-                                  self.drop_iter, i, self.row0, self.dH[i], self.ldh[i])
-            if self.prelu:              # dL/d(PReLU out) -> dL/d(its input) in place, slope gradients
-                ops.prelu_bwd(self.dH[i], self.ldh[i], self.H[i], self.ldh[i], lay.view(w, 'alpha%d' % i), B, h,
-                              lay.view(g, 'alpha%d' % i), self.ws_prelu)
-            if self._layer_small(B, i):
-                # the layer's whole backward in one launch: d beta, dZ, weight / bias gradient, input gradient
-                Kp = lay.hidden[i - 1]
-                ops.dense_bn_bwd_small(self.dH[i], self.ldh[i], self.H[i], self.ldh[i],
-                                       self.XH[i] if lay.batchnorm else None, self.ldh[i], self.inv_std[i],
-                                       self.Hcur[i - 1], self.ldh[i - 1], lay.view(w, 'W%d' % i), h, B, Kp, h,
-                                       lay.batchnorm, float(Bg), self.act, lay.view(g, 'W%d' % i), h,
-                                       lay.view(g, 'beta%d' % i) if lay.batchnorm else None,
-                                       self.dH[i - 1], self.ldh[i - 1])
-                continue
-            if lay.batchnorm and self._bn_small(B):
-                ops.bn_bwd_small(self.dH[i], self.ldh[i], self.H[i], self.ldh[i], self.XH[i], self.ldh[i],
-                                 self.inv_std[i], float(Bg), B, h, self.dZ[i], self.ldh[i],
-                                 lay.view(g, 'beta%d' % i), self.act)
-            elif lay.batchnorm:
-                ops.bn_bwd_sums(self.dH[i], self.ldh[i], self.H[i], self.ldh[i], self.XH[i],
-                                self.ldh[i], B, h, self.bpart[i], self.act)
-                E = ops.col_moments_chunks(B)
-                local_s1 = None
-                if comm.world > 1:
-                    E, local_s1 = self._reduce_bwd_sums(i, E, h)
-                ops.bn_bwd_apply(self.dH[i], self.ldh[i], self.H[i], self.ldh[i], self.XH[i],
-                                 self.ldh[i], self.inv_std[i], self.bpart[i], E, float(Bg), B, h,
-                                 self.dZ[i], self.ldh[i], lay.view(g, 'beta%d' % i), self.act)
-                if local_s1 is not None:
-                    # bn_bwd_apply wrote d beta from the GLOBAL sums; the gradient bucket is summed
-                    # over ranks afterwards, so each rank must contribute its LOCAL share only
-                    lay.view(g, 'beta%d' % i).copy_(local_s1)
+        coop = self._stack_coop(B)
+        if coop:
+            layers = []
+            for i, h in enumerate(lay.hidden):
+                d = dict(H=h, Hact=self.H[i], ldh=self.ldh[i], xhat=self.XH[i], ldx=self.ldh[i], inv_std=self.inv_std[i],
+                         dbeta=lay.view(g, 'beta%d' % i), dH=self.dH[i], lddh=self.ldh[i])
+                if i > 0:
+                    d.update(W=lay.view(w, 'W%d' % i), ldw=h, K=lay.hidden[i - 1], Hprev=self.H[i - 1], ldp=self.ldh[i - 1],
+                             gW=lay.view(g, 'W%d' % i), ldg=h)
+                layers.append(d)
+            if self.stack_mode == 'coop' and B <= 256 * 64:
+                ops.hidden_stack_bwd(layers, B, float(Bg), self.act, self.dZ[0], self.ldh[0], self.ws_stack, rows_per_wg=64)
             else:
-                ops.relu_bwd(self.dH[i], self.ldh[i], self.H[i], self.ldh[i], B, h, self.dZ[i],
-                             self.ldh[i], self.act)
+                for st in range(L + 2):
+                    ops.hidden_stack_bwd(layers, B, float(Bg), self.act, self.dZ[0], self.ldh[0], self.ws_stack,
+                                         rows_per_wg=self._stack_rows(B), steps=(st, st))
+        for i in reversed(range(L)):
+            if coop and i > 0:
+                continue                # K-STACK wrote d beta, the weight / bias gradients and (for layer 0) dZ
+            h = lay.hidden[i]
+            if not coop:        # (K-STACK has produced dZ of the first layer already)
+                if self.drop[i] > 0.0:      # gradient through the dropout of this layer's output: same mask
+                    ops.dropout_apply(self.dH[i], self.ldh[i], None, None, B, h, self.drop[i], self.drop_seed,
+                                      self.drop_iter, i, self.row0, self.dH[i], self.ldh[i])
+                if self.prelu:              # dL/d(PReLU out) -> dL/d(its input) in place, slope gradients
+                    ops.prelu_bwd(self.dH[i], self.ldh[i], self.H[i], self.ldh[i], lay.view(w, 'alpha%d' % i), B, h,
+                                  lay.view(g, 'alpha%d' % i), self.ws_prelu)
+                if self._layer_small(B, i):
+                    # the layer's whole backward in one launch: d beta, dZ, weight / bias gradient, input gradient
+                    Kp = lay.hidden[i - 1]
+                    ops.dense_bn_bwd_small(self.dH[i], self.ldh[i], self.H[i], self.ldh[i],
+                                           self.XH[i] if lay.batchnorm else None, self.ldh[i], self.inv_std[i],
+                                           self.Hcur[i - 1], self.ldh[i - 1], lay.view(w, 'W%d' % i), h, B, Kp, h,
+                                           lay.batchnorm, float(Bg), self.act, lay.view(g, 'W%d' % i), h,
+                                           lay.view(g, 'beta%d' % i) if lay.batchnorm else None,
+                                           self.dH[i - 1], self.ldh[i - 1])
+                    continue
+                if lay.batchnorm and self._bn_small(B):
+                    ops.bn_bwd_small(self.dH[i], self.ldh[i], self.H[i], self.ldh[i], self.XH[i], self.ldh[i],
+                                     self.inv_std[i], float(Bg), B, h, self.dZ[i], self.ldh[i],
+                                     lay.view(g, 'beta%d' % i), self.act)
+                elif lay.batchnorm:
+                    ops.bn_bwd_sums(self.dH[i], self.ldh[i], self.H[i], self.ldh[i], self.XH[i],
+                                    self.ldh[i], B, h, self.bpart[i], self.act)
+                    E = ops.col_moments_chunks(B)
+                    local_s1 = None
+                    if comm.world > 1:
+                        E, local_s1 = self._reduce_bwd_sums(i, E, h)
+                    ops.bn_bwd_apply(self.dH[i], self.ldh[i], self.H[i], self.ldh[i], self.XH[i],
+                                     self.ldh[i], self.inv_std[i], self.bpart[i], E, float(Bg), B, h,
+                                     self.dZ[i], self.ldh[i], lay.view(g, 'beta%d' % i), self.act)
+                    if local_s1 is not None:
+                        # bn_bwd_apply wrote d beta from the GLOBAL sums; the gradient bucket is summed
+                        # over ranks afterwards, so each rank must contribute its LOCAL share only
+                        lay.view(g, 'beta%d' % i).copy_(local_s1)
+                else:
+                    ops.relu_bwd(self.dH[i], self.ldh[i], self.H[i], self.ldh[i], B, h, self.dZ[i],
+                                 self.ldh[i], self.act)
             Kp = lay.G_in if i == 0 else lay.hidden[i - 1]
             gW = lay.view(g, 'W%d' % i)
             if i == 0:

@@ -30,6 +30,14 @@ class SmallLayer(_c.Structure):
                 ('Hout', _c.c_void_p), ('ldh', _c.c_long), ('inv_std', _c.c_void_p)]
 
 
+class StackBwdLayer(_c.Structure):
+    """dcahip_stack_bwd_layer (include/dcahip.h)."""
+    _fields_ = [('W', _c.c_void_p), ('ldw', _c.c_long), ('K', _c.c_int), ('H', _c.c_int),
+                ('Hact', _c.c_void_p), ('ldh', _c.c_long), ('xhat', _c.c_void_p), ('ldx', _c.c_long),
+                ('inv_std', _c.c_void_p), ('Hprev', _c.c_void_p), ('ldp', _c.c_long),
+                ('gW', _c.c_void_p), ('ldg', _c.c_long), ('dbeta', _c.c_void_p), ('dH', _c.c_void_p), ('lddh', _c.c_long)]
+
+
 class RegDesc(_c.Structure):
     """dcahip_reg_desc (include/dcahip.h)."""
     _fields_ = [('nseg', _c.c_int), ('start', _c.c_long * REG_MAX_SEGS), ('end', _c.c_long * REG_MAX_SEGS),
@@ -132,6 +140,12 @@ _SIGNATURES = {
     'dcahip_prep_scale': (_c.c_int, [_f32p, _c.c_long, _c.c_int, _c.c_int, _f32p, _f32p, _vp]),
     'dcahip_rmsprop_clip': (_c.c_int, [_f32p, _f32p, _f32p, _c.c_long, _f32p, _c.c_float,
                                        _c.c_float, _c.c_float, _vp]),
+    'dcahip_hidden_stack_max_rows': (_c.c_int, []),
+    'dcahip_hidden_stack_workspace_bytes': (_c.c_long, [_c.c_int, _c.c_int]),
+    'dcahip_hidden_stack_fwd': (_c.c_int, [_c.POINTER(SmallLayer), _c.c_int, _c.c_int, _c.c_float, _c.c_float, _c.c_int,
+                                           _c.c_int, _c.c_int, _c.c_int, _vp, _c.c_long, _vp]),
+    'dcahip_hidden_stack_bwd': (_c.c_int, [_c.POINTER(StackBwdLayer), _c.c_int, _c.c_int, _c.c_float, _c.c_int,
+                                           _f32p, _c.c_long, _c.c_int, _c.c_int, _c.c_int, _vp, _c.c_long, _vp]),
     'dcahip_counts_compact_ld': (_c.c_long, [_c.c_int]),
     'dcahip_counts_compact': (_c.c_int, [_f32p, _c.c_long, _c.c_int, _c.c_int, _vp, _c.c_long, _i32p, _vp]),
     'dcahip_enc0_sparse_supported': (_c.c_int, [_c.c_int]),

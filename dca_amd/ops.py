@@ -195,6 +195,40 @@ class HipOps:
         hip.check(self.L.dcahip_hidden_small_chain(arr, len(layers), hip.ptr(Hin), ldin, B, int(batchnorm), momentum, eps,
                                                    int(act), hip.stream()), 'hidden_small_chain')
 
+    # ------------------------------------------------------------------ K-STACK (throughput batches, one launch per direction)
+    @property
+    def hidden_stack_max_rows(self):
+        return int(self.L.dcahip_hidden_stack_max_rows())
+
+    def hidden_stack_workspace_bytes(self, n_layers, B):
+        return int(self.L.dcahip_hidden_stack_workspace_bytes(n_layers, B))
+
+    def hidden_stack_fwd(self, layers, B, momentum, eps, act, ws, rows_per_wg=64, steps=None):
+        """layers: dicts with the fields of dcahip_small_layer; entry 0 without a kernel (its Z comes from the first GEMM).
+        steps = (first, last) of the pass's n + 1 steps in ONE launch (default: all of them, cooperative)."""
+        arr = (hip.SmallLayer * len(layers))()
+        for q, d in zip(arr, layers):
+            for k in ('W', 'bias', 'beta', 'moving_mean', 'moving_var', 'Z', 'xhat', 'Hout', 'inv_std'):
+                setattr(q, k, hip.ptr(d.get(k)))
+            for k in ('ldw', 'K', 'H', 'ldz', 'ldx', 'ldh'):
+                setattr(q, k, int(d.get(k, 0)))
+        first, last = steps if steps is not None else (0, len(layers))
+        hip.check(self.L.dcahip_hidden_stack_fwd(arr, len(layers), B, momentum, eps, int(act), int(rows_per_wg), first, last,
+                                                 hip.ptr(ws), ws.numel() * ws.element_size(), hip.stream()), 'hidden_stack_fwd')
+
+    def hidden_stack_bwd(self, layers, B, n_total, act, dZ0, ldz0, ws, rows_per_wg=64, steps=None):
+        """layers: dicts with the fields of dcahip_stack_bwd_layer; steps = (first, last) of the pass's n + 2 steps."""
+        arr = (hip.StackBwdLayer * len(layers))()
+        for q, d in zip(arr, layers):
+            for k in ('W', 'Hact', 'xhat', 'inv_std', 'Hprev', 'gW', 'dbeta', 'dH'):
+                setattr(q, k, hip.ptr(d.get(k)))
+            for k in ('ldw', 'K', 'H', 'ldh', 'ldx', 'ldp', 'ldg', 'lddh'):
+                setattr(q, k, int(d.get(k, 0)))
+        first, last = steps if steps is not None else (0, len(layers) + 1)
+        hip.check(self.L.dcahip_hidden_stack_bwd(arr, len(layers), B, float(n_total), int(act), hip.ptr(dZ0), ldz0,
+                                                 int(rows_per_wg), first, last, hip.ptr(ws), ws.numel() * ws.element_size(),
+                                                 hip.stream()), 'hidden_stack_bwd')
+
     def dense_bn_bwd_small(self, dH, ldd, Hact, ldh, xhat, ldx, inv_std, Hp, ldp, W, ldw, B, K, H, batchnorm, n_total, act,
                            gW, ldg, dbeta, dHp, lddp):
         p = hip.ptr

@@ -266,6 +266,43 @@ typedef struct dcahip_small_layer {
 } dcahip_small_layer;
 int dcahip_hidden_small_chain(const dcahip_small_layer* layers, int n, const float* Hin, long ldin, int B,
                               int batchnorm, float momentum, float eps, int act, void* stream);
+/* K-STACK: the same hidden stack at THROUGHPUT batches (B up to dcahip_hidden_stack_max_rows(), every layer <= 64
+ * units, batch normalisation on, one GPU) in one launch per direction: workgroups own blocks of batch rows and exchange
+ * only the batch-norm statistics (and, at the end of the backward pass, the weight-gradient partials) through grid-wide
+ * barriers -- at most 256 workgroups, all resident: launch it on an otherwise idle device (the stream order of a training
+ * step guarantees that).  Forward: entry 0 (W == NULL) normalises + activates its own Z (written by dcahip_sgemm), every
+ * further entry is Dense -> BatchNormalization -> activation (dca/network.py:124-135); outputs as dcahip_bn_relu_apply /
+ * dcahip_sgemm (Z optional when the whole pass is one launch).  Backward: per layer dbeta, for every layer
+ * behind the first gW [K + 1, H] (row K = bias gradient), and dZ0 = gradient w.r.t. the first layer's pre-activation
+ * (dcahip_bn_bwd_* + dcahip_sgemm x 2 per layer on the same operands).  workspace >=
+ * dcahip_hidden_stack_workspace_bytes(n, B) bytes, 16-byte aligned, ZERO before the first call (arrival counters; every
+ * call leaves them at zero), shared by both directions.  Deterministic. */
+typedef struct dcahip_stack_bwd_layer {
+    const float* W; long ldw; int K, H;             /* kernel [K, H] (unused for the first layer) */
+    const float* Hact; long ldh;                    /* the layer's output (activation derivative through the output) */
+    const float* xhat; long ldx; const float* inv_std;
+    const float* Hprev; long ldp;                   /* the layer's input activations [B, K] (unused for the first layer) */
+    float* gW; long ldg; float* dbeta;              /* OUT (gW unused for the first layer) */
+    float* dH; long lddh;                           /* gradient w.r.t. the layer's output: IN for the last layer, scratch
+                                                       (written, then read by the next launch) for the others */
+} dcahip_stack_bwd_layer;
+/* Both passes are a sequence of STEPS separated by a batch-wide dependency (the batch-norm statistics):
+ *   forward  (n + 1 steps): 0 = partial statistics of the first layer's pre-activation; 1 + i = layer i (merge the
+ *             statistics, normalise + activate, next layer's pre-activation and ITS partial statistics);
+ *   backward (n + 2 steps): 0 = dy and the batch sums of the last layer; 1 + j = layer n - 1 - j (dZ, d beta, weight-gradient
+ *             partial, input gradient, dy and sums of the layer below); n + 1 = sum of the weight-gradient partials.
+ * A call runs steps [first_step, last_step] in ONE launch: a range of several steps synchronises with grid barriers
+ * (every workgroup resident: at most 256 of them -- rows_per_wg * 256 >= B), a single step needs none (the kernel
+ * boundary is the barrier; up to 1024 workgroups).  rows_per_wg (16 .. 64) fixes the row partition and must be the same
+ * for every call of a pass. */
+int dcahip_hidden_stack_max_rows(void);
+long dcahip_hidden_stack_workspace_bytes(int n_layers, int B);
+int dcahip_hidden_stack_fwd(const dcahip_small_layer* layers, int n, int B, float momentum, float eps, int act,
+                            int rows_per_wg, int first_step, int last_step,
+                            void* workspace, long workspace_bytes, void* stream);
+int dcahip_hidden_stack_bwd(const dcahip_stack_bwd_layer* layers, int n, int B, float n_total, int act,
+                            float* dZ0, long ldz0, int rows_per_wg, int first_step, int last_step,
+                            void* workspace, long workspace_bytes, void* stream);
 int dcahip_bn_relu_train_small(const float* Z, long ldz, int B, int H, const float* beta,
                                float* moving_mean, float* moving_var, float momentum, float eps,
                                int act, float* Hout, long ldh, float* xhat, long ldx,

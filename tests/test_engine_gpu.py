@@ -413,3 +413,33 @@ def test_c3_first_steps_match_oracle(ops):
     assert abs(got.mean() / want.mean() - 1) < 1e-4
     val = float(eng.acc[1].item())
     assert abs(val / float(z['val_loss']) - 1) < 1e-4, (val, float(z['val_loss']))
+
+
+@pytest.mark.parametrize('mode', ['steps', 'coop'])
+@pytest.mark.parametrize('hs,B', [((64, 32, 64), 65), ((64, 32, 64), 1000), ((64, 32, 64), 4097), ((64, 32, 64), 9000),
+                                  ((48, 20, 7, 33), 513), ((10,), 300)])
+def test_fused_hidden_stack_equals_the_per_operation_kernels(ops, hs, B, mode, monkeypatch):
+    """K-STACK (the hidden stack as one launch per batch-wide dependency -- 'steps' -- or as ONE cooperative launch per
+    direction with grid barriers at the batch-norm statistics -- 'coop') against the per-operation kernels it replaces,
+    one full training step from the same state: loss, every gradient, the batch-norm moving statistics -- and twice in a
+    row (the arrival counters of the cooperative form must be back at zero)."""
+    n, G = B + 40, 120
+    X, Y, sf, p = make_problem(n, G, hs, 'zinb-conddisp', True, seed=B)
+    rows = np.random.RandomState(2).permutation(n)[:B]
+    out = []
+    for m in (mode, 'off'):
+        monkeypatch.setenv('DCA_AMD_STACK', m)
+        eng = make_engine(ops, 'zinb-conddisp', G, hs, True, 0.0, p, X, Y, sf)
+        eng.reserve(B)
+        assert eng._stack_coop(B) == (m != 'off')
+        res = [run_single_step(eng, rows) for _ in range(2)]
+        if eng.ws_stack is not None:
+            assert int(eng.ws_stack[:3].view(torch.int32).abs().sum().item()) == 0      # counters at zero, no error flag
+        out.append(res)
+    for (l1, g1, p1), (l0, g0, p0) in zip(*out):
+        assert abs(l1 - l0) < 2e-6 * abs(l0)
+        zero_b = tuple('b%d' % i for i in range(len(hs)))
+        assert_grads_close(g1, {k: np.asarray(v, np.float64) for k, v in g0.items()}, rtol=2e-4, atol_scale=2e-6, skip=zero_b)
+        for i in range(len(hs)):
+            np.testing.assert_allclose(p1['mm%d' % i], p0['mm%d' % i], rtol=1e-5, atol=1e-7)
+            np.testing.assert_allclose(p1['mv%d' % i], p0['mv%d' % i], rtol=1e-5, atol=1e-7)
