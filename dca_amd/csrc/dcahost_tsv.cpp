@@ -284,6 +284,75 @@ extern "C" int dcahost_write_tsv_f64(const char* path, const double* data, long 
     return write_tsv<double>(path, data, nrows, ncols, row_stride, col_stride, rownames, colnames, nthreads);
 }
 
+// ---- streaming form: header once, then row blocks appended in call order (each block formatted by a pool of threads)
+namespace {
+struct TsvStream {
+    int fd;
+    long ncols;
+    bool has_index;
+    std::vector<std::string> bufs;
+    std::vector<std::vector<float>> scratch;
+};
+}  // namespace
+
+extern "C" int dcahost_tsv_stream_open(const char* path, long ncols, const char* const* colnames, int has_index,
+                                       void** handle) {
+    if (!path || ncols < 0 || !handle) return DCAHOST_EINVAL;
+    const int fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) return DCAHOST_EIO;
+    if (colnames) {
+        std::string h;
+        for (long c = 0; c < ncols; ++c) {
+            if (c || has_index) h.push_back('\t');
+            h.append(colnames[c]);
+        }
+        h.push_back('\n');
+        if (!write_all(fd, h.data(), h.size())) { const int e = errno; ::close(fd); errno = e; return DCAHOST_EIO; }
+    }
+    auto* st = new TsvStream{fd, ncols, has_index != 0, {}, {}};
+    *handle = st;
+    return DCAHOST_OK;
+}
+
+extern "C" int dcahost_tsv_stream_rows_f32(void* handle, const float* data, long nrows, long ld,
+                                           const char* const* rownames, int nthreads) {
+    auto* st = static_cast<TsvStream*>(handle);
+    if (!st || nrows < 0 || (nrows > 0 && !data) || ld < st->ncols || (st->has_index && nrows > 0 && !rownames))
+        return DCAHOST_EINVAL;
+    if (nrows == 0) return DCAHOST_OK;
+    if (nthreads <= 0) {
+        nthreads = (int)std::thread::hardware_concurrency();
+        if (nthreads <= 0) nthreads = 1;
+        if (nthreads > 64) nthreads = 64;
+    }
+    long rows_per = st->ncols > 0 ? 400000 / st->ncols : nrows;            // ~4 MB of text per piece
+    if (rows_per < 1) rows_per = 1;
+    const long want = (nrows + rows_per - 1) / rows_per;
+    if (want < nthreads) nthreads = (int)want;
+    rows_per = (nrows + nthreads - 1) / nthreads;
+    if ((int)st->bufs.size() < nthreads) { st->bufs.resize(nthreads); st->scratch.resize(nthreads); }
+    std::vector<std::thread> th;
+    for (int k = 0; k < nthreads; ++k) {
+        const long r0 = (long)k * rows_per, r1 = r0 + rows_per < nrows ? r0 + rows_per : nrows;
+        if (r0 >= r1) { st->bufs[k].clear(); continue; }
+        auto job = [=] { format_block<float>(data, r0, r1, st->ncols, ld, 1, st->has_index ? rownames : nullptr,
+                                             st->scratch[k], st->bufs[k]); };
+        if (k + 1 < nthreads) th.emplace_back(job); else job();
+    }
+    for (auto& t : th) t.join();
+    for (int k = 0; k < nthreads; ++k)
+        if (!st->bufs[k].empty() && !write_all(st->fd, st->bufs[k].data(), st->bufs[k].size())) return DCAHOST_EIO;
+    return DCAHOST_OK;
+}
+
+extern "C" int dcahost_tsv_stream_close(void* handle) {
+    auto* st = static_cast<TsvStream*>(handle);
+    if (!st) return DCAHOST_EINVAL;
+    const int rc = ::close(st->fd);
+    delete st;
+    return rc == 0 ? DCAHOST_OK : DCAHOST_EIO;
+}
+
 extern "C" long dcahost_format_f32(const float* v, long n, char* out, long cap) {
     if (!v || !out || n < 0) return DCAHOST_EINVAL;
     return format_values<float>(v, n, out, cap);

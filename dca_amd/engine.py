@@ -1215,6 +1215,53 @@ class Engine:
                 out['dropout'] = p[:b, :1 if 'pi' in lay.shared else lay.G_out]
         return out
 
+    # ------------------------------------------------------------------ inference, gene-major (the fused result writer)
+    def hidden_all(self, chunk=4096):
+        """Inference forward of the hidden stack over ALL storage rows: the decoder output of every cell stays resident
+        ([n, ldh]: 17 MB at 68 579 cells), the latent code is returned ([n, h_centre] device tensor)."""
+        lay = self.lay
+        n = self.n
+        self.reserve(min(chunk, n))
+        hL = lay.hidden[-1]
+        self.HL_all = torch.zeros(n, self.ldh[-1], dtype=torch.float32, device=self.dev)
+        latent = torch.zeros(n, lay.hidden[self.center], dtype=torch.float32, device=self.dev)
+        for s in range(0, n, self.Bmax):
+            b = min(self.Bmax, n - s)
+            self._hidden_forward(b, ('range', s), False)
+            self.HL_all[s:s + b].copy_(self.Hcur[-1][:b])
+            latent[s:s + b].copy_(self.Z[self.center][:b, :lay.hidden[self.center]])
+        return latent
+
+    def heads_gene_block(self, g0, gb, want, out):
+        """The heads of genes [g0, g0 + gb) for ALL cells, written gene-major: out[k] [gb, >= n] device tensors for k in
+        want (mean = mean * size factor, dispersion, dropout) -- a [n, hL] x [hL, gb] product per head, the inference
+        activations, one transpose.  Needs hidden_all() first; plain per-gene Dense heads only."""
+        lay, ops = self.lay, self.ops
+        assert not (lay.shared or lay.fork or lay.elempi)
+        n = self.n
+        Wh, bh = lay.view(self.w, 'Wh'), lay.view(self.w, 'bh')
+        gbp = _r4(gb)
+        nh = len(lay.planes)
+        if getattr(self, '_Ablk', None) is None or self._Ablk.shape[1] < nh * gbp or self._Ablk.shape[0] != n:
+            self._Ablk = torch.zeros(n, nh * gbp, dtype=torch.float32, device=self.dev)
+            self._ws_blk = torch.zeros(max(ops.sgemm_workspace_bytes(0, 0, n, gbp, lay.hL) // 4, 4), dtype=torch.float32,
+                                       device=self.dev)
+        A = self._Ablk
+        lda = A.shape[1]
+        planes = {}
+        for k, hd in enumerate(lay.planes):
+            c0 = k * lay.Gp + g0
+            ops.sgemm(0, 0, n, gb, lay.hL, self.HL_all, self.ldh[-1], Wh[:, c0:], lay.NH, A[:, k * gbp:], lda,
+                      bias=bh[c0:], ws=self._ws_blk)
+            planes[hd] = A[:, k * gbp:]
+        m = planes.get('mean')
+        d = planes.get('disp') if 'dispersion' in want else None
+        p = planes.get('pi') if 'dropout' in want else None
+        ops.heads_infer(m, d, p, lda, self.sf, n, gb, m if 'mean' in want else None, d, p, lda, self.flags & 8)
+        for key, src in (('mean', m), ('dispersion', d), ('dropout', p)):
+            if key in want and src is not None:
+                ops.transpose(src, lda, n, gb, out[key], out[key].shape[1])
+
     def const_dispersion(self):
         """layers.py:21: theta = clip(exp(w), 1e-3, 1e4), per gene."""
         tw = self.lay.view(self.w, 'theta_w')[:self.lay.G_out]

@@ -25,6 +25,11 @@ _SIGNATURES = {
     'dcahost_tsv_read_f32': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_char_p, ctypes.c_long,
                                             ctypes.c_char_p, ctypes.c_long]),
     'dcahost_tsv_close': (None, [ctypes.c_void_p]),
+    'dcahost_tsv_stream_open': (ctypes.c_int, [ctypes.c_char_p, ctypes.c_long, _cpp, ctypes.c_int,
+                                               ctypes.POINTER(ctypes.c_void_p)]),
+    'dcahost_tsv_stream_rows_f32': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_long, _cpp,
+                                                   ctypes.c_int]),
+    'dcahost_tsv_stream_close': (ctypes.c_int, [ctypes.c_void_p]),
 }
 
 
@@ -77,6 +82,45 @@ def write_tsv(path, matrix, rownames=None, colnames=None, threads=0):
         raise OSError(err, os.strerror(err), str(path))
     if rc != 0:
         raise ValueError('dcahost_write_tsv: invalid arguments')
+
+
+class TsvStream:
+    """A '%.6f' TSV written row block by row block (dcahost_tsv_stream_*): header at once, then rows(values, names) in
+    order.  Same bytes as write_tsv of the whole matrix."""
+
+    def __init__(self, path, ncols, colnames=None, index=True):
+        self.h = ctypes.c_void_p()
+        self.ncols, self.index = int(ncols), bool(index)
+        cn, _keep = _names(colnames, self.ncols)
+        rc = lib().dcahost_tsv_stream_open(os.fsencode(path), self.ncols, cn, int(self.index), ctypes.byref(self.h))
+        if rc != 0:
+            err = ctypes.get_errno()
+            raise OSError(err, os.strerror(err), str(path))
+
+    def rows(self, values, rownames=None, threads=0):
+        """values: float32 [nrows, >= ncols] with unit column stride (any row stride)."""
+        v = np.asarray(values)
+        assert v.ndim == 2 and v.dtype == np.float32 and v.shape[1] >= self.ncols
+        assert v.shape[0] == 0 or v.strides[1] == 4
+        ld = v.strides[0] // 4 if v.shape[0] > 1 else max(self.ncols, v.shape[1])
+        rn, _keep = _names(rownames, v.shape[0]) if self.index else (None, None)
+        rc = lib().dcahost_tsv_stream_rows_f32(self.h, v.ctypes.data, v.shape[0], ld, rn, int(threads))
+        if rc != 0:
+            raise OSError(ctypes.get_errno(), 'dcahost_tsv_stream_rows_f32 failed (%d)' % rc)
+
+    def close(self):
+        if self.h:
+            rc = lib().dcahost_tsv_stream_close(self.h)
+            self.h = ctypes.c_void_p()
+            if rc != 0:
+                raise OSError(ctypes.get_errno(), 'closing the result file failed')
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+        return False
 
 
 def format_values(values):

@@ -275,6 +275,122 @@ class Autoencoder():
         if mode == 'latent':
             adata.X = adata.raw.X.copy()  # recover normalized expression values (network.py:208-209)
 
+    # ------------------------------------------------------------------ predict + write in one pass (the CLI's last step)
+    def _write_extra(self, adata, file_path, colnames):
+        """Result files that do not come from per-cell heads (the per-gene dispersion of the constant-dispersion types)."""
+
+    def predict_write(self, adata, file_path, mode='full', colnames=None, gene_block=None):
+        """``predict(adata, mode, return_info=True)`` followed by ``write(adata, file_path, mode, colnames)``
+        (dca/train.py:176-190 -> dca/network.py:188-231, 395-421) for a caller whose only consumer is the output
+        directory: the same files, byte for byte, without a cells x genes result matrix on the host.
+
+        The reference computes cell by cell and writes gene by gene (``write_text_matrix(..., transpose=True)``); here
+        the hidden stack runs once over all cells (its 64-unit output stays in HBM), then blocks of genes go through
+        heads GEMM -> inference activations -> transpose on the device, arrive gene x cell in page-locked chunks and are
+        formatted by the native writer (one thread per result file feeding its own pool) while the next block computes.
+        ``adata.X`` / ``adata.obsm`` are NOT filled.  Networks whose heads are not per-gene Dense layers (shared, fork,
+        elempi), tiny gene counts, or a host without the native writer take predict() + write()."""
+        import queue
+        import threading
+        eng = self.engine
+        lay = eng.lay
+        cells = adata.obs_names.values
+        genes = adata.var_names.values if colnames is None else colnames
+        want = self._wanted(mode, True)
+        head_keys = [k for k in ('mean', 'dispersion', 'dropout') if k in want]
+        try:
+            from . import hostlib
+            hostlib.lib()
+            native = not hostlib.names_need_quoting(cells) and not hostlib.names_need_quoting(genes)
+        except Exception:
+            native = False
+        fusable = (native and eng.dev.type == 'cuda' and hasattr(eng.ops, 'transpose') and lay.G_out >= 256 and head_keys
+                   and not (lay.shared or lay.fork or lay.elempi) and mode in ('denoise', 'full')
+                   and len(genes) == lay.G_out and os.environ.get('DCA_AMD_FUSED_WRITE', '1') != '0')
+        if not fusable:
+            self.predict(adata, mode=mode, return_info=True)
+            self.write(adata, file_path, mode=mode, colnames=colnames)
+            return
+        n, G = adata.n_obs, lay.G_out
+        sf = np.asarray(adata.obs['size_factors'].values, dtype=np.float32)
+        dd = getattr(adata, '_dca_device', None)
+        if dd is not None and dd.n == n and dd.G == lay_G(eng) and dd.X.device == eng.dev and dd.matches(adata.X):
+            eng.attach_device_data(dd.X, dd.Y, dd.sf, norm=dd.norm, compact=dd.compact)
+            dd.compact = eng.cc
+        else:
+            eng.load_data(adata.X, None, sf)
+        print('dca: Calculating low dimensional representations...')
+        print('dca: Calculating reconstructions...')
+        print('dca: Saving output(s)...')
+        os.makedirs(file_path, exist_ok=True)
+        latent = eng.hidden_all()
+        gb = gene_block or int(min(1024, max(128, 64e6 // (4 * n))))
+        nblk = max(1, G // gb)
+        bounds = [G * i // nblk for i in range(nblk + 1)]          # near-equal blocks, none below 128 genes
+        gbmax = max(b - a for a, b in zip(bounds[:-1], bounds[1:]))
+        ldn = (n + 3) // 4 * 4
+        dev_out = [{k: torch.zeros(gbmax, ldn, dtype=torch.float32, device=eng.dev) for k in head_keys} for _ in range(2)]
+        stage = [{k: torch.empty((gbmax, n), dtype=torch.float32, pin_memory=True) for k in head_keys} for _ in range(2)]
+        files = {'mean': 'mean.tsv', 'dispersion': 'dispersion.tsv', 'dropout': 'dropout.tsv'}
+        # (the reference passes the cell names to the mean file only: dispersion.tsv / dropout.tsv have no header line,
+        # network.py:413-421)
+        streams = {k: hostlib.TsvStream(os.path.join(file_path, files[k]), n, colnames=cells if k == 'mean' else None,
+                                        index=True) for k in head_keys}
+        free = [{k: threading.Event() for k in head_keys} for _ in range(2)]
+        for slot in free:
+            for ev in slot.values():
+                ev.set()
+        jobs = {k: queue.Queue() for k in head_keys}
+        errors = []
+        threads_per_file = max(1, (os.cpu_count() or 1) // len(head_keys))
+
+        def writer(k):
+            try:
+                while True:
+                    job = jobs[k].get()
+                    if job is None:
+                        return
+                    slot, g0, g1, ev = job
+                    ev.synchronize()
+                    streams[k].rows(stage[slot][k][:g1 - g0].numpy(), genes[g0:g1], threads=threads_per_file)
+                    free[slot][k].set()
+            except Exception as e:          # noqa: BLE001 -- surfaced on the main thread below
+                errors.append(e)
+                for slot in free:
+                    slot[k].set()
+
+        workers = [threading.Thread(target=writer, args=(k,), daemon=True) for k in head_keys]
+        for t in workers:
+            t.start()
+        try:
+            for i in range(nblk):
+                slot, g0, g1 = i % 2, bounds[i], bounds[i + 1]
+                for k in head_keys:
+                    free[slot][k].wait()
+                    free[slot][k].clear()
+                if errors:
+                    break
+                eng.heads_gene_block(g0, g1 - g0, set(head_keys), dev_out[slot])
+                for k in head_keys:
+                    stage[slot][k][:g1 - g0].copy_(dev_out[slot][k][:g1 - g0, :n], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                for k in head_keys:
+                    jobs[k].put((slot, g0, g1, ev))
+        finally:
+            for k in head_keys:
+                jobs[k].put(None)
+            for t in workers:
+                t.join()
+            for st in streams.values():
+                st.close()
+        if errors:
+            raise errors[0]
+        if 'latent' in want:
+            print('dca: Saving latent representations...')
+            write_text_matrix(latent.cpu().numpy(), os.path.join(file_path, 'latent.tsv'), rownames=cells, transpose=False)
+        self._write_extra(adata, file_path, genes)
+
     def write(self, adata, file_path, mode='denoise', colnames=None):
         """network.py:213-231."""
         colnames = adata.var_names.values if colnames is None else colnames
@@ -305,6 +421,11 @@ class NBConstantDispAutoencoder(Autoencoder):
         if return_info:
             adata.var['X_dca_dispersion'] = self.engine.const_dispersion()      # network.py:278
         return adata if copy else None
+
+    def _write_extra(self, adata, file_path, colnames):
+        adata.var['X_dca_dispersion'] = self.engine.const_dispersion()          # network.py:278
+        write_text_matrix(np.asarray(adata.var['X_dca_dispersion']).reshape(1, -1),
+                          os.path.join(file_path, 'dispersion.tsv'), colnames=colnames, transpose=True)
 
     def write(self, adata, file_path, mode='denoise', colnames=None):
         colnames = adata.var_names.values if colnames is None else colnames
@@ -412,6 +533,11 @@ class ZINBConstantDispAutoencoder(Autoencoder):
         if return_info:
             adata.var['X_dca_dispersion'] = self.engine.const_dispersion()      # network.py:530
         return adata if copy else None
+
+    def _write_extra(self, adata, file_path, colnames):
+        adata.var['X_dca_dispersion'] = self.engine.const_dispersion()          # network.py:530
+        write_text_matrix(adata.var['X_dca_dispersion'].values.reshape(1, -1),
+                          os.path.join(file_path, 'dispersion.tsv'), colnames=colnames, transpose=True)
 
     def write(self, adata, file_path, mode='denoise', colnames=None):
         colnames = adata.var_names.values if colnames is None else colnames

@@ -361,5 +361,6 @@ def train_with_args(args):
 
     names = adata.var_names
     columns = names[[int(np.where(names == g)[0][0]) for g in subset]] if subset else names
-    net.predict(adata, mode='full', return_info=True)
-    net.write(adata, args.outputdir, mode='full', colnames=columns)
+    # predict(mode='full', return_info=True) + write(...) of the reference (train.py:176-190) as one streaming pass: the
+    # result files are the only consumer here, so no cells x genes matrix is staged on the host (network.predict_write)
+    net.predict_write(adata, args.outputdir, mode='full', colnames=columns)

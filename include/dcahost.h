@@ -42,6 +42,16 @@ int dcahost_write_tsv_f64(const char* path, const double* data, long nrows, long
                           long row_stride, long col_stride,
                           const char* const* rownames, const char* const* colnames, int nthreads);
 
+/* The same file written row block by row block: open writes the header line (colnames NULL: none; has_index: an
+ * empty first cell), every rows call appends nrows rows of ncols values (row r at data + r * ld) in call order --
+ * the fused predict writer (dca/network.py:407-421 written gene x cell, dca/io.py:120-129) hands over gene blocks of
+ * the result as they leave the GPU, so that no cells x genes matrix is ever staged on the host.  Same bytes as
+ * dcahost_write_tsv_f32 on the whole matrix. */
+int dcahost_tsv_stream_open(const char* path, long ncols, const char* const* colnames, int has_index, void** handle);
+int dcahost_tsv_stream_rows_f32(void* handle, const float* data, long nrows, long ld,
+                                const char* const* rownames, int nthreads);
+int dcahost_tsv_stream_close(void* handle);
+
 /* Formats n values as '%.6f' separated by tabs into out (capacity cap bytes); returns the number of
  * bytes written or DCAHOST_EINVAL when cap is too small (64 bytes per value always suffice).
  * The formatting kernel of the writers, exported for the parity tests. */

@@ -86,3 +86,26 @@ def test_staged_upload_and_download_are_exact():
     np.testing.assert_array_equal(prep._download(d, n, G), X)
     Y, totals = prep.resident_counts(np.abs(np.round(X * 3)))
     np.testing.assert_array_equal(totals, np.abs(np.round(X * 3)).sum(axis=0, dtype=np.float64))
+
+
+@pytest.mark.parametrize('ae_type', ['zinb-conddisp', 'zinb', 'nb-conddisp', 'nb'])
+def test_fused_predict_writer_writes_the_files_of_predict_then_write(tmp_path, ae_type):
+    """network.predict_write (the CLI's last step as one streaming pass: hidden stack over all cells, then gene blocks
+    through heads GEMM -> inference activations -> transpose on the device -> native writer; no cells x genes matrix on
+    the host) writes the files predict(mode='full', return_info=True) + write(mode='full') write (dca/network.py:188-231,
+    395-421; dca/io.py:120-129) -- byte for byte."""
+    import os
+    from dca_amd.train import train
+    ad = _prepared(n=333, G=530, seed=4)
+    net = AE_types[ae_type](input_size=ad.n_vars, hidden_size=(64, 32, 64), file_path=str(tmp_path))
+    net.seed = 0
+    net.build()
+    train(ad, net, epochs=1, batch_size=32, verbose=False, early_stop=0, reduce_lr=0)
+    a, b = str(tmp_path / 'fused'), str(tmp_path / 'plain')
+    net.predict_write(ad, a, mode='full', gene_block=140)            # three gene blocks of ~177 genes
+    net.predict(ad, mode='full', return_info=True)
+    net.write(ad, b, mode='full')
+    files = sorted(os.listdir(b))
+    assert 'mean.tsv' in files and 'latent.tsv' in files and sorted(os.listdir(a)) == files
+    for f in files:
+        assert open(os.path.join(a, f), 'rb').read() == open(os.path.join(b, f), 'rb').read(), f

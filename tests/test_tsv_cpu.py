@@ -140,3 +140,18 @@ def test_exports():
     assert declared == set(hostlib._SIGNATURES)
     for name in declared:
         assert hasattr(L, name)
+
+
+def test_streamed_writer_writes_the_bytes_of_the_one_shot_writer(tmp_path):
+    """dcahost_tsv_stream_* (the fused predict writer hands over gene blocks as they leave the GPU) = dcahost_write_tsv_f32
+    of the whole matrix: header, row names, values, with row blocks of any size, padded rows and any thread count."""
+    from dca_amd import hostlib
+    rng = np.random.RandomState(0)
+    m = (rng.randn(37, 211) * 100).astype(np.float32)
+    m[3, 5] = np.nan; m[0, 0] = -0.0; m[7, 7] = np.inf
+    rn = ['g%d' % i for i in range(37)]; cn = ['c%d' % i for i in range(211)]
+    hostlib.write_tsv(str(tmp_path / 'a.tsv'), m, rn, cn)
+    padded = np.zeros((37, 300), np.float32); padded[:, :211] = m
+    with hostlib.TsvStream(str(tmp_path / 'b.tsv'), 211, colnames=cn, index=True) as st:
+        st.rows(padded[:10], rn[:10]); st.rows(padded[10:11], rn[10:11]); st.rows(padded[11:11], []); st.rows(padded[11:], rn[11:], threads=3)
+    assert (tmp_path / 'a.tsv').read_bytes() == (tmp_path / 'b.tsv').read_bytes()

@@ -28,6 +28,7 @@ dio.normalize = timed('normalize (upload, K-PREP, download)', dio.normalize)
 T.train = timed('train', T.train)
 NW.Autoencoder.predict = timed('predict', NW.Autoencoder.predict)
 NW.write_text_matrix = timed('write the result files', NW.write_text_matrix)
+NW.Autoencoder.predict_write = timed('predict + write, one call (contains the two above when not fused)', NW.Autoencoder.predict_write)
 from dca_amd.__main__ import main
 sys.argv = ['dca', inp, out, '-e', str(epochs), '--earlystop', '0', '--reducelr', '0']
 s = time.perf_counter()
@@ -36,7 +37,9 @@ torch.cuda.synchronize()
 total = time.perf_counter() - s
 for k, v in marks.items():
     print('  %-40s %7.2f s' % (k, v))
-print('  %-40s %7.2f s' % ('everything else', total - sum(marks.values())))
+print('  %-40s %7.2f s' % ('everything else', total - sum(v for k, v in marks.items() if not k.startswith('predict + write'))
+                            - (marks.get([k for k in marks if k.startswith('predict + write')][0], 0.0) if os.environ.get('DCA_AMD_FUSED_WRITE', '1') != '0' else 0.0)
+                            + (sum(v for k, v in marks.items() if k in ('predict', 'write the result files')) if os.environ.get('DCA_AMD_FUSED_WRITE', '1') != '0' else 0.0)))
 files = sorted(os.listdir(out))
 print('dca CLI total %.2f s; wrote %s (%.0f MB)' % (total, files, sum(os.path.getsize(os.path.join(out, f)) for f in files) / 1e6))
 shutil.rmtree(tmp)
