@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <type_traits>
 #include "dcahip.h"
 
 namespace {
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(256) void counts_compact_kernel(const float* Y, lon
 // A wave owns a 32-gene tile and all H1 columns; K = the batch rows, 16 per step.  The A operand (32 genes x 16 rows
 // of L as three bf16 pieces) is LOOKED UP, not computed: 8 byte loads of counts per lane and step, each the index
 // into the cell's table of pre-split values lutp[cell][count] (counts 0 .. 15; larger ones take the formula -- a
-// wave-uniform branch that is rare on count data; stores with escapes, i.e. counts >= 255, keep the dense path).  The B operand (dZ as three bf16 pieces, laid out
+// wave-uniform branch that is rare on count data; an escape byte looks its count up in the row's overflow list there).  The B operand (dZ as three bf16 pieces, laid out
 // for the MFMA by enc0_split_dz once per call) is shared by the workgroup's 8 waves through LDS, 128 rows at a time.
 // Six bf16 products per fp32 product, fp32 accumulation (the arithmetic of K-HEADS / K-GEMM); fixed order.
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
@@ -211,6 +212,7 @@ __global__ __launch_bounds__(64 * kDwWaves) void enc0_dw_kernel(DwArgs a) {
     __shared__ __attribute__((aligned(16))) uint2 lutl[RB * kLut];
     __shared__ __attribute__((aligned(16))) unsigned char codes[RB * kCodeLd];
     __shared__ float rfac[RB];
+    __shared__ int srows[RB];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -241,19 +243,28 @@ __global__ __launch_bounds__(64 * kDwWaves) void enc0_dw_kernel(DwArgs a) {
         const int r = rg0 + row;
         return a.srowb[r < re ? r : re - 1];
     };
-    int sr_c0, sr_c1, sr_l[LUT_PER], sr_t;               // storage rows of this thread's pieces of the NEXT block to request
-    u32x4 r_c0, r_c1, r_l[LUT_PER], r_dz[DZ_PER];
+    // Pipeline: the count tiles (the only reads that come from HBM: 256 B per gathered row) are requested TWO blocks ahead
+    // into the register pair the deposit of the current block has just emptied; the table rows and the split dZ (L2) one
+    // block ahead; the storage rows of a block one step before its first request.
+    int sc0, sc1;                                        // storage rows of the count pieces to request next (block + 2)
+    int sr_l[LUT_PER], sr_t;                             // storage rows of the table / divisor pieces of block + 1
+    u32x4 cq[2][2], r_l[LUT_PER], r_dz[DZ_PER];
     float r_fac = 1.f;
-    auto load_rows = [&](int rg0) __attribute__((always_inline)) {
-        sr_c0 = srow_of(rg0, crow); sr_c1 = srow_of(rg0, 32 + crow);
+    int r_srow = 0;
+    auto rows_counts = [&](int rg0) __attribute__((always_inline)) { sc0 = srow_of(rg0, crow); sc1 = srow_of(rg0, 32 + crow); };
+    auto rows_others = [&](int rg0) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < LUT_PER; ++i) sr_l[i] = srow_of(rg0, lrow + i * LROWS);
         sr_t = srow_of(rg0, tid < RB ? tid : 0);
     };
-    auto request = [&](int rg0) __attribute__((always_inline)) {
+    auto request_counts = [&](auto slot, int rg0) __attribute__((always_inline)) {
+        constexpr int S = decltype(slot)::value;
         const u32x4 z = {0u, 0u, 0u, 0u};
-        r_c0 = (cseg_ok && rg0 + crow < re) ? *reinterpret_cast<const u32x4*>(a.c.yc + (long)sr_c0 * a.c.ldc + gbase + cseg * 16) : z;
-        r_c1 = (cseg_ok && rg0 + 32 + crow < re) ? *reinterpret_cast<const u32x4*>(a.c.yc + (long)sr_c1 * a.c.ldc + gbase + cseg * 16) : z;
+        cq[S][0] = (cseg_ok && rg0 + crow < re) ? *reinterpret_cast<const u32x4*>(a.c.yc + (long)sc0 * a.c.ldc + gbase + cseg * 16) : z;
+        cq[S][1] = (cseg_ok && rg0 + 32 + crow < re) ? *reinterpret_cast<const u32x4*>(a.c.yc + (long)sc1 * a.c.ldc + gbase + cseg * 16) : z;
+    };
+    auto request_others = [&](int rg0) __attribute__((always_inline)) {
+        const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int i = 0; i < LUT_PER; ++i) r_l[i] = *reinterpret_cast<const u32x4*>(a.lutp + (long)sr_l[i] * kLut + lseg * 2);
         const int ks0 = rg0 / kKS;
@@ -265,10 +276,12 @@ __global__ __launch_bounds__(64 * kDwWaves) void enc0_dw_kernel(DwArgs a) {
             r_dz[i] = (u < DZ_UNITS && ks0 + k < nks_total) ? src[u] : z;
         }
         r_fac = a.fac ? a.fac[sr_t] : 1.f;
+        r_srow = sr_t;
     };
-    auto deposit = [&]() __attribute__((always_inline)) {
-        *reinterpret_cast<u32x4*>(codes + crow * kCodeLd + cseg * 16) = r_c0;
-        *reinterpret_cast<u32x4*>(codes + (32 + crow) * kCodeLd + cseg * 16) = r_c1;
+    auto deposit = [&](auto slot) __attribute__((always_inline)) {
+        constexpr int S = decltype(slot)::value;
+        *reinterpret_cast<u32x4*>(codes + crow * kCodeLd + cseg * 16) = cq[S][0];
+        *reinterpret_cast<u32x4*>(codes + (32 + crow) * kCodeLd + cseg * 16) = cq[S][1];
 #pragma unroll
         for (int i = 0; i < LUT_PER; ++i) *reinterpret_cast<u32x4*>(lutl + (lrow + i * LROWS) * kLut + lseg * 2) = r_l[i];
 #pragma unroll
@@ -276,18 +289,25 @@ __global__ __launch_bounds__(64 * kDwWaves) void enc0_dw_kernel(DwArgs a) {
             const int u = tid + i * NT;
             if (u < DZ_UNITS) reinterpret_cast<u32x4*>(dzp)[u] = r_dz[i];
         }
-        if (tid < RB) rfac[tid] = r_fac;
+        if (tid < RB) { rfac[tid] = r_fac; srows[tid] = r_srow; }
     };
 
-    if (rb < re) { load_rows(rb); request(rb); if (rb + RB < re) load_rows(rb + RB); }
-#pragma unroll 1
-    for (int rg0 = rb; rg0 < re; rg0 += RB) {
+    using Slot0 = std::integral_constant<int, 0>;
+    using Slot1 = std::integral_constant<int, 1>;
+    if (rb < re) {
+        rows_counts(rb); rows_others(rb);
+        request_counts(Slot0{}, rb); request_others(rb);
+        if (rb + RB < re) { rows_counts(rb + RB); request_counts(Slot1{}, rb + RB); rows_others(rb + RB); }
+        if (rb + 2 * RB < re) rows_counts(rb + 2 * RB);
+    }
+    auto block = [&](auto slot, int rg0) __attribute__((always_inline)) {
         const int nrow = min(RB, re - rg0);
         __syncthreads();                    // everyone is done with the previous block
-        deposit();
+        deposit(slot);
         __syncthreads();
-        if (rg0 + RB < re) { request(rg0 + RB); if (rg0 + 2 * RB < re) load_rows(rg0 + 2 * RB); }
-        if (!wave_on) continue;
+        if (rg0 + 2 * RB < re) { request_counts(slot, rg0 + 2 * RB); if (rg0 + 3 * RB < re) rows_counts(rg0 + 3 * RB); }
+        if (rg0 + RB < re) { request_others(rg0 + RB); if (rg0 + 2 * RB < re) rows_others(rg0 + 2 * RB); }
+        if (!wave_on) return;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
             if (ks * kKS >= nrow) break;
@@ -309,7 +329,11 @@ __global__ __launch_bounds__(64 * kDwWaves) void enc0_dw_kernel(DwArgs a) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     if (__ballot(code[j] >= (unsigned)kLut)) {
-                        float x = a.fac ? __fdiv_rn((float)code[j], rfac[rl0 + j]) : (float)code[j];
+                        float val = (float)code[j];
+                        if (__ballot(code[j] == 255u)) {            // an escape: the count itself from the row's overflow list
+                            if (code[j] == 255u) val = escaped_count(a.c, srows[rl0 + j], gene);
+                        }
+                        float x = a.fac ? __fdiv_rn(val, rfac[rl0 + j]) : val;
                         if (a.do_log) x = log1pf(x);
                         const uint2 e = split_entry(x);
                         if (code[j] >= (unsigned)kLut) { lo[j] = e.x; hx[j] = e.y; }
@@ -333,6 +357,11 @@ __global__ __launch_bounds__(64 * kDwWaves) void enc0_dw_kernel(DwArgs a) {
                 MFMA_X3(A, Bf, acc[t])
             }
         }
+    };
+#pragma unroll 1
+    for (int rg0 = rb; rg0 < re; rg0 += 2 * RB) {
+        block(Slot0{}, rg0);
+        if (rg0 + RB < re) block(Slot1{}, rg0 + RB);
     }
     if (blockIdx.x == 0 && tid < H1) {                   // column sums of this split's rows: its K steps in order
         float s = 0.f;

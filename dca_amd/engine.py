@@ -576,9 +576,11 @@ class Engine:
         if compact is None:
             return                          # not a count matrix (check_counts=False on arbitrary data): fp32 path
         self.cc = compact
-        # (stores with escapes -- counts >= 255 -- keep the dense first layer: the operand tables stop at the byte code)
+        # (the escapes of a batch -- counts >= 255 -- are corrected by one workgroup one after the other: a store with more
+        # than one escape in 1e5 counts is not count data of the kind this path is for and keeps the dense first layer)
+        n_esc = 0 if compact.ovf_col is None else int(compact.ovf_col.numel())
         if norm is not None and lay.G_in == lay.G_out and ops.enc0_sparse_supported(lay.hidden[0]) \
-                and compact.ovf_ptr is None and os.environ.get('DCA_AMD_SPARSE_ENC0', '1') != '0':
+                and n_esc <= 1e-5 * self.Y.shape[0] * lay.G_out and os.environ.get('DCA_AMD_SPARSE_ENC0', '1') != '0':
             self.cc_in = compact.with_input(norm.get('fac'), norm.get('do_log', False), norm.get('mean'), norm.get('std'), ops=ops)
         self._sparse_workspaces()
 

@@ -143,8 +143,8 @@ def test_sparse_first_layer_vs_numpy(ops, B, G, H1, gather, use_fac, do_log, sca
     err = np.abs(Zd.cpu().numpy() - Z_ref)
     assert (err <= 1e-6 * Z_abs + 1e-30).all(), float((err / Z_abs).max())
     # ---- weight + bias gradient
-    if not ops.enc0_sparse_supported(H1) or cc.ovf_ptr is not None:
-        return              # (stores with escapes keep the dense weight gradient: Engine.attach_compact)
+    if not ops.enc0_sparse_supported(H1):
+        return
     gWd = torch.full((G + 1, H1), 7.0, device='cuda')
     ws = torch.full((ops.enc0_dw_sparse_workspace_bytes(B, G, H1) // 4 + 4,), float('nan'), device='cuda')
     ops.enc0_dw_sparse(cc, dperm, dcur, base, B, G, H1, ddZ, H1, gWd, H1, ws)
@@ -224,8 +224,8 @@ def test_step_with_compact_counts_matches_oracle(ops, ae_type, B):
     norm = dict(fac=dev(sf), do_log=True, mean=dev(mean), std=dev(std))
     eng.attach_device_data(Xd, Yd, dev(sf), norm=norm)
     assert eng.cc is not None and eng.cc_in is not None
-    if B == 32:             # a store with escapes (a count >= 255) keeps the dense first layer, K-HEADS still reads the bytes
-        Ye = Yd.clone(); Ye[0, 0] = 300.0
+    if B == 32:             # a store dense with escapes (counts >= 255) keeps the dense first layer, K-HEADS still reads the bytes
+        Ye = Yd.clone(); Ye[:, :40] = 300.0
         e3 = Engine(ae_type, G, G, hs, True, 0.0, ops=ops)
         e3.attach_device_data(Xd, Ye, dev(sf), norm=norm)
         assert e3.cc is not None and e3.cc.ovf_ptr is not None and e3.cc_in is None
