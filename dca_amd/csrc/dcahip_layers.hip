@@ -1366,6 +1366,49 @@ __global__ __launch_bounds__(256) void hidden_stack_bwd_kernel(StackBwdArgs a) {
     if (nbar) grid_exit(a.sync, (unsigned)nwg);
 }
 
+// A [K <= 64, H <= 64] kernel into registers (float4 number tid + 256 q, 16 per row): every load UNCONDITIONAL on a clamped
+// address, no control flow between them, so they all leave back to back; w_tile_store zeroes what lies outside.
+// (VEC: 0 = decide here whether rows can be read as float4, 1 / 2 = the caller knows they can / cannot -- no branch)
+__device__ __forceinline__ bool w_tile_vec(const float* W, long ldw, int H) {
+    return (H & 3) == 0 && (ldw & 3) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0;
+}
+template <int VEC = 0>
+__device__ __forceinline__ void w_tile_request(const float* W, long ldw, int K, int H, int tid, float4 (&wv)[4]) {
+    if (VEC == 0 && (!W || K <= 0)) {                      // (uniform)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    const bool vec = VEC == 1 || (VEC == 0 && w_tile_vec(W, ldw, H));
+    if (vec) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = tid + 256 * q, k = min(idx >> 4, K - 1), c4 = min((idx & 15) * 4, H - 4);
+            wv[q] = *reinterpret_cast<const float4*>(W + (long)k * ldw + c4);
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = tid + 256 * q, k = min(idx >> 4, K - 1), c4 = (idx & 15) * 4;
+            const float* src = W + (long)k * ldw;
+            wv[q].x = src[min(c4 + 0, H - 1)]; wv[q].y = src[min(c4 + 1, H - 1)];
+            wv[q].z = src[min(c4 + 2, H - 1)]; wv[q].w = src[min(c4 + 3, H - 1)];
+        }
+    }
+}
+__device__ __forceinline__ void w_tile_store(float* wl, int K, int H, int tid, const float4 (&wv)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int idx = tid + 256 * q, k = idx >> 4, c4 = (idx & 15) * 4;
+        float4 v = wv[q];
+        if (k >= K || c4 + 0 >= H) v.x = 0.f;
+        if (k >= K || c4 + 1 >= H) v.y = 0.f;
+        if (k >= K || c4 + 2 >= H) v.z = 0.f;
+        if (k >= K || c4 + 3 >= H) v.w = 0.f;
+        *reinterpret_cast<float4*>(wl + k * kStackLd + c4) = v;
+    }
+}
+
 // ---- K-STACK, one step per launch: the same steps with every global read of a step issued UP FRONT (the block's tile,
 // the other blocks' partial statistics, the layer's kernel: all independent of each other), so a launch waits for ONE
 // memory round trip instead of one per phase -- at these sizes a step is nothing but latency.
@@ -1411,21 +1454,7 @@ __global__ __launch_bounds__(256) void stack_fwd_step_kernel(StepFwdArgs a) {
         const SmallLayer& N = a.nxt;
         const int K = H, HN = N.W ? N.H : 0;
         float4 wv[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {                      // the next layer's kernel [K, HN]: float t of row k = (tid + 256 q) / 16
-            const int idx = tid + 256 * q, k = idx >> 4, c4 = (idx & 15) * 4;
-            wv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (N.W && k < K) {
-                const float* src = N.W + (long)k * N.ldw + c4;
-                if (c4 + 3 < HN && (N.ldw & 3) == 0 && (reinterpret_cast<uintptr_t>(N.W) & 15) == 0) wv[q] = *reinterpret_cast<const float4*>(src);
-                else {
-                    if (c4 + 0 < HN) wv[q].x = src[0];
-                    if (c4 + 1 < HN) wv[q].y = src[1];
-                    if (c4 + 2 < HN) wv[q].z = src[2];
-                    if (c4 + 3 < HN) wv[q].w = src[3];
-                }
-            }
-        }
+        w_tile_request(N.W, N.ldw, N.W ? K : 0, HN, tid, wv);      // the next layer's kernel [K, HN]
         const float beta = L.beta ? L.beta[cc] : 0.f;
         const float nbias = (N.W && N.bias && c < HN) ? N.bias[c] : 0.f;
         // ---- statistics of the whole batch (one pass, fp64: N, sum n m, sum (M2 + n m^2)), every block the same order
@@ -1477,11 +1506,7 @@ __global__ __launch_bounds__(256) void stack_fwd_step_kernel(StepFwdArgs a) {
             ht[r * kStackLd + c] = h;                      // zero beyond the layer's width / the block's rows
         }
         if (!N.W) return;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int idx = tid + 256 * q, k = idx >> 4, c4 = (idx & 15) * 4;
-            *reinterpret_cast<float4*>(wl + k * kStackLd + c4) = wv[q];
-        }
+        w_tile_store(wl, K, HN, tid, wv);
         __syncthreads();
         float acc[kStepRows / 4];
 #pragma unroll
@@ -1576,21 +1601,7 @@ __global__ __launch_bounds__(256) void stack_bwd_step_kernel(StepBwdArgs a) {
     const int K = has_low ? L.K : 0;
     float4 wv[4];
     float hp[kStepRows / 4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {                          // this layer's kernel [K, H]
-        const int idx = tid + 256 * q, k = idx >> 4, c4 = (idx & 15) * 4;
-        wv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (has_low && k < K) {
-            const float* src = L.W + (long)k * L.ldw + c4;
-            if (c4 + 3 < H && (L.ldw & 3) == 0 && (reinterpret_cast<uintptr_t>(L.W) & 15) == 0) wv[q] = *reinterpret_cast<const float4*>(src);
-            else {
-                if (c4 + 0 < H) wv[q].x = src[0];
-                if (c4 + 1 < H) wv[q].y = src[1];
-                if (c4 + 2 < H) wv[q].z = src[2];
-                if (c4 + 3 < H) wv[q].w = src[3];
-            }
-        }
-    }
+    w_tile_request(has_low ? L.W : nullptr, L.ldw, K, H, tid, wv);     // this layer's kernel [K, H]
 #pragma unroll
     for (int j = 0; j < kStepRows / 4; ++j) {              // the layer's input activations (= the layer below's output) and its xhat
         const int r = ty + 4 * j;
@@ -1630,11 +1641,7 @@ __global__ __launch_bounds__(256) void stack_bwd_step_kernel(StepBwdArgs a) {
         ht[r * kStackLd + tx] = (r < nrows && tx < K) ? hp[j] : 0.f;
     }
     if (!has_low) return;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int idx = tid + 256 * q, k = idx >> 4, c4 = (idx & 15) * 4;
-        *reinterpret_cast<float4*>(wl + k * kStackLd + c4) = wv[q];
-    }
+    w_tile_store(wl, K, H, tid, wv);
     __syncthreads();
     // (the layer below's output and xhat of the block's rows, column k = tx: requested now, used after the two products)
     float lh[kStepRows / 4], lx[kStepRows / 4];
@@ -1698,6 +1705,144 @@ __global__ __launch_bounds__(256) void stack_bwd_step_kernel(StepBwdArgs a) {
     }
     const float t1 = wg_rowlane_sum(s1, smf), t2 = wg_rowlane_sum(s2, smf);
     if (tx < K && ty == 0) { a.part_out[((long)wg * 2 + 0) * K + tx] = t1; a.part_out[((long)wg * 2 + 1) * K + tx] = t2; }
+}
+
+// ---- K-STACK, a batch that fits ONE workgroup (the reference's batch of 32): the whole backward of the stack in one launch.
+// The block holds every row, so the batch sums are its own and nothing crosses blocks; the gradient w.r.t. a layer's input
+// stays in registers (the product's thread layout IS the next layer's element layout).  The layer loop is unrolled (NL
+// layers, 4 R rows) and EVERY operand of every layer -- activations, xhat, kernels; a layer's input is the activation tile
+// of the layer below -- is requested in the first instructions, top layer first: one memory round trip for the launch.
+struct ChainBwdArgs {
+    StackBwdLayer l[4];
+    int B, act;
+    float n_total;
+    float* dZ0; long ldz0;
+};
+
+template <int NL, int R, bool VEC>
+__global__ __launch_bounds__(256) void stack_bwd_chain_kernel(ChainBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float dyt[4 * R * kStackLd];
+    __shared__ __attribute__((aligned(16))) float ht[4 * R * kStackLd];
+    __shared__ __attribute__((aligned(16))) float wl[64 * kStackLd];
+    __shared__ float smf[256];
+    const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+    const int nrows = a.B, c = tx;
+    float hv[NL][R], xv[NL][R], inv[NL], dh[R];
+    float4 wv[NL][4];
+    {
+        const StackBwdLayer& T = a.l[NL - 1];
+        const int cc = c < T.H ? c : T.H - 1;
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const int r = ty + 4 * j;
+            dh[j] = T.dHin[(long)(r < nrows ? r : nrows - 1) * T.lddh + cc];
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NL; ++t) {
+        const int i = NL - 1 - t;
+        const StackBwdLayer& L = a.l[i];
+        const int cc = c < L.H ? c : L.H - 1;
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const int r = ty + 4 * j;
+            const long row = r < nrows ? r : nrows - 1;
+            hv[i][j] = L.Hact[row * L.ldh + cc]; xv[i][j] = L.xhat[row * L.ldx + cc];
+        }
+        inv[i] = L.inv_std[cc];
+        if (i > 0) w_tile_request<VEC ? 1 : 2>(L.W, L.ldw, L.K, L.H, tid, wv[i]);
+    }
+#pragma unroll
+    for (int t = 0; t < NL; ++t) {
+        const int i = NL - 1 - t;
+        const StackBwdLayer& L = a.l[i];
+        const int H = L.H, K = i > 0 ? L.K : 0;
+        float dy[R], s1 = 0.f, s2 = 0.f;
+        if (a.act == 1) {                                  // (one uniform branch around the rows, none per element)
+#pragma unroll
+            for (int j = 0; j < R; ++j) dy[j] = hv[i][j] > 0.f ? dh[j] : 0.f;
+        } else {
+#pragma unroll
+            for (int j = 0; j < R; ++j) dy[j] = dh[j] * act_grad(a.act, hv[i][j]);
+        }
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            dy[j] = (ty + 4 * j < nrows && c < H) ? dy[j] : 0.f;
+            s1 += dy[j]; s2 += dy[j] * xv[i][j];
+        }
+        const float v1 = wg_rowlane_sum(s1, smf), v2 = wg_rowlane_sum(s2, smf);
+        if (ty == 0 && c < H && L.dbeta) L.dbeta[c] = v1;
+        const float m1 = v1 / a.n_total, m2 = v2 / a.n_total;
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const int r = ty + 4 * j;
+            const float dz = (r < nrows && c < H) ? inv[i] * (dy[j] - m1 - xv[i][j] * m2) : 0.f;
+            if (i == 0 && r < nrows && c < H) a.dZ0[(long)r * a.ldz0 + c] = dz;
+            dyt[r * kStackLd + c] = dz;
+            if (i > 0) ht[r * kStackLd + tx] = (r < nrows && tx < K) ? hv[i > 0 ? i - 1 : 0][j] : 0.f;
+        }
+        if (i == 0) break;
+        w_tile_store(wl, K, H, tid, wv[i]);
+        __syncthreads();
+        // ---- weight gradient, complete: gW[k][c] = sum_r Hprev[r][k] dz[r][c], k in [16 ty, 16 ty + 16); bias row = column sums
+        {
+            float acc[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+            float bs = 0.f;
+#pragma unroll 4
+            for (int r = 0; r < nrows; ++r) {
+                const float d = dyt[r * kStackLd + c];
+                bs += d;
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const float4 h4 = *reinterpret_cast<const float4*>(ht + r * kStackLd + 16 * ty + 4 * q4);
+                    acc[4 * q4 + 0] = fmaf(h4.x, d, acc[4 * q4 + 0]); acc[4 * q4 + 1] = fmaf(h4.y, d, acc[4 * q4 + 1]);
+                    acc[4 * q4 + 2] = fmaf(h4.z, d, acc[4 * q4 + 2]); acc[4 * q4 + 3] = fmaf(h4.w, d, acc[4 * q4 + 3]);
+                }
+            }
+            if (c < H) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int k = 16 * ty + j;
+                    if (k < K) L.gW[(long)k * L.ldg + c] = acc[j];
+                }
+                if (ty == 0) L.gW[(long)K * L.ldg + c] = bs;
+            }
+        }
+        // ---- gradient w.r.t. the layer's input: dHp[r][k] = sum_c dz[r][c] W[k][c]; thread: k = tx, rows ty + 4 j --
+        // the element layout of the layer below, so it never leaves the registers
+#pragma unroll
+        for (int j = 0; j < R; ++j) dh[j] = 0.f;
+#pragma unroll 4
+        for (int c4 = 0; c4 < 64; c4 += 4) {
+            const float4 w4 = *reinterpret_cast<const float4*>(wl + tx * kStackLd + c4);
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                const float4 d4 = *reinterpret_cast<const float4*>(dyt + (ty + 4 * j) * kStackLd + c4);
+                dh[j] = fmaf(d4.w, w4.w, fmaf(d4.z, w4.z, fmaf(d4.y, w4.y, fmaf(d4.x, w4.x, dh[j]))));
+            }
+        }
+        const StackBwdLayer& P = a.l[i > 0 ? i - 1 : 0];
+        if (P.dHin) {
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                const int r = ty + 4 * j;
+                if (r < nrows && tx < K) P.dHin[(long)r * P.lddh + tx] = dh[j];
+            }
+        }
+        __syncthreads();                                   // the tiles are free for the layer below
+    }
+}
+
+template <int R, bool VEC>
+static void launch_bwd_chain(int n, const ChainBwdArgs& q, hipStream_t st) {
+    switch (n) {
+        case 1: hipLaunchKernelGGL((stack_bwd_chain_kernel<1, R, VEC>), dim3(1), dim3(256), 0, st, q); break;
+        case 2: hipLaunchKernelGGL((stack_bwd_chain_kernel<2, R, VEC>), dim3(1), dim3(256), 0, st, q); break;
+        case 3: hipLaunchKernelGGL((stack_bwd_chain_kernel<3, R, VEC>), dim3(1), dim3(256), 0, st, q); break;
+        default: hipLaunchKernelGGL((stack_bwd_chain_kernel<4, R, VEC>), dim3(1), dim3(256), 0, st, q); break;
+    }
 }
 
 inline int stack_workgroups(int B, int rows) {
@@ -2141,12 +2286,13 @@ extern "C" int dcahip_hidden_stack_fwd(const dcahip_small_layer* layers, int n, 
 extern "C" int dcahip_hidden_stack_bwd(const dcahip_stack_bwd_layer* layers, int n, int B, float n_total, int act,
                                        float* dZ0, long ldz0, int rows_per_wg, int first_step, int last_step,
                                        void* workspace, long workspace_bytes, void* stream) {
-    if (!layers || n < 1 || n > kStackMaxLayers || B <= 0 || B > kStackMaxWG * kStackRows || !workspace || !dZ0)
+    if (!layers || n < 1 || n > kStackMaxLayers || B <= 0 || B > kStackMaxWG * kStackRows || !dZ0) return DCAHIP_EINVAL;
+    const bool one_launch = first_step == 0 && last_step == n + 1;
+    const bool chain = one_launch && B <= kStackRows && n <= 4;  // one workgroup holds the batch: no workspace
+    if (!chain && (!workspace || workspace_bytes < dcahip_hidden_stack_workspace_bytes(n, B) || !al16(workspace)))
         return DCAHIP_EINVAL;
-    if (workspace_bytes < dcahip_hidden_stack_workspace_bytes(n, B) || !al16(workspace)) return DCAHIP_EINVAL;
     StackBwdArgs a{};
     if (stack_plan(n, B, rows_per_wg, first_step, last_step, n + 2, &a.nwg)) return DCAHIP_EINVAL;
-    const bool one_launch = first_step == 0 && last_step == n + 1;
     for (int i = 0; i < n; ++i) {
         const dcahip_stack_bwd_layer& q = layers[i];
         if (q.H <= 0 || q.H > 64 || !q.Hact || !q.xhat || !q.inv_std) return DCAHIP_EINVAL;
@@ -2157,6 +2303,18 @@ extern "C" int dcahip_hidden_stack_bwd(const dcahip_stack_bwd_layer* layers, int
     }
     a.n = n; a.B = B; a.act = act; a.first = first_step; a.last = last_step; a.n_total = n_total;
     a.dZ0 = dZ0; a.ldz0 = ldz0;
+    if (chain) {
+        // the batch fits one workgroup: the chain kernel (no partials, no workspace traffic)
+        ChainBwdArgs q{};
+        for (int i = 0; i < n; ++i) q.l[i] = a.l[i];
+        q.B = B; q.act = act; q.n_total = n_total; q.dZ0 = dZ0; q.ldz0 = ldz0;
+        bool vec = true;                                         // every kernel readable as float4 rows?
+        for (int i = 1; i < n; ++i) vec = vec && (q.l[i].H & 3) == 0 && (q.l[i].ldw & 3) == 0 && al16(q.l[i].W);
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        if (B <= 32) { if (vec) launch_bwd_chain<8, true>(n, q, st); else launch_bwd_chain<8, false>(n, q, st); }
+        else { if (vec) launch_bwd_chain<16, true>(n, q, st); else launch_bwd_chain<16, false>(n, q, st); }
+        return (int)hipGetLastError();
+    }
     a.sync = static_cast<unsigned*>(workspace);
     a.part = reinterpret_cast<float*>(static_cast<char*>(workspace) + 256);
     a.gwp = a.part + (long)n * a.nwg * 2 * 64;

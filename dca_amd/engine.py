@@ -825,6 +825,12 @@ class Engine:
                 and all(self._layer_small(B, i) for i in range(1, L)) and self.lay.hidden[0] <= 64
                 and os.environ.get('DCA_AMD_SMALL_CHAIN', '1') != '0')
 
+    def _stack_chain(self, B):
+        """The backward of the whole hidden stack in ONE single-workgroup launch: batches of at most 64 rows (the
+        reference's default 32) through small batch-normalised layers."""
+        return (self._stack_small(B) and B <= 64 and hasattr(self.ops, 'hidden_stack_bwd')
+                and os.environ.get('DCA_AMD_BWD_CHAIN', '1') != '0')
+
     def _stack_coop(self, B):
         """The hidden stack in one cooperative launch per direction (K-STACK): one GPU, batch norm on, every layer at
         most 64 units, no dropout / PReLU, batches beyond the single-workgroup kernels."""
@@ -1058,7 +1064,8 @@ class Engine:
         self._launch_heads_bucket()
         # ---- backward: hidden stack
         L = len(lay.hidden)
-        coop = self._stack_coop(B)
+        chain = self._stack_chain(B)
+        coop = chain or self._stack_coop(B)
         if coop:
             layers = []
             for i, h in enumerate(lay.hidden):
@@ -1068,7 +1075,9 @@ class Engine:
                     d.update(W=lay.view(w, 'W%d' % i), ldw=h, K=lay.hidden[i - 1], Hprev=self.H[i - 1], ldp=self.ldh[i - 1],
                              gW=lay.view(g, 'W%d' % i), ldg=h)
                 layers.append(d)
-            if self.stack_mode == 'coop' and B <= 256 * 64:
+            if chain:
+                ops.hidden_stack_bwd(layers, B, float(Bg), self.act, self.dZ[0], self.ldh[0], None, rows_per_wg=64)
+            elif self.stack_mode == 'coop' and B <= 256 * 64:
                 ops.hidden_stack_bwd(layers, B, float(Bg), self.act, self.dZ[0], self.ldh[0], self.ws_stack, rows_per_wg=64)
             else:
                 for st in range(L + 2):

@@ -217,7 +217,8 @@ class HipOps:
                                                  hip.ptr(ws), ws.numel() * ws.element_size(), hip.stream()), 'hidden_stack_fwd')
 
     def hidden_stack_bwd(self, layers, B, n_total, act, dZ0, ldz0, ws, rows_per_wg=64, steps=None):
-        """layers: dicts with the fields of dcahip_stack_bwd_layer; steps = (first, last) of the pass's n + 2 steps."""
+        """layers: dicts with the fields of dcahip_stack_bwd_layer; steps = (first, last) of the pass's n + 2 steps.
+        A whole pass over a batch of at most 64 rows is one workgroup's work and needs no workspace (ws=None)."""
         arr = (hip.StackBwdLayer * len(layers))()
         for q, d in zip(arr, layers):
             for k in ('W', 'Hact', 'xhat', 'inv_std', 'Hprev', 'gW', 'dbeta', 'dH'):
@@ -226,7 +227,8 @@ class HipOps:
                 setattr(q, k, int(d.get(k, 0)))
         first, last = steps if steps is not None else (0, len(layers) + 1)
         hip.check(self.L.dcahip_hidden_stack_bwd(arr, len(layers), B, float(n_total), int(act), hip.ptr(dZ0), ldz0,
-                                                 int(rows_per_wg), first, last, hip.ptr(ws), ws.numel() * ws.element_size(),
+                                                 int(rows_per_wg), first, last, hip.ptr(ws),
+                                                 0 if ws is None else ws.numel() * ws.element_size(),
                                                  hip.stream()), 'hidden_stack_bwd')
 
     def dense_bn_bwd_small(self, dH, ldd, Hact, ldh, xhat, ldx, inv_std, Hp, ldp, W, ldw, B, K, H, batchnorm, n_total, act,

@@ -294,7 +294,9 @@ typedef struct dcahip_stack_bwd_layer {
  * A call runs steps [first_step, last_step] in ONE launch: a range of several steps synchronises with grid barriers
  * (every workgroup resident: at most 256 of them -- rows_per_wg * 256 >= B), a single step needs none (the kernel
  * boundary is the barrier; up to 1024 workgroups).  rows_per_wg (16 .. 64) fixes the row partition and must be the same
- * for every call of a pass. */
+ * for every call of a pass.  A whole backward pass (steps 0 .. n + 1) over B <= 64 rows -- the reference's default batch of
+ * 32 -- is ONE workgroup's work: the batch sums are its own, the input gradients stay in registers between layers, the
+ * operands of the layer below are requested while a layer computes; that call takes no workspace (NULL, 0). */
 int dcahip_hidden_stack_max_rows(void);
 long dcahip_hidden_stack_workspace_bytes(int n_layers, int B);
 int dcahip_hidden_stack_fwd(const dcahip_small_layer* layers, int n, int B, float momentum, float eps, int act,

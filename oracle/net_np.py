@@ -228,6 +228,12 @@ class OracleAE:
         self.ridge = ridge
         self.dtype = params['W0'].dtype
         self.row_threads = 0                                # > 1: likelihood of large batches on a thread pool
+        # {layer: boolean [B, h]}: evaluate ReLU layers on a GIVEN linear piece (unit active where True) instead of the sign
+        # of this evaluation's own pre-activation.  A test of an fp32 implementation at sizes where some of its millions of
+        # pre-activations land within round-off of zero compares on the implementation's piece (and checks separately that
+        # the two patterns differ only where the fp64 pre-activation is ~0).
+        self.relu_pattern = None
+        self.cache = None                                   # the last training forward's intermediates
 
     # ---------------------------------------------------------------- forward
     def forward(self, X, sf, training):
@@ -263,6 +269,8 @@ class OracleAE:
                 H = np.maximum(Yb, 0) + p['alpha%d' % i] * np.minimum(Yb, 0)
             else:
                 H = act_fwd(self.act, Yb)
+            if self.act == 1 and self.relu_pattern is not None and i in self.relu_pattern:
+                H = np.where(self.relu_pattern[i], Yb, dt.type(0))
             if training and self.hidden_dropout[i] > 0.0:    # network.py:137-138
                 keep = dropout_keep(self.dropout_seed, self.step, i, self.row0, H.shape[0], H.shape[1],
                                     self.hidden_dropout[i])
@@ -323,7 +331,7 @@ class OracleAE:
     def loss_and_grads(self, X, Y, sf, n_total=None):
         """One training-mode forward + backward. Returns (mean loss, grads dict)."""
         p = self.p
-        c = self.forward(X, sf, training=True)
+        c = self.cache = self.forward(X, sf, training=True)
         _, loss, d_mean, d_disp, d_pi = self._loss_grads(c, Y, n_total)
         g = {}
         pen, greg = (0.0, {})
@@ -358,6 +366,8 @@ class OracleAE:
             if self.act == 9:
                 g['alpha%d' % i] = (dH * np.minimum(c['Yb'][i], 0)).sum(axis=0)
                 dYb = dH * np.where(c['Yb'][i] > 0, 1.0, p['alpha%d' % i])
+            elif self.act == 1 and self.relu_pattern is not None and i in self.relu_pattern:
+                dYb = dH * self.relu_pattern[i]
             else:
                 dYb = dH * act_grad(self.act, c['Yb'][i])
             if self.batchnorm:

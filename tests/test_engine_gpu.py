@@ -190,6 +190,43 @@ def test_wide_network_step(ops):
     assert_grads_close(g, rg)
 
 
+def test_wide_network_step_at_benchmark_size(ops):
+    """BASELINE configs[4]'s network (512-256-128-256-512 on 25 000 genes, batch 2048) for one step against the fp64 oracle:
+    the separate-kernel path (no fused heads: hL = 512), the split-bf16 products on the transposed activations
+    (engine._wide_transposed) and the NT first-layer weight gradient at the sizes they are used at.
+
+    2.9 M hidden pre-activations per step: a handful of them lie within fp32 round-off of zero, and there the fp32 network
+    and the fp64 oracle may sit on different sides of a ReLU (one such unit moves its column of the weight gradient by
+    ~1/sqrt(B)).  So: the loss against the plain oracle; the two activation patterns may differ only where the oracle's
+    pre-activation is ~0, in a handful of places; the gradients against the oracle evaluated on the engine's linear piece."""
+    import os
+    n, G, hs, B = 2100, 25000, (512, 256, 128, 256, 512), 2048
+    X, Y, sf, p = make_problem(n, G, hs, 'zinb-conddisp', True, seed=7)
+    rows = np.random.RandomState(0).permutation(n)[:B]
+    x64, y64, s64 = X[rows].astype(np.float64), Y[rows].astype(np.float64), sf[rows].astype(np.float64)
+    ref = oracle_net('zinb-conddisp', p, hs, True)
+    ref.row_threads = max(1, min(64, os.cpu_count() or 1))
+    rl, _ = ref.loss_and_grads(x64, y64, s64)
+    eng = make_engine(ops, 'zinb-conddisp', G, hs, True, 0.0, p, X, Y, sf)
+    loss, g, _ = run_single_step(eng, rows)
+    assert eng.ws_heads is None and eng._wide_transposed(B)
+    assert abs(loss - rl) < 1e-5 * abs(rl)
+    pattern, flips = {}, 0
+    for i, h in enumerate(hs):
+        pattern[i] = (eng.H[i][:B, :h] > 0).cpu().numpy()
+        differ = pattern[i] != (ref.cache['Yb'][i] > 0)
+        flips += int(differ.sum())
+        assert np.abs(ref.cache['Yb'][i][differ]).max(initial=0.0) < 1e-5, (i, int(differ.sum()))
+    assert flips <= 16, flips
+    same = oracle_net('zinb-conddisp', p, hs, True)
+    same.row_threads, same.relu_pattern = ref.row_threads, pattern
+    sl, sg = same.loss_and_grads(x64, y64, s64)
+    assert abs(loss - sl) < 1e-5 * abs(sl)
+    # (an element of a 512-wide layer's d beta is a sum over 2048 rows that cancels to ~1e-4 of its terms: the absolute part
+    # of the tolerance covers the fp32 round-off of such a sum: 5e-4 of the tensor's largest element)
+    assert_grads_close(g, sg, atol_scale=5e-4)
+
+
 def test_large_batch_step(ops):
     """Throughput regime (B = 2048 rows, G = 2000): split-K / 128x128 tile paths."""
     n, G, hs, B = 2100, 2000, (64, 32, 64), 2048
@@ -214,8 +251,8 @@ def c3(ops):
     Y = synth.generate_counts(n, G, device=dev)
     counts = prep.cell_counts(ops, Y, n, G)
     sf = counts / counts.median()
-    X = prep.transform(ops, Y, n, G, sf, True, True)
-    yield dict(n=n, G=G, X=X, Y=Y, sf=sf, hs=(64, 32, 64))
+    X, norm = prep.transform(ops, Y, n, G, sf, True, True, return_norm=True)
+    yield dict(n=n, G=G, X=X, Y=Y, sf=sf, hs=(64, 32, 64), norm=norm)
     del X, Y, sf
     torch.cuda.empty_cache()
 
@@ -239,7 +276,8 @@ def test_full_size_step_matches_oracle(ops, c3, B):
     eng = Engine('zinb-conddisp', G, G, hs, True, 0.0, ops=ops)
     assert eng.use_fused
     eng.set_params(p)
-    eng.attach_device_data(c3['X'], c3['Y'], c3['sf'])
+    eng.attach_device_data(c3['X'], c3['Y'], c3['sf'], norm=c3['norm'])     # as bench.py: byte store + its first-layer gradient
+    assert eng.cc is not None and eng.cc_in is not None
     rows = np.random.RandomState(1).permutation(n)[:B]
     rt = torch.as_tensor(rows).cuda()
     Xr = c3['X'][rt][:, :G].cpu().numpy().astype(np.float64)
@@ -252,6 +290,7 @@ def test_full_size_step_matches_oracle(ops, c3, B):
     N.rmsprop_step(ref.p, rg, {}, 1e-3)
     loss, g, newp = run_single_step(eng, rows)
     assert eng.ws_heads is not None                          # K-HEADS ran
+    assert eng._sparse_dw(B) == (B >= 512) and eng._stack_coop(B) == (B > 64)
     assert abs(loss - rl) < 1e-5 * abs(rl), (loss, rl)
     assert_grads_close(g, rg)
     for i in range(len(hs)):
@@ -443,3 +482,26 @@ def test_fused_hidden_stack_equals_the_per_operation_kernels(ops, hs, B, mode, m
         for i in range(len(hs)):
             np.testing.assert_allclose(p1['mm%d' % i], p0['mm%d' % i], rtol=1e-5, atol=1e-7)
             np.testing.assert_allclose(p1['mv%d' % i], p0['mv%d' % i], rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize('hs,B', [((64, 32, 64), 32), ((64, 32, 64), 1), ((64, 32, 64), 64), ((48, 20, 7, 33), 37), ((16, 8), 5)])
+def test_single_workgroup_backward_chain_equals_the_per_layer_kernels(ops, hs, B, monkeypatch):
+    """Batches of at most 64 rows (the reference's default 32): the backward of the whole hidden stack in one
+    single-workgroup launch (dcahip_hidden_stack_bwd over all steps) against the per-layer kernels, one full training step
+    from the same state, twice in a row: loss, every gradient, the updated parameters."""
+    n, G = B + 9, 150
+    X, Y, sf, p = make_problem(n, G, hs, 'zinb-conddisp', True, seed=B)
+    rows = np.random.RandomState(3).permutation(n)[:B]
+    out = []
+    for on in ('1', '0'):
+        monkeypatch.setenv('DCA_AMD_BWD_CHAIN', on)
+        eng = make_engine(ops, 'zinb-conddisp', G, hs, True, 0.0, p, X, Y, sf)
+        eng.reserve(B)
+        assert eng._stack_chain(B) == (on == '1')
+        out.append([run_single_step(eng, rows) for _ in range(2)])
+    zero_b = tuple('b%d' % i for i in range(len(hs)))
+    for (l1, g1, p1), (l0, g0, p0) in zip(*out):
+        assert abs(l1 - l0) < 2e-6 * abs(l0)
+        assert_grads_close(g1, {k: np.asarray(v, np.float64) for k, v in g0.items()}, rtol=2e-4, atol_scale=2e-6, skip=zero_b)
+        for k in p0:
+            np.testing.assert_allclose(p1[k], p0[k], rtol=2e-4, atol=2e-6)
