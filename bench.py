@@ -457,13 +457,15 @@ def main():
                 roof['peak_bf16_pipe_over_6'] = MFMA_BF16_PEAK_TFLOPS / 6.0
                 roof['frac_of_bf16_pipe_over_6'] = e['achieved'] / (MFMA_BF16_PEAK_TFLOPS / 6.0)
                 roof['note'] = ('K-HEADS is bound by the SUM of its matrix and vector instruction cycles per SIMD '
-                                '(DESIGN.md 4.1): MfmaUtil 29 %, VALUBusy 52 % (profiles/r02z_sq_counters_per_kernel.csv)')
+                                '(DESIGN.md 4.1): MfmaUtil 29 %, VALUBusy 52 % (round-2 counters of the same kernel body, '
+                                'profiles/r02z_sq_counters_per_kernel.csv)')
             m = pmc.get(e['kernel'])
             if m and m['shape']['B'] == B and m['shape']['G'] == G and m['shape']['hL'] == hidden[-1]:
                 roof['traffic'] = m['traffic_bytes']
                 roof['traffic_source'] = ('rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same kernel and shape '
-                                          '(profiles/pmc_traffic.json, profiles/r02z_pmc_traffic/): bytes per launch; '
-                                          'algorithmic HBM bytes %.0f' % m['algorithmic_hbm_bytes'])
+                                          '(profiles/pmc_traffic.json, profiles/r03_pmc_traffic/; %s): bytes per launch; '
+                                          'algorithmic HBM bytes %.0f' % (m.get('tree', 'tree not recorded'),
+                                                                          m['algorithmic_hbm_bytes']))
             break
 
     extra = {}

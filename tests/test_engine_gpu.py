@@ -222,9 +222,7 @@ def test_wide_network_step_at_benchmark_size(ops):
     same.row_threads, same.relu_pattern = ref.row_threads, pattern
     sl, sg = same.loss_and_grads(x64, y64, s64)
     assert abs(loss - sl) < 1e-5 * abs(sl)
-    # (an element of a 512-wide layer's d beta is a sum over 2048 rows that cancels to ~1e-4 of its terms: the absolute part
-    # of the tolerance covers the fp32 round-off of such a sum: 5e-4 of the tensor's largest element)
-    assert_grads_close(g, sg, atol_scale=5e-4)
+    assert_grads_close(g, sg)
 
 
 def test_large_batch_step(ops):

@@ -1,5 +1,5 @@
 """Times dcahip_heads_fused alone (C3 shape by default) next to the separate kernels it replaces.
-  python tools/bench_heads.py [B] [G] [hL] [flags] [iters]
+  python tools/bench_heads.py [B] [G] [hL] [flags] [iters]          (COMPACT=1: counts read from the byte store)
 """
 import os, sys
 import numpy as np, torch
@@ -50,9 +50,17 @@ if os.environ.get('TILE_ORDER', '1') != '0':          # pair gene tiles of simil
     order = torch.cat([o, torch.arange(ntg, ops.heads_tile_order_len(G), dtype=torch.int32, device=dev)]).contiguous()
 
 
+cc = None
+if os.environ.get('COMPACT', '0') == '1':             # the counts as bytes (what the engine hands K-HEADS on count data)
+    from dca_amd import compact
+    cc = compact.build(ops, Y, n, G)
+    assert cc is not None
+
+
 def fused():
     return ops.heads_fused(H, hL, Wh, NH, Wh[hL], Gp, tw if flags & 2 else None, Y, Gp, sf, perm, cur, B, hL, G,
-                           0.0, inv_n, flags, gW, NH, gth if flags & 2 else None, dH, hL, part, ws, tile_order=order)
+                           0.0, inv_n, flags, gW, NH, gth if flags & 2 else None, dH, hL, part, ws, tile_order=order,
+                           **({'compact': cc} if cc is not None else {}))
 
 def timeit(fn, n):
     fn(); torch.cuda.synchronize()
