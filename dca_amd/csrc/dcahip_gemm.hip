@@ -539,6 +539,447 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, int
     }
 }
 
+// =====================================================================================================
+// K-GEMM from PRE-SPLIT operands ("planes"): the same six-product arithmetic, the three bf16 pieces of every element
+// already in memory as three planes [3][rows][ld] of bf16 (dcahip_split_planes, or a producer kernel that writes them
+// directly).  An operand that is used by several products per step (the gradient planes of the heads: weight AND input
+// gradient; the head weights: forward AND input gradient; the normalised counts: every epoch) is split once instead of
+// in every K loop, and the loop has no vector arithmetic left: 16-byte loads -> LDS -> fragments -> MFMA.  Either
+// operand may be k-contiguous (fragment = one ds_read_b128) or m/n-contiguous (the transposing ds_read_b64_tr_b16), so
+// ONE stored layout of a matrix serves the products that contract over its rows and over its columns: no transposed
+// copies.  128 x 128 tiles, 4 waves, 64 x 64 per wave, K chunks of 32 staged through registers.
+// =====================================================================================================
+struct Gemm3Args {
+    const unsigned short* A;
+    const unsigned short* B;
+    long lda, ldb, pa, pb;              // leading dimensions and plane strides, in elements
+    float* C;
+    const float* bias;
+    const int* perm;
+    const long long* cursor;
+    float* ws;
+    long ldc;
+    int M, N, K;
+    int split, kslab;
+    int colsum;
+    int mtiles, ntiles;
+};
+
+// one operand tile (DIM rows/cols x 32 k, three pieces) as 16-byte units: 12 DIM units over 256 threads
+template <bool KC, int DIM>
+struct PlaneTile {
+    static constexpr int PER = 12 * DIM / 256;           // units per thread (6 at DIM = 128): piece = i / (PER / 3)
+    static constexpr int RPT = PER / 3;                  // rows (KC) or k rows (MN) per thread and piece
+    static_assert(PER % 3 == 0 && RPT >= 1, "tile");
+    u32x4 r[PER];
+    long off[RPT];                                       // KC: storage offset of this thread's rows (looked up once)
+    long koff[RPT], knext[RPT];                          // MN: storage offset of this chunk's / the next chunk's k rows
+
+    // KC: unit (row, kq): row = t / 4 + 64 j, kq = t % 4.   MN: unit (k, cq): k = t / (DIM / 8) + (256 * 8 / DIM) j
+    template <class Map>
+    __device__ __forceinline__ void prepare(long ld, int idx0, int nidx, int k0, int kend, const Map& map) {
+        const int t = threadIdx.x;
+        if (KC) {
+#pragma unroll
+            for (int j = 0; j < RPT; ++j) {
+                const int row = idx0 + (t >> 2) + 64 * j;
+                off[j] = map(row < nidx ? row : nidx - 1) * ld;
+            }
+        } else {
+            lookup(ld, k0, kend, map, knext);
+        }
+    }
+    template <class Map>
+    __device__ __forceinline__ void lookup(long ld, int k0, int kend, const Map& map, long (&dst)[RPT]) {
+        constexpr int KSTEP = 256 * 8 / DIM;
+        const int t = threadIdx.x;
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) {
+            const int k = k0 + t / (DIM / 8) + KSTEP * j;
+            dst[j] = k < kend ? map(k) * ld : -1;
+        }
+    }
+    // the chunk at k0 into registers; MN: also looks up the storage rows of the chunk after it
+    template <class Map>
+    __device__ __forceinline__ void load(const unsigned short* base, long ld, long pstride, int idx0, int nidx, int k0,
+                                         int kend, const Map& map) {
+        const int t = threadIdx.x;
+        if (KC) {
+            const int k = k0 + (t & 3) * 8;
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int j = 0; j < RPT; ++j) {
+                    r[q * RPT + j] = u32x4{0u, 0u, 0u, 0u};
+                    if (k < kend) r[q * RPT + j] = *reinterpret_cast<const u32x4*>(base + q * pstride + off[j] + k);
+                }
+        } else {
+#pragma unroll
+            for (int j = 0; j < RPT; ++j) koff[j] = knext[j];
+            const int c = idx0 + (t % (DIM / 8)) * 8;
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int j = 0; j < RPT; ++j) {
+                    r[q * RPT + j] = u32x4{0u, 0u, 0u, 0u};
+                    if (koff[j] >= 0 && c < nidx) r[q * RPT + j] = *reinterpret_cast<const u32x4*>(base + q * pstride + koff[j] + c);
+                }
+            lookup(ld, k0 + 32, kend, map, knext);
+        }
+    }
+};
+
+template <bool KC, int DIM>
+__device__ __forceinline__ void plane_store(unsigned char* S, const PlaneTile<KC, DIM>& l) {
+    using I = X3Image<KC, DIM>;
+    using T = PlaneTile<KC, DIM>;
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int j = 0; j < T::RPT; ++j) {
+            if (KC) {
+                const int row = (t >> 2) + 64 * j, kq = t & 3;
+                *reinterpret_cast<u32x4*>(S + q * I::PIECE + row * 64 + (((kq + (row >> 2)) & 3) << 4)) = l.r[q * T::RPT + j];
+            } else {
+                const int k = t / (DIM / 8) + (256 * 8 / DIM) * j, cq = t % (DIM / 8);
+                *reinterpret_cast<u32x4*>(S + q * I::PIECE + k * I::STRIDE + cq * 16) = l.r[q * T::RPT + j];
+            }
+        }
+}
+
+__device__ __forceinline__ float bf16_lo(unsigned w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_p3_kernel(Gemm3Args p) {
+    constexpr int BM = 128, BN = 128, BK = 32, WGN = 2, WM = 64, WN = 64, TM = 2, TN = 2;
+    using IA = X3Image<A_KC, BM>;
+    using IB = X3Image<B_KC, BN>;
+    __shared__ __attribute__((aligned(16))) unsigned char As[IA::BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[IB::BYTES];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    int id = blockIdx.x;
+    const int s = id % p.split; id /= p.split;
+    const int nt = id % p.ntiles;
+    const int mt = id / p.ntiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int kbeg = s * p.kslab;
+    const int kend = min(p.K, kbeg + p.kslab);
+    const RowMap amap{p.perm, p.cursor ? *p.cursor : 0};
+    const Identity ident;
+
+    PlaneTile<A_KC, BM> la;
+    PlaneTile<B_KC, BN> lb;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const bool do_colsum = !B_KC && p.colsum && mt == 0;     // column sums of B (the Dense bias gradient)
+    float csum[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) csum[j] = 0.f;
+
+    const int wm0 = (wave / WGN) * WM, wn0 = (wave % WGN) * WN;
+    const int nchunks = (kend - kbeg + BK - 1) / BK;
+
+    la.prepare(p.lda, m0, p.M, kbeg, kend, amap);
+    lb.prepare(p.ldb, n0, p.N, kbeg, kend, ident);
+    la.load(p.A, p.lda, p.pa, m0, p.M, kbeg, kend, amap);
+    lb.load(p.B, p.ldb, p.pb, n0, p.N, kbeg, kend, ident);
+    for (int c = 0; c < nchunks; ++c) {
+        plane_store<A_KC, BM>(As, la);
+        plane_store<B_KC, BN>(Bs, lb);
+        if constexpr (!B_KC) {
+            if (do_colsum) {
+                using T = PlaneTile<false, BN>;
+#pragma unroll
+                for (int u = 0; u < T::PER; ++u)
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) { csum[2 * w] += bf16_lo(lb.r[u][w]); csum[2 * w + 1] += bf16_hi(lb.r[u][w]); }
+            }
+        }
+        __syncthreads();
+        if (c + 1 < nchunks) {
+            const int k0 = kbeg + (c + 1) * BK;
+            la.load(p.A, p.lda, p.pa, m0, p.M, k0, kend, amap);
+            lb.load(p.B, p.ldb, p.pb, n0, p.N, k0, kend, ident);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            u32x4 a[TM][3], b[TN][3];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) a[i][q] = IA::frag(As, wm0 + i * 32, ks, q, lane);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) b[j][q] = IB::frag(Bs, wn0 + j * 32, ks, q, lane);
+#pragma unroll
+            for (int pr = 0; pr < 6; ++pr) {
+                constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = MFMA16(a[i][PA[pr]], b[j][PB[pr]], acc[i][j]);
+            }
+        }
+        __syncthreads();
+    }
+
+    const int Mo = p.M + (p.colsum ? 1 : 0);
+    float* out = p.split > 1 ? p.ws + (long)s * Mo * p.N : p.C;
+    const long ldo = p.split > 1 ? (long)p.N : p.ldc;
+    const bool add_bias = p.split == 1 && p.bias != nullptr;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn0 + j * 32 + (lane & 31);
+        const float bv = (add_bias && n < p.N) ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < p.M && n < p.N) out[(long)m * ldo + n] = acc[i][j][r] + bv;
+            }
+        }
+    }
+    if constexpr (!B_KC) {
+        if (do_colsum) {
+            // per-thread sums of the k rows this thread stored (columns 8 (t % 16) .. + 7), combined over the 16 row groups
+            float* red = reinterpret_cast<float*>(As);             // safe: the loop ended with a barrier
+            static_assert(16 * BN * 4 <= IA::BYTES, "column-sum scratch");
+            const int c8 = (t & 15) * 8, kr = t >> 4;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) red[kr * BN + c8 + j] = csum[j];
+            __syncthreads();
+            if (t < BN) {
+                float v = 0.f;
+                for (int q = 0; q < 16; ++q) v += red[q * BN + t];
+                const int n = n0 + t;
+                if (n < p.N) out[(long)p.M * ldo + n] = v;
+            }
+        }
+    }
+}
+
+// ---- the same product for LARGE outputs: 256 x 256 tiles, 8 waves (2 x 4, 128 x 64 per wave), K steps of 16 staged
+// DIRECTLY global -> LDS (global_load_lds_dwordx4: no staging registers, no LDS store pass) into a ring of three stages,
+// requested two steps ahead and retired with a counted s_waitcnt vmcnt (never 0 in the steady state), ONE barrier per
+// step.  Per step and wave: 18 fragment reads feed 48 MFMAs (the 128 x 128 kernel above: 24 feed 48, with a store pass
+// and two barriers per 32 k) -- the LDS pipe is what bounds that one (75 % busy at its MFMA rate).
+// LDS images, one plane of one operand of one stage:
+//   k-contiguous    [256 rows][16 k] bf16 = 32-byte rows; a fragment (8 k of one row) is half a row: one wave's
+//                   ds_read_b128 covers 1 KB contiguous -- conflict-free.  Thread t brings row t / 2, half t % 2.
+//   m/n-contiguous  16 k rows of 256 columns; wave w brings k rows w and w + 8 as ONE 1 KB chunk (a wave's
+//                   global_load_lds lands lane-linear), chunks 1088 bytes apart: the four consecutive k rows a lane group
+//                   of the transposing read touches sit 64 bytes modulo 128 apart (X3Image's rule).
+// Order of events in step k (stage k % 3):  wait vmcnt(6) [own requests of step k have landed; step k + 1's 6 stay in
+// flight] -> barrier [everybody's have; everybody has read step k - 1] -> request step k + 2 into the stage step k - 1
+// used -> fragments of step k -> MFMAs.
+constexpr int kWBK = 16;
+template <bool KC>
+struct WideImage {
+    static constexpr int CHUNK = KC ? 1024 : 1088;         // bytes between the LDS destinations of consecutive waves
+    static constexpr int PLANE = 8 * CHUNK;
+    static constexpr int BYTES = 3 * PLANE;
+    // Fragment reads are ISSUED here (inline asm: the compiler neither reorders them nor guards them with a vmcnt(0)
+    // against the LDS-DMA requests in flight) and RETIRED by the caller with a counted s_waitcnt lgkmcnt.
+    // lane_off: this lane's byte offset inside a plane for row / column tile 0 of the wave
+    static __device__ __forceinline__ unsigned lane_off(int idx0, int lane) {
+        const int l31 = lane & 31, hi = lane >> 5;
+        if (KC) return (unsigned)((idx0 + l31) * 32 + hi * 16);
+        const int t16 = lane & 15, r = t16 >> 2;           // k rows 8 hi + r and 8 hi + r + 4
+        return (unsigned)(r * CHUNK + hi * 512 + (idx0 + 16 * ((lane >> 4) & 1) + 4 * (t16 & 3)) * 2);
+    }
+    static constexpr int READS = KC ? 1 : 2;               // LDS instructions per fragment
+    // fragment of piece Q, tile TILE (32 rows / columns further per tile) at LDS address `addr` (stage + operand + lane_off)
+    template <int Q, int TILE>
+    static __device__ __forceinline__ void issue(u32x4& f, unsigned addr) {
+        if constexpr (KC) {
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f) : "v"(addr), "n"(Q * PLANE + TILE * 32 * 32));
+        } else {
+            u32x2 lo, hi;
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(addr), "n"(Q * PLANE + TILE * 64));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "n"(Q * PLANE + TILE * 64 + 4 * CHUNK));
+            f = u32x4{lo[0], lo[1], hi[0], hi[1]};
+        }
+    }
+    // this thread's source element offset inside a plane at k = 0 (add k for KC, k * ld for MN)
+    static __device__ __forceinline__ long src_off(int t, long ld, int idx0, int nidx) {
+        if (KC) {
+            const int row = idx0 + (t >> 1);
+            return (long)(row < nidx ? row : nidx - 1) * ld + (t & 1) * 8;
+        } else {
+            const int l = t & 63, kk = (t >> 6) + 8 * (l >> 5);
+            int c = idx0 + (l & 31) * 8;
+            if (c >= nidx) c = 0;                            // (columns outside the matrix: any readable address)
+            return (long)kk * ld + c;
+        }
+    }
+};
+
+template <bool A_KC, bool B_KC, bool CS>
+__global__ __launch_bounds__(512) void gemm_p3w_kernel(Gemm3Args p) {
+    using IA = WideImage<A_KC>;
+    using IB = WideImage<B_KC>;
+    constexpr int STAGE = IA::BYTES + IB::BYTES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    int id = blockIdx.x;
+    const int s = id % p.split; id /= p.split;
+    const int nt = id % p.ntiles;
+    const int mt = id / p.ntiles;
+    const int m0 = mt * 256, n0 = nt * 256;
+    const int kbeg = s * p.kslab;
+    const int kend = min(p.K, kbeg + p.kslab);
+    const int nsteps = (kend - kbeg) / kWBK;
+
+    // the source of this thread's unit in the step to request next (advanced by one step per request)
+    const unsigned short* ga = p.A + IA::src_off(t, p.lda, m0, p.M) + (A_KC ? (long)kbeg : (long)kbeg * p.lda);
+    const unsigned short* gb = p.B + IB::src_off(t, p.ldb, n0, p.N) + (B_KC ? (long)kbeg : (long)kbeg * p.ldb);
+    const long sa = A_KC ? (long)kWBK : (long)kWBK * p.lda, sb = B_KC ? (long)kWBK : (long)kWBK * p.ldb;
+    const int wa = wave * IA::CHUNK, wb = IA::BYTES + wave * IB::CHUNK;
+
+    auto request = [&](int stage) __attribute__((always_inline)) {
+        unsigned char* st = lds + stage * STAGE;
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga + q * p.pa),
+                                             (__attribute__((address_space(3))) void*)(st + q * IA::PLANE + wa), 16, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + q * p.pb),
+                                             (__attribute__((address_space(3))) void*)(st + q * IB::PLANE + wb), 16, 0, 0);
+        ga += sa; gb += sb;
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int wm0 = (wave >> 2) * 128, wn0 = (wave & 3) * 64;
+    const unsigned aoff = IA::lane_off(wm0, lane), boff = IB::lane_off(wn0, lane);
+    const bool do_colsum = CS && !B_KC && p.colsum && mt == 0 && (wave >> 2) == 0;
+    float csum[2] = {0.f, 0.f};
+
+    if (nsteps > 0) request(0);
+    if (nsteps > 1) request(1);
+    int cur = 0, nxt = 2;                                  // stage of step k, stage step k + 2 goes to
+#pragma unroll 1
+    for (int k = 0; k < nsteps; ++k) {
+        if (k + 1 < nsteps) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const unsigned sa_ = (unsigned)(cur * STAGE) + aoff, sb_ = (unsigned)(cur * STAGE + IA::BYTES) + boff;
+        const int rq = nxt;
+        cur = cur == 2 ? 0 : cur + 1; nxt = nxt == 2 ? 0 : nxt + 1;
+        // fragments: B (2 column tiles x 3 pieces), then A row tile by row tile, each requested one tile ahead of its
+        // products; waits are counted in LDS instructions still allowed in flight (they return in order)
+        u32x4 b[2][3], a[2][3];
+        IB::template issue<0, 0>(b[0][0], sb_); IB::template issue<1, 0>(b[0][1], sb_); IB::template issue<2, 0>(b[0][2], sb_);
+        IB::template issue<0, 1>(b[1][0], sb_); IB::template issue<1, 1>(b[1][1], sb_); IB::template issue<2, 1>(b[1][2], sb_);
+        IA::template issue<0, 0>(a[0][0], sa_); IA::template issue<1, 0>(a[0][1], sa_); IA::template issue<2, 0>(a[0][2], sa_);
+#define DCA_TIE6(x) "+v"(x[0][0]), "+v"(x[0][1]), "+v"(x[0][2]), "+v"(x[1][0]), "+v"(x[1][1]), "+v"(x[1][2])
+#define DCA_WAIT_LGKM(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" : DCA_TIE6(a), DCA_TIE6(b))
+#define DCA_PRODUCTS(I, AI) do { _Pragma("unroll") for (int pr = 0; pr < 6; ++pr) { \
+            constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0}; \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[I][j] = MFMA16(a[AI][PA[pr]], b[j][PB[pr]], acc[I][j]); } } while (0)
+        IA::template issue<0, 1>(a[1][0], sa_); IA::template issue<1, 1>(a[1][1], sa_); IA::template issue<2, 1>(a[1][2], sa_);
+        if (k + 2 < nsteps) request(rq);                   // (behind the first fragment reads: their latency covers the issue)
+        if constexpr (IA::READS == 1) DCA_WAIT_LGKM(3); else DCA_WAIT_LGKM(6);
+        if constexpr (CS && !B_KC) {
+            if (do_colsum) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) csum[j] += bf16_lo(b[j][q][w]) + bf16_hi(b[j][q][w]);
+            }
+        }
+        DCA_PRODUCTS(0, 0);
+        IA::template issue<0, 2>(a[0][0], sa_); IA::template issue<1, 2>(a[0][1], sa_); IA::template issue<2, 2>(a[0][2], sa_);
+        if constexpr (IA::READS == 1) DCA_WAIT_LGKM(3); else DCA_WAIT_LGKM(6);
+        DCA_PRODUCTS(1, 1);
+        IA::template issue<0, 3>(a[1][0], sa_); IA::template issue<1, 3>(a[1][1], sa_); IA::template issue<2, 3>(a[1][2], sa_);
+        if constexpr (IA::READS == 1) DCA_WAIT_LGKM(3); else DCA_WAIT_LGKM(6);
+        DCA_PRODUCTS(2, 0);
+        DCA_WAIT_LGKM(0);
+        DCA_PRODUCTS(3, 1);
+#undef DCA_PRODUCTS
+#undef DCA_WAIT_LGKM
+#undef DCA_TIE6
+    }
+
+    const int Mo = p.M + (p.colsum ? 1 : 0);
+    float* out = p.split > 1 ? p.ws + (long)s * Mo * p.N : p.C;
+    const long ldo = p.split > 1 ? (long)p.N : p.ldc;
+    const bool add_bias = p.split == 1 && p.bias != nullptr;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn0 + j * 32 + (lane & 31);
+        const float bv = (add_bias && n < p.N) ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < p.M && n < p.N) out[(long)m * ldo + n] = acc[i][j][r] + bv;
+            }
+        }
+        if (CS && do_colsum) {
+            // the lane holds the k rows 8 hi .. + 7 of column n: the other half's share through a lane exchange
+            const float tot = csum[j] + __shfl_xor(csum[j], 32, 64);
+            if ((lane >> 5) == 0 && n < p.N) out[(long)p.M * ldo + n] = tot;
+        }
+    }
+}
+
+// fp32 [R, C] (leading dimension ld) -> three bf16 planes [3][R][ldp]: x = p0 + p1 + p2 to 2^-24 |x|; columns C .. ldp - 1
+// are written as zeros (ldp % 8 == 0: 16-byte rows).  One thread = 8 consecutive elements of a row.
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* src, long ld, const int* perm, const long long* cursor,
+                                                           long R, int C, unsigned short* dst, long ldp, long pstride) {
+    const long units = ldp / 8;
+    const long total = R * units;
+    const long long cur = cursor ? *cursor : 0;
+    for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < total; u += (long)gridDim.x * 256) {
+        const long r = u / units;
+        const int c = (int)(u - r * units) * 8;
+        const long sr = perm ? (long)perm[cur + r] : (cursor ? (long)(cur + r) : r);
+        const float* sp = src + sr * ld + c;
+        float v[8];
+        if (c + 8 <= C && (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+            const float4 a = *reinterpret_cast<const float4*>(sp), b = *reinterpret_cast<const float4*>(sp + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = c + j < C ? sp[j] : 0.f;
+        }
+        u32x4 q0, q1, q2;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            unsigned a0, a1, a2;
+            split_pair(v[2 * w], v[2 * w + 1], a0, a1, a2);
+            q0[w] = a0; q1[w] = a1; q2[w] = a2;
+        }
+        unsigned short* dp = dst + r * ldp + c;
+        *reinterpret_cast<u32x4*>(dp) = q0;
+        *reinterpret_cast<u32x4*>(dp + pstride) = q1;
+        *reinterpret_cast<u32x4*>(dp + 2 * pstride) = q2;
+    }
+}
+
 struct Plan {
     int cfg;       // 0: 128x64, 1: 64x128, 2: 128x128, 3: 64x64
     int BM, BN;
@@ -664,6 +1105,110 @@ extern "C" int dcahip_sgemm(int ta, int tb, int M, int N, int K, const float* A,
             hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3((int)g), dim3(256), 0, s, a.ws, p.split, Mo, N,
                                bias, M, C, ldc);
         }
+        rc = (int)hipGetLastError();
+    }
+    return rc;
+}
+
+
+// ---- pre-split operands
+extern "C" int dcahip_split_planes(const float* src, long ld, const int* perm, const long long* cursor, long R, int C,
+                                   void* planes, long ldp, long plane_stride, void* stream) {
+    if (!src || !planes || R <= 0 || C <= 0 || ld < C || ldp < C || ldp % 8 != 0 || plane_stride < R * ldp) return DCAHIP_EINVAL;
+    if (!al16(planes) || plane_stride % 8 != 0) return DCAHIP_EINVAL;
+    const long total = R * (ldp / 8);
+    long g = (total + 255) / 256;
+    if (g > 16384) g = 16384;
+    hipLaunchKernelGGL(split_planes_kernel, dim3((int)g), dim3(256), 0, static_cast<hipStream_t>(stream), src, ld, perm, cursor,
+                       R, C, static_cast<unsigned short*>(planes), ldp, plane_stride);
+    return (int)hipGetLastError();
+}
+
+// wide: the 256 x 256 kernel (large outputs, K a multiple of 16, no row gather: the caller says so)
+static Plan make_plan3(int M, int N, int K, int split_k, bool wide) {
+    Plan p;
+    p.cfg = wide ? 4 : 2; p.BM = p.BN = wide ? 256 : 128;
+    p.mtiles = (M + p.BM - 1) / p.BM;
+    p.ntiles = (N + p.BN - 1) / p.BN;
+    const int nchunks = (K + kBK - 1) / kBK;
+    int S = split_k;
+    if (S <= 0) {
+        const long tiles = (long)p.mtiles * p.ntiles;
+        const long target = wide ? 256 : 512;           // one / two workgroups per CU
+        S = 1;
+        if (tiles < target) {
+            S = (int)(target / tiles);
+            if (S > nchunks / 4) S = nchunks / 4;
+            if (S > 64) S = 64;
+            if (S < 1) S = 1;
+        }
+    }
+    if (S > nchunks) S = nchunks;
+    if (S < 1) S = 1;
+    const int cps = (nchunks + S - 1) / S;
+    p.kslab = cps * kBK;
+    p.split = (nchunks + cps - 1) / cps;
+    return p;
+}
+
+static bool p3_wide(int M, int N, int K, const int* perm, const long long* cursor) {
+    return M >= 256 && N >= 256 && K % 16 == 0 && (long)M * N >= 512L * 512 && !perm && !cursor;
+}
+
+extern "C" long dcahip_gemm_p3_workspace_bytes(int M, int N, int K, int colsum_row, int split_k) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    // (the larger of the two plans a call of this shape can take: with and without a row gather)
+    const Plan pw = make_plan3(M, N, K, split_k, p3_wide(M, N, K, nullptr, nullptr));
+    const Plan pn = make_plan3(M, N, K, split_k, false);
+    const Plan p = pw.split > pn.split ? pw : pn;
+    if (p.split <= 1) return 0;
+    return (long)p.split * (M + (colsum_row ? 1 : 0)) * N * (long)sizeof(float);
+}
+
+extern "C" int dcahip_gemm_p3(int ta, int tb, int M, int N, int K, const void* A, long lda, long plane_a,
+                              const void* B, long ldb, long plane_b, float* C, long ldc, const float* bias,
+                              const int* perm, const long long* cursor, int colsum_row, int split_k,
+                              void* workspace, long workspace_bytes, void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C || ldc < N) return DCAHIP_EINVAL;
+    if (colsum_row && tb) return DCAHIP_EINVAL;
+    if (!al16(A) || !al16(B) || lda % 8 != 0 || ldb % 8 != 0 || plane_a % 8 != 0 || plane_b % 8 != 0) return DCAHIP_EINVAL;
+    // k-contiguous operands are read in units of 8 k: K must be a multiple of 8 (pad both operands with zeros)
+    if ((!ta || tb) && K % 8 != 0) return DCAHIP_EINVAL;
+    // rows must cover the 16-byte units the tile reads: ld >= the extent rounded up to 8
+    if ((ta ? lda < (M + 7) / 8 * 8 : lda < K) || (tb ? ldb < K : ldb < (N + 7) / 8 * 8)) return DCAHIP_EINVAL;
+    const Plan p = make_plan3(M, N, K, split_k, p3_wide(M, N, K, perm, cursor));
+    const long need = p.split > 1 ? (long)p.split * (M + (colsum_row ? 1 : 0)) * N * (long)sizeof(float) : 0;
+    if (need > 0 && (!workspace || workspace_bytes < need)) return DCAHIP_EINVAL;
+    Gemm3Args a{static_cast<const unsigned short*>(A), static_cast<const unsigned short*>(B), lda, ldb, plane_a, plane_b,
+                C, bias, perm, cursor, static_cast<float*>(workspace), ldc, M, N, K, p.split, p.kslab, colsum_row,
+                p.mtiles, p.ntiles};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int grid = p.mtiles * p.ntiles * p.split;
+    if (p.cfg == 4) {
+        // (dynamic LDS above 64 KB needs the attribute once per kernel)
+#define DCA_W(AKC, BKC, CSV) do { \
+            constexpr int bytes = 3 * (WideImage<AKC>::BYTES + WideImage<BKC>::BYTES); \
+            static bool set = false; \
+            if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_p3w_kernel<AKC, BKC, CSV>), \
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, bytes); set = true; } \
+            hipLaunchKernelGGL((gemm_p3w_kernel<AKC, BKC, CSV>), dim3(grid), dim3(512), bytes, s, a); } while (0)
+        if (!ta && !tb) { if (colsum_row) DCA_W(true, false, true); else DCA_W(true, false, false); }
+        else if (!ta && tb) DCA_W(true, true, false);
+        else if (ta && !tb) { if (colsum_row) DCA_W(false, false, true); else DCA_W(false, false, false); }
+        else DCA_W(false, true, false);
+#undef DCA_W
+    } else if (!ta && !tb) hipLaunchKernelGGL((gemm_p3_kernel<true, false>), dim3(grid), dim3(256), 0, s, a);
+    else if (!ta && tb) hipLaunchKernelGGL((gemm_p3_kernel<true, true>), dim3(grid), dim3(256), 0, s, a);
+    else if (ta && !tb) hipLaunchKernelGGL((gemm_p3_kernel<false, false>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((gemm_p3_kernel<false, true>), dim3(grid), dim3(256), 0, s, a);
+    int rc = (int)hipGetLastError();
+    if (rc != 0) return rc;
+    if (p.split > 1) {
+        const int Mo = M + (colsum_row ? 1 : 0);
+        const long total = (long)Mo * N;
+        long g = (total + 255) / 256;
+        if (g > 4096) g = 4096;
+        hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3((int)g), dim3(256), 0, s, a.ws, p.split, Mo, N, bias, M, C, ldc);
         rc = (int)hipGetLastError();
     }
     return rc;

@@ -86,6 +86,12 @@ _SIGNATURES = {
                                 _f32p, _c.c_long, _f32p, _c.c_long, _f32p, _i32p, _i64p, _c.c_int,
                                 _c.c_int, _vp, _c.c_long, _vp]),
     'dcahip_sgemm_workspace_bytes': (_c.c_long, [_c.c_int] * 7),
+    'dcahip_split_planes': (_c.c_int, [_f32p, _c.c_long, _c.c_void_p, _c.c_void_p, _c.c_long, _c.c_int, _c.c_void_p,
+                                       _c.c_long, _c.c_long, _c.c_void_p]),
+    'dcahip_gemm_p3': (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_long, _c.c_long,
+                                  _c.c_void_p, _c.c_long, _c.c_long, _f32p, _c.c_long, _f32p, _c.c_void_p, _c.c_void_p,
+                                  _c.c_int, _c.c_int, _c.c_void_p, _c.c_long, _c.c_void_p]),
+    'dcahip_gemm_p3_workspace_bytes': (_c.c_long, [_c.c_int] * 5),
     'dcahip_col_moments_chunks': (_c.c_int, [_c.c_int]),
     'dcahip_col_moments': (_c.c_int, [_f32p, _c.c_long, _c.c_int, _c.c_int, _f32p, _vp]),
     'dcahip_moments_combine': (_c.c_int, [_f32p, _f32p, _c.c_int, _c.c_int, _f32p, _vp]),

@@ -7,6 +7,8 @@ same methods; that object lives under oracle/ and is never imported from this pa
 """
 import ctypes
 
+import torch
+
 from . import hip
 
 
@@ -121,6 +123,28 @@ class HipOps:
         hip.check(self.L.dcahip_sgemm(int(ta), int(tb), M, N, K, p(A), lda, p(B), ldb, p(C), ldc,
                                       p(bias), p(perm), p(cursor), int(colsum_row), split_k, p(ws),
                                       wsb, hip.stream()), 'sgemm')
+
+    # ------------------------------------------------------------------ products from pre-split operands
+    def planes_alloc(self, rows, cols, device):
+        """Three bf16 planes [3, rows, r8(cols)] (zeros)."""
+        return torch.zeros(3, rows, (cols + 7) // 8 * 8, dtype=torch.bfloat16, device=device)
+
+    def split_planes(self, src, ld, R, C, planes, perm=None, cursor=None):
+        """planes [3, >= R, ldp] <- the three bf16 pieces of src [R, C] (rows gathered through perm / cursor)."""
+        hip.check(self.L.dcahip_split_planes(hip.ptr(src), ld, hip.ptr(perm), hip.ptr(cursor), R, C, hip.ptr(planes),
+                                             planes.shape[2], planes.stride(0), hip.stream()), 'split_planes')
+
+    def gemm_p3_workspace_bytes(self, M, N, K, colsum_row=False, split_k=0):
+        return self.L.dcahip_gemm_p3_workspace_bytes(M, N, K, int(colsum_row), split_k)
+
+    def gemm_p3(self, ta, tb, M, N, K, A, B, C, ldc, bias=None, perm=None, cursor=None, colsum_row=False, split_k=0,
+                ws=None):
+        """C = op(A) op(B) from planes A, B ([3, rows, ld] bf16 tensors or views of them)."""
+        p = hip.ptr
+        wsb = ws.numel() * ws.element_size() if ws is not None else 0
+        hip.check(self.L.dcahip_gemm_p3(int(ta), int(tb), M, N, K, p(A), A.stride(1), A.stride(0), p(B), B.stride(1),
+                                        B.stride(0), p(C), ldc, p(bias), p(perm), p(cursor), int(colsum_row), split_k,
+                                        p(ws), wsb, hip.stream()), 'gemm_p3')
 
     def transpose(self, src, ld_src, R, C, dst, ld_dst, perm=None, cursor=None):
         """dst [C, R] = src[rows]^T; rows = perm[cursor : cursor + R] when perm is given."""

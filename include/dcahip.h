@@ -191,6 +191,28 @@ int dcahip_sgemm(int ta, int tb, int M, int N, int K,
                  int colsum_row, int split_k, void* workspace, long workspace_bytes,
                  void* stream);
 long dcahip_sgemm_workspace_bytes(int ta, int tb, int M, int N, int K, int colsum_row, int split_k);
+/*
+ * The same products from PRE-SPLIT operands.  "Planes" = the three bf16 pieces of a matrix as three images
+ * [3][rows][ld] of bf16 (ld % 8 == 0; plane_stride elements from one piece to the next): x = p0 + p1 + p2 to 2^-24 |x|,
+ * the split dcahip_sgemm performs on the fly, done ONCE for an operand that enters several products (the gradient
+ * planes of the heads, the head weights, the normalised counts) or written directly by the kernel that produces it.
+ * dcahip_gemm_p3 has no vector arithmetic in its K loop, and either operand may be contiguous along k or along m / n
+ * (the m / n-contiguous one goes through the transposing LDS read), so ONE stored layout serves the products that
+ * contract over a matrix's rows and over its columns: no transposed copies.  Same arithmetic and accuracy contract as
+ * dcahip_sgemm (dcahip_x3_product_32x32), same argument meaning: ta / tb as there, lda / ldb in elements,
+ * perm / cursor gather A's storage rows, colsum_row (tb == 0) writes the column sums of B into row M of C, split_k 0 =
+ * library heuristic.  An operand contiguous along k is read in units of 8 k: K % 8 == 0 (pad BOTH operands with zeros);
+ * rows of an m / n-contiguous operand must be allocated up to the next multiple of 8 columns.
+ * dcahip_split_planes: fp32 [R, C] (rows gathered through perm / cursor when given) -> planes, columns C .. ldp - 1 zero.
+ * Replaces the same MatMul kernels as dcahip_sgemm (dca/network.py:124-126, 369-380 and autodiff) where an operand is
+ * reused. */
+int dcahip_split_planes(const float* src, long ld, const int* perm, const long long* cursor, long R, int C,
+                        void* planes, long ldp, long plane_stride, void* stream);
+int dcahip_gemm_p3(int ta, int tb, int M, int N, int K, const void* A, long lda, long plane_a,
+                   const void* B, long ldb, long plane_b, float* C, long ldc, const float* bias,
+                   const int* perm, const long long* cursor, int colsum_row, int split_k,
+                   void* workspace, long workspace_bytes, void* stream);
+long dcahip_gemm_p3_workspace_bytes(int M, int N, int K, int colsum_row, int split_k);
 /* dst [C, ld_dst] = src [R, ld_src]^T.  The first Dense layer's kernel W0 [genes, h1] is transposed once per step at
  * throughput batches so that its forward product X W0 runs in the NT form (both operands contiguous along the
  * contraction: the fast operand path of dcahip_sgemm). */
