@@ -775,8 +775,10 @@ __global__ __launch_bounds__(256) void gemm_p3_kernel(Gemm3Args p) {
 // step.  Per step and wave: 18 fragment reads feed 48 MFMAs (the 128 x 128 kernel above: 24 feed 48, with a store pass
 // and two barriers per 32 k) -- the LDS pipe is what bounds that one (75 % busy at its MFMA rate).
 // LDS images, one plane of one operand of one stage:
-//   k-contiguous    [256 rows][16 k] bf16 = 32-byte rows; a fragment (8 k of one row) is half a row: one wave's
-//                   ds_read_b128 covers 1 KB contiguous -- conflict-free.  Thread t brings row t / 2, half t % 2.
+//   k-contiguous    [256 rows][16 k] bf16 = 32-byte rows; a fragment (8 k of one row) is half a row.  Thread t brings row
+//                   t / 2, half t % 2 -- with the halves of rows 8..15 (mod 16) swapped: the 16 lanes of one phase of a
+//                   ds_read_b128 (16 consecutive rows, one k half) then cover the 64 banks once (unswapped, rows r and
+//                   r + 8 collide: SQ_LDS_BANK_CONFLICT 40 % of the LDS cycles).
 //   m/n-contiguous  16 k rows of 256 columns; wave w brings k rows w and w + 8 as ONE 1 KB chunk (a wave's
 //                   global_load_lds lands lane-linear), chunks 1088 bytes apart: the four consecutive k rows a lane group
 //                   of the transposing read touches sit 64 bytes modulo 128 apart (X3Image's rule).
@@ -794,7 +796,7 @@ struct WideImage {
     // lane_off: this lane's byte offset inside a plane for row / column tile 0 of the wave
     static __device__ __forceinline__ unsigned lane_off(int idx0, int lane) {
         const int l31 = lane & 31, hi = lane >> 5;
-        if (KC) return (unsigned)((idx0 + l31) * 32 + hi * 16);
+        if (KC) return (unsigned)((idx0 + l31) * 32 + ((hi ^ ((l31 >> 3) & 1)) * 16));   // (halves of rows 8..15 mod 16 swapped)
         const int t16 = lane & 15, r = t16 >> 2;           // k rows 8 hi + r and 8 hi + r + 4
         return (unsigned)(r * CHUNK + hi * 512 + (idx0 + 16 * ((lane >> 4) & 1) + 4 * (t16 & 3)) * 2);
     }
@@ -814,8 +816,10 @@ struct WideImage {
     // this thread's source element offset inside a plane at k = 0 (add k for KC, k * ld for MN)
     static __device__ __forceinline__ long src_off(int t, long ld, int idx0, int nidx) {
         if (KC) {
-            const int row = idx0 + (t >> 1);
-            return (long)(row < nidx ? row : nidx - 1) * ld + (t & 1) * 8;
+            // LDS slot t = (row t / 2, physical half t % 2); rows 8..15 (mod 16) keep their halves swapped, so that the
+            // 16 lanes of a ds_read_b128 phase (rows r .. r + 15, one k half) cover the 64 banks once
+            const int r = t >> 1, row = idx0 + r;
+            return (long)(row < nidx ? row : nidx - 1) * ld + (((t & 1) ^ ((r >> 3) & 1)) * 8);
         } else {
             const int l = t & 63, kk = (t >> 6) + 8 * (l >> 5);
             int c = idx0 + (l & 31) * 8;
@@ -877,9 +881,15 @@ __global__ __launch_bounds__(512) void gemm_p3w_kernel(Gemm3Args p) {
     int cur = 0, nxt = 2;                                  // stage of step k, stage step k + 2 goes to
 #pragma unroll 1
     for (int k = 0; k < nsteps; ++k) {
+#ifdef DCA_EXP_W_NOLOAD
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
         if (k + 1 < nsteps) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+#ifndef DCA_EXP_W_NOBAR
         __builtin_amdgcn_s_barrier();
+#endif
         asm volatile("" ::: "memory");
         const unsigned sa_ = (unsigned)(cur * STAGE) + aoff, sb_ = (unsigned)(cur * STAGE + IA::BYTES) + boff;
         const int rq = nxt;
@@ -896,7 +906,9 @@ __global__ __launch_bounds__(512) void gemm_p3w_kernel(Gemm3Args p) {
             constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0}; \
             _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[I][j] = MFMA16(a[AI][PA[pr]], b[j][PB[pr]], acc[I][j]); } } while (0)
         IA::template issue<0, 1>(a[1][0], sa_); IA::template issue<1, 1>(a[1][1], sa_); IA::template issue<2, 1>(a[1][2], sa_);
+#ifndef DCA_EXP_W_NOLOAD
         if (k + 2 < nsteps) request(rq);                   // (behind the first fragment reads: their latency covers the issue)
+#endif
         if constexpr (IA::READS == 1) DCA_WAIT_LGKM(3); else DCA_WAIT_LGKM(6);
         if constexpr (CS && !B_KC) {
             if (do_colsum) {

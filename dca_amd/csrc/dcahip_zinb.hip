@@ -28,7 +28,39 @@ struct NllArgs {
     double* partials;
     int B, G;
     float ridge, inv_n;
+    // gradient planes as pre-split bf16 pieces (dcahip_zinb_nll_planes): piece q of head plane h, element (row, g) at
+    // pl[h] + q * pstride + row * ldp + g
+    unsigned short* pl[3];
+    long ldp, pstride;
 };
+
+// the three bf16 pieces of fp32 values (x = p0 + p1 + p2 to 2^-24 |x|: the split of dcahip_sgemm / dcahip_split_planes)
+using bf16x2v = __attribute__((ext_vector_type(2))) __bf16;
+using f32x2v = __attribute__((ext_vector_type(2))) float;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{a, b}, bf16x2v));
+}
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& p0, unsigned& p1, unsigned& p2) {
+    p0 = pk_bf16(x0, x1);
+    const float r0 = x0 - __uint_as_float(p0 << 16), r1 = x1 - __uint_as_float(p0 & 0xffff0000u);
+    p1 = pk_bf16(r0, r1);
+    const float q0 = r0 - __uint_as_float(p1 << 16), q1 = r1 - __uint_as_float(p1 & 0xffff0000u);
+    p2 = pk_bf16(q0, q1);
+}
+__device__ __forceinline__ void store_planes4(unsigned short* base, long pstride, const float (&v)[4]) {
+    unsigned a0, a1, a2, b0, b1, b2;
+    split_pair(v[0], v[1], a0, a1, a2);
+    split_pair(v[2], v[3], b0, b1, b2);
+    *reinterpret_cast<u32x2*>(base) = u32x2{a0, b0};
+    *reinterpret_cast<u32x2*>(base + pstride) = u32x2{a1, b1};
+    *reinterpret_cast<u32x2*>(base + 2 * pstride) = u32x2{a2, b2};
+}
+__device__ __forceinline__ void store_planes1(unsigned short* base, long pstride, float v) {
+    unsigned a0, a1, a2;
+    split_pair(v, 0.f, a0, a1, a2);
+    base[0] = (unsigned short)a0; base[pstride] = (unsigned short)a1; base[2 * pstride] = (unsigned short)a2;
+}
 
 __device__ __forceinline__ double block_reduce_sum(double v) {
     __shared__ double red[4];
@@ -127,9 +159,10 @@ __global__ __launch_bounds__(256) void zinb_nll_kernel(NllArgs a) {
 //     16-byte stores of the same wave: `s_waitcnt vmcnt(0)` in between orders them).
 // Before: both branches for every wave-row (~370 VALU per element) at 3.0-3.2 TB/s = 0.38-0.40 of the HBM peak.
 constexpr int kNzCap = 64 + 256;      // entries per wave: < 64 left over + up to 4 x 64 pushed per row
-struct NzEntry { float am, ad, ap, y, sf; unsigned dof; };
+struct NzEntry { float am, ad, ap, y, sf; unsigned dof, dof2; };     // dof2: the fp32 dispersion plane beside bf16 planes
 
-template <bool HAS_PI, bool CONST_DISP, bool GRAD>
+// PL: the gradient planes leave as pre-split bf16 pieces (a.pl; the per-gene dispersion plane of CONST_DISP stays fp32)
+template <bool HAS_PI, bool CONST_DISP, bool GRAD, bool PL = false>
 __global__ __launch_bounds__(256, 4) void zinb_nll_compact_kernel(NllArgs a) {     // 4 waves per SIMD: 128 registers
     constexpr int V = 4;
     __shared__ NzEntry queue[4][kNzCap];
@@ -158,9 +191,15 @@ __global__ __launch_bounds__(256, 4) void zinb_nll_compact_kernel(NllArgs a) {  
             lsp += act ? nll : 0.f;
             if (GRAD && act) {
                 __builtin_amdgcn_s_waitcnt(0x0f70);                       // vmcnt(0): the dense stores of these addresses are done
-                a.d_mean[e.dof] = o1 * a.inv_n;
-                a.d_disp[e.dof] = o2 * a.inv_n;
-                if (HAS_PI) a.d_pi[e.dof] = o3 * a.inv_n;
+                if (PL) {
+                    store_planes1(a.pl[0] + e.dof, a.pstride, o1 * a.inv_n);
+                    if (CONST_DISP) a.d_disp[e.dof2] = o2 * a.inv_n; else store_planes1(a.pl[1] + e.dof, a.pstride, o2 * a.inv_n);
+                    if (HAS_PI) store_planes1(a.pl[2] + e.dof, a.pstride, o3 * a.inv_n);
+                } else {
+                    a.d_mean[e.dof] = o1 * a.inv_n;
+                    a.d_disp[e.dof] = o2 * a.inv_n;
+                    if (HAS_PI) a.d_pi[e.dof] = o3 * a.inv_n;
+                }
             }
             qn -= c;
         }
@@ -180,7 +219,8 @@ __global__ __launch_bounds__(256, 4) void zinb_nll_compact_kernel(NllArgs a) {  
             srow_n = a.perm ? (long)a.perm[cur + rown] : (long)(cur + rown);
             const float sf = a.sf[srow];
             const long ao = (long)row * a.lda + g;
-            const long dof = (long)row * a.ldd + g;
+            const long dof2 = (long)row * a.ldd + g;
+            const long dof = PL ? (long)row * a.ldp + g : dof2;
             float vm[V] = {0.f, 0.f, 0.f, 0.f}, vp[V] = {0.f, 0.f, 0.f, 0.f}, vy[V] = {0.f, 0.f, 0.f, 0.f};
             if (qv) {
                 ldv<V>(a.a_mean + ao, vm);
@@ -203,16 +243,22 @@ __global__ __launch_bounds__(256, 4) void zinb_nll_compact_kernel(NllArgs a) {  
                 om[j] = gmv * sc; od[j] = gdv * sc; op[j] = gpv * sc;
             }
             if (GRAD && qv) {
-                stv<V>(a.d_mean + dof, om);
-                stv<V>(a.d_disp + dof, od);
-                if (HAS_PI) stv<V>(a.d_pi + dof, op);
+                if (PL) {
+                    store_planes4(a.pl[0] + dof, a.pstride, om);
+                    if (CONST_DISP) stv<V>(a.d_disp + dof2, od); else store_planes4(a.pl[1] + dof, a.pstride, od);
+                    if (HAS_PI) store_planes4(a.pl[2] + dof, a.pstride, op);
+                } else {
+                    stv<V>(a.d_mean + dof, om);
+                    stv<V>(a.d_disp + dof, od);
+                    if (HAS_PI) stv<V>(a.d_pi + dof, op);
+                }
             }
 #pragma unroll
             for (int j = 0; j < V; ++j) {
                 const unsigned long long m = __ballot(nz[j]);
                 if (m) {
                     const int slot = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                    if (nz[j]) Q[slot] = NzEntry{vm[j], vd[j], vp[j], vy[j], sf, (unsigned)(dof + j)};
+                    if (nz[j]) Q[slot] = NzEntry{vm[j], vd[j], vp[j], vy[j], sf, (unsigned)(dof + j), (unsigned)(dof2 + j)};
                     qn += __popcll(m);
                 }
             }
@@ -350,7 +396,7 @@ extern "C" int dcahip_zinb_nll(const float* a_mean, const float* a_disp, const f
                lda >= ((G + 3) & ~3) && ldy >= ((G + 3) & ~3);
     if (grad) vec = vec && (ldd % 4 == 0) && ldd >= ((G + 3) & ~3) && al16(d_mean) && (loss != 0 || al16(d_disp)) && (!has_pi || al16(d_pi));
     NllArgs a{a_mean, a_disp, a_pi, theta_w, y, sf, perm, cursor, lda, ldy, ldd,
-              d_mean, d_disp, d_pi, loss_partials, B, G, ridge, inv_n};
+              d_mean, d_disp, d_pi, loss_partials, B, G, ridge, inv_n, {nullptr, nullptr, nullptr}, 0, 0};
     const int V = vec ? 4 : 1;
     const int nvec = (G + V - 1) / V;
     const int nseg = (nvec + 255) / 256;
@@ -370,6 +416,46 @@ extern "C" int dcahip_zinb_nll(const float* a_mean, const float* a_disp, const f
     if (cdisp) { DCA_DISPATCH(false, true); }
     DCA_DISPATCH(false, false);
 #undef DCA_DISPATCH
+}
+
+extern "C" int dcahip_zinb_nll_planes(const float* a_mean, const float* a_disp, const float* a_pi, long lda,
+                                      const float* theta_w, const float* y, long ldy, const float* sf,
+                                      const int* perm, const long long* cursor, int B, int G, float ridge,
+                                      float inv_n, int flags, void* d_planes, long ldp, long plane_stride,
+                                      long col_mean, long col_disp, long col_pi, float* d_theta, long ldd_theta,
+                                      double* loss_partials, int* n_partials_out, void* stream) {
+    const bool has_pi = flags & DCAHIP_NLL_HAS_PI, cdisp = flags & DCAHIP_NLL_CONST_DISP;
+    if (flags & (DCAHIP_NLL_POISSON | DCAHIP_NLL_MSE)) return DCAHIP_EINVAL;
+    if (B <= 0 || G <= 0 || !a_mean || !y || !sf || !loss_partials || !d_planes) return DCAHIP_EINVAL;
+    if ((has_pi && !a_pi) || (cdisp ? (!theta_w || !d_theta) : !a_disp)) return DCAHIP_EINVAL;
+    const int G4 = (G + 3) & ~3;
+    // 16-byte vectors in, 8-byte piece vectors out; 32-bit element offsets inside a plane
+    if (lda % 4 || ldy % 4 || lda < G4 || ldy < G4 || !al16(a_mean) || !al16(y) || (has_pi && !al16(a_pi)) ||
+        (cdisp ? !al16(theta_w) : !al16(a_disp)))
+        return DCAHIP_EINVAL;
+    if (ldp % 4 || plane_stride % 4 || !al16(d_planes) || col_mean % 4 || (!cdisp && col_disp % 4) || (has_pi && col_pi % 4) ||
+        (long)B * ldp >= (1L << 32) || plane_stride < (long)B * ldp)
+        return DCAHIP_EINVAL;
+    if (col_mean + G4 > ldp || (!cdisp && col_disp + G4 > ldp) || (has_pi && col_pi + G4 > ldp)) return DCAHIP_EINVAL;
+    if (cdisp && (ldd_theta % 4 || ldd_theta < G4 || !al16(d_theta) || (long)B * ldd_theta >= (1L << 32))) return DCAHIP_EINVAL;
+    unsigned short* P = static_cast<unsigned short*>(d_planes);
+    NllArgs a{a_mean, a_disp, a_pi, theta_w, y, sf, perm, cursor, lda, ldy, cdisp ? ldd_theta : 0,
+              nullptr, cdisp ? d_theta : nullptr, nullptr, loss_partials, B, G, ridge, inv_n,
+              {P + col_mean, cdisp ? nullptr : P + col_disp, has_pi ? P + col_pi : nullptr}, ldp, plane_stride};
+    const int nvec = (G + 3) / 4;
+    const int nseg = (nvec + 255) / 256;
+    const int gx = nseg < kMaxPartials ? nseg : kMaxPartials;
+    int gy = kMaxPartials / gx;
+    if (gy > B) gy = B;
+    if (gy < 1) gy = 1;
+    const dim3 grid(gx, gy);
+    if (n_partials_out) *n_partials_out = gx * gy;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (has_pi && cdisp) hipLaunchKernelGGL((zinb_nll_compact_kernel<true, true, true, true>), grid, dim3(256), 0, s, a);
+    else if (has_pi) hipLaunchKernelGGL((zinb_nll_compact_kernel<true, false, true, true>), grid, dim3(256), 0, s, a);
+    else if (cdisp) hipLaunchKernelGGL((zinb_nll_compact_kernel<false, true, true, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((zinb_nll_compact_kernel<false, false, true, true>), grid, dim3(256), 0, s, a);
+    return (int)hipGetLastError();
 }
 
 extern "C" int dcahip_loss_finalize(const double* partials, int n_partials, double scale,

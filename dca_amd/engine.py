@@ -55,6 +55,10 @@ def _r4(x):
     return (x + 3) // 4 * 4
 
 
+def _r16(x):
+    return (x + 15) // 16 * 16
+
+
 class _NullSection:
     def __enter__(self):
         return self
@@ -319,6 +323,7 @@ class Engine:
         self._pending = None        # in-flight all-reduce of the heads bucket (data parallel)
         self.W0T = None             # transposed first-layer kernel (throughput batches)
         self.WhT = self.HT = self.XT = self.dZT = None     # wide networks: transposed head weights / last activations / minibatch / dZ0
+        self.pl = None              # wide networks: operands as bf16 planes (reserve)
         self.opt_kind = 'rmsprop'   # train.py:54-57 picks the Keras optimizer by name
         self.slot2 = None
         self.m_sched = None         # Nadam: running product of the momentum schedule
@@ -693,6 +698,20 @@ class Engine:
                         need = max(need, ops.sgemm_workspace_bytes(0, 0, lay.hL, nc, b, True))
                     if self.XT is not None:
                         need = max(need, ops.sgemm_workspace_bytes(0, 1, lay.G_in, lay.hidden[0], b))
+        self.pl = None
+        if self._wide_planes(B):
+            def planes(rows, cols):
+                return torch.zeros(3, rows, _r16(cols), dtype=torch.bfloat16, device=self.dev)
+            self.pl = {'H': planes(B, lay.hL), 'Wh': planes(_r16(lay.hL), lay.NH), 'D': planes(B, lay.NH)}
+            if lay.hidden[0] >= 128:          # a wide first layer as well: the minibatch, its kernel, its output gradient
+                self.pl.update(X=planes(B, lay.G_in), W0=planes(_r16(lay.G_in), lay.hidden[0]), dZ0=planes(B, lay.hidden[0]))
+            for b in cand:
+                need = max(need, ops.gemm_p3_workspace_bytes(b, lay.NH, _r16(lay.hL)),
+                           ops.gemm_p3_workspace_bytes(lay.hL, lay.NH, b, True),
+                           ops.gemm_p3_workspace_bytes(b, lay.hL, _r16(lay.NH)))
+                if 'X' in self.pl:
+                    need = max(need, ops.gemm_p3_workspace_bytes(b, lay.hidden[0], _r16(lay.G_in)),
+                               ops.gemm_p3_workspace_bytes(lay.G_in, lay.hidden[0], b, True))
         self.ws = torch.zeros(max(need // 4, 4), **f32)
         self.ws_stack = None
         if hasattr(ops, 'hidden_stack_fwd') and max(lay.hidden) <= 64 and len(lay.hidden) <= 8:
@@ -717,6 +736,16 @@ class Engine:
                         ops.enc0_fwd_sparse(self.cc_in, self.perm if gather else None, self.cursor if gather else None,
                                             0 if gather else rows_from[1], B, K, h, Wi, h, bi, self.Z[0], self.ldh[0],
                                             self.ws_enc0f)
+                elif self._planes_enc0(B, training):
+                    # wide first layer at throughput batches: the minibatch split into planes once (the weight gradient
+                    # reads the same planes, contracting over their rows), the kernel split, the product from planes
+                    gather = rows_from[0] == 'perm'
+                    with self._t('gemm_enc0_fwd'):
+                        ops.split_planes(self.X if gather else self.X[rows_from[1]:], self.ldx, B, K, self.pl['X'],
+                                         perm=self.perm if gather else None, cursor=self.cursor if gather else None)
+                        ops.split_planes(Wi, h, K, h, self.pl['W0'])
+                        ops.gemm_p3(0, 0, B, h, _r16(K), self.pl['X'], self.pl['W0'], self.Z[0], self.ldh[0], bias=bi,
+                                    ws=self.ws)
                 elif training and self.in_drop > 0.0:
                     assert rows_from[0] == 'perm'
                     if self.Xb is None or self.Xb.shape[0] < self.Bmax:
@@ -810,12 +839,31 @@ class Engine:
             K = h
         return K
 
+    def _planes_nll(self, B):
+        """K-ZINB writes the heads' gradient planes as bf16 pieces itself (NB / ZINB likelihoods on vector-aligned rows)."""
+        return (self.pl is not None and self._wide_planes(B) and B <= self.pl['D'].shape[1]
+                and not (self.flags & (AE_LOSS_FLAG['poisson'] | AE_LOSS_FLAG['normal'])) and self.ldy % 4 == 0 and self.lay.ldA % 4 == 0
+                and hasattr(self.ops, 'zinb_nll_planes'))
+
+    def _planes_enc0(self, B, training):
+        return (self.pl is not None and 'X' in self.pl and self._wide_planes(B) and B <= self.pl['X'].shape[1]
+                and not (training and self.in_drop > 0.0) and not self._sparse_fwd(B, training))
+
     def _enc0_nt(self, B):
         return self.W0T is not None and B >= 256 and os.environ.get('DCA_AMD_ENC0_NT', '1') != '0'
 
+    def _wide_planes(self, B):
+        """Throughput batches of a network whose heads run as separate kernels (decoder wider than 64 units): every large
+        product from pre-split bf16 planes (dcahip_gemm_p3) -- the operands that enter several products of a step (the
+        heads' gradient planes, the head weights, the minibatch) are split once, and one stored layout serves the products
+        that contract over its rows and over its columns, so no transposed copies are kept."""
+        lay = self.lay
+        return (self.ws_heads is None and B >= 256 and hasattr(self.ops, 'gemm_p3') and not lay.fork and not lay.elempi
+                and not lay.shared and self.comm.world >= 1 and os.environ.get('DCA_AMD_WIDE_PLANES', '1') != '0')
+
     def _wide_transposed(self, B):
-        """Throughput batches of a network whose heads run as separate kernels: transposed operand copies (see reserve)."""
-        return (self.ws_heads is None and B >= 256 and hasattr(self.ops, 'transpose')
+        """The same networks without the planes path: transposed operand copies for K-GEMM's fast forms (see reserve)."""
+        return (self.ws_heads is None and B >= 256 and hasattr(self.ops, 'transpose') and not self._wide_planes(B)
                 and os.environ.get('DCA_AMD_WIDE_T', '1') != '0')
 
     def _stack_small(self, B):
@@ -895,7 +943,11 @@ class Engine:
         lay, ops = self.lay, self.ops
         Wh, bh = lay.view(self.w, 'Wh'), lay.view(self.w, 'bh')
         with self._t('gemm_heads_fwd'):
-            if self.WhT is not None and B >= 256:
+            if self.pl is not None and self._wide_planes(B) and B <= self.pl['H'].shape[1]:
+                ops.split_planes(self.Hcur[-1], self.ldh[-1], B, lay.hL, self.pl['H'])
+                ops.split_planes(Wh, lay.NH, lay.hL, lay.NH, self.pl['Wh'])
+                ops.gemm_p3(0, 0, B, lay.NH, _r16(lay.hL), self.pl['H'], self.pl['Wh'], self.A, lay.ldA, bias=bh, ws=self.ws)
+            elif self.WhT is not None and B >= 256:
                 ops.transpose(Wh, lay.NH, lay.hL, lay.NH, self.WhT, self.WhT.shape[1])
                 for c0, nc, h0 in self._head_blocks():
                     ops.sgemm(0, 1, B, nc, lay.hL, self.Hcur[-1][:, h0:], self.ldh[-1], self.WhT[c0:], self.WhT.shape[1],
@@ -929,6 +981,14 @@ class Engine:
         lay, ops = self.lay, self.ops
         A, D = self.A, self.D
         tw = lay.view(self.w, 'theta_w') if lay.const_disp else None
+        if grad and self._planes_nll(B):
+            # wide networks: the gradient planes leave K-ZINB as the bf16 pieces the two backward products read
+            return ops.zinb_nll_planes(self._plane(A, 'mean'), self._plane(A, 'disp'), self._plane(A, 'pi'), lay.ldA, tw,
+                                       Y, self.ldy, sf, perm, cursor, B, lay.G_out, self.ridge, inv_n, self.flags,
+                                       self.pl['D'], lay.plane_offset('mean'),
+                                       0 if lay.const_disp else lay.plane_offset('disp'),
+                                       lay.plane_offset('pi') if 'pi' in lay.heads else 0,
+                                       self.Dth, self.ldD, self.partials)
         d_disp = (self.Dth if lay.const_disp else self._plane(D, 'disp')) if grad else None
         n = ops.zinb_nll(self._plane(A, 'mean'), self._plane(A, 'disp'), self._plane(A, 'pi'),
                          lay.ldA, tw, Y, self.ldy, sf, perm, cursor, B, lay.G_out, self.ridge,
@@ -1132,6 +1192,10 @@ class Engine:
                     if self._sparse_dw(B):
                         ops.enc0_dw_sparse(self.cc_in, self.perm, self.cursor, 0, B, Kp, h, self.dZ[0], self.ldh[0], gW, h,
                                            self.ws_enc0)
+                    elif self._planes_enc0(B, True):
+                        # the forward's planes of the minibatch, contracted over their rows; bias gradient = column sums
+                        ops.split_planes(self.dZ[0], self.ldh[0], B, h, self.pl['dZ0'])
+                        ops.gemm_p3(1, 0, Kp, h, B, self.pl['X'], self.pl['dZ0'], gW, h, colsum_row=True, ws=self.ws)
                     elif self.in_drop > 0.0:
                         ops.sgemm(1, 0, Kp, h, B, self.Xb, self.ldx, self.dZ[0], self.ldh[0], gW, h,
                                   colsum_row=True, ws=self.ws)
@@ -1161,6 +1225,17 @@ class Engine:
             n = self._nll(B, self.perm, self.cursor, self.Y, self.sf, inv_n, True)
         ops.loss_finalize(self.partials, n, inv_n, g[lay.P:])
         gWh, Wh = lay.view(g, 'Wh'), lay.view(w, 'Wh')
+        if self.pl is not None and self._wide_planes(B) and B <= self.pl['H'].shape[1]:
+            # the gradient planes split once for both products; pl['H'] and pl['Wh'] are the forward's
+            with self._t('gemm_heads_dW'):
+                if not self._planes_nll(B):
+                    ops.split_planes(self.D, self.ldD, B, lay.NH, self.pl['D'])
+                ops.gemm_p3(1, 0, lay.hL, lay.NH, B, self.pl['H'], self.pl['D'], gWh, lay.NH, colsum_row=True, ws=self.ws)
+            if lay.const_disp:
+                ops.colsum_chain(self.Dth, self.ldD, B, lay.G_out, lay.view(w, 'theta_w'), lay.view(g, 'theta_w'))
+            with self._t('gemm_heads_dH'):
+                ops.gemm_p3(0, 1, B, lay.hL, _r16(lay.NH), self.pl['D'], self.pl['Wh'], self.dH[-1], self.ldh[-1], ws=self.ws)
+            return
         with self._t('gemm_heads_dW'):
             if self.HT is not None and B >= 256:
                 hin = self.HT.shape[0]

@@ -56,6 +56,10 @@ _SIGNATURES = {
                                    _i32p, _i64p, _c.c_int, _c.c_int, _c.c_float, _c.c_float,
                                    _c.c_int, _f32p, _f32p, _f32p, _c.c_long, _f64p,
                                    _c.POINTER(_c.c_int), _vp]),
+    'dcahip_zinb_nll_planes': (_c.c_int, [_f32p, _f32p, _f32p, _c.c_long, _f32p, _f32p, _c.c_long, _f32p,
+                                          _i32p, _i64p, _c.c_int, _c.c_int, _c.c_float, _c.c_float, _c.c_int,
+                                          _c.c_void_p, _c.c_long, _c.c_long, _c.c_long, _c.c_long, _c.c_long,
+                                          _f32p, _c.c_long, _f64p, _c.POINTER(_c.c_int), _vp]),
     'dcahip_loss_finalize': (_c.c_int, [_f64p, _c.c_int, _c.c_double, _f32p, _vp]),
     'dcahip_step_end': (_c.c_int, [_f32p, _c.c_double, _f32p, _c.c_int, _f64p, _i64p, _c.c_int, _vp]),
     'dcahip_zinb_heads_infer': (_c.c_int, [_f32p, _f32p, _f32p, _c.c_long, _f32p, _c.c_int, _c.c_int,

@@ -32,6 +32,18 @@ class HipOps:
                                          ctypes.byref(n), hip.stream()), 'zinb_nll')
         return n.value
 
+    def zinb_nll_planes(self, a_mean, a_disp, a_pi, lda, theta_w, Y, ldy, sf, perm, cursor, B, G, ridge, inv_n, flags,
+                        planes, col_mean, col_disp, col_pi, d_theta, ldd_theta, partials):
+        """zinb_nll with the gradient planes written as pre-split bf16 pieces into planes [3, rows, ld] at the given
+        columns (the operand of gemm_p3); the per-gene dispersion gradient (const. dispersion) stays fp32 in d_theta."""
+        n = ctypes.c_int(0)
+        p = hip.ptr
+        hip.check(self.L.dcahip_zinb_nll_planes(p(a_mean), p(a_disp), p(a_pi), lda, p(theta_w), p(Y), ldy, p(sf), p(perm),
+                                                p(cursor), B, G, ridge, inv_n, flags, p(planes), planes.stride(1),
+                                                planes.stride(0), col_mean, col_disp, col_pi, p(d_theta), ldd_theta,
+                                                p(partials), ctypes.byref(n), hip.stream()), 'zinb_nll_planes')
+        return n.value
+
     def loss_finalize(self, partials, n, scale, loss_out):
         hip.check(self.L.dcahip_loss_finalize(hip.ptr(partials), n, scale, hip.ptr(loss_out),
                                               hip.stream()), 'loss_finalize')

@@ -78,6 +78,22 @@ int dcahip_zinb_nll(const float* a_mean, const float* a_disp, const float* a_pi,
                     double* loss_partials, int* n_partials_out, void* stream);
 
 /*
+ * dcahip_zinb_nll with the gradient planes leaving as PRE-SPLIT bf16 pieces (see dcahip_gemm_p3): the operand of the
+ * heads' weight- and input-gradient products is written once in the form both read, instead of fp32 planes that each
+ * product splits again.  d_planes [3][>= B][ldp] bf16 (plane_stride elements between pieces); the head planes start at
+ * columns col_mean / col_disp / col_pi of a row (multiples of 4; columns nobody writes must be zero: the products read
+ * whole rows).  Constant dispersion: d nll / d theta still goes to the fp32 plane d_theta (ld ldd_theta) that
+ * dcahip_colsum_chain reduces, col_disp is ignored.  NB / ZINB only, gradient always, 16-byte aligned vector operands
+ * (lda, ldy multiples of 4).  Same loss partials as dcahip_zinb_nll.
+ */
+int dcahip_zinb_nll_planes(const float* a_mean, const float* a_disp, const float* a_pi, long lda,
+                           const float* theta_w, const float* y, long ldy, const float* sf,
+                           const int* perm, const long long* cursor, int B, int G, float ridge,
+                           float inv_n, int flags, void* d_planes, long ldp, long plane_stride,
+                           long col_mean, long col_disp, long col_pi, float* d_theta, long ldd_theta,
+                           double* loss_partials, int* n_partials_out, void* stream);
+
+/*
  * Deterministic second stage of the loss reduction: loss = scale * sum(partials) with
  * nan -> inf (dca/loss.py:148), written to *loss_out (fp32, device).
  */

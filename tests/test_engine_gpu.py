@@ -174,26 +174,31 @@ def test_graph_replay_equals_eager(ops):
         np.testing.assert_array_equal(res[0][1][k], res[1][1][k])
 
 
-def test_wide_network_step(ops):
+@pytest.mark.parametrize('planes,ae,B', [('1', 'zinb-conddisp', 640), ('1', 'zinb', 641), ('1', 'nb-conddisp', 300),
+                                          ('1', 'nb', 512), ('1', 'poisson', 400), ('0', 'zinb-conddisp', 640)])
+def test_wide_network_step(ops, planes, ae, B, monkeypatch):
     """BASELINE configs[4] architecture (512-256-128-256-512) at test size: decoder width > 64,
-    i.e. the heads run as separate kernels (GEMM + K-ZINB + 2 GEMMs), MFMA-bound regime."""
-    n, G, hs, B = 700, 1500, (512, 256, 128, 256, 512), 640
-    X, Y, sf, p = make_problem(n, G, hs, 'zinb-conddisp', True, seed=5)
+    i.e. the heads run as separate kernels (GEMM + K-ZINB + 2 GEMMs), MFMA-bound regime.  planes '1': every large
+    product from pre-split bf16 planes (engine._wide_planes; batches that are and are not a multiple of 16), '0': the
+    transposed-copy path it replaces."""
+    monkeypatch.setenv('DCA_AMD_WIDE_PLANES', planes)
+    n, G, hs = 700, 1500, (512, 256, 128, 256, 512)
+    X, Y, sf, p = make_problem(n, G, hs, ae, True, seed=5)
     rows = np.random.RandomState(0).permutation(n)[:B]
-    ref = oracle_net('zinb-conddisp', p, hs, True)
+    ref = oracle_net(ae, p, hs, True)
     rl, rg = ref.loss_and_grads(X[rows].astype(np.float64), Y[rows].astype(np.float64),
                                 sf[rows].astype(np.float64))
-    eng = make_engine(ops, 'zinb-conddisp', G, hs, True, 0.0, p, X, Y, sf)
+    eng = make_engine(ops, ae, G, hs, True, 0.0, p, X, Y, sf)
     loss, g, _ = run_single_step(eng, rows)
-    assert eng.ws_heads is None
+    assert eng.ws_heads is None and eng._wide_planes(B) == (planes == '1') and eng._wide_transposed(B) == (planes == '0')
     assert abs(loss - rl) < 1e-5 * abs(rl)
     assert_grads_close(g, rg)
 
 
 def test_wide_network_step_at_benchmark_size(ops):
     """BASELINE configs[4]'s network (512-256-128-256-512 on 25 000 genes, batch 2048) for one step against the fp64 oracle:
-    the separate-kernel path (no fused heads: hL = 512), the split-bf16 products on the transposed activations
-    (engine._wide_transposed) and the NT first-layer weight gradient at the sizes they are used at.
+    the separate-kernel path (no fused heads: hL = 512) with every large product from pre-split bf16 planes
+    (engine._wide_planes: the 256 x 256 direct-to-LDS kernel on the five big products) at the sizes they are used at.
 
     2.9 M hidden pre-activations per step: a handful of them lie within fp32 round-off of zero, and there the fp32 network
     and the fp64 oracle may sit on different sides of a ReLU (one such unit moves its column of the weight gradient by
@@ -209,7 +214,7 @@ def test_wide_network_step_at_benchmark_size(ops):
     rl, _ = ref.loss_and_grads(x64, y64, s64)
     eng = make_engine(ops, 'zinb-conddisp', G, hs, True, 0.0, p, X, Y, sf)
     loss, g, _ = run_single_step(eng, rows)
-    assert eng.ws_heads is None and eng._wide_transposed(B)
+    assert eng.ws_heads is None and eng._wide_planes(B) and 'X' in eng.pl
     assert abs(loss - rl) < 1e-5 * abs(rl)
     pattern, flips = {}, 0
     for i, h in enumerate(hs):

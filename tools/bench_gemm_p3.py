@@ -6,6 +6,10 @@ import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+if os.environ.get('DCA_AMD_LIB'):                      # an ablation build of the library
+    from dca_amd import build as _b
+    _b.LIB = os.environ['DCA_AMD_LIB']
+    _b.needs_build = lambda: False
 from dca_amd.ops import HipOps
 
 ops = HipOps()
@@ -38,6 +42,7 @@ SHAPES = [  # name, ta, tb, M, N, K
 ]
 g = torch.Generator(device='cpu'); g.manual_seed(0)
 for name, ta, tb, M, N, K in SHAPES:
+    K = (K + 15) // 16 * 16                              # (zero padding: what the engine allocates)
     ra, ca = (K, M) if ta else (M, K)
     rb, cb = (N, K) if tb else (K, N)
     A = torch.randn(ra, r8(ca), device=dev); B = torch.randn(rb, r8(cb), device=dev)
