@@ -881,15 +881,9 @@ __global__ __launch_bounds__(512) void gemm_p3w_kernel(Gemm3Args p) {
     int cur = 0, nxt = 2;                                  // stage of step k, stage step k + 2 goes to
 #pragma unroll 1
     for (int k = 0; k < nsteps; ++k) {
-#ifdef DCA_EXP_W_NOLOAD
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
         if (k + 1 < nsteps) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-#ifndef DCA_EXP_W_NOBAR
         __builtin_amdgcn_s_barrier();
-#endif
         asm volatile("" ::: "memory");
         const unsigned sa_ = (unsigned)(cur * STAGE) + aoff, sb_ = (unsigned)(cur * STAGE + IA::BYTES) + boff;
         const int rq = nxt;
@@ -906,9 +900,6 @@ __global__ __launch_bounds__(512) void gemm_p3w_kernel(Gemm3Args p) {
             constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0}; \
             _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[I][j] = MFMA16(a[AI][PA[pr]], b[j][PB[pr]], acc[I][j]); } } while (0)
         IA::template issue<0, 1>(a[1][0], sa_); IA::template issue<1, 1>(a[1][1], sa_); IA::template issue<2, 1>(a[1][2], sa_);
-#ifndef DCA_EXP_W_NOLOAD
-        if (k + 2 < nsteps) request(rq);                   // (behind the first fragment reads: their latency covers the issue)
-#endif
         if constexpr (IA::READS == 1) DCA_WAIT_LGKM(3); else DCA_WAIT_LGKM(6);
         if constexpr (CS && !B_KC) {
             if (do_colsum) {
@@ -921,6 +912,9 @@ __global__ __launch_bounds__(512) void gemm_p3w_kernel(Gemm3Args p) {
             }
         }
         DCA_PRODUCTS(0, 0);
+        // the next-but-one step's requests go out BEHIND the first products: their issue (an M0 write and an address per
+        // piece) fills the gaps of the matrix pipe instead of standing between the barrier and the first product
+        if (k + 2 < nsteps) request(rq);
         IA::template issue<0, 2>(a[0][0], sa_); IA::template issue<1, 2>(a[0][1], sa_); IA::template issue<2, 2>(a[0][2], sa_);
         if constexpr (IA::READS == 1) DCA_WAIT_LGKM(3); else DCA_WAIT_LGKM(6);
         DCA_PRODUCTS(1, 1);
