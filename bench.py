@@ -60,7 +60,9 @@ def kernel_model(name, B, G, hidden, nheads=3):
     Gp = (G + 3) // 4 * 4
     h1, hL = hidden[0], hidden[-1]
     if name == 'zinb_nll':
-        return 'hbm', 28.0 * B * G                      # 3 pre-acts + y read, 3 grads written
+        # 3 pre-activations + y read, 3 gradient planes written: fp32 (12 B) or, on the wide networks' planes path, as
+        # three bf16 pieces each (18 B)
+        return 'hbm', (34.0 if hL > 64 else 28.0) * B * G
     if name == 'rmsprop_clip':
         return 'hbm', None
     if name == 'heads_fused':                           # heads forward + dW + dH in one launch
@@ -434,6 +436,11 @@ def main():
                 ent.update(bound='hbm', achieved=work / (st['mean_ms'] * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit='GB/s')
             else:
                 ent.update(bound='mfma', achieved=work / (st['mean_ms'] * 1e-3) / 1e12, peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s')
+                # both denominators: the fp32-MFMA peak prices the algorithmic fp32 flops; the products execute as six bf16
+                # MFMAs per fp32 product, whose bound for the same result is the dense bf16 peak / 6 (a fraction above 1
+                # of the former is possible and means nothing more than that)
+                ent['peak_bf16_pipe_over_6'] = MFMA_BF16_PEAK_TFLOPS / 6.0
+                ent['frac_of_bf16_pipe_over_6'] = ent['achieved'] / (MFMA_BF16_PEAK_TFLOPS / 6.0)
             ent['frac'] = ent['achieved'] / ent['peak']
         kernels.append(ent)
     kernels.sort(key=lambda e: -e['mean_ms'])
