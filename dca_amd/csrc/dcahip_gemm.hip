@@ -10,6 +10,13 @@
 // The minibatch gather (storage row = perm[*cursor + r]) is folded into the A loads, so the
 // shuffled batch of the resident [n_cells, n_genes] matrix is never copied.
 //
+// Three kernel families live here (all fp32 results):
+//   gemm_kernel       exact fp32 MFMA (the yardstick; TN and narrow NN shapes of the 64-unit networks)
+//   gemm_x3_kernel    operands split into three bf16 pieces inside the K loop, six products on the bf16 pipe
+//   gemm_p3_kernel / gemm_p3w_kernel   the same six products from operands that arrive PRE-SPLIT ("planes"):
+//                     128 x 128 register-staged tiles, and 256 x 256 tiles fed global -> LDS by DMA through a
+//                     three-stage ring (the wide networks' step)
+//
 // LDS image: As[k][m], Bs[k][n] (k-major).  A wave's MFMA fragment read is then 32
 // consecutive floats per half-wave: conflict-free ds_read_b32.  k-contiguous sources are
 // transposed on the way in (4 x ds_write_b32, odd row stride -> conflict-free), m/n-

@@ -859,7 +859,7 @@ class Engine:
         that contract over its rows and over its columns, so no transposed copies are kept."""
         lay = self.lay
         return (self.ws_heads is None and B >= 256 and hasattr(self.ops, 'gemm_p3') and not lay.fork and not lay.elempi
-                and not lay.shared and self.comm.world >= 1 and os.environ.get('DCA_AMD_WIDE_PLANES', '1') != '0')
+                and not lay.shared and os.environ.get('DCA_AMD_WIDE_PLANES', '1') != '0')
 
     def _wide_transposed(self, B):
         """The same networks without the planes path: transposed operand copies for K-GEMM's fast forms (see reserve)."""
