@@ -863,7 +863,7 @@ __global__ __launch_bounds__(256) void rmsprop_clip_kernel(float* w, const float
             float gj = gp[j];
             if (clip > 0.f) gj = fminf(fmaxf(gj, -clip), clip);
             mp[j] = rho * mp[j] + (1.f - rho) * gj * gj;
-            wp[j] = wp[j] - lr * gj / sqrtf(mp[j] + eps);
+            wp[j] = wp[j] - lr * gj / (sqrtf(mp[j]) + eps);
         }
         reinterpret_cast<float4*>(ms)[i] = mv;
         reinterpret_cast<float4*>(w)[i] = wv;
@@ -873,7 +873,7 @@ __global__ __launch_bounds__(256) void rmsprop_clip_kernel(float* w, const float
         if (clip > 0.f) gj = fminf(fmaxf(gj, -clip), clip);
         const float m = rho * ms[i] + (1.f - rho) * gj * gj;
         ms[i] = m;
-        w[i] = w[i] - lr * gj / sqrtf(m + eps);
+        w[i] = w[i] - lr * gj / (sqrtf(m) + eps);
     }
 }
 

@@ -424,8 +424,11 @@ int dcahip_prep_scale(float* X, long ldx, int n, int G, const float* mean, const
                       void* stream);
 
 /*
- * Keras clipvalue + tf.keras RMSprop on one flat parameter buffer:
- *   g = clip(g, -clip, clip); ms = rho*ms + (1-rho)*g*g; w -= lr * g / sqrt(ms + eps)
+ * Keras clipvalue + Keras RMSprop (momentum 0) on one flat parameter buffer:
+ *   g = clip(g, -clip, clip); ms = rho*ms + (1-rho)*g*g; w -= lr * g / (sqrt(ms) + eps)
+ * (epsilon OUTSIDE the root: standalone keras 2.2 / 2.3 `p - lr * g / (K.sqrt(new_a) + self.epsilon)` and tf.keras
+ * OptimizerV2's dense update without momentum `var - lr_t * grad / (sqrt(rms_t) + epsilon)` alike; only TF's fused
+ * ApplyRMSProp kernel, taken with momentum > 0, puts it inside.)
  * Replaces opt.RMSprop(lr, clipvalue) (dca/train.py:54-57).  *lr is read from device memory
  * so ReduceLROnPlateau does not invalidate a captured graph.  clip <= 0 disables clipping.
  */

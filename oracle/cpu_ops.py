@@ -430,4 +430,4 @@ class CpuRefOps:
             gv = np.clip(gv, -clip, clip)
         m = rho * mv.astype(np.float64) + (1 - rho) * gv * gv
         mv[:] = m
-        wv[:] = wv - float(lr[0].item()) * gv / np.sqrt(m + eps)
+        wv[:] = wv - float(lr[0].item()) * gv / (np.sqrt(m) + eps)

@@ -16,7 +16,11 @@ see oracle/__init__.py):
   Dense:       y = x W + b
   BatchNorm:   momentum .99, eps 1e-3, train = biased batch moments, moving stats updated
                with the biased variance; inference = moving stats
-  RMSprop:     ms = .9 ms + .1 g^2 ; w -= lr g / sqrt(ms + 1e-7)  (eps inside the sqrt)
+  RMSprop:     ms = .9 ms + .1 g^2 ; w -= lr g / (sqrt(ms) + 1e-7)  (eps OUTSIDE the sqrt: what both Keras stacks the
+               reference runs on compute with momentum = 0 -- standalone keras 2.2 / 2.3, optimizers.py:
+               `new_p = p - lr * g / (K.sqrt(new_a) + self.epsilon)`; tf.keras OptimizerV2 (keras >= 2.4), rmsprop.py
+               _resource_apply_dense without momentum: `var - lr_t * grad / (sqrt(rms_t) + epsilon)`.  Only TF's fused
+               ApplyRMSProp kernel, which OptimizerV2 takes with momentum > 0, has the epsilon inside the root.)
   clipvalue:   g = clip(g, -c, c) element-wise before the update
   fit:         validation = last n - int(n*(1-split)) rows; per epoch a fresh arange is
                shuffled with the numpy global RNG; last partial batch kept; epoch loss =
@@ -419,7 +423,7 @@ def rmsprop_step(params, grads, ms, lr, rho=0.9, eps=1e-7, clip=5.0):
         if k not in ms:
             ms[k] = np.zeros_like(params[k])
         ms[k] = dt.type(rho) * ms[k] + dt.type(1 - rho) * np.square(g)
-        params[k] = params[k] - dt.type(lr) * g / np.sqrt(ms[k] + dt.type(eps))
+        params[k] = params[k] - dt.type(lr) * g / (np.sqrt(ms[k]) + dt.type(eps))
 
 
 KERAS_DEFAULT_LR = {'sgd': 0.01, 'rmsprop': 0.001, 'adagrad': 0.001, 'adadelta': 0.001, 'adam': 0.001,
@@ -439,7 +443,7 @@ def optimizer_update(kind, w, g, a, b, lr, t, clip=5.0):
         return w - lr * g, a, b
     if kind == 'rmsprop':
         a = 0.9 * a + 0.1 * g * g
-        return w - lr * g / np.sqrt(a + 1e-7), a, b
+        return w - lr * g / (np.sqrt(a) + 1e-7), a, b
     if kind == 'adagrad':
         a = a + g * g
         return w - lr * g / (np.sqrt(a) + 1e-7), a, b

@@ -128,11 +128,11 @@ class TorchAE:
         return loss.detach(), {k: v.grad for k, v in self.p.items() if v.requires_grad}
 
     def train_step(self, X, Y, sf, lr=1e-3, rho=0.9, eps=1e-7, clip=5.0):
-        """clipvalue + Keras RMSprop (eps inside the sqrt), train.py:54-57."""
+        """clipvalue + Keras RMSprop (momentum 0: eps outside the sqrt, see oracle/net_np.py), train.py:54-57."""
         loss, g = self.grads(X, Y, sf)
         with torch.no_grad():
             for k, gk in g.items():
                 gk = gk.clamp(-clip, clip)
                 self.ms[k].mul_(rho).addcmul_(gk, gk, value=1 - rho)
-                self.p[k] -= lr * gk / torch.sqrt(self.ms[k] + eps)
+                self.p[k] -= lr * gk / (torch.sqrt(self.ms[k]) + eps)
         return loss

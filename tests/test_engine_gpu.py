@@ -58,7 +58,8 @@ def _golden_fit():
     return {k: g[k] for k in g.files}
 
 
-FIT_TIGHT, FIT_LOOSE = 1e-5, 5e-3
+# "per-epoch loss to 1e-4" (BASELINE north_star) / still the same optimisation after a ReLU-mask flip
+FIT_TIGHT, FIT_LOOSE = 1e-4, 5e-3
 
 
 def fit_distance(hist, gold, key, ref='f64'):
@@ -67,17 +68,21 @@ def fit_distance(hist, gold, key, ref='f64'):
 
 
 def fit_acceptance(dist, dist_fp32_oracle):
-    """The acceptance statement for a set of seeds (dist: per-seed distance of a fit to the fp64 oracle's):
-      (1) every seed within 5e-3 -- a trajectory whose ReLU mask flipped once is still the same optimisation;
-      (2) the number of seeds beyond 1e-5 (left the fp64 trajectory) exceeds the fp32 ORACLE's number on the same
-          seeds by at most max(1, n_seeds // 5) -- leaving is a property of fp32 arithmetic on the problem (the fp32
-          oracle leaves at 1 of 10 zinb-conddisp seeds, 3 of 10 nb seeds, 2 of 4 zinb seeds), and a different fp32
-          summation order leaves at different seeds;
-      (3) the seeds that stay agree to 1e-6 at best (typical 2e-7): the loop computes the same numbers."""
+    """The acceptance statement for a set of seeds (dist: per-seed distance of a fit to the fp64 oracle's).
+    Keras' RMSprop without momentum (epsilon outside the root) takes sign-like steps of ~3 lr while its accumulator is below
+    epsilon -- the first steps of every parameter whose gradient is small -- so gradient components at the fp32 noise floor
+    become O(lr) differences: an fp32 evaluation of the ORACLE agrees with its fp64 evaluation to 1e-6 .. 1e-5 on the
+    per-epoch losses at most seeds and leaves it (> 1e-4: a ReLU mask flipped early) at 2 of 10 zinb-conddisp seeds, 1 of
+    10 nb seeds, 1 - 3 of 4 of the other types (tests/test_oracle_golden.py).  The statement for a fit loop:
+      (1) every seed within 5e-3;
+      (2) no more seeds beyond 1e-4 than the fp32 ORACLE has on the same seeds, plus one (a different fp32 summation
+          order leaves at different seeds);
+      (3) the closest seed within 2e-5 (or twice the fp32 oracle's closest): the loop computes the same numbers as an
+          fp32 evaluation of the reference's formulas does."""
     dist, dist_fp32_oracle = np.asarray(dist), np.asarray(dist_fp32_oracle)
     assert (dist <= FIT_LOOSE).all(), dist
-    assert (dist > FIT_TIGHT).sum() <= (dist_fp32_oracle > FIT_TIGHT).sum() + max(1, len(dist) // 5), (dist, dist_fp32_oracle)
-    assert dist.min() <= 1e-6, dist
+    assert (dist > FIT_TIGHT).sum() <= (dist_fp32_oracle > FIT_TIGHT).sum() + 1, (dist, dist_fp32_oracle)
+    assert dist.min() <= max(2e-5, 2 * dist_fp32_oracle.min()), (dist, dist_fp32_oracle)
 
 
 @pytest.mark.parametrize('ae_type,use_graph', [('zinb-conddisp', True), ('zinb-conddisp', False),
@@ -105,15 +110,16 @@ def test_fit_epoch_losses_match_oracle(ops, ae_type, use_graph):
                        shuffle_rng=np.random.RandomState(SHUFFLE_SEED), use_graph=use_graph)
         key = '%s/%d' % (ae_type, seed)
         dist.append(fit_distance(h.history, gold, key))
-        if seed == seeds[0] and dist[-1] <= FIT_TIGHT:
-            # outputs after training: mean / dispersion / dropout / latent (first N_PREDICT cells)
+        if seed == seeds[0] and dist[-1] <= 1e-5:
+            # outputs after training (a fit that stayed on the fp64 trajectory to 1e-5): mean / dispersion / dropout /
+            # latent (first N_PREDICT cells)
             eng.reserve(64)
             want = {'mean', 'latent'} | ({'dispersion'} if 'disp' in eng.lay.heads else set()) \
                 | ({'dropout'} if 'pi' in eng.lay.heads else set())
             out = eng.predict_chunk(0, N_PREDICT, want)
             torch.cuda.synchronize()
-            for k in want:
-                np.testing.assert_allclose(out[k].cpu().numpy(), gold[key + '/f64/out_' + k], rtol=2e-3, atol=2e-4,
+            for k in want:       # (parameters of two fits that agree to 1e-5 on the losses still differ by O(lr))
+                np.testing.assert_allclose(out[k].cpu().numpy(), gold[key + '/f64/out_' + k], rtol=2e-2, atol=1e-2,
                                            err_msg=k)
     d32 = [fit_distance({q: gold['%s/%d/f32/%s' % (ae_type, sd, q)] for q in ('loss', 'val_loss')}, gold, '%s/%d' % (ae_type, sd))
            for sd in seeds]
@@ -356,7 +362,7 @@ def test_other_optimizers_fit_matches_oracle(ops, optimizer):
     -- the exact-fp32 and the split-bf16 matrix products are equally accurate (test_x3_products_are_fp32_accurate) but
     round differently, and the trajectories separate at the 1e-4 level from the first epoch on."""
     from _opt_cases import run_fit_parity
-    run_fit_parity(ops, optimizer=optimizer, rtol=5e-4 if optimizer in ('Adam', 'Adamax', 'Nadam', 'Adadelta') else 1e-4)
+    run_fit_parity(ops, optimizer=optimizer, rtol=5e-4 if optimizer in ('RMSprop', 'Adam', 'Adamax', 'Nadam', 'Adadelta') else 1e-4)
 
 
 @pytest.mark.parametrize('reg', __import__('_opt_cases').REG_CASES)
@@ -451,10 +457,18 @@ def test_c3_first_steps_match_oracle(ops):
     got = eng.hist[:steps].cpu().numpy().astype(np.float64)
     want = z['step_loss']
     rel = np.abs(got / want - 1)
-    assert rel.max() < 1e-5, (int(rel.argmax()), float(rel.max()))
-    assert abs(got.mean() / want.mean() - 1) < 1e-4
+    # Yardstick: the fp32 evaluation of the oracle itself over the same 64 steps (fixture).  The first steps agree to
+    # round-off; then Keras' RMSprop (epsilon outside the root: sign-like steps while an accumulator is small) grows fp32
+    # noise in small gradients into O(lr) differences of those parameters, for the engine and for the fp32 oracle alike.
+    rel32 = np.abs(z['step_loss_f32'] / want - 1)
+    print('C3 first steps, |loss / fp64 oracle - 1|: engine step 0..3 %s, max %.1e at step %d; fp32 oracle max %.1e at step %d'
+          % (['%.1e' % v for v in rel[:4]], rel.max(), int(rel.argmax()), rel32.max(), int(rel32.argmax())))
+    assert rel[:4].max() < 2e-6, rel[:4]
+    assert rel.max() <= 3 * rel32.max() + 1e-5, (int(rel.argmax()), float(rel.max()), float(rel32.max()))
+    assert abs(got.mean() / want.mean() - 1) <= rel32.mean() + 1e-4, (got.mean(), want.mean(), float(rel32.mean()))
     val = float(eng.acc[1].item())
-    assert abs(val / float(z['val_loss']) - 1) < 1e-4, (val, float(z['val_loss']))
+    assert abs(val / float(z['val_loss']) - 1) <= 3 * abs(float(z['val_loss_f32']) / float(z['val_loss']) - 1) + 1e-4, \
+        (val, float(z['val_loss']), float(z['val_loss_f32']))
 
 
 @pytest.mark.parametrize('mode', ['steps', 'coop'])
@@ -478,12 +492,17 @@ def test_fused_hidden_stack_equals_the_per_operation_kernels(ops, hs, B, mode, m
         if eng.ws_stack is not None:
             assert int(eng.ws_stack[:3].view(torch.int32).abs().sum().item()) == 0      # counters at zero, no error flag
         out.append(res)
-    for (l1, g1, p1), (l0, g0, p0) in zip(*out):
+    for step, ((l1, g1, p1), (l0, g0, p0)) in enumerate(zip(*out)):
         assert abs(l1 - l0) < 2e-6 * abs(l0)
         zero_b = tuple('b%d' % i for i in range(len(hs)))
-        assert_grads_close(g1, {k: np.asarray(v, np.float64) for k, v in g0.items()}, rtol=2e-4, atol_scale=2e-6, skip=zero_b)
+        # (the second step starts from parameters that differ already: Keras' RMSprop turns the round-off between the two
+        # engines' first gradients into O(lr) differences of the parameters whose gradients are small)
+        assert_grads_close(g1, {k: np.asarray(v, np.float64) for k, v in g0.items()}, rtol=2e-4 if step == 0 else 2e-2,
+                           atol_scale=2e-6 if step == 0 else 1e-3, skip=zero_b)
         for i in range(len(hs)):
-            np.testing.assert_allclose(p1['mm%d' % i], p0['mm%d' % i], rtol=1e-5, atol=1e-7)
+            # (the moving mean follows the layer's bias, whose gradient in front of a batch norm is round-off and which
+            # Keras' RMSprop therefore moves by a different ~1e-5 per step in the two engines: 1 % of that per update)
+            np.testing.assert_allclose(p1['mm%d' % i], p0['mm%d' % i], rtol=1e-5, atol=5e-6)
             np.testing.assert_allclose(p1['mv%d' % i], p0['mv%d' % i], rtol=1e-5, atol=1e-7)
 
 

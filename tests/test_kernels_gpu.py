@@ -516,6 +516,8 @@ def test_rmsprop_clip(ops):
     n = 4 * 1000 + 3
     w = rng.normal(0, 1, n).astype(np.float32); g = (rng.normal(0, 4, n)).astype(np.float32)
     ms = rng.uniform(0, 1, n).astype(np.float32)
+    ms[5:400] *= 1e-12                                      # accumulators far below epsilon: where its placement matters
+    g[5:400] *= 1e-6
     g[:5] = [0, 1e-9, 7.5, -9, 5.0]
     dw, dg, dms = dev(w), dev(g), dev(ms)
     lr = torch.tensor([1e-3], device='cuda')
@@ -523,7 +525,7 @@ def test_rmsprop_clip(ops):
     torch.cuda.synchronize()
     gc = np.clip(g.astype(np.float64), -5, 5)
     ms_ref = 0.9 * ms + 0.1 * gc * gc
-    w_ref = w - 1e-3 * gc / np.sqrt(ms_ref + 1e-7)
+    w_ref = w - 1e-3 * gc / (np.sqrt(ms_ref) + 1e-7)        # Keras RMSprop without momentum: epsilon outside the root
     np.testing.assert_allclose(dms.cpu().numpy(), ms_ref, rtol=1e-6)
     np.testing.assert_allclose(dw.cpu().numpy(), w_ref, rtol=1e-6, atol=1e-7)
 

@@ -118,6 +118,24 @@ def test_network_backward_matches_autograd(ae_type, batchnorm):
         np.testing.assert_allclose(net.p['mv1'], tnet.p['mv1'].numpy(), rtol=1e-12)
 
 
+def test_rmsprop_epsilon_sits_outside_the_root():
+    """keras.optimizers.RMSprop(lr, clipvalue) with the default momentum 0 (dca/train.py:54-57): standalone keras 2.2/2.3
+    `p - lr * g / (K.sqrt(new_a) + epsilon)`, tf.keras OptimizerV2 `var - lr_t * grad / (sqrt(rms_t) + epsilon)`.  With
+    the gradients of this loss (O(1e-5): a mean over B x G elements) the first steps have ms << epsilon, where the
+    placement changes the step by an order of magnitude: outside gives the sign-like step of ~3 lr."""
+    g = 1e-5
+    p, ms = {'w': np.array([1.0])}, {}
+    N.rmsprop_step(p, {'w': np.array([g])}, ms, 1e-3)
+    assert abs(ms['w'][0] - 0.1 * g * g) < 1e-25
+    want = 1.0 - 1e-3 * g / (np.sqrt(0.1 * g * g) + 1e-7)
+    assert abs(p['w'][0] - want) < 1e-15 and 3.0e-3 < 1.0 - p['w'][0] < 3.1e-3        # (epsilon inside: 3.2e-5)
+    w2, a2, _ = N.optimizer_update('rmsprop', np.array([1.0]), np.array([g]), np.array([0.0]), None, 1e-3, 1)
+    assert abs(w2[0] - want) < 1e-15
+    t = T.TorchAE('zinb-conddisp', N.init_params('zinb-conddisp', 6, (4, 2, 4), seed=0), (4, 2, 4), dtype=torch.float64)
+    import inspect
+    assert 'torch.sqrt(self.ms[k]) + eps' in inspect.getsource(type(t))
+
+
 def test_rmsprop_and_fit_loop_semantics():
     """Keras split / partial batch / callbacks bookkeeping on a tiny problem; fp64 vs torch."""
     n, G, hs = 50, 12, (4, 2, 4)
@@ -185,9 +203,11 @@ def test_fit_golden_fixture_is_what_the_oracle_computes():
 
 def test_fp32_oracle_leaves_the_fp64_trajectory_at_some_seeds():
     """Why tests/test_engine_gpu.py::test_fit_epoch_losses_match_oracle is a statement about a SET of seeds: the fp32
-    ORACLE itself (same restatement, fp32 arithmetic) stays within 5e-3 of the fp64 oracle at every seed, within 1e-7
-    at most seeds, and leaves the fp64 trajectory (> 1e-5: one ReLU-mask flip) at 1 of 10 zinb-conddisp seeds, 3 of 10
-    nb seeds, 2 of 4 zinb seeds.  A single-seed 1e-4 assertion would be luck; these counts are the yardstick."""
+    ORACLE itself (same restatement, fp32 arithmetic) stays within 5e-3 of the fp64 oracle at every seed, within 1e-5 at
+    the typical seed (Keras' RMSprop takes sign-like first steps: fp32 noise in small gradients becomes O(lr)), and
+    leaves the fp64 trajectory (> 1e-4: a ReLU-mask flip early in the fit) at 2 of 10 zinb-conddisp seeds, 1 of 10 nb
+    seeds and 1 - 3 of 4 seeds of the other types.  A single-seed 1e-4 assertion would be luck; these counts are the
+    yardstick."""
     from golden.make_fit_c2_golden import SEEDS
     gold = _fit_golden()
     left = {}
@@ -196,10 +216,10 @@ def test_fp32_oracle_leaves_the_fp64_trajectory_at_some_seeds():
                           for a, b in zip(gold['%s/%d/f32/%s' % (ae_type, s, q)], gold['%s/%d/f64/%s' % (ae_type, s, q)]))
                       for s in seeds])
         assert (d <= 5e-3).all(), (ae_type, d)
-        assert d.min() <= 1e-6, (ae_type, d)
-        left[ae_type] = int((d > 1e-5).sum())
+        assert d.min() <= 5e-5, (ae_type, d)
+        left[ae_type] = int((d > 1e-4).sum())
     assert left['zinb-conddisp'] >= 1 and left['nb'] >= 1, left
-    assert all(v <= len(SEEDS[k]) // 2 for k, v in left.items()), left
+    assert all(v <= (len(SEEDS[k]) + 1) // 2 + 1 for k, v in left.items()), left
 
 
 def test_threaded_likelihood_equals_the_single_call():
