@@ -464,8 +464,7 @@ def main():
                 roof['peak_bf16_pipe_over_6'] = MFMA_BF16_PEAK_TFLOPS / 6.0
                 roof['frac_of_bf16_pipe_over_6'] = e['achieved'] / (MFMA_BF16_PEAK_TFLOPS / 6.0)
                 roof['note'] = ('K-HEADS is bound by the SUM of its matrix and vector instruction cycles per SIMD '
-                                '(DESIGN.md 4.1): MfmaUtil 29 %, VALUBusy 52 % (round-2 counters of the same kernel body, '
-                                'profiles/r02z_sq_counters_per_kernel.csv)')
+                                '(DESIGN.md 4.1): MfmaUtil 30 %, VALUBusy 54 % at 2.10 GHz (profiles/r03z_sq_counters_per_kernel.csv)')
             m = pmc.get(e['kernel'])
             if m and m['shape']['B'] == B and m['shape']['G'] == G and m['shape']['hL'] == hidden[-1]:
                 roof['traffic'] = m['traffic_bytes']

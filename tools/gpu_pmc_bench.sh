@@ -14,7 +14,7 @@ done
 python tools/pmc_summary.py $OUT $OUT/sq_summary.csv
 # keep the raw rows of our kernels only (the torch data-generation kernels are not of interest)
 for f in $(find $OUT -name '*counter_collection.csv'); do
-  (head -1 $f; grep -E "heads_fused|heads_reduce|gemm_|splitk_reduce|zinb_nll|transpose|bn_|col_moments|rmsprop" $f) > $f.filtered; mv $f.filtered $f
+  (head -1 $f; grep -E "heads_fused|heads_reduce|gemm_|splitk_reduce|zinb_nll|transpose|bn_|col_moments|rmsprop|enc0_|stack_" $f) > $f.filtered; mv $f.filtered $f
 done
 find $OUT -name '*kernel_trace.csv' -delete
 cut -c1-200 $OUT/sq_summary.csv | head -30

@@ -14,7 +14,7 @@ import re
 import sys
 from collections import defaultdict
 
-KEEP = re.compile(r'heads_fused|heads_reduce|gemm_|transpose|splitk_reduce|zinb_nll|bn_|col_moments|rmsprop|moments_combine|'
+KEEP = re.compile(r'heads_fused|heads_reduce|gemm_|transpose|splitk_reduce|zinb_nll|bn_|col_moments|rmsprop|moments_combine|enc0_|stack_|'
                   r'loss_finalize|step_end|relu_|dropout|optimizer|prelu|elempi')
 
 
