@@ -570,6 +570,11 @@ struct Gemm3Args {
     int split, kslab;
     int colsum;
     int mtiles, ntiles;
+    // 256 x 256 kernel, split == 1: the tiles of the last, partial round of workgroups (tile index >= tail_first) are cut
+    // into tail_split K slices each, so that the round is as short as its share of the work (a partial round of whole
+    // tiles costs a full tile's time); their partial tiles [tile - tail_first][slice][256][256] are summed afterwards
+    int tail_first, tail_split, tail_kslab;
+    float* tail_ws;
 };
 
 // one operand tile (DIM rows/cols x 32 k, three pieces) as 16-byte units: 12 DIM units over 256 threads
@@ -844,12 +849,23 @@ __global__ __launch_bounds__(512) void gemm_p3w_kernel(Gemm3Args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     int id = blockIdx.x;
-    const int s = id % p.split; id /= p.split;
+    int s, kbeg, kend;
+    const bool tail = p.tail_split > 1 && id >= p.tail_first;          // (tail_split > 1 only with split == 1)
+    if (tail) {
+        const int r = id - p.tail_first;
+        id = p.tail_first + r / p.tail_split;
+        s = r % p.tail_split;
+        kbeg = s * p.tail_kslab;
+        kend = min(p.K, kbeg + p.tail_kslab);
+    } else {
+        s = id % p.split; id /= p.split;
+        kbeg = s * p.kslab;
+        kend = min(p.K, kbeg + p.kslab);
+    }
+    const int tile = id;
     const int nt = id % p.ntiles;
     const int mt = id / p.ntiles;
     const int m0 = mt * 256, n0 = nt * 256;
-    const int kbeg = s * p.kslab;
-    const int kend = min(p.K, kbeg + p.kslab);
     const int nsteps = (kend - kbeg) / kWBK;
 
     // the source of this thread's unit in the step to request next (advanced by one step per request)
@@ -936,6 +952,18 @@ __global__ __launch_bounds__(512) void gemm_p3w_kernel(Gemm3Args p) {
     }
 
     const int Mo = p.M + (p.colsum ? 1 : 0);
+    if (tail) {
+        // a K slice of a tail tile: the partial tile, tile-local, into the tail workspace
+        float* pt = p.tail_ws + ((long)(tile - p.tail_first) * p.tail_split + s) * (256L * 256);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    pt[(wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 256 + wn0 + j * 32 + (lane & 31)] = acc[i][j][r];
+        return;                                            // (no column sums here: the host keeps m tile 0 out of the tail)
+    }
     float* out = p.split > 1 ? p.ws + (long)s * Mo * p.N : p.C;
     const long ldo = p.split > 1 ? (long)p.N : p.ldc;
     const bool add_bias = p.split == 1 && p.bias != nullptr;
@@ -956,6 +984,25 @@ __global__ __launch_bounds__(512) void gemm_p3w_kernel(Gemm3Args p) {
             const float tot = csum[j] + __shfl_xor(csum[j], 32, 64);
             if ((lane >> 5) == 0 && n < p.N) out[(long)p.M * ldo + n] = tot;
         }
+    }
+}
+
+// C tile = bias + sum over the K slices of a tail tile (ordered: deterministic); one workgroup per 16 rows of a tile
+__global__ __launch_bounds__(256) void gemm_p3w_tail_sum_kernel(const float* tail_ws, int tail_first, int tail_split, int ntiles,
+                                                               int M, int N, const float* bias, float* C, long ldc) {
+    const int tt = blockIdx.x >> 4, rg = blockIdx.x & 15;            // tail tile, row group of 16
+    const int tile = tail_first + tt;
+    const int m0 = (tile / ntiles) * 256, n0 = (tile % ntiles) * 256;
+    const int col = threadIdx.x;
+    const int n = n0 + col;
+    const float bv = (bias && n < N) ? bias[n] : 0.f;
+    const float* src = tail_ws + (long)tt * tail_split * (256L * 256) + (long)(rg * 16) * 256 + col;
+#pragma unroll 4
+    for (int r = 0; r < 16; ++r) {
+        float v = 0.f;
+        for (int q = 0; q < tail_split; ++q) v += src[(long)q * (256L * 256) + r * 256];
+        const int m = m0 + rg * 16 + r;
+        if (m < M && n < N) C[(long)m * ldc + n] = v + bv;
     }
 }
 
@@ -1168,12 +1215,38 @@ static bool p3_wide(int M, int N, int K, const int* perm, const long long* curso
     return M >= 256 && N >= 256 && K % 16 == 0 && (long)M * N >= 512L * 512 && !perm && !cursor;
 }
 
+// tail splitting of the 256 x 256 kernel (split == 1 only): T tiles on 256 CUs run as ceil(T / 256) rounds; a last round of
+// r < 256 whole tiles lasts as long as a full one.  Cut its tiles into S K slices (r S <= 256 workgroups, each 1 / S of a
+// tile): the round shrinks to its share of the work, for r S partial tiles written and summed (heads' weight gradient of
+// the 512-wide network: 586 tiles = 2.29 rounds ran as 3; 0.89 -> 0.7 ms)
+struct TailPlan { int first, split, kslab; long ws_bytes; };
+static TailPlan tail_plan(const Plan& p, int M, int K, int colsum_row) {
+    TailPlan t{0, 1, 0, 0};
+    if (p.cfg != 4 || p.split != 1) return t;
+    const int T = p.mtiles * p.ntiles, rem = T % 256, nsteps = K / kWBK;
+    if (T < 256 || rem == 0 || rem > 200) return t;
+    int S = 256 / rem;
+    if (S > nsteps / 4) S = nsteps / 4;
+    if (S > 8) S = 8;
+    if (S < 2) return t;
+    const int first = T - rem;
+    if (colsum_row && first / p.ntiles == 0) return t;                  // the column sums come from whole tiles of m tile 0
+    const int sps = (nsteps + S - 1) / S;
+    t.first = first; t.kslab = sps * kWBK; t.split = (nsteps + sps - 1) / sps;
+    if (t.split < 2) { t.split = 1; return t; }
+    t.ws_bytes = (long)rem * t.split * 256L * 256 * (long)sizeof(float);
+    (void)M;
+    return t;
+}
+
 extern "C" long dcahip_gemm_p3_workspace_bytes(int M, int N, int K, int colsum_row, int split_k) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     // (the larger of the two plans a call of this shape can take: with and without a row gather)
     const Plan pw = make_plan3(M, N, K, split_k, p3_wide(M, N, K, nullptr, nullptr));
     const Plan pn = make_plan3(M, N, K, split_k, false);
     const Plan p = pw.split > pn.split ? pw : pn;
+    const long tail = tail_plan(pw, M, K, colsum_row).ws_bytes;
+    if (tail > 0 && p.split <= 1) return tail;
     if (p.split <= 1) return 0;
     return (long)p.split * (M + (colsum_row ? 1 : 0)) * N * (long)sizeof(float);
 }
@@ -1190,13 +1263,15 @@ extern "C" int dcahip_gemm_p3(int ta, int tb, int M, int N, int K, const void* A
     // rows must cover the 16-byte units the tile reads: ld >= the extent rounded up to 8
     if ((ta ? lda < (M + 7) / 8 * 8 : lda < K) || (tb ? ldb < K : ldb < (N + 7) / 8 * 8)) return DCAHIP_EINVAL;
     const Plan p = make_plan3(M, N, K, split_k, p3_wide(M, N, K, perm, cursor));
-    const long need = p.split > 1 ? (long)p.split * (M + (colsum_row ? 1 : 0)) * N * (long)sizeof(float) : 0;
+    const TailPlan tp = tail_plan(p, M, K, colsum_row);
+    const long need = p.split > 1 ? (long)p.split * (M + (colsum_row ? 1 : 0)) * N * (long)sizeof(float) : tp.ws_bytes;
     if (need > 0 && (!workspace || workspace_bytes < need)) return DCAHIP_EINVAL;
     Gemm3Args a{static_cast<const unsigned short*>(A), static_cast<const unsigned short*>(B), lda, ldb, plane_a, plane_b,
                 C, bias, perm, cursor, static_cast<float*>(workspace), ldc, M, N, K, p.split, p.kslab, colsum_row,
-                p.mtiles, p.ntiles};
+                p.mtiles, p.ntiles, tp.first, tp.split, tp.kslab, static_cast<float*>(workspace)};
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int grid = p.mtiles * p.ntiles * p.split;
+    int grid = p.mtiles * p.ntiles * p.split;
+    if (tp.split > 1) grid = tp.first + (p.mtiles * p.ntiles - tp.first) * tp.split;
     if (p.cfg == 4) {
         // (dynamic LDS above 64 KB needs the attribute once per kernel)
 #define DCA_W(AKC, BKC, CSV) do { \
@@ -1222,6 +1297,11 @@ extern "C" int dcahip_gemm_p3(int ta, int tb, int M, int N, int K, const void* A
         long g = (total + 255) / 256;
         if (g > 4096) g = 4096;
         hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3((int)g), dim3(256), 0, s, a.ws, p.split, Mo, N, bias, M, C, ldc);
+        rc = (int)hipGetLastError();
+    } else if (tp.split > 1) {
+        const int ntail = p.mtiles * p.ntiles - tp.first;
+        hipLaunchKernelGGL(gemm_p3w_tail_sum_kernel, dim3(ntail * 16), dim3(256), 0, s, a.tail_ws, tp.first, tp.split, p.ntiles,
+                           M, N, bias, C, ldc);
         rc = (int)hipGetLastError();
     }
     return rc;

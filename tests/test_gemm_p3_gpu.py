@@ -70,6 +70,10 @@ SHAPES = [
     (1, 1, 530, 600, 96, False, False, False, 0),
     (0, 1, 2048, 512, 4800, False, False, False, 0),
     (1, 0, 1024, 3000, 48, False, False, True, 2),
+    # more than 256 tiles with a partial last round: its tiles are cut into K slices and summed afterwards
+    (1, 0, 512, 38400, 128, False, False, True, 0),        # 300 tiles: 44 tail tiles x 2 slices, column sums from m tile 0
+    (0, 0, 768, 25000, 256, False, True, False, 0),        # 294 tiles: 38 tail tiles x 4 slices, bias, ragged N
+    (0, 1, 8300, 2100, 4096, False, False, False, 0),      # 33 x 9 = 297 tiles: 41 tail tiles x 6 slices, ragged M and N
 ]
 
 
