@@ -272,6 +272,160 @@ __global__ __launch_bounds__(256, 4) void zinb_nll_compact_kernel(NllArgs a) {  
     if (threadIdx.x == 0) a.partials[blockIdx.y * gridDim.x + blockIdx.x] = r;
 }
 
+// ---- the training form of the kernel above (gradients wanted): nothing is stored twice.  The wave takes TWO batch rows of
+// its 256 genes per iteration, evaluates the y = 0 formulas of both into registers, queues the non-zero elements of both
+// rows in LDS (row 0 first), evaluates the queue 64 entries at a time with the NB branch -- each result written back over
+// its queue entry -- and every lane then fetches the results of its own non-zero elements (its slot follows from the
+// wave-uniform ballot masks) before the one dense store of the two rows.  Against the patching form: no 2- / 4-byte
+// scattered stores behind the dense ones (measured at configs[4]'s decoder, 2048 x 25 000, bf16 pieces out: 0.445 ms, of
+// which 0.145 ms were the patches -- partial-line writes -- profiles/r03_zinb_rows_notes.txt).
+#ifdef DCA_ZINB_ROWS
+constexpr int kRowsPerIter = DCA_ZINB_ROWS;
+#else
+constexpr int kRowsPerIter = 2;
+#endif
+template <bool HAS_PI, bool CONST_DISP, bool PL>
+__global__ __launch_bounds__(256, kRowsPerIter <= 2 ? 4 : 3) void zinb_nll_rows_kernel(NllArgs a) {
+    constexpr int V = 4, R = kRowsPerIter;
+    __shared__ float4 queue[4][R * 256];                   // 8 KB per wave: every element of both rows may be non-zero
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float4* Q = queue[wave];
+    const int nvec = (a.G + V - 1) / V;
+    const int nseg = (nvec + 255) >> 8;
+    const long long cur = a.cursor ? *a.cursor : 0;
+    double dacc = 0.0;
+    float lsp = 0.f;
+    for (int seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
+        const int q = seg * 256 + threadIdx.x;
+        const bool qv = q < nvec;
+        const int g = (qv ? q : 0) * V;
+        float vd[R][V];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int j = 0; j < V; ++j) vd[r][j] = 0.f;
+        if (CONST_DISP && qv) {
+            ldv<V>(a.theta_w + g, vd[0]);
+#pragma unroll
+            for (int r = 1; r < R; ++r)
+#pragma unroll
+                for (int j = 0; j < V; ++j) vd[r][j] = vd[0][j];
+        }
+        // storage rows of the NEXT iteration requested one iteration ahead (perm -> size factor / counts is a chain)
+        long srow_n[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int rw = blockIdx.y + r * gridDim.y;
+            const int rc = rw < a.B ? rw : 0;
+            srow_n[r] = a.perm ? (long)a.perm[cur + rc] : (long)(cur + rc);
+        }
+        for (int row0 = blockIdx.y; row0 < a.B; row0 += R * gridDim.y) {
+            long srow[R];
+            float sf[R];
+            bool rv[R];
+            float vm[R][V], vp[R][V], vy[R][V];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int row = row0 + r * gridDim.y;
+                rv[r] = row < a.B;
+                srow[r] = srow_n[r];
+                const int rn = row + R * gridDim.y;
+                const int rc = rn < a.B ? rn : (rv[r] ? row : 0);
+                srow_n[r] = a.perm ? (long)a.perm[cur + rc] : (long)(cur + rc);
+                sf[r] = a.sf[srow[r]];
+#pragma unroll
+                for (int j = 0; j < V; ++j) { vm[r][j] = 0.f; vp[r][j] = 0.f; vy[r][j] = 0.f; }
+                if (qv && rv[r]) {
+                    const long ao = (long)row * a.lda + g;
+                    ldv<V>(a.a_mean + ao, vm[r]);
+                    if (!CONST_DISP) ldv<V>(a.a_disp + ao, vd[r]);
+                    if (HAS_PI) ldv<V>(a.a_pi + ao, vp[r]);
+                    ldv<V>(a.y + srow[r] * a.ldy + g, vy[r]);
+                }
+            }
+            float om[R][V], od[R][V], op[R][V];
+            bool nz[R][V];
+            unsigned long long mask[R][V];
+            int base[R][V];
+            int qn = 0, nend[R];
+            float lacc = 0.f;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    const bool valid = qv && rv[r] && (g + j) < a.G;
+                    nz[r][j] = valid && (HAS_PI ? !(vy[r][j] < kZeroThresh) : (vy[r][j] != 0.f));
+                    float gmv, gdv, gpv = 0.f, nll;
+                    if (HAS_PI) nll = zinb_zero_elem<CONST_DISP>(vm[r][j], vd[r][j], vp[r][j], sf[r], a.ridge, gmv, gdv, gpv);
+                    else nll = nb_zero_elem<CONST_DISP>(vm[r][j], vd[r][j], sf[r], gmv, gdv);
+                    lacc += (valid && !nz[r][j]) ? nll : 0.f;
+                    const float sc = valid ? a.inv_n : 0.f;
+                    om[r][j] = gmv * sc; od[r][j] = gdv * sc; op[r][j] = gpv * sc;
+                    const unsigned long long m = __ballot(nz[r][j]);
+                    mask[r][j] = m; base[r][j] = qn;
+                    if (nz[r][j]) {
+                        const int slot = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                        Q[slot] = make_float4(vm[r][j], vd[r][j], vp[r][j], vy[r][j]);
+                    }
+                    qn += __popcll(m);
+                }
+                nend[r] = qn;
+            }
+            dacc += (double)lacc;
+            __builtin_amdgcn_wave_barrier();
+            for (int b = 0; b < qn; b += 64) {                 // the NB branch, 64 queued elements at a time
+                const int idx = b + lane;
+                const bool act = idx < qn;
+                const float4 e = Q[act ? idx : b];
+                float esf = sf[R - 1];
+#pragma unroll
+                for (int r = R - 2; r >= 0; --r) esf = idx < nend[r] ? sf[r] : esf;
+                float o1, o2, o3 = 0.f, nll;
+                if (HAS_PI) {
+                    nll = zinb_nz_elem<CONST_DISP>(e.x, e.y, e.z, esf, e.w, a.ridge, o1, o2, o3);
+                } else {
+                    float dmu = 0.f, dth = 0.f, dpi = 0.f;
+                    const Heads hd = head_acts<false, CONST_DISP>(e.x, e.y, 0.f, esf);
+                    nll = nll_elem<false, true, true>(hd, e.w, a.ridge, dmu, dth, dpi);
+                    o1 = dmu * hd.gm; o2 = dth * hd.gd;
+                }
+                lsp += act ? nll : 0.f;
+                if (act) Q[idx] = make_float4(o1 * a.inv_n, o2 * a.inv_n, o3 * a.inv_n, 0.f);
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    if (nz[r][j]) {
+                        const unsigned long long m = mask[r][j];
+                        const float4 o = Q[base[r][j] + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))];
+                        om[r][j] = o.x; od[r][j] = o.y; op[r][j] = o.z;
+                    }
+                }
+                if (qv && rv[r]) {
+                    const int row = row0 + r * gridDim.y;
+                    const long dof2 = (long)row * a.ldd + g;
+                    if (PL) {
+                        const long dof = (long)row * a.ldp + g;
+                        store_planes4(a.pl[0] + dof, a.pstride, om[r]);
+                        if (CONST_DISP) stv<V>(a.d_disp + dof2, od[r]); else store_planes4(a.pl[1] + dof, a.pstride, od[r]);
+                        if (HAS_PI) store_planes4(a.pl[2] + dof, a.pstride, op[r]);
+                    } else {
+                        stv<V>(a.d_mean + dof2, om[r]);
+                        stv<V>(a.d_disp + dof2, od[r]);
+                        if (HAS_PI) stv<V>(a.d_pi + dof2, op[r]);
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    dacc += (double)lsp;
+    const double r = block_reduce_sum(dacc);
+    if (threadIdx.x == 0) a.partials[blockIdx.y * gridDim.x + blockIdx.x] = r;
+}
+
 __global__ __launch_bounds__(256) void loss_finalize_kernel(const double* partials, int n,
                                                             double scale, float* out) {
     double v = 0.0;
@@ -357,8 +511,14 @@ int launch_nll(const NllArgs& a, bool vec, dim3 grid, hipStream_t s) {
 #else
     constexpr bool plain = false;
 #endif
+#ifdef DCA_ZINB_PATCH          // A/B builds only: the non-zero elements patched behind the dense stores (round-2 form)
+    constexpr bool patching = true;
+#else
+    constexpr bool patching = false;
+#endif
     const bool fits = !GRAD || (long)a.B * a.ldd < (1L << 32);
-    if (vec && fits && !plain) hipLaunchKernelGGL((zinb_nll_compact_kernel<HAS_PI, CONST_DISP, GRAD>), grid, dim3(256), 0, s, a);
+    if (vec && fits && !plain && GRAD && !patching) hipLaunchKernelGGL((zinb_nll_rows_kernel<HAS_PI, CONST_DISP, false>), grid, dim3(256), 0, s, a);
+    else if (vec && fits && !plain) hipLaunchKernelGGL((zinb_nll_compact_kernel<HAS_PI, CONST_DISP, GRAD>), grid, dim3(256), 0, s, a);
     else if (vec) hipLaunchKernelGGL((zinb_nll_kernel<HAS_PI, CONST_DISP, GRAD, 4>), grid, dim3(256), 0, s, a);
     else     hipLaunchKernelGGL((zinb_nll_kernel<HAS_PI, CONST_DISP, GRAD, 1>), grid, dim3(256), 0, s, a);
     return (int)hipGetLastError();
@@ -451,10 +611,16 @@ extern "C" int dcahip_zinb_nll_planes(const float* a_mean, const float* a_disp, 
     const dim3 grid(gx, gy);
     if (n_partials_out) *n_partials_out = gx * gy;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (has_pi && cdisp) hipLaunchKernelGGL((zinb_nll_compact_kernel<true, true, true, true>), grid, dim3(256), 0, s, a);
-    else if (has_pi) hipLaunchKernelGGL((zinb_nll_compact_kernel<true, false, true, true>), grid, dim3(256), 0, s, a);
-    else if (cdisp) hipLaunchKernelGGL((zinb_nll_compact_kernel<false, true, true, true>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((zinb_nll_compact_kernel<false, false, true, true>), grid, dim3(256), 0, s, a);
+#ifdef DCA_ZINB_PATCH
+#define DCA_ZK(P, C) zinb_nll_compact_kernel<P, C, true, true>
+#else
+#define DCA_ZK(P, C) zinb_nll_rows_kernel<P, C, true>
+#endif
+    if (has_pi && cdisp) hipLaunchKernelGGL((DCA_ZK(true, true)), grid, dim3(256), 0, s, a);
+    else if (has_pi) hipLaunchKernelGGL((DCA_ZK(true, false)), grid, dim3(256), 0, s, a);
+    else if (cdisp) hipLaunchKernelGGL((DCA_ZK(false, true)), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((DCA_ZK(false, false)), grid, dim3(256), 0, s, a);
+#undef DCA_ZK
     return (int)hipGetLastError();
 }
 

@@ -123,6 +123,72 @@ def test_zinb_nll_vs_oracle(ops, flags, B, G, edge):
     assert abs(loss.item() - got) <= (3e-5 if edge else 3e-6) * abs(got)
 
 
+@pytest.mark.parametrize('flags', [1, 3, 0])
+@pytest.mark.parametrize('B,G,dense', [(2500, 1000, False), (2500, 1000, True), (4099, 520, False)])
+def test_zinb_nll_row_pairs_and_planes(ops, flags, B, G, dense):
+    """The training kernel takes two batch rows per iteration and keeps both in registers until the non-zero elements are
+    evaluated (zinb_nll_rows_kernel): batches deep enough that a workgroup walks several row pairs, the second row of the
+    last pair missing for some workgroups and present for others; `dense` makes EVERY element non-zero (the queue at its
+    capacity of 2 x 256 entries per wave).  The plane-output entry point must hold the same numbers as three bf16 pieces."""
+    has_pi, cdisp = bool(flags & 1), bool(flags & 2)
+    am, ad, ap, y, sf = _heads(B, G, 3 + B, False)
+    if dense:
+        y = y + 1.0
+    rng = np.random.RandomState(9)
+    tw = rng.normal(0, 1.5, G).astype(np.float32).astype(np.float64)
+    ridge = 0.01 if has_pi else 0.0
+    inv_n = 1.0 / (B * G)
+    if has_pi:
+        ls, lm, dm, dd, dp = Z.zinb_loss_and_grads(am, None if cdisp else ad, ap, y, sf, ridge, theta_w=tw if cdisp else None)
+    else:
+        ls, lm, dm, dd = Z.nb_loss_and_grads(am, None if cdisp else ad, y, sf, theta_w=tw if cdisp else None)
+        dp = None
+    Gp = (G + 7) // 8 * 8
+    lda = 3 * Gp
+    A = np.zeros((B, lda)); A[:, :G] = am; A[:, Gp:Gp + G] = ad; A[:, 2 * Gp:2 * Gp + G] = ap
+    dA = dev(A); dD = torch.full((B, lda), 7.0, device='cuda')
+    dY, dsf, dtw = dev(pad_cols(y, Gp)), dev(sf), dev(tw)
+    part = torch.zeros(ops.max_partials, dtype=torch.float64, device='cuda')
+    a_mean, a_disp, a_pi = dA[:, 0:], dA[:, Gp:], dA[:, 2 * Gp:]
+    d_mean, d_disp, d_pi = dD[:, 0:], dD[:, Gp:], dD[:, 2 * Gp:]
+    n = ops.zinb_nll(a_mean, None if cdisp else a_disp, a_pi if has_pi else None, lda, dtw if cdisp else None, dY, Gp, dsf,
+                     None, None, B, G, ridge, inv_n, flags, d_mean, d_disp, d_pi if has_pi else None, lda, part)
+    loss = torch.zeros(1, device='cuda')
+    ops.loss_finalize(part, n, inv_n, loss)
+    torch.cuda.synchronize()
+    got = loss.item()
+    assert abs(got - lm) <= 3e-6 * abs(lm), (got, lm)
+    D = dD.cpu().numpy().astype(np.float64)
+
+    def close(g, ref, name):
+        err = np.abs(g - ref)
+        bad = err > (2e-4 * np.abs(ref) + 2e-6 * np.abs(ref).max())
+        assert not bad.any(), (name, int(bad.sum()), np.argwhere(bad)[:5], g[bad][:5], ref[bad][:5])
+    close(D[:, :G], dm, 'd_mean')
+    if not cdisp:
+        close(D[:, Gp:Gp + G], dd, 'd_disp')
+    if has_pi:
+        close(D[:, 2 * Gp:2 * Gp + G], dp, 'd_pi')
+    # the same launch with plane output: piece 0 + piece 1 + piece 2 = the fp32 value to 2^-22 of it
+    P = ops.planes_alloc(B, lda, 'cuda')
+    P.fill_(3.0)
+    Dth = torch.full((B, Gp), 7.0, device='cuda')
+    part.zero_()
+    n2 = ops.zinb_nll_planes(a_mean, None if cdisp else a_disp, a_pi if has_pi else None, lda, dtw if cdisp else None, dY, Gp, dsf,
+                             None, None, B, G, ridge, inv_n, flags, P, 0, 0 if cdisp else Gp, 2 * Gp if has_pi else 0,
+                             Dth if cdisp else None, Gp, part)
+    ops.loss_finalize(part, n2, inv_n, loss)
+    torch.cuda.synchronize()
+    assert loss.item() == got
+    S = P.double().sum(0).cpu().numpy()
+    heads = [(0, 'mean')] + ([] if cdisp else [(Gp, 'disp')]) + ([(2 * Gp, 'pi')] if has_pi else [])
+    for c0, name in heads:
+        ref = D[:, c0:c0 + G]
+        assert np.abs(S[:, c0:c0 + G] - ref).max() <= 2.0 ** -22 * np.abs(ref).max() + 1e-38, name
+    if cdisp:
+        assert torch.equal(Dth[:, :G], dD[:, Gp:Gp + G])
+
+
 @pytest.mark.parametrize('flag,B,G', [(4, 8, 40), (4, 33, 1000), (8, 16, 203), (8, 5, 6)])
 def test_poisson_and_mse_vs_oracle(ops, flag, B, G):
     """DCAHIP_NLL_POISSON / DCAHIP_NLL_MSE (ae_types 'poisson', 'normal'): loss and d loss / d a_mean."""
