@@ -1058,6 +1058,16 @@ Plan make_plan(int M, int N, int K, int split_k) {
     else if (N <= 64) { p.cfg = 0; p.BM = 128; p.BN = 64; }
     else if (M <= 64) { p.cfg = 1; p.BM = 64; p.BN = 128; }
     else { p.cfg = 2; p.BM = 128; p.BN = 128; }
+    // mid-size outputs (the hidden stack of the wide networks at throughput batches: 2048 x 256 x 512, 512 x 256 x 2048 ...):
+    // at most 64 tiles of 128 x 128 -- a quarter of the chip -- which only a deep split-K (+ its reduce launch) could spread;
+    // 64 x 64 tiles fill it with little or no split (tools/bench_hidden_gemm.py: the twelve products of configs[4]'s stack
+    // 283 -> 160 us; profiles/r03_hidden_gemm_notes.txt)
+#ifndef DCA_GEMM_NO_MID64
+    const bool mid = p.cfg == 2 && (long)M * N <= 2048L * 512;
+#else
+    const bool mid = false;
+#endif
+    if (mid) { p.cfg = 3; p.BM = 64; p.BN = 64; }
     p.mtiles = (M + p.BM - 1) / p.BM;
     p.ntiles = (N + p.BN - 1) / p.BN;
     const int nchunks = (K + kBK - 1) / kBK;
@@ -1069,7 +1079,11 @@ Plan make_plan(int M, int N, int K, int split_k) {
         // workgroups (0.147 ms vs 0.239 at 384), 20000x64x4096 at 157 x 6 = 942 (0.160 vs 0.214)
         S = 1;
         const long target = p.cfg == 3 ? 1536 : 1024;
-        if (tiles < target) {
+        if (mid) {                                       // one workgroup per CU, K slices of at least 128
+            S = (int)(256 / tiles);
+            if (S > nchunks / 4) S = nchunks / 4;
+            if (S < 1) S = 1;
+        } else if (tiles < target) {
             S = (int)(target / tiles);
             if (S > nchunks / 2) S = nchunks / 2;
             if (S > 128) S = 128;

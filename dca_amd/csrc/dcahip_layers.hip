@@ -67,6 +67,14 @@ __host__ __device__ inline int n_chunks(int B) {
     return r < 1 ? 1 : (r > kMaxChunks ? kMaxChunks : r);
 }
 __host__ __device__ inline int chunk_rows(int B, int R) { return (B + R - 1) / R; }
+// layers wider than 64 units: the 64-column strips of the BatchNorm kernels go to grid.y while the row blocks alone do not
+// fill the chip (512 units at batch 2048: 32 row chunks x 8 strips instead of 32 workgroups walking 8 strips each)
+inline int strip_blocks(int H, int row_blocks) {
+    const int strips = (H + 63) / 64;
+    int y = row_blocks > 0 ? 512 / row_blocks : strips;
+    if (y < 1) y = 1;
+    return y < strips ? y : strips;
+}
 
 // sum over the 4 row lanes (waves) of a workgroup; result valid in every thread
 __device__ __forceinline__ float wg_rowlane_sum(float v, float* sm /*[4][64]*/) {
@@ -86,7 +94,7 @@ __global__ __launch_bounds__(256) void col_moments_kernel(const float* Z, long l
     const int r0 = r * cr, r1 = min(B, r0 + cr);
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const float cnt = (float)max(r1 - r0, 0);
-    for (int c0 = 0; c0 < H; c0 += 64) {
+    for (int c0 = blockIdx.y * 64; c0 < H; c0 += 64 * gridDim.y) {     // column strips spread over grid.y
         const int c = c0 + tx;
         float s = 0.f;
         if (c < H) {
@@ -217,7 +225,7 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(BnApplyArgs a) {
     float* s_mean = dyn;
     float* s_inv = dyn + a.H;
     __shared__ double smd[512];
-    for (int c0 = 0; c0 < a.H; c0 += 64) {
+    for (int c0 = blockIdx.y * 64; c0 < a.H; c0 += 64 * gridDim.y) {
         const int c = c0 + (threadIdx.x & 63);
         float mean = 0.f, var = 1.f;
         if (a.entries) {
@@ -242,7 +250,7 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(BnApplyArgs a) {
     __syncthreads();
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int r0 = blockIdx.x * kApplyRows, r1 = min(a.B, r0 + kApplyRows);
-    for (int c0 = 0; c0 < a.H; c0 += 64) {
+    for (int c0 = blockIdx.y * 64; c0 < a.H; c0 += 64 * gridDim.y) {
         const int c = c0 + tx;
         if (c >= a.H) continue;
         const float mean = s_mean[c], inv = s_inv[c], beta = a.beta ? a.beta[c] : 0.f;
@@ -274,7 +282,7 @@ __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(const float* dH, long 
     const int cr = chunk_rows(B, R);
     const int r0 = r * cr, r1 = min(B, r0 + cr);
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    for (int c0 = 0; c0 < H; c0 += 64) {
+    for (int c0 = blockIdx.y * 64; c0 < H; c0 += 64 * gridDim.y) {
         const int c = c0 + tx;
         float s1 = 0.f, s2 = 0.f;
         if (c < H)
@@ -311,7 +319,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
     float* s1 = dyn;
     float* s2 = dyn + a.H;
     __shared__ float smf[256];
-    for (int c0 = 0; c0 < a.H; c0 += 64) {
+    for (int c0 = blockIdx.y * 64; c0 < a.H; c0 += 64 * gridDim.y) {
         const int c = c0 + (threadIdx.x & 63);
         float v1 = 0.f, v2 = 0.f;
         if (c < a.H)
@@ -330,7 +338,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
     __syncthreads();
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int r0 = blockIdx.x * kApplyRows, r1 = min(a.B, r0 + kApplyRows);
-    for (int c0 = 0; c0 < a.H; c0 += 64) {
+    for (int c0 = blockIdx.y * 64; c0 < a.H; c0 += 64 * gridDim.y) {
         const int c = c0 + tx;
         if (c >= a.H) continue;
         const float m1 = s1[c], m2 = s2[c], inv = a.inv_std[c];
@@ -1875,7 +1883,7 @@ extern "C" int dcahip_col_moments_chunks(int B) { return n_chunks(B); }
 
 extern "C" int dcahip_col_moments(const float* Z, long ldz, int B, int H, float* part, void* stream) {
     if (!Z || !part || B <= 0 || H <= 0) return DCAHIP_EINVAL;
-    hipLaunchKernelGGL(col_moments_kernel, dim3(n_chunks(B)), dim3(256), 0,
+    hipLaunchKernelGGL(col_moments_kernel, dim3(n_chunks(B), strip_blocks(H, n_chunks(B))), dim3(256), 0,
                        static_cast<hipStream_t>(stream), Z, ldz, B, H, part);
     return (int)hipGetLastError();
 }
@@ -1900,7 +1908,7 @@ extern "C" int dcahip_bn_relu_apply(const float* Z, long ldz, int B, int H, cons
     BnApplyArgs a{Z, ldz, B, H, entries, counts, E, beta, moving_mean, moving_var, momentum, eps,
                   relu, Hout, ldh, xhat, ldx, inv_std};
     const int grid = B > 0 ? (B + kApplyRows - 1) / kApplyRows : 1;
-    hipLaunchKernelGGL(bn_relu_apply_kernel, dim3(grid), dim3(256), 2 * H * sizeof(float),
+    hipLaunchKernelGGL(bn_relu_apply_kernel, dim3(grid, strip_blocks(H, grid)), dim3(256), 2 * H * sizeof(float),
                        static_cast<hipStream_t>(stream), a);
     return (int)hipGetLastError();
 }
@@ -1909,7 +1917,7 @@ extern "C" int dcahip_bn_bwd_sums(const float* dH, long ldd, const float* Hact, 
                                   const float* xhat, long ldx, int B, int H, float* part,
                                   int act, void* stream) {
     if (!dH || !Hact || !xhat || !part || B <= 0 || H <= 0) return DCAHIP_EINVAL;
-    hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(n_chunks(B)), dim3(256), 0,
+    hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(n_chunks(B), strip_blocks(H, n_chunks(B))), dim3(256), 0,
                        static_cast<hipStream_t>(stream), dH, ldd, Hact, ldh, xhat, ldx, B, H, part, act);
     return (int)hipGetLastError();
 }
@@ -1922,7 +1930,7 @@ extern "C" int dcahip_bn_bwd_apply(const float* dH, long ldd, const float* Hact,
         return DCAHIP_EINVAL;
     BnBwdArgs a{dH, ldd, Hact, ldh, xhat, ldx, inv_std, sums, E, n_total, B, H, dZ, ldz, dbeta, act};
     const int grid = (B + kApplyRows - 1) / kApplyRows;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 2 * H * sizeof(float),
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid, strip_blocks(H, grid)), dim3(256), 2 * H * sizeof(float),
                        static_cast<hipStream_t>(stream), a);
     return (int)hipGetLastError();
 }

@@ -18,6 +18,8 @@ import torch.distributed as dist
 
 
 class TorchDistComm:
+    dp = True             # the data-parallel step (exchanges in place) -- also with ONE rank (init_from_env(force=True))
+
     def __init__(self, group=None):
         assert dist.is_initialized()
         self.group = group
@@ -107,13 +109,20 @@ class TorchDistComm:
         return out
 
 
-def init_from_env(backend=None):
+def init_from_env(backend=None, force=None):
     """Initialises torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun contract) and
-    binds this process to its GPU. Returns a communicator (SingleProcess if WORLD_SIZE <= 1)."""
+    binds this process to its GPU. Returns a communicator (SingleProcess if WORLD_SIZE <= 1).
+    force (or DCA_AMD_DIST_FORCE=1): a real communicator with ONE rank as well -- the data-parallel step with its RCCL
+    calls, streams and waits on a one-GPU box (tests/test_dist_gpu.py)."""
     from .engine import SingleProcess
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world <= 1:
+    if force is None:
+        force = os.environ.get('DCA_AMD_DIST_FORCE', '0') == '1'
+    if world <= 1 and not force:
         return SingleProcess()
+    if world <= 1:
+        os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
+        os.environ.setdefault('MASTER_PORT', '29533')
     local_rank = int(os.environ.get('LOCAL_RANK', os.environ.get('RANK', '0')))
     if backend is None:
         # DCA_AMD_DIST_BACKEND=gloo: functional multi-rank runs on a box with fewer GPUs than ranks

@@ -109,6 +109,7 @@ class EventProfiler:
 class SingleProcess:
     """Communication stub for one GPU."""
     world, rank = 1, 0
+    dp = False            # no communicator: the single-GPU kernel choices (fused BatchNorm, graphs) apply
 
     def all_reduce_sum(self, t):
         return t
@@ -298,7 +299,7 @@ class Engine:
         # parameters (and keeps only that shard of the RMSprop slots current) -> all-gather of the parameters, instead of
         # all-reducing the whole gradient and updating everything everywhere.  Same bytes on the wire
         # (2 (N-1)/N P either way), 1/N of the optimizer traffic per rank; DCA_AMD_DP_SHARDED_OPT=1 switches it on.
-        self.sharded_opt = self.comm.world > 1 and os.environ.get('DCA_AMD_DP_SHARDED_OPT', '0') == '1'
+        self.sharded_opt = self.comm.dp and os.environ.get('DCA_AMD_DP_SHARDED_OPT', '0') == '1'
         self.mm = [torch.zeros(h, **f32) for h in lay.hidden] if batchnorm else []
         self.mv = [torch.ones(h, **f32) for h in lay.hidden] if batchnorm else []
         self.lr = torch.full((1,), 1e-3, **f32)
@@ -496,7 +497,7 @@ class Engine:
         extra = {} if self.slot2 is None else {'slot2': self.slot2.cpu().numpy()}
         if self.m_sched is not None:
             extra['m_sched'] = self.m_sched.cpu().numpy()
-        if self.sharded_opt and self.comm.world > 1:      # every rank holds one shard of the slots: collect them
+        if self.sharded_opt and self.comm.dp:      # every rank holds one shard of the slots: collect them
             sh = self.flat_len // self.comm.world
             self.ms.copy_(self.comm.all_gather(self.ms[self.comm.rank * sh:(self.comm.rank + 1) * sh]).reshape(-1))
         T = self.lay.total
@@ -883,7 +884,7 @@ class Engine:
         """The hidden stack in one cooperative launch per direction (K-STACK): one GPU, batch norm on, every layer at
         most 64 units, no dropout / PReLU, batches beyond the single-workgroup kernels."""
         lay = self.lay
-        return (self.comm.world == 1 and lay.batchnorm and not self.prelu and not self.has_dropout
+        return (not self.comm.dp and lay.batchnorm and not self.prelu and not self.has_dropout
                 and hasattr(self.ops, 'hidden_stack_fwd') and self.ws_stack is not None
                 and 1 <= len(lay.hidden) <= 8 and max(lay.hidden) <= 64 and not self._bn_small(B)
                 and B <= self.ops.hidden_stack_max_rows and self.stack_mode != 'off')
@@ -914,7 +915,7 @@ class Engine:
     def _bn_small(self, B):
         """Small batches on one GPU take the single-launch batch-norm kernels (the reference-default batch of 32 is
         bound by launch gaps, not by kernels)."""
-        return self.comm.world == 1 and 0 < B <= getattr(self.ops, 'bn_fused_max_rows', 0)
+        return not self.comm.dp and 0 < B <= getattr(self.ops, 'bn_fused_max_rows', 0)
 
     def _batch_moments(self, i, B, h, counts):
         """Batch statistics of layer i as (entries, counts, E) for bn_relu_apply.  One GPU: the
@@ -923,7 +924,7 @@ class Engine:
         ops = self.ops
         if B > 0:
             ops.col_moments(self.Z[i], self.ldh[i], B, h, self.part[i])
-        if self.comm.world == 1:
+        if not self.comm.dp:
             return self.part[i], None, ops.col_moments_chunks(B)
         R = ops.col_moments_chunks(max(B, 1))
         if B > 0:
@@ -1017,7 +1018,7 @@ class Engine:
         Bg = B if B_global is None else B_global
         inv_n = 1.0 / (float(Bg) * lay.G_out)
         w, g = self.w, self.g
-        if comm.world > 1:
+        if comm.dp:
             key = tuple(world_counts)
             if self._counts_world_key != key:
                 self.counts_world.copy_(torch.as_tensor(world_counts, dtype=torch.float32))
@@ -1027,7 +1028,7 @@ class Engine:
             self._forward_backward(B, Bg, inv_n)
         else:
             self._empty_step()
-        if comm.world > 1 and self._use_sharded_opt():
+        if comm.dp and self._use_sharded_opt():
             # reduce-scatter -> this rank's shard of clip + RMSprop -> all-gather of the updated parameters
             sh = self.flat_len // comm.world
             lo = comm.rank * sh
@@ -1042,7 +1043,7 @@ class Engine:
                 ops.counter_add(self.drop_iter, 1)
             ops.step_end(g[lay.P:], float(Bg), self.hist, rows_per_slot or max(self.Bmax, 1), self.acc, self.cursor, B)
             return
-        if comm.world > 1:
+        if comm.dp:
             # bucket 2: hidden layers; bucket 1 (heads + loss) has been travelling since the heads'
             # backward finished (_launch_heads_bucket)
             comm.all_reduce_sum(g[:lay.seg['Wh'][0]])
@@ -1086,7 +1087,7 @@ class Engine:
     def _launch_heads_bucket(self):
         """Data parallel: all-reduce of g[Wh .. P] (head weights, biases, log-dispersion, batch
         loss) starts now, asynchronously."""
-        if self.comm.world > 1 and not self._use_sharded_opt():
+        if self.comm.dp and not self._use_sharded_opt():
             lay = self.lay
             self._pending = self.comm.all_reduce_sum_async(self.g[lay.seg['Wh'][0]:lay.P + 1])
 
@@ -1173,7 +1174,7 @@ class Engine:
                                     self.ldh[i], B, h, self.bpart[i], self.act)
                     E = ops.col_moments_chunks(B)
                     local_s1 = None
-                    if comm.world > 1:
+                    if comm.dp:
                         E, local_s1 = self._reduce_bwd_sums(i, E, h)
                     ops.bn_bwd_apply(self.dH[i], self.ldh[i], self.H[i], self.ldh[i], self.XH[i],
                                      self.ldh[i], self.inv_std[i], self.bpart[i], E, float(Bg), B, h,

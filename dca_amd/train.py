@@ -183,7 +183,7 @@ class _StepRunner:
         self.eng = eng
         if use_graph is None:
             use_graph = os.environ.get('DCA_AMD_GRAPH', '1') != '0'
-        self.use_graph = bool(use_graph) and eng.ops.device_type == 'cuda' and eng.comm.world == 1
+        self.use_graph = bool(use_graph) and eng.ops.device_type == 'cuda' and not eng.comm.dp
         self.graphs = {}
 
     def _capture(self, args, k):

@@ -107,3 +107,80 @@ def test_bench_multi_rank_branch_runs_on_one_gpu():
     assert abs(out['value'] - 3 * 512 / (out['ms_per_step'] * 3e-3)) < 1e-6 * out['value']
     assert np.isfinite(out['loss_first']) and np.isfinite(out['loss_last'])
     assert out['cpu_baseline'] is None                            # rank 0 at N = 1 only
+
+
+def _run_rccl_one_rank(port, cfg, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    os.environ.pop('DCA_AMD_DIST_BACKEND', None)
+    try:
+        from dca_amd.engine import Engine
+        from dca_amd.train import fit_engine
+        comm = ddist.init_from_env(force=True)                       # backend nccl = RCCL, one rank
+        assert comm.dp and comm.world == 1 and dist.get_backend() == 'nccl'
+        # the communicator's own calls on device tensors
+        t = torch.arange(10000, dtype=torch.float32, device='cuda')
+        assert torch.equal(comm.all_reduce_sum(t.clone()), t)
+        w = comm.all_reduce_sum_async(t)
+        comm.wait(w)
+        assert torch.equal(comm.all_gather(t[:7])[0], t[:7])
+        out = torch.zeros(10000, device='cuda')
+        comm.reduce_scatter_sum(t, out)
+        assert torch.equal(out, t)
+        comm.all_gather_into(out, out[:10000])
+        n, G, hs, ae, bn, B, epochs, seed, sharded = cfg
+        os.environ['DCA_AMD_DP_SHARDED_OPT'] = '1' if sharded else '0'
+        X, Y, sf, p = make_problem(n, G, hs, ae, bn, seed=3)
+        n_train = int(n * 0.9)
+        eng = Engine(ae, G, G, hs, bn, 0.0, comm=comm)
+        eng.set_params(p)
+        eng.load_data(X, Y, sf)
+        comm.timer = {}
+        h = fit_engine(eng, n_train, n - n_train, n_train, n - n_train, 0, epochs=epochs, batch_size=B,
+                       shuffle_rng=np.random.RandomState(seed), reduce_lr=1, early_stop=0)
+        torch.cuda.synchronize()
+        spans = comm.timer_summary()
+        q.put((h.history, eng.get_params(), {k: v[0] for k, v in spans.items()}))
+        dist.barrier()
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('sharded', [False, True])
+@pytest.mark.parametrize('ae,n,B,hs', [('zinb-conddisp', 300, 64, (64, 32, 64)), ('zinb-conddisp', 700, 256, (128, 32, 128))])
+def test_rccl_communicator_with_one_rank_runs_the_data_parallel_step(ae, n, B, hs, sharded):
+    """The data-parallel step over the REAL backend (nccl = RCCL) on the one GPU of the box: a one-rank communicator
+    (init_from_env(force=True)) puts every exchange of the step -- the asynchronous heads bucket on its own RCCL
+    communicator and stream, the SyncBN all-gathers / all-reduces, the loss slot, and with DCA_AMD_DP_SHARDED_OPT the
+    reduce-scatter / all-gather pair -- between the kernels exactly as N ranks would; with one rank every exchange is the
+    identity, so the fit must reproduce the single-process engine."""
+    G, epochs, seed, bn = 150, 2, 17, True
+    cfg = (n, G, hs, ae, bn, B, epochs, seed, sharded)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    pr = ctx.Process(target=_run_rccl_one_rank, args=(_free_port(), cfg, q))
+    pr.start()
+    hist_dp, p_dp, calls = q.get(timeout=300)
+    pr.join(timeout=120)
+    assert pr.exitcode == 0
+    assert any(k.startswith('wait_async') for k in calls) or sharded, calls      # the exchanges did run
+    assert sum(calls.values()) > 0
+
+    from dca_amd.engine import Engine
+    from dca_amd.train import fit_engine
+    X, Y, sf, p = make_problem(n, G, hs, ae, bn, seed=3)
+    n_train = int(n * 0.9)
+    eng = Engine(ae, G, G, hs, bn, 0.0)
+    eng.set_params(p)
+    eng.load_data(X, Y, sf)
+    h1 = fit_engine(eng, n_train, n - n_train, n_train, n - n_train, 0, epochs=epochs, batch_size=B,
+                    shuffle_rng=np.random.RandomState(seed), reduce_lr=1, early_stop=0)
+    # the data-parallel step takes the separate BatchNorm kernels (statistics exchanged between two launches): same
+    # numbers to fp32 re-association
+    np.testing.assert_allclose(hist_dp['loss'], h1.history['loss'], rtol=3e-5)
+    np.testing.assert_allclose(hist_dp['val_loss'], h1.history['val_loss'], rtol=3e-5)
+    p1 = eng.get_params()
+    for k in p1:
+        if k[0] == 'b' and k[1:].isdigit():
+            continue                                                  # biases in front of BatchNorm: zero true gradient
+        np.testing.assert_allclose(p_dp[k], p1[k], rtol=2e-3, atol=2e-4, err_msg=k)

@@ -296,6 +296,14 @@ GEMM_SHAPES = [
     (0, 0, 128, 700, 300, False, False, True, 0),
     (0, 0, 64, 3000, 260, False, False, True, 2),
     (0, 0, 333, 130, 257, False, False, True, 0),
+    # mid-size outputs (hidden stack of the wide networks): 64 x 64 tiles, K slices of >= 128
+    (0, 0, 2048, 256, 512, False, True, False, 0),
+    (0, 0, 2048, 512, 256, False, True, False, 0),   # exactly 2048 x 512: the last size on this plan
+    (0, 0, 2049, 512, 256, False, True, False, 0),   # one row more: 128 x 128 tiles
+    (1, 0, 512, 256, 2048, False, False, True, 0),
+    (1, 0, 130, 250, 2047, False, False, True, 0),   # ragged, deep split
+    (0, 1, 2048, 128, 256, False, False, False, 0),
+    (0, 1, 1999, 257, 130, False, False, False, 0),
 ]
 
 

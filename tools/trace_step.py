@@ -1,16 +1,19 @@
 """Per-kernel durations and gaps of the batch-32 training step from a rocprofv3 kernel trace of bench.py:
   rocprofv3 --kernel-trace -d out -o bench --output-format csv -- python bench.py ...
-  python tools/trace_step.py out/.../bench_kernel_trace.csv [marker-kernel-substring]
-One step = the kernels between two consecutive launches of the marker kernel (default: the small-batch K-HEADS)."""
+  python tools/trace_step.py out/.../bench_kernel_trace.csv [marker-kernel-substring] [max kernels per step]
+One step = the kernels between two consecutive launches of the marker kernel (default: the small-batch K-HEADS); intervals with
+more kernels than the limit (default 16) are not steps (epoch ends, validation) and are skipped."""
 import csv, collections, sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 marker = sys.argv[2] if len(sys.argv) > 2 else 'heads_fused_small'
+limit = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 idx = [i for i, r in enumerate(rows) if marker in r['Kernel_Name']]
 dur = collections.OrderedDict(); gaps = []; steps = []
-for a, b in zip(idx[10:-10], idx[11:-9]):
-    if b - a > 16:
+skip = 10 if len(idx) > 40 else 2
+for a, b in zip(idx[skip:-skip], idx[skip + 1:-skip + 1]):
+    if b - a > limit:
         continue
     pe = None
     for r in rows[a:b]:
