@@ -134,7 +134,7 @@ def graph_kernel_nodes(graph):
         return None
 
 
-def capture_step(eng, b, counts, k=1, rows_per_slot=None):
+def capture_step(eng, b, counts, k=1, rows_per_slot=None, b_global=None):
     """k consecutive training steps in one hipGraph (the device cursor advances inside the graph)."""
     try:
         g = torch.cuda.CUDAGraph(keep_graph=True)
@@ -144,7 +144,7 @@ def capture_step(eng, b, counts, k=1, rows_per_slot=None):
     with torch.cuda.stream(st):
         with torch.cuda.graph(g, stream=st):
             for _ in range(k):
-                eng.train_step(b, b, counts, rows_per_slot or b)
+                eng.train_step(b, b if b_global is None else b_global, counts, rows_per_slot or b)
     torch.cuda.current_stream().wait_stream(st)
     return g
 
@@ -296,6 +296,9 @@ def main():
     from dca_amd.engine import Engine, EventProfiler
     comm = ddist.init_from_env()
     W, rank = comm.world, comm.rank
+    # the N-rank branch also runs with ONE rank under DCA_AMD_DIST_FORCE=1 (a one-rank RCCL communicator: every exchange of
+    # the data-parallel step in place, on a one-GPU box)
+    multi = bool(getattr(comm, 'dp', W > 1))
     if args.gpus != W:
         if W == 1 and args.gpus > 1:
             raise SystemExit('bench.py --gpus %d must be launched with torch.distributed.run' % args.gpus)
@@ -305,7 +308,7 @@ def main():
     n_train_global = int(args.cells * 0.9)               # validation_split=0.1 tail is not trained on
     t0, n_local = ddist.shard(n_train_global, W, rank)
     n_local = n_train_global // W                         # equal shards (all-gather of stats)
-    n_val = args.cells - n_train_global if W == 1 else 0  # one GPU: the held-out rows sit behind the train rows
+    n_val = args.cells - n_train_global if not multi else 0  # one GPU: the held-out rows sit behind the train rows
     n_store = n_local + n_val
 
     # ---- synthetic data, generated and normalised in HBM (not timed)
@@ -316,23 +319,23 @@ def main():
     from dca_amd.ops import HipOps
     pops = HipOps()
     counts = prep.cell_counts(pops, Y, n_store, G)
-    med = (comm.all_gather(counts).flatten() if W > 1 else counts).median()
+    med = (comm.all_gather(counts).flatten() if multi else counts).median()
     sf = counts / med
-    X, norm = prep.transform(pops, Y, n_store, G, sf, True, True, comm if W > 1 else None, return_norm=True)
+    X, norm = prep.transform(pops, Y, n_store, G, sf, True, True, comm if multi else None, return_norm=True)
     eng = Engine('zinb-conddisp', G, G, hidden, True, 0.0, comm=comm)
     eng.init_params(0)
     # norm: how X was made from Y -> the engine keeps the counts as bytes and runs the first layer on the non-zero ones
     eng.attach_device_data(X, Y, sf, norm=norm)
-    eng.reserve(max(B, 1024) if W == 1 else B)           # validation runs in chunks of up to 1024 rows
+    eng.reserve(max(B, 1024) if not multi else B)           # validation runs in chunks of up to 1024 rows
     eng.clip = 5.0
     eng.set_lr(1e-3)
     counts = [B] * W
     # one GPU: the steps are replayed as hipGraphs -- ~30 launches per 1.3 ms step leave the host little slack (a busy
     # host starves the GPU); replay is GPU-paced.  N > 1 stays eager (collectives).
-    use_graph = ((args.graph == 'on') or (args.graph == 'auto' and W == 1)) and W == 1
+    use_graph = ((args.graph == 'on') or (args.graph == 'auto' and not multi)) and not multi
 
     def barrier():
-        if W > 1:
+        if multi:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -348,7 +351,7 @@ def main():
 
     prof = None
     comm_ms = None
-    if W == 1:
+    if not multi:
         # ---- one GPU: the K timed steps are K consecutive steps of the FIT LOOP's sequence -- epoch after epoch over the
         # train rows in shuffled order, full batches then the partial one -- after W eager warm-up steps and one
         # untimed epoch through the graphs.  The default K is three epochs: `value` is then the >= 3-epoch figure.
@@ -381,10 +384,14 @@ def main():
                        'its own graph (%d launches per %d-step epoch)' % (runner.launches_per_epoch(), runner.spe)) \
             if use_graph else 'eager'
     else:
-        # ---- N GPUs: weak scaling, every rank takes B rows of its shard per step, eager (collectives)
+        # ---- N GPUs: weak scaling, every rank takes B rows of its shard per step.  The steps are replayed as hipGraphs with
+        # the RCCL exchanges captured inside (8 consecutive steps per launch, as train.py::_StepRunner does for the fit
+        # loop): an eager data-parallel step is host-bound.  --graph off, DCA_AMD_DP_GRAPH=0 or a capture that raises on
+        # any rank -> eager steps on every rank.
         runner = None
         K = args.steps if args.steps > 0 else 48
-        total_steps = args.warmup + K
+        EXTRA = 8 + 8 + 8 + 24                        # eager steps with the exchange timers, first replays, per-kernel timing
+        total_steps = args.warmup + K + EXTRA
         gen = torch.Generator(device='cpu'); gen.manual_seed(1234 + rank)
         need = total_steps * B
         perms = []
@@ -396,22 +403,52 @@ def main():
         eng.cursor.zero_(); eng.acc.zero_()
         for i in range(args.warmup):
             eng.train_step(B, B * W, counts, B)
-        prof = EventProfiler(); eng.prof = prof
+        # exposed communication of the EAGER step: what the compute stream spent inside (or waiting for) each exchange
         comm.timer = {}
+        for i in range(8):
+            eng.train_step(B, B * W, counts, B)
+        comm_ms = {k: {'calls_per_step': v[0] / 8, 'ms_per_step': v[1] / 8} for k, v in comm.timer_summary().items()}
+        comm.timer = None
+        use_graph = args.graph != 'off' and os.environ.get('DCA_AMD_DP_GRAPH', '1') != '0' and getattr(comm, 'capturable', False)
+        graphs = {}
+        if use_graph:
+            ok = 1.0
+            try:
+                for k in {min(8, K), K % 8} - {0}:
+                    graphs[k] = capture_step(eng, B, counts, k, rows_per_slot=B, b_global=B * W)
+            except Exception as e:                    # noqa: BLE001
+                print('bench: capture of the data-parallel step failed on rank %d (%s: %s); eager' % (rank, type(e).__name__, e),
+                      file=sys.stderr)
+                ok = 0.0
+            flag = torch.tensor([ok], device=dev)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+            use_graph = bool(flag.item() > 0.5)
+        if use_graph:
+            for k, g in graphs.items():              # untimed: the first replay of every graph
+                g.replay()
+            torch.cuda.synchronize()
+            if not bool(torch.isfinite(eng.g[eng.lay.P]).item()):
+                raise SystemExit('bench: the replayed data-parallel steps left a non-finite loss')
+        else:
+            prof = EventProfiler(); eng.prof = prof
         barrier()
         t_start = time.perf_counter()
-        for i in range(K):
-            eng.train_step(B, B * W, counts, B)
+        if use_graph:
+            for i in range(K // 8):
+                graphs[8].replay()
+            if K % 8:
+                graphs[K % 8].replay()
+        else:
+            for i in range(K):
+                eng.train_step(B, B * W, counts, B)
         barrier()
         el = time.perf_counter() - t_start
-        # exposed communication: what the compute stream spent inside (or waiting for) each exchange, per step
-        comm_ms = {k: {'calls_per_step': v[0] / K, 'ms_per_step': v[1] / K} for k, v in comm.timer_summary().items()}
-        comm.timer = None
         cells_timed = K * B * W
         steps_timed = K
-        launch_desc = 'eager'
+        launch_desc = ('hipGraph replay with the RCCL exchanges captured, 8 consecutive steps per graph launch'
+                       if use_graph else 'eager')
     elt = torch.tensor([el], dtype=torch.float64, device=dev)
-    if W > 1:
+    if multi:
         torch.distributed.all_reduce(elt, op=torch.distributed.ReduceOp.MAX)
     el = float(elt.item())
     eng.prof = None
@@ -476,7 +513,7 @@ def main():
 
     extra = {}
     _mark('timed region and kernel timing done')
-    if W == 1:
+    if not multi:
         extra = after_measurements(eng, args, B, n_local, n_val, G, dev, runner)
     _mark('after-measurements done')
 
@@ -495,9 +532,11 @@ def main():
                        'parallelism': 'dp%d' % W, 'launch': launch_desc,
                        'timed_region': ('%d consecutive steps of the fit loop (epochs of %d full batches of %d cells + one of %d), '
                                         '%d cells; ms_per_step averages over full and partial batches'
-                                        % (steps_timed, n_local // B, B, n_local % B, cells_timed)) if W == 1 else
+                                        % (steps_timed, n_local // B, B, n_local % B, cells_timed)) if not multi else
                                        ('%d steps of %d cells per GPU' % (steps_timed, B)),
                        'exposed_comm_ms_per_step': comm_ms,
+                       'exposed_comm_source': ('8 eager steps before the timed region: events round each exchange (and each wait for '
+                                               'the asynchronous bucket) on the compute stream') if multi else None,
                        'optimizer': 'RMSprop+clipvalue', 'params': int(eng.lay.P),
                        'arithmetic': 'fp32 results: matrix products as three-way bf16 splits, six products, fp32 accumulation '
                                      '(fp32-dot-product accuracy, tests/test_heads_fused_gpu.py::test_x3_products_are_fp32_accurate); '
@@ -506,7 +545,7 @@ def main():
             'loss_first': loss_first, 'loss_last': loss_last,
             'roofline': roof, 'kernels': kernels,
         }
-        if not args.no_cpu_baseline and W == 1:
+        if not args.no_cpu_baseline and not multi:
             nb = min(n_local, max(B, 4 * B))
             p = eng.get_params()
             # host copy of a bounded sample of the same matrix; weights = current device weights
@@ -515,7 +554,7 @@ def main():
         else:
             out['cpu_baseline'] = None
         print(json.dumps(out), flush=True)
-    if W > 1:
+    if multi:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

@@ -24,6 +24,8 @@ class TorchDistComm:
         assert dist.is_initialized()
         self.group = group
         self.world = dist.get_world_size(group)
+        # the exchanges may be captured into hipGraphs with the step only over RCCL (gloo stages through the host)
+        self.capturable = dist.get_backend(group) == 'nccl'
         self.rank = dist.get_rank(group)
         # a second communicator (its own RCCL stream) for the bulk gradient bucket: on the main
         # one it would queue the small SyncBN exchanges of the backward pass behind 15 MB
@@ -42,6 +44,10 @@ class TorchDistComm:
         def __enter__(self):
             if self.comm.timer is None:
                 return self
+            # inside a graph capture the call is only counted: events recorded there have no time of their own
+            self.captured = self.cuda and torch.cuda.is_current_stream_capturing()
+            if self.captured:
+                return self
             if self.cuda:
                 self.s = torch.cuda.Event(enable_timing=True); self.e = torch.cuda.Event(enable_timing=True)
                 self.s.record()
@@ -52,6 +58,9 @@ class TorchDistComm:
 
         def __exit__(self, *a):
             if self.comm.timer is None:
+                return False
+            if self.captured:
+                self.comm.timer.setdefault(self.name, []).append(None)
                 return False
             if self.cuda:
                 self.e.record()
@@ -67,8 +76,8 @@ class TorchDistComm:
         if torch.cuda.is_available():
             torch.cuda.synchronize()
         for k, lst in (self.timer or {}).items():
-            ms = [x * 1e3 if isinstance(x, float) else x[0].elapsed_time(x[1]) for x in lst]
-            out[k] = (len(ms), float(sum(ms)))
+            ms = [x * 1e3 if isinstance(x, float) else x[0].elapsed_time(x[1]) for x in lst if x is not None]
+            out[k] = (len(lst), float(sum(ms)))
         return out
 
     def all_reduce_sum(self, t):

@@ -331,7 +331,8 @@ class Engine:
         self.opt_iter = torch.zeros(1, dtype=torch.int64, device=self.dev)
         self.reg = None             # l1 / l2 kernel regularisers (network.py:114-126)
         self.reg_ws = None
-        self._counts_local_key = self._counts_world_key = None
+        self._counts_world_key = None
+        self._counts_local, self._counts_world = {}, {}
         # Dropout (network.py:98-99, 137-138): rates per hidden layer + input; masks are a function of
         # (seed, step counter in device memory, layer, global batch row, unit) -- K-DROP
         n_conf = len(tuple(hidden_size))                    # rates come per configured layer (network.py:87-90)
@@ -656,9 +657,9 @@ class Engine:
         self.part = [torch.zeros(max(R, self.comm.world) * 2 * h, **f32) for h in lay.hidden]
         self.bpart = [torch.zeros(R * 2 * h, **f32) for h in lay.hidden]
         self.stat_local = [torch.zeros(2 * h, **f32) for h in lay.hidden]
-        self.counts_local = torch.zeros(kMaxCounts, **f32)
         self.counts_world = torch.zeros(self.comm.world, **f32)
-        self._counts_local_key = self._counts_world_key = None
+        self._counts_world_key = None
+        self._counts_local, self._counts_world = {}, {}
         # split-K workspace: the maximum any GEMM of a step can ask for, over every batch size up
         # to B (the split plan is a function of the shape: a smaller last batch may split more)
         cand = sorted({B} | {b for k in range(0, B // 64 + 2) for b in (64 * k, 64 * k + 1) if 1 <= b <= B})
@@ -929,11 +930,15 @@ class Engine:
         R = ops.col_moments_chunks(max(B, 1))
         if B > 0:
             cr = -(-B // R)
-            if self._counts_local_key != (B, R):        # host -> device only when the batch size changes
-                self.counts_local[:R] = torch.as_tensor(
-                    [max(0, min(B, (r + 1) * cr) - r * cr) for r in range(R)], dtype=torch.float32)
-                self._counts_local_key = (B, R)
-            ops.moments_combine(self.part[i], self.counts_local, R, h, self.stat_local[i])
+            cl = self._counts_local.get((B, R))
+            if cl is None:
+                # one device buffer per batch size, written once and never again: a captured step keeps reading ITS
+                # buffer when steps of another batch size run in between (a shared buffer refreshed "when the batch size
+                # changes" is refreshed by the host -- which a graph replay does not involve)
+                self._not_capturing('row-chunk counts of a new batch size')
+                cl = torch.as_tensor([max(0, min(B, (r + 1) * cr) - r * cr) for r in range(R)], dtype=torch.float32).to(self.dev)
+                self._counts_local[(B, R)] = cl
+            ops.moments_combine(self.part[i], cl, R, h, self.stat_local[i])
         else:
             self.stat_local[i].zero_()
         gathered = self.comm.all_gather(self.stat_local[i])          # [W, 2h]
@@ -1009,6 +1014,25 @@ class Engine:
                 ops.row_sums_strided(self._plane(D, hd), self.ldD, B, lay.G_out, D[:, c0:], self.ldD)
         return n
 
+    def _not_capturing(self, what):
+        if self.dev.type == 'cuda' and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('host -> device copy inside a graph capture (%s): run one eager step of this shape first' % what)
+
+    def set_world_counts(self, world_counts):
+        """Data parallel: the rows every rank holds in the coming step(s) (SyncBN weights, dropout row offset).  The device
+        copy is refreshed only when the counts change -- and never inside a graph capture: a step runner that replays
+        captured steps calls this before the replay (train.py::_StepRunner)."""
+        key = tuple(world_counts)
+        if self._counts_world_key != key:
+            cw = self._counts_world.get(key)
+            if cw is None:                               # (one buffer per distinct tuple, written once: see _batch_moments)
+                self._not_capturing('per-rank row counts not seen before')
+                cw = torch.as_tensor(world_counts, dtype=torch.float32).to(self.dev)
+                self._counts_world[key] = cw
+            self.counts_world = cw
+            self._counts_world_key = key
+        self.row0 = int(sum(world_counts[:self.comm.rank]))
+
     # ------------------------------------------------------------------ one training step
     def train_step(self, B, B_global=None, world_counts=None, rows_per_slot=None):
         """Forward + backward + clipvalue/RMSprop on the B rows perm[cursor : cursor+B].
@@ -1019,11 +1043,7 @@ class Engine:
         inv_n = 1.0 / (float(Bg) * lay.G_out)
         w, g = self.w, self.g
         if comm.dp:
-            key = tuple(world_counts)
-            if self._counts_world_key != key:
-                self.counts_world.copy_(torch.as_tensor(world_counts, dtype=torch.float32))
-                self._counts_world_key = key
-            self.row0 = int(sum(world_counts[:comm.rank]))
+            self.set_world_counts(world_counts)
         if B > 0:
             self._forward_backward(B, Bg, inv_n)
         else:
@@ -1355,4 +1375,3 @@ class Engine:
         return torch.clamp(torch.exp(tw), 1e-3, 1e4).cpu().numpy()
 
 
-kMaxCounts = 256

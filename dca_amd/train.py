@@ -172,10 +172,14 @@ def fit_engine(eng, n_train_global, n_val_global, nt_local, nv_local, t0_global,
 
 
 class _StepRunner:
-    """Launches training steps; on one GPU the step (10-25 kernels, no host sync) is captured once per distinct batch
+    """Launches training steps; the step (10-25 kernels, no host sync) is captured once per distinct batch
     size into a hipGraph and replayed -- the device cursor makes the same graph valid for every batch of every epoch.
     Runs of equal steps are replayed GRAPH_STEPS at a time from a second graph holding that many consecutive steps:
-    the device idles ~9 us between two graph launches, 6 % of a batch-32 step (profiles/r02w_batch32_step_trace.txt)."""
+    the device idles ~9 us between two graph launches, 6 % of a batch-32 step (profiles/r02w_batch32_step_trace.txt).
+    Data parallel: the RCCL exchanges of the step are captured with it (every rank replays the same sequence of
+    collectives; an eager data-parallel step is host-bound: ~45 launches + 8 collectives took 2.17 ms against 1.25 ms of
+    kernels, profiles/r03_dp_one_rank.txt).  DCA_AMD_DP_GRAPH=0 keeps the data-parallel steps eager; a capture that raises
+    does the same for the rest of the run (a capture executes nothing, so ranks that did capture stay in step)."""
 
     GRAPH_STEPS = int(os.environ.get('DCA_AMD_GRAPH_STEPS', '8'))
 
@@ -183,7 +187,8 @@ class _StepRunner:
         self.eng = eng
         if use_graph is None:
             use_graph = os.environ.get('DCA_AMD_GRAPH', '1') != '0'
-        self.use_graph = bool(use_graph) and eng.ops.device_type == 'cuda' and not eng.comm.dp
+        self.use_graph = bool(use_graph) and eng.ops.device_type == 'cuda' and \
+            (not eng.comm.dp or (getattr(eng.comm, 'capturable', False) and os.environ.get('DCA_AMD_DP_GRAPH', '1') != '0'))
         self.graphs = {}
 
     def _capture(self, args, k):
@@ -197,31 +202,53 @@ class _StepRunner:
         torch.cuda.current_stream().wait_stream(s)
         return g
 
+    def _graph(self, key, args, k):
+        """The graph of k consecutive steps of this shape; None (and eager from now on) if the capture raises."""
+        if self.graphs.get((key, k)) is None:
+            try:
+                self.graphs[(key, k)] = self._capture(args, k)
+            except Exception as e:                       # noqa: BLE001 -- whatever the runtime refuses, the eager step still runs
+                if not self.eng.comm.dp:
+                    raise
+                import sys
+                print('dca_amd: capture of the data-parallel step failed (%s: %s); eager steps from here'
+                      % (type(e).__name__, e), file=sys.stderr)
+                self.use_graph = False
+                return None
+        return self.graphs[(key, k)]
+
     def run(self, b, b_global, world_counts, rows_per_slot, n=1):
         """n consecutive steps of the same shape."""
         eng = self.eng
         args = (b, b_global, world_counts, rows_per_slot)
-        if not self.use_graph or b == 0:
-            for _ in range(n):
+        dp = eng.comm.dp
+        key = (b, b_global, tuple(world_counts)) if dp else b
+        if dp and self.use_graph:
+            eng.set_world_counts(world_counts)           # (host -> device copy when the counts change: outside the graphs)
+
+        def eager(m):
+            for _ in range(m):
                 eng.train_step(*args)
-            return
-        if (b, 1) not in self.graphs:
-            # the first step of each batch size runs eagerly (loads the code objects outside a capture)
+
+        if not self.use_graph or b == 0:
+            return eager(n)
+        if (key, 1) not in self.graphs:
+            # the first step of each shape runs eagerly (loads the code objects outside a capture)
             eng.train_step(*args)
-            self.graphs[(b, 1)] = None
+            self.graphs[(key, 1)] = None
             n -= 1
         K = self.GRAPH_STEPS
         if K > 1 and n >= K:
-            if self.graphs.get((b, K)) is None:
-                self.graphs[(b, K)] = self._capture(args, K)
-            gk = self.graphs[(b, K)]
+            gk = self._graph(key, args, K)
+            if gk is None:
+                return eager(n)
             for _ in range(n // K):
                 gk.replay()
             n %= K
         if n > 0:
-            if self.graphs[(b, 1)] is None:
-                self.graphs[(b, 1)] = self._capture(args, 1)
-            g1 = self.graphs[(b, 1)]
+            g1 = self._graph(key, args, 1)
+            if g1 is None:
+                return eager(n)
             for _ in range(n):
                 g1.replay()
 

@@ -131,16 +131,25 @@ def _run_rccl_one_rank(port, cfg, q):
         os.environ['DCA_AMD_DP_SHARDED_OPT'] = '1' if sharded else '0'
         X, Y, sf, p = make_problem(n, G, hs, ae, bn, seed=3)
         n_train = int(n * 0.9)
-        eng = Engine(ae, G, G, hs, bn, 0.0, comm=comm)
-        eng.set_params(p)
-        eng.load_data(X, Y, sf)
-        comm.timer = {}
-        h = fit_engine(eng, n_train, n - n_train, n_train, n - n_train, 0, epochs=epochs, batch_size=B,
-                       shuffle_rng=np.random.RandomState(seed), reduce_lr=1, early_stop=0)
-        torch.cuda.synchronize()
-        spans = comm.timer_summary()
-        q.put((h.history, eng.get_params(), {k: v[0] for k, v in spans.items()}))
+        res = []
+        for graph in ('0', '1'):                                     # eager steps, then the same fit from captured steps
+            os.environ['DCA_AMD_DP_GRAPH'] = graph
+            eng = Engine(ae, G, G, hs, bn, 0.0, comm=comm)
+            eng.set_params(p)
+            eng.load_data(X, Y, sf)
+            comm.timer = {}
+            h = fit_engine(eng, n_train, n - n_train, n_train, n - n_train, 0, epochs=epochs, batch_size=B,
+                           shuffle_rng=np.random.RandomState(seed), reduce_lr=1, early_stop=0)
+            torch.cuda.synchronize()
+            spans = comm.timer_summary()
+            comm.timer = None
+            res.append((h.history, eng.get_params(), {k: v[0] for k, v in spans.items()}))
+        q.put(tuple(res))
         dist.barrier()
+    except BaseException as e:                                       # the parent must not wait for its timeout
+        import traceback
+        q.put(('error', '%s: %s\n%s' % (type(e).__name__, e, traceback.format_exc()), None))
+        raise
     finally:
         if dist.is_initialized():
             dist.destroy_process_group()
@@ -153,18 +162,26 @@ def test_rccl_communicator_with_one_rank_runs_the_data_parallel_step(ae, n, B, h
     (init_from_env(force=True)) puts every exchange of the step -- the asynchronous heads bucket on its own RCCL
     communicator and stream, the SyncBN all-gathers / all-reduces, the loss slot, and with DCA_AMD_DP_SHARDED_OPT the
     reduce-scatter / all-gather pair -- between the kernels exactly as N ranks would; with one rank every exchange is the
-    identity, so the fit must reproduce the single-process engine."""
+    identity, so the fit must reproduce the single-process engine.  The fit loop captures these steps -- exchanges included --
+    into hipGraphs (train.py::_StepRunner) exactly as it would with N ranks."""
     G, epochs, seed, bn = 150, 2, 17, True
     cfg = (n, G, hs, ae, bn, B, epochs, seed, sharded)
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     pr = ctx.Process(target=_run_rccl_one_rank, args=(_free_port(), cfg, q))
     pr.start()
-    hist_dp, p_dp, calls = q.get(timeout=300)
-    pr.join(timeout=120)
+    got = q.get(timeout=150)
+    pr.join(timeout=60)
+    assert got[0] != 'error', got[1]
     assert pr.exitcode == 0
+    (hist_dp, p_dp, calls), (hist_gr, p_gr, calls_gr) = got
     assert any(k.startswith('wait_async') for k in calls) or sharded, calls      # the exchanges did run
     assert sum(calls.values()) > 0
+    # captured steps (exchanges inside the graphs) = eager steps, bit for bit; fewer host-side calls (capture only)
+    assert hist_gr == hist_dp
+    for k in p_dp:
+        assert np.array_equal(p_gr[k], p_dp[k]), k
+    assert sum(calls_gr.values()) < sum(calls.values())
 
     from dca_amd.engine import Engine
     from dca_amd.train import fit_engine
@@ -175,12 +192,14 @@ def test_rccl_communicator_with_one_rank_runs_the_data_parallel_step(ae, n, B, h
     eng.load_data(X, Y, sf)
     h1 = fit_engine(eng, n_train, n - n_train, n_train, n - n_train, 0, epochs=epochs, batch_size=B,
                     shuffle_rng=np.random.RandomState(seed), reduce_lr=1, early_stop=0)
-    # the data-parallel step takes the separate BatchNorm kernels (statistics exchanged between two launches): same
-    # numbers to fp32 re-association
-    np.testing.assert_allclose(hist_dp['loss'], h1.history['loss'], rtol=3e-5)
-    np.testing.assert_allclose(hist_dp['val_loss'], h1.history['val_loss'], rtol=3e-5)
+    # the data-parallel step takes the separate BatchNorm kernels (statistics exchanged between two launches) where the
+    # single-process step takes the fused ones: the same numbers to fp32 re-association in the first epoch, and what
+    # RMSprop's sign-like early steps make of that in the second (the 5e-4 class of DESIGN.md 7; measured 1.5e-4)
+    np.testing.assert_allclose(hist_dp['loss'][:1], h1.history['loss'][:1], rtol=3e-6)
+    np.testing.assert_allclose(hist_dp['loss'], h1.history['loss'], rtol=5e-4)
+    np.testing.assert_allclose(hist_dp['val_loss'], h1.history['val_loss'], rtol=5e-4)
     p1 = eng.get_params()
     for k in p1:
         if k[0] == 'b' and k[1:].isdigit():
             continue                                                  # biases in front of BatchNorm: zero true gradient
-        np.testing.assert_allclose(p_dp[k], p1[k], rtol=2e-3, atol=2e-4, err_msg=k)
+        np.testing.assert_allclose(p_dp[k], p1[k], rtol=2e-3, atol=2e-3, err_msg=k)
