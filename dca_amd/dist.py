@@ -109,11 +109,11 @@ class TorchDistComm:
             dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, group=self.group)
         return out
 
-    def all_gather_into(self, out, shard):
+    def all_gather_into(self, out, shard, name='all_gather_params'):
         """out = concatenation of every rank's shard (shard may be a slice of out)."""
         src = shard.clone() if shard.data_ptr() >= out.data_ptr() and \
             shard.data_ptr() < out.data_ptr() + out.numel() * out.element_size() else shard
-        with self._Span(self, 'all_gather_params', out):
+        with self._Span(self, name, out):
             dist.all_gather_into_tensor(out, src, group=self.group)
         return out
 

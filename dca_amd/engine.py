@@ -941,8 +941,8 @@ class Engine:
             ops.moments_combine(self.part[i], cl, R, h, self.stat_local[i])
         else:
             self.stat_local[i].zero_()
-        gathered = self.comm.all_gather(self.stat_local[i])          # [W, 2h]
-        self.part[i][:gathered.numel()].copy_(gathered.reshape(-1))
+        # [W, 2h] straight into the entries buffer of bn_relu_apply (no staging tensor, no copy launch)
+        self.comm.all_gather_into(self.part[i][:self.comm.world * 2 * h], self.stat_local[i], name='all_gather_small')
         return self.part[i], counts, self.comm.world
 
     def _heads_forward(self, B, K):
