@@ -1193,16 +1193,15 @@ class Engine:
                     ops.bn_bwd_sums(self.dH[i], self.ldh[i], self.H[i], self.ldh[i], self.XH[i],
                                     self.ldh[i], B, h, self.bpart[i], self.act)
                     E = ops.col_moments_chunks(B)
-                    local_s1 = None
+                    sums, dbeta = self.bpart[i], lay.view(g, 'beta%d' % i)
                     if comm.dp:
-                        E, local_s1 = self._reduce_bwd_sums(i, E, h)
+                        # SyncBN backward: the apply kernel needs the GLOBAL sums; d beta must stay this rank's LOCAL
+                        # share (the gradient bucket is summed over the ranks afterwards)
+                        sums, E = self._reduce_bwd_sums(i, E, h, dbeta), 1
+                        dbeta = None
                     ops.bn_bwd_apply(self.dH[i], self.ldh[i], self.H[i], self.ldh[i], self.XH[i],
-                                     self.ldh[i], self.inv_std[i], self.bpart[i], E, float(Bg), B, h,
-                                     self.dZ[i], self.ldh[i], lay.view(g, 'beta%d' % i), self.act)
-                    if local_s1 is not None:
-                        # bn_bwd_apply wrote d beta from the GLOBAL sums; the gradient bucket is summed
-                        # over ranks afterwards, so each rank must contribute its LOCAL share only
-                        lay.view(g, 'beta%d' % i).copy_(local_s1)
+                                     self.ldh[i], self.inv_std[i], sums, E, float(Bg), B, h,
+                                     self.dZ[i], self.ldh[i], dbeta, self.act)
                 else:
                     ops.relu_bwd(self.dH[i], self.ldh[i], self.H[i], self.ldh[i], B, h, self.dZ[i],
                                  self.ldh[i], self.act)
@@ -1276,13 +1275,13 @@ class Engine:
                 ops.sgemm(0, 1, B, lay.hL, nc, self.D[:, c0:], self.ldD, Wh[:, c0:], lay.NH,
                           self.dH[-1][:, h0:], self.ldh[-1], ws=self.ws)
 
-    def _reduce_bwd_sums(self, i, E, h):
-        """SyncBN backward: local chunk sums -> one [2h] vector -> all-reduce."""
+    def _reduce_bwd_sums(self, i, E, h, dbeta_local):
+        """SyncBN backward: local chunk sums -> one [2h] vector (its first half = this rank's d beta, stored) -> all-reduce;
+        returns the global [sum dy | sum dy xhat]."""
         s = self.bpart[i][:E * 2 * h].view(E, 2 * h).sum(dim=0)
-        local_s1 = s[:h].clone()
+        dbeta_local.copy_(s[:h])
         self.comm.all_reduce_sum(s)
-        self.bpart[i][:2 * h].copy_(s)
-        return 1, local_s1
+        return s
 
     # ------------------------------------------------------------------ evaluation / inference
     def eval_loss_sum(self, r0, r1, scale, chunk=None):
