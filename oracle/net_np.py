@@ -20,7 +20,9 @@ see oracle/__init__.py):
                reference runs on compute with momentum = 0 -- standalone keras 2.2 / 2.3, optimizers.py:
                `new_p = p - lr * g / (K.sqrt(new_a) + self.epsilon)`; tf.keras OptimizerV2 (keras >= 2.4), rmsprop.py
                _resource_apply_dense without momentum: `var - lr_t * grad / (sqrt(rms_t) + epsilon)`.  Only TF's fused
-               ApplyRMSProp kernel, which OptimizerV2 takes with momentum > 0, has the epsilon inside the root.)
+               ApplyRMSProp kernel, which OptimizerV2 takes with momentum > 0, has the epsilon inside the root.
+               Pinned on torch.optim.RMSprop -- the same rule -- in tests/test_oracle_golden.py, with Adagrad /
+               Adadelta / SGD; Dense + BatchNorm forward / backward on the torch autograd twin, torch_ref.py.)
   clipvalue:   g = clip(g, -c, c) element-wise before the update
   fit:         validation = last n - int(n*(1-split)) rows; per epoch a fresh arange is
                shuffled with the numpy global RNG; last partial batch kept; epoch loss =

@@ -136,6 +136,45 @@ def test_rmsprop_epsilon_sits_outside_the_root():
     assert 'torch.sqrt(self.ms[k]) + eps' in inspect.getsource(type(t))
 
 
+@pytest.mark.parametrize('kind', ['sgd', 'rmsprop', 'adagrad', 'adadelta'])
+def test_optimizer_updates_match_torch_optim(kind):
+    """An independent pin of the update rules (Keras / TF are absent here): torch.optim implements the same rules for
+    these four -- RMSprop `p - lr g / (sqrt(a) + eps)` with a = rho a + (1 - rho) g^2 (epsilon OUTSIDE the root, like
+    Keras' momentum-free RMSprop; alpha = Keras' rho 0.9, eps 1e-7), Adagrad with tf.keras' initial accumulator 0.1 and
+    `p - lr g / (sqrt(a) + eps)`, Adadelta (rho 0.95; `sqrt(d + eps) / sqrt(a + eps)`), plain SGD.  Twelve steps in fp64
+    on gradients spanning 1e-9 .. 1e3 (the loss's gradients are O(1e-5): ms << eps in the first steps).  Adam / Adamax /
+    Nadam place epsilon differently in torch and are not compared."""
+    rng = np.random.RandomState(4)
+    n = 64
+    w0 = rng.normal(size=n)
+    mags = 10.0 ** rng.uniform(-9, 3, size=n)
+    lr = 0.01 if kind == 'sgd' else 1e-3
+    tw = torch.tensor(w0, dtype=torch.float64, requires_grad=True)
+    opt = {'sgd': lambda: torch.optim.SGD([tw], lr=lr),
+           'rmsprop': lambda: torch.optim.RMSprop([tw], lr=lr, alpha=0.9, eps=1e-7, momentum=0.0, centered=False),
+           'adagrad': lambda: torch.optim.Adagrad([tw], lr=lr, lr_decay=0.0, initial_accumulator_value=0.1, eps=1e-7),
+           'adadelta': lambda: torch.optim.Adadelta([tw], lr=lr, rho=0.95, eps=1e-7)}[kind]()
+    w = w0.copy()
+    a = np.full(n, 0.1) if kind == 'adagrad' else np.zeros(n)
+    b = np.zeros(n)
+    for t in range(1, 13):
+        g = rng.normal(size=n) * mags
+        w, a, b = N.optimizer_update(kind, w, g, a, b, lr, t, clip=None)
+        tw.grad = torch.tensor(g, dtype=torch.float64)
+        opt.step()
+        np.testing.assert_allclose(w, tw.detach().numpy(), rtol=1e-13, atol=1e-15, err_msg='%s step %d' % (kind, t))
+    if kind == 'rmsprop':                                   # ... and the dict form the fit loop uses, with clipvalue
+        p, ms = {'w': w0.copy()}, {}
+        tw2 = torch.tensor(w0, dtype=torch.float64, requires_grad=True)
+        o2 = torch.optim.RMSprop([tw2], lr=lr, alpha=0.9, eps=1e-7)
+        for t in range(5):
+            g = rng.normal(size=n) * mags
+            N.rmsprop_step(p, {'w': g}, ms, lr, clip=5.0)
+            tw2.grad = torch.tensor(np.clip(g, -5.0, 5.0), dtype=torch.float64)
+            o2.step()
+            np.testing.assert_allclose(p['w'], tw2.detach().numpy(), rtol=1e-13, atol=1e-15)
+
+
 def test_rmsprop_and_fit_loop_semantics():
     """Keras split / partial batch / callbacks bookkeeping on a tiny problem; fp64 vs torch."""
     n, G, hs = 50, 12, (4, 2, 4)
