@@ -22,7 +22,8 @@ see oracle/__init__.py):
                _resource_apply_dense without momentum: `var - lr_t * grad / (sqrt(rms_t) + epsilon)`.  Only TF's fused
                ApplyRMSProp kernel, which OptimizerV2 takes with momentum > 0, has the epsilon inside the root.
                Pinned on torch.optim.RMSprop -- the same rule -- in tests/test_oracle_golden.py, with Adagrad /
-               Adadelta / SGD; Dense + BatchNorm forward / backward on the torch autograd twin, torch_ref.py.)
+               Adadelta / SGD; Dense + BatchNorm forward / backward / moving statistics on torch.nn.Linear +
+               torch.nn.BatchNorm1d under autograd, same file, and on the torch autograd twin, torch_ref.py.)
   clipvalue:   g = clip(g, -c, c) element-wise before the update
   fit:         validation = last n - int(n*(1-split)) rows; per epoch a fresh arange is
                shuffled with the numpy global RNG; last partial batch kept; epoch loss =

@@ -136,6 +136,71 @@ def test_rmsprop_epsilon_sits_outside_the_root():
     assert 'torch.sqrt(self.ms[k]) + eps' in inspect.getsource(type(t))
 
 
+def test_dense_and_batchnorm_match_torch_nn_layers():
+    """An independent pin of the Dense -> BatchNormalization(scale=False) -> ReLU stack (dca/network.py:101-135) and of its
+    backward pass: the same network assembled from torch.nn's OWN layers (nn.Linear, nn.BatchNorm1d with eps 1e-3 and
+    momentum 1 - 0.99, its scale frozen at 1; F.mse_loss on the 'normal' autoencoder, whose output is mean x size factor)
+    under autograd, fp64.  Loss, every gradient and the moving mean agree to round-off; torch folds the UNBIASED batch
+    variance into its running variance where Keras folds the biased one -- the biased variance recovered from torch's
+    update is what the oracle's moving variance holds."""
+    n, G, hs = 24, 10, (6, 3, 6)
+    rng = np.random.RandomState(8)
+    p = N.init_params('normal', G, hs, seed=5)
+    for i, h in enumerate(hs):
+        p['b%d' % i] = rng.normal(0, 0.3, h); p['beta%d' % i] = rng.normal(0, 0.5, h)
+        p['mm%d' % i] = rng.normal(0, 0.2, h); p['mv%d' % i] = rng.uniform(0.5, 1.5, h)
+    p['b_mean'] = rng.normal(0, 0.3, G)
+    X = rng.normal(size=(n, G)); Y = synth_counts(n, G, 3).astype(np.float64); sf = rng.lognormal(0, 0.3, n)
+    p0 = {k: v.copy() for k, v in p.items()}
+    net = N.OracleAE('normal', p, hs)
+    loss, grads = net.loss_and_grads(X, Y, sf)
+
+    tt = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)
+    lins, bns, K = [], [], G
+    for i, h in enumerate(hs):
+        lin = torch.nn.Linear(K, h).double()
+        bn = torch.nn.BatchNorm1d(h, eps=1e-3, momentum=1.0 - 0.99).double()
+        with torch.no_grad():
+            lin.weight.copy_(tt(p0['W%d' % i]).t()); lin.bias.copy_(tt(p0['b%d' % i]))
+            bn.weight.fill_(1.0); bn.bias.copy_(tt(p0['beta%d' % i]))
+            bn.running_mean.copy_(tt(p0['mm%d' % i])); bn.running_var.copy_(tt(p0['mv%d' % i]))
+        bn.weight.requires_grad_(False)
+        lins.append(lin); bns.append(bn); K = h
+    head = torch.nn.Linear(K, G).double()
+    with torch.no_grad():
+        head.weight.copy_(tt(p0['W_mean']).t()); head.bias.copy_(tt(p0['b_mean']))
+    H = tt(X)
+    for lin, bn in zip(lins, bns):
+        bn.train()
+        H = torch.relu(bn(lin(H)))
+    out = head(H) * tt(sf)[:, None]
+    tl = torch.nn.functional.mse_loss(out, tt(Y))
+    tl.backward()
+    assert abs(loss - tl.item()) <= 1e-12 * abs(tl.item())
+    for i, (lin, bn) in enumerate(zip(lins, bns)):
+        np.testing.assert_allclose(grads['W%d' % i], lin.weight.grad.t().numpy(), rtol=1e-9, atol=1e-13)
+        np.testing.assert_allclose(grads['beta%d' % i], bn.bias.grad.numpy(), rtol=1e-9, atol=1e-13)
+        # a bias in front of BatchNorm has zero gradient: both sides hold round-off only
+        assert np.abs(grads['b%d' % i]).max() < 1e-12 and lin.bias.grad.abs().max().item() < 1e-12
+        np.testing.assert_allclose(net.p['mm%d' % i], bn.running_mean.numpy(), rtol=1e-12, atol=1e-15)
+        var_biased_torch = (bn.running_var.numpy() - 0.99 * p0['mv%d' % i]) / 0.01 * (n - 1) / n
+        var_biased_oracle = (net.p['mv%d' % i] - 0.99 * p0['mv%d' % i]) / 0.01
+        np.testing.assert_allclose(var_biased_oracle, var_biased_torch, rtol=1e-9)
+    np.testing.assert_allclose(grads['W_mean'], head.weight.grad.t().numpy(), rtol=1e-9, atol=1e-13)
+    np.testing.assert_allclose(grads['b_mean'], head.bias.grad.numpy(), rtol=1e-9, atol=1e-13)
+    # inference mode = the moving statistics (torch's running variance replaced by the Keras-style one first)
+    for i, bn in enumerate(bns):
+        bn.eval()
+        with torch.no_grad():
+            bn.running_var.copy_(tt(net.p['mv%d' % i]))
+    with torch.no_grad():
+        H = tt(X)
+        for lin, bn in zip(lins, bns):
+            H = torch.relu(bn(lin(H)))
+        out = (head(H) * tt(sf)[:, None]).numpy()
+    np.testing.assert_allclose(net.predict(X, sf)['mean'], out, rtol=1e-10, atol=1e-12)
+
+
 @pytest.mark.parametrize('kind', ['sgd', 'rmsprop', 'adagrad', 'adadelta'])
 def test_optimizer_updates_match_torch_optim(kind):
     """An independent pin of the update rules (Keras / TF are absent here): torch.optim implements the same rules for
