@@ -23,5 +23,11 @@ Pinning status
   in scanpy (filter/normalize_per_cell/log1p/scale) is restated from the
   libraries' documented behaviour; the reference cannot be imported in the
   build image (tensorflow, keras, scanpy, anndata are absent) and its tests pin
-  no numbers there: **parity unpinned** for those pieces.
+  no numbers there: **parity unpinned** for those pieces with respect to Keras /
+  scanpy themselves.  What an independent implementation present in this image
+  can pin is pinned (tests/test_oracle_golden.py): the Dense -> BatchNorm ->
+  ReLU stack with its backward pass and moving statistics on ``torch.nn.Linear``
+  / ``torch.nn.BatchNorm1d`` under autograd; RMSprop (epsilon outside the
+  root), Adagrad, Adadelta and SGD on ``torch.optim``; whole-network gradients
+  of all autoencoder types on the autograd twin ``torch_ref.py``.
 """
