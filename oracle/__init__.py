@@ -28,6 +28,7 @@ Pinning status
   can pin is pinned (tests/test_oracle_golden.py): the Dense -> BatchNorm ->
   ReLU stack with its backward pass and moving statistics on ``torch.nn.Linear``
   / ``torch.nn.BatchNorm1d`` under autograd; RMSprop (epsilon outside the
-  root), Adagrad, Adadelta and SGD on ``torch.optim``; whole-network gradients
+  root), Adagrad, Adadelta and SGD on ``torch.optim``; ReduceLROnPlateau on
+  torch's scheduler (absolute threshold, patience p - 1); whole-network gradients
   of all autoencoder types on the autograd twin ``torch_ref.py``.
 """

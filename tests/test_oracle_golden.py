@@ -136,6 +136,30 @@ def test_rmsprop_epsilon_sits_outside_the_root():
     assert 'torch.sqrt(self.ms[k]) + eps' in inspect.getsource(type(t))
 
 
+@pytest.mark.parametrize('patience', [1, 3, 10])
+def test_reduce_lr_on_plateau_matches_torch_scheduler(patience):
+    """keras.callbacks.ReduceLROnPlateau (train.py:70-72: factor 0.1, min_delta 1e-4 absolute, mode min, cooldown 0) against
+    torch.optim.lr_scheduler.ReduceLROnPlateau in its absolute-threshold mode: the same bookkeeping except that Keras reduces
+    when `wait >= patience` and torch when `num_bad_epochs > patience` -- Keras' patience p is torch's p - 1.  Random
+    validation-loss curves with improvements smaller and larger than min_delta, plateaus and rebounds."""
+    for seed in range(6):
+        rng = np.random.RandomState(100 * patience + seed)
+        base = 2.0 * np.exp(-np.arange(70) / 15.0) + 0.5
+        curve = base + rng.choice([0.0, 5e-5, 2e-4, 1e-2], size=70) * rng.standard_normal(70)
+        curve[30:45] = curve[30]                                         # a flat stretch
+        w = torch.zeros(1, requires_grad=True)
+        opt = torch.optim.SGD([w], lr=1e-3)
+        sch = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, mode='min', factor=0.1, patience=patience - 1, threshold=1e-4,
+                                                         threshold_mode='abs', cooldown=0, min_lr=0.0, eps=0.0)
+        rl = N.ReduceLROnPlateau(patience)
+        lr = 1e-3
+        for e, v in enumerate(curve):
+            lr = rl.on_epoch_end(float(v), lr)
+            sch.step(float(v))
+            assert abs(lr - opt.param_groups[0]['lr']) <= 1e-6 * lr, (seed, e, lr, opt.param_groups[0]['lr'])
+        assert lr < 1e-3                                                 # the curves do trigger reductions
+
+
 def test_dense_and_batchnorm_match_torch_nn_layers():
     """An independent pin of the Dense -> BatchNormalization(scale=False) -> ReLU stack (dca/network.py:101-135) and of its
     backward pass: the same network assembled from torch.nn's OWN layers (nn.Linear, nn.BatchNorm1d with eps 1e-3 and
