@@ -16,7 +16,9 @@ Pinning status
   reference ``dca/loss.py:60-156``) is PINNED by the reference's own
   R-generated fixtures ``data/biochemists*.tsv``: the summed NLL at the
   published MLE reproduces pscl/MASS log-likelihoods (-1549.99 / -1560.96) and
-  the gradient vanishes there (tests/test_oracle_golden.py).
+  the gradient vanishes there (tests/test_oracle_golden.py); element-wise it
+  is held to ``scipy.stats.nbinom`` and its zero-inflated mixture over a grid
+  of counts, means, dispersions and dropout probabilities (same file).
 * everything whose arithmetic lives in the un-vendored Keras/TensorFlow
   (``keras>=2.4,<2.6``, ``tensorflow>=2.0,<2.5``: Dense, BatchNormalization,
   RMSprop, clipvalue, the ``fit`` loop, ReduceLROnPlateau, EarlyStopping) and

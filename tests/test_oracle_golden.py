@@ -136,6 +136,32 @@ def test_rmsprop_epsilon_sits_outside_the_root():
     assert 'torch.sqrt(self.ms[k]) + eps' in inspect.getsource(type(t))
 
 
+def test_nb_and_zinb_likelihoods_match_scipy_over_a_grid():
+    """Element-wise pin beside the R fixtures (which pin the SUM at one parameter point): -log pmf of
+    scipy.stats.nbinom(n = theta, p = theta / (theta + mu)) and of its zero-inflated mixture over a grid of counts, means,
+    dispersions and dropout probabilities.  The reference adds eps = 1e-10 inside its logarithms (dca/loss.py:65, 95-103,
+    139-146): with the grid's smallest mean 1e-3 the term y (log(theta + eps) - log(mu + eps)) alone is off by y eps / mu =
+    1e-7 y from the exact pmf, hence 1e-7 relative + 1e-8 absolute (measured 3.8e-8)."""
+    from scipy.stats import nbinom
+    y = np.array([0., 1., 2., 3., 7., 15., 16., 17., 40., 250., 3000.])[:, None, None]
+    mu = np.array([1e-3, 0.05, 0.7, 3.0, 25.0, 400.0, 2e4])[None, :, None]
+    th = np.array([1e-2, 0.3, 1.0, 4.5, 60.0, 9e3])[None, None, :]
+    Y, MU, TH = np.broadcast_arrays(y, mu, th)
+    want = -nbinom.logpmf(Y, TH, TH / (TH + MU))
+    got = Z.nb_nll(Y.astype(np.float64), MU.astype(np.float64), TH.astype(np.float64))
+    np.testing.assert_allclose(got, want, rtol=1e-7, atol=1e-8)
+    for pi in (1e-6, 0.03, 0.5, 0.97):
+        nb0 = nbinom.logpmf(0, TH, TH / (TH + MU))
+        want_z = np.where(Y < 1e-8, -np.log(pi + (1 - pi) * np.exp(nb0)), want - np.log(1 - pi))
+        got_z = Z.zinb_nll(Y.astype(np.float64), MU.astype(np.float64), TH.astype(np.float64), np.full(Y.shape, pi))
+        # (the reference's eps inside -log(pi + (1 - pi) p0 + eps) and -log(1 - pi + eps): eps / argument in absolute terms)
+        tol = 1e-7 * np.abs(want_z) + 1e-8 + 1.5e-10 / np.where(Y < 1e-8, pi + (1 - pi) * np.exp(nb0), 1 - pi)
+        assert (np.abs(got_z - want_z) <= tol).all(), (pi, float(np.abs(got_z - want_z).max()))
+        # the ridge term of ZINB.loss: + ridge * pi^2 per element
+        got_r = Z.zinb_nll(Y.astype(np.float64), MU.astype(np.float64), TH.astype(np.float64), np.full(Y.shape, pi), ridge=0.7)
+        np.testing.assert_allclose(got_r - got_z, 0.7 * pi * pi, rtol=1e-9, atol=1e-10)      # (a difference of values up to 3e4)
+
+
 @pytest.mark.parametrize('patience', [1, 3, 10])
 def test_reduce_lr_on_plateau_matches_torch_scheduler(patience):
     """keras.callbacks.ReduceLROnPlateau (train.py:70-72: factor 0.1, min_delta 1e-4 absolute, mode min, cooldown 0) against
