@@ -18,6 +18,22 @@ def _adata(n=60, G=40, seed=0, dtype=np.float32):
                    var=pd.DataFrame(index=['g%d' % i for i in range(G)]))
 
 
+def test_zscore_of_the_oracle_matches_sklearn_standard_scaler():
+    """The last step of the preprocessing (scanpy's pp.scale: zero mean, unit UNBIASED variance per gene, constant genes
+    left at 0) against scikit-learn's StandardScaler, which divides by the biased standard deviation: the oracle's
+    columns are StandardScaler's times sqrt((n - 1) / n).  scanpy itself is not installable here."""
+    from sklearn.preprocessing import StandardScaler
+    y = synth_counts(80, 25, 4).astype(np.float64)
+    y[:, 7] = 0.0                                   # a gene that is constant after the normalisation too
+    x, sf, n_counts = P.normalize(y, size_factors=True, logtrans=True, zscore=True)
+    lib = y.sum(1)
+    assert np.array_equal(n_counts, lib) and np.allclose(sf, lib / np.median(lib), rtol=1e-15)
+    pre = np.log1p(y / sf[:, None])
+    want = StandardScaler().fit_transform(pre) * np.sqrt((len(y) - 1) / len(y))
+    np.testing.assert_allclose(x, want, rtol=1e-10, atol=1e-12)
+    assert (x[:, 7] == 0).all()
+
+
 def test_filter_masks_bit_exact():
     rng = np.random.RandomState(0)
     y = synth_counts(50, 30, 1)
