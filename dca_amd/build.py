@@ -39,16 +39,38 @@ def needs_build():
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
-def build_hip(force=False, verbose=True):
-    if not force and not needs_build():
+def _obj_path(src, tag):
+    return os.path.join(CSRC, '_obj', os.path.basename(src) + ('.' + tag if tag else '') + '.o')
+
+
+def build_hip(force=False, verbose=True, defines=(), out=None):
+    """One object per source (compiled side by side, rebuilt only when the source or a header is newer), then the link.
+    ``defines`` / ``out``: experiment builds next to the product library (tools/)."""
+    out = out or LIB
+    if not force and not defines and out == LIB and not needs_build():
         return LIB
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(os.path.join(CSRC, '_obj'), exist_ok=True)
+    tag = '_'.join(d.replace('=', '-') for d in defines)
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(ROOT, 'include', 'dcahip.h')]
+    hdr_t = max(os.path.getmtime(h) for h in hdrs if os.path.exists(h))
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    cmd = [_hipcc(), '--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-shared',
-           '-I' + os.path.join(ROOT, 'include'), '-o', LIB] + srcs
+    jobs = []
+    for src in srcs:
+        obj = _obj_path(src, tag)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
+            jobs.append([_hipcc(), '--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-c',
+                         '-I' + os.path.join(ROOT, 'include')] + ['-D' + d for d in defines] + ['-o', obj, src])
+    if verbose:
+        for j in jobs:
+            print(' '.join(j), flush=True)
+    with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
+        list(ex.map(subprocess.check_call, jobs))
+    cmd = [_hipcc(), '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', out] + [_obj_path(s, tag) for s in srcs]
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return LIB
+    return out
 
 
 def host_needs_build():

@@ -282,7 +282,9 @@ __device__ __forceinline__ float nb_zero_elem(float am, float ad, float sf, floa
 // The y > 0 element (nb_case, loss.py:87-88,130) with the same activations: compacted non-zero pass of K-HEADS.
 // log(tp) - log(mu + eps) is taken as one log of the ratio (both reciprocals are needed by the gradient anyway),
 // log1p(mu / tp) through the 1 / u = tp / (tp + mu) identity.
-template <bool CONST_DISP>
+// INT_Y: the caller guarantees integer counts (the byte store of K-HEADS holds nothing else): the libm route for
+// non-integer "counts" -- an out-of-line call with a stack slot -- is not compiled in.
+template <bool CONST_DISP, bool INT_Y = false>
 __device__ __forceinline__ float zinb_nz_elem(float am, float ad, float ap, float sf, float y, float ridge,
                                               float& g_m, float& g_d, float& g_p) {
     const ZAct a = zinb_acts<CONST_DISP>(am, ad, ap, sf);
@@ -294,7 +296,7 @@ __device__ __forceinline__ float zinb_nz_elem(float am, float ad, float ap, floa
     float t1, dpsi = 0.f;
     if (y > (float)kSmallY) {
         nb_t1_large<true>(tp, y, t1, dpsi);
-    } else if (y == floorf(y)) {
+    } else if (INT_Y || y == floorf(y)) {
         const int n = (int)y;
         float p1 = 1.f, p2 = 1.f;
         for (int i = 0; i < n; ++i) {
@@ -320,7 +322,7 @@ __device__ __forceinline__ float zinb_nz_elem(float am, float ad, float ap, floa
 
 // One element of the loss and (GRAD) its gradient w.r.t. (mu, theta, pi).
 // ASSUME_NZ: the caller guarantees y >= kZeroThresh (compacted non-zero pass of K-HEADS).
-template <bool HAS_PI, bool GRAD, bool ASSUME_NZ = false>
+template <bool HAS_PI, bool GRAD, bool ASSUME_NZ = false, bool INT_Y = false>
 __device__ __forceinline__ float nll_elem(const Heads& h, float y, float ridge,
                                           float& dmu, float& dth, float& dpi) {
     const float theta = h.theta, mu = h.mu;
@@ -353,7 +355,7 @@ __device__ __forceinline__ float nll_elem(const Heads& h, float y, float ridge,
         float t1, dpsi = 0.f;
         if (y > (float)kSmallY) {
             nb_t1_large<GRAD>(tp, y, t1, dpsi);
-        } else if (y == floorf(y)) {
+        } else if (INT_Y || y == floorf(y)) {
             // lgamma(y+tp) - lgamma(tp) = log prod_{i<y}(tp+i); psi difference = sum 1/(tp+i)
             const int n = (int)y;
             float p1 = 1.f, p2 = 1.f;
