@@ -37,7 +37,6 @@
 //   * deterministic: fixed summation orders everywhere (no atomics).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 #include <type_traits>
 #include "dcahip.h"
 #include "zinb_math.hpp"
@@ -435,11 +434,14 @@ __global__ __launch_bounds__(64 * WR) void heads_fused_x3_kernel(HeadsArgs2 p) {
             const int row0 = t * kTR;
             const int tn = t + tstep < p.NT ? t + tstep : t;
             // ---- F: pre-activations, K = 64 as 4 steps of 16 (lane half hi covers k in [32 hi, 32 hi + 32))
+            // (the accumulators start from the bias of the lane's gene: one LDS read per head instead of 16 additions)
             f32x16 acc[NH];
 #pragma unroll
-            for (int h = 0; h < NH; ++h)
+            for (int h = 0; h < NH; ++h) {
+                const float bias_h = Bs[h * 32 + l31];
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[h][e] = 0.f;
+                for (int e = 0; e < 16; ++e) acc[h][e] = bias_h;
+            }
             {
                 u32x4 hb[2][3];
 #pragma unroll
@@ -458,16 +460,10 @@ __global__ __launch_bounds__(64 * WR) void heads_fused_x3_kernel(HeadsArgs2 p) {
             TSTAMP(1)
             TSTAMP(2)
             // ---- stage [gene][row] (row stride 1, gene stride 33)
-            {
-                float bias[NH];                      // read once per tile (the stores below could alias Bs for all the compiler knows)
 #pragma unroll
-                for (int h = 0; h < NH; ++h) bias[h] = Bs[h * 32 + l31];
+            for (int h = 0; h < NH; ++h)
 #pragma unroll
-                for (int h = 0; h < NH; ++h)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e)
-                        St[h * ST_PLANE + l31 * kLdS + rowmap(e, hi)] = acc[h][e] + bias[h];
-            }
+                for (int e = 0; e < 16; ++e) St[h * ST_PLANE + l31 * kLdS + rowmap(e, hi)] = acc[h][e];
             const float thw = CONST_DISP ? Bs[NH * 32 + l31] : 0.f;
             const int srow_n = load_srow(tn);
             wave_sync();
@@ -549,14 +545,20 @@ __global__ __launch_bounds__(64 * WR) void heads_fused_x3_kernel(HeadsArgs2 p) {
                 const float ad = CONST_DISP ? Bs[NH * 32 + gq] : St[ST_PLANE + idx];
                 const float ap = HAS_PI ? St[PI_H * ST_PLANE + idx] : 0.f;
                 float yq = (float)(e >> 16);
-                if ((e >> 16) == 0xFFFFu) yq = YC ? escaped_count(p, sr, g0 + gq) : p.y[(long)sr * p.ldy + g0 + gq];
+                // counts that do not fit the queue's 16 bits (rare): a wave-uniform branch around the memory access, and the
+                // wait for it INSIDE the branch -- left to the compiler, the join in front of the first use of yq waits for
+                // vmcnt(0), i.e. for every prefetch in flight, in every batch
+                if (__ballot(act && (e >> 16) == 0xFFFFu)) {
+                    if (act && (e >> 16) == 0xFFFFu) yq = YC ? escaped_count(p, sr, g0 + gq) : p.y[(long)sr * p.ldy + g0 + gq];
+                    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
+                }
                 float o1, o2, o3 = 0.f, nll;
                 if (HAS_PI) {
-                    nll = zinb_nz_elem<CONST_DISP>(am, ad, ap, sfr, yq, p.ridge, o1, o2, o3);
+                    nll = zinb_nz_elem<CONST_DISP, YC>(am, ad, ap, sfr, yq, p.ridge, o1, o2, o3);
                 } else {
                     float dmu = 0.f, dth = 0.f, dpi = 0.f;
                     const Heads hd = head_acts<HAS_PI, CONST_DISP>(am, ad, ap, sfr);
-                    nll = nll_elem<HAS_PI, true, true>(hd, yq, p.ridge, dmu, dth, dpi);
+                    nll = nll_elem<HAS_PI, true, true, YC>(hd, yq, p.ridge, dmu, dth, dpi);
                     o1 = dmu * hd.gm; o2 = dth * hd.gd;
                 }
                 lacc += act ? nll : 0.f;
@@ -787,625 +789,6 @@ __global__ __launch_bounds__(64 * WR) void heads_fused_x3_kernel(HeadsArgs2 p) {
 }
 
 
-// =====================================================================================================
-// K-HEADS, wave-specialised form (round 4): the same work items, products, formulas and summation orders as
-// heads_fused_x3_kernel above, but the two waves that share a SIMD no longer both alternate between matrix and vector
-// phases (measured: MfmaUtil 30 % + VALUBusy 54 % ~ additive, profiles/r03z_sq_counters_per_kernel.csv) --
-//   PRODUCER  wave: F (72 MFMA) -> likelihood + gradient ON THE ACCUMULATOR REGISTERS (a lane's 16 rows x heads of gene
-//             l31 never leave it: no pre-activation staging) -> gradient tile D [head][gene][row] fp32 in LDS, the ~7 %
-//             non-zero elements through the per-pair queue exactly as before -> "full" flag;
-//   CONSUMER  wave: waits for the tile, dH = D W^T (72 MFMA, partial read-modify-write in HBM), dW += H^T D (72 MFMA,
-//             96 accumulator registers for the lifetime of the item) -> "done" flag.
-// One producer and one consumer per SIMD (pairs formed from the hardware SIMD id, any pairing is correct): the vector
-// pipe of the SIMD runs the producer's likelihood while its matrix pipe runs the consumer's 144 MFMAs, continuously and
-// without any phase alignment between waves.  Two D tiles per pair (double buffer); flags are plain LDS words (release =
-// s_waitcnt lgkmcnt(0) before the store, acquire = the polling read).  The producer holds no weight-gradient
-// accumulators (the 96 registers that forced spills above), the consumer no likelihood temporaries.
-// Work of pair q of workgroup (s, wq): row tiles t = s * 4 + q, step 4 S -- fixed, so every sum has a fixed order
-// whichever physical waves form the pair.
-// =====================================================================================================
-constexpr int kNPair = 4;
-
-template <bool HAS_PI, bool CONST_DISP, bool YC>
-__global__ __launch_bounds__(64 * 2 * kNPair) void heads_fused_ps_kernel(HeadsArgs2 p) {
-    using YV = std::conditional_t<YC, unsigned, float>;
-    constexpr int NH = 1 + (CONST_DISP ? 0 : 1) + (HAS_PI ? 1 : 0);
-    constexpr int PI_H = NH - 1;
-    constexpr int KT = 64;
-    constexpr int ST_PLANE = kTG * kLdS;
-    constexpr int NP = NH + (CONST_DISP ? 1 : 0);
-    constexpr int TH_P = NH;
-    constexpr int ST_TILE = NP * ST_PLANE;
-    constexpr int NTHREADS = 64 * 2 * kNPair;
-    constexpr int W_PIECE = 64 * 64;
-    constexpr int W_FLOATS = NH * 3 * W_PIECE / 4;
-    constexpr int NRED = NH * 2 * 16 + NH + 1;
-    constexpr int BIAS_FLOATS = (NH + 1) * 32;
-    constexpr int TILES_FLOATS = kNPair * 2 * ST_TILE;
-    constexpr int FLAG_WORDS = 4 * kNPair + 4;               // full[pair][2], done[pair][2], watchdog
-    constexpr int LDS_FLOATS = W_FLOATS + TILES_FLOATS + kNPair * kQCap + BIAS_FLOATS + FLAG_WORDS;
-    static_assert((kNPair / 2) * NRED * 64 <= TILES_FLOATS, "dW reduce scratch");
-    static_assert(LDS_FLOATS * 4 + 128 <= 160 * 1024, "one workgroup per CU");
-    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
-    __shared__ double lred[kNPair];
-    __shared__ int simd_of[2 * kNPair];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, hi = lane >> 5;
-    const long long cur = p.cursor ? *p.cursor : 0;
-
-    // ---- roles: a producer and a consumer on every SIMD if the hardware spread the 8 waves 2-2-2-2 (it does: round
-    // robin), otherwise waves (q, q + 4) pair up.  The role of a wave decides nothing about the results.
-    int pr, role;
-    {
-        const int simd = __builtin_amdgcn_s_getreg((4) | (4 << 6) | ((2 - 1) << 11));      // HW_REG_HW_ID[5:4] = SIMD_ID
-        if (lane == 0) simd_of[wave] = simd;
-        if (tid == 0) reinterpret_cast<volatile int*>(lds + W_FLOATS + TILES_FLOATS + kNPair * kQCap + BIAS_FLOATS)[4 * kNPair] = 0;
-        __syncthreads();
-        int cnt[4] = {0, 0, 0, 0};
-        int before = 0;
-#pragma unroll
-        for (int w = 0; w < 2 * kNPair; ++w) {
-            const int sw = __builtin_amdgcn_readfirstlane(simd_of[w]);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) cnt[q] += sw == q ? 1 : 0;
-            before += (sw == simd && w < wave) ? 1 : 0;
-        }
-        const bool balanced = cnt[0] == 2 && cnt[1] == 2 && cnt[2] == 2 && cnt[3] == 2;
-        pr = balanced ? simd : (wave & 3);
-        role = balanced ? before : (wave >> 2);
-    }
-    const bool producer = role == 0;
-
-    unsigned char* const Wimg = reinterpret_cast<unsigned char*>(lds);
-    float* const Tl = lds + W_FLOATS + pr * 2 * ST_TILE;                      // the pair's two D tiles
-    unsigned* const Q = reinterpret_cast<unsigned*>(lds + W_FLOATS + TILES_FLOATS) + pr * kQCap;
-    float* const Bs = lds + W_FLOATS + TILES_FLOATS + kNPair * kQCap;         // [head][32] biases, then [32] log-dispersion
-    volatile int* const flags = reinterpret_cast<volatile int*>(lds + W_FLOATS + TILES_FLOATS + kNPair * kQCap + BIAS_FLOATS);
-    volatile int* const f_full = flags + pr * 2;
-    volatile int* const f_done = flags + 2 * kNPair + pr * 2;
-    // (watchdog: a wait that outlasts ~2^21 polls -- tens of milliseconds, a thousand times a tile -- gives up, lets every
-    // later wait of the workgroup through and poisons the workgroup's loss partial: a protocol error shows up as a NaN loss
-    // in the tests instead of a hung GPU)
-    volatile int* const f_broken = flags + 4 * kNPair;
-    bool broken = false;
-    auto wait_ge = [&](volatile int* f, int v) {
-        int spins = 0;
-        while (__builtin_amdgcn_readfirstlane(*f) < v) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1 << 21) || __builtin_amdgcn_readfirstlane(*f_broken) != 0) {
-                if (lane == 0) *f_broken = 1;
-                broken = true;
-                break;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-    };
-    auto signal = [&](volatile int* f, int v) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");       // s_waitcnt lgkmcnt(0): the tile's LDS traffic is done
-        if (lane == 0) *f = v;
-    };
-
-    double dacc = 0.0;
-    bool first_item = true;
-    const int s_wg = blockIdx.x % p.S, wq = blockIdx.x / p.S;
-    const int ngb = p.nitems / p.S;
-    const int full = ngb / p.npart, rem = ngb - full * p.npart;
-    const int nrounds = full + ((rem > 0 && ((full & 1) ? p.npart - 1 - wq : wq) < rem) ? 1 : 0);
-#ifdef DCA_HEADS_TIMING
-    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    long long tlast = __builtin_readcyclecounter();
-    const long long t_entry = tlast;
-#endif
-    const int tstep = p.S * kNPair;
-    // barriers between the tile loop and the end of the item: one in front of the weight-gradient tree + two per tree level
-    constexpr int TAIL_BARRIERS = 1 + 2 * 2;
-    static_assert(kNPair == 4, "two tree levels");
-    // head weights of a gene tile -> LDS as bf16 pieces (same image as heads_fused_x3_kernel), biases, flags; both roles
-    auto item_prologue = [&](int g0, bool tile_ok) {
-        // ---- head weights of this gene tile -> LDS as bf16 pieces (same image as heads_fused_x3_kernel), biases, flags
-        if (tile_ok) {
-            constexpr int UNR = 3;
-            constexpr int ITEMS = NH * 64 * 8;
-            for (int base = tid; base < ITEMS; base += NTHREADS * UNR) {
-                float4 v[UNR];
-    #pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                    const int idx = base + u * NTHREADS;
-                    const int c4 = idx & 7, kq = (idx >> 3) & 63, h = (idx >> 9) < NH ? (idx >> 9) : NH - 1;
-                    const int kc = kq < p.hL ? kq : p.hL - 1;
-                    long gcol = g0 + c4 * 4;
-                    if (gcol > p.plane - 4) gcol = p.plane - 4;
-                    v[u] = *reinterpret_cast<const float4*>(p.Wh + (long)kc * p.ldw + (long)h * p.plane + gcol);
-                }
-    #pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                    const int idx = base + u * NTHREADS;
-                    if (idx >= ITEMS) continue;
-                    const int c4 = idx & 7, kq = (idx >> 3) & 63, h = idx >> 9;
-                    const int gcol = g0 + c4 * 4;
-                    const bool kv = kq < p.hL && gcol <= p.plane - 4;
-                    float4 w = v[u];
-                    if (!kv || gcol + 0 >= p.G) w.x = 0.f;
-                    if (!kv || gcol + 1 >= p.G) w.y = 0.f;
-                    if (!kv || gcol + 2 >= p.G) w.z = 0.f;
-                    if (!kv || gcol + 3 >= p.G) w.w = 0.f;
-                    unsigned a0, a1, a2, b0, b1, b2;
-                    split_pair(w.x, w.y, a0, a1, a2);
-                    split_pair(w.z, w.w, b0, b1, b2);
-                    const int off = kq * 64 + ((((c4 >> 1) + (kq >> 2)) & 3) << 4) + ((c4 & 1) << 3);
-                    *reinterpret_cast<u32x2*>(Wimg + (h * 3 + 0) * W_PIECE + off) = u32x2{a0, b0};
-                    *reinterpret_cast<u32x2*>(Wimg + (h * 3 + 1) * W_PIECE + off) = u32x2{a1, b1};
-                    *reinterpret_cast<u32x2*>(Wimg + (h * 3 + 2) * W_PIECE + off) = u32x2{a2, b2};
-                }
-            }
-            if (tid < 32) {
-                const bool gv = g0 + tid < p.G;
-    #pragma unroll
-                for (int h = 0; h < NH; ++h) Bs[h * 32 + tid] = gv ? p.bh[(long)h * p.plane + g0 + tid] : 0.f;
-                Bs[NH * 32 + tid] = (CONST_DISP && gv) ? p.theta_w[g0 + tid] : 0.f;
-            }
-        }
-        if (tid < 4 * kNPair) flags[tid] = 0;
-        __syncthreads();
-        TSTAMP(0)
-    };
-    // The two roles are two separate loop nests over the same work items (not two branches inside one loop): whatever a
-    // role keeps in registers across its tiles and items is live only in its own nest.
-    if (producer) {
-#pragma unroll 1
-    for (int j = 0; j < nrounds; ++j) {
-    const int gb = j * p.npart + ((j & 1) ? p.npart - 1 - wq : wq);
-    int s = s_wg;
-    asm volatile("" : "+s"(s));
-    const int gt = p.tile_order ? p.tile_order[gb] : gb;
-    const int g0 = gt * kTG;
-    const int gene = g0 + l31;
-    const bool tile_ok = g0 < p.G;
-    const bool gvalid = gene < p.G;
-
-    item_prologue(g0, tile_ok);
-    if (tile_ok) {
-        // ================================================================== PRODUCER
-        const int gene_c = gvalid ? gene : p.G - 1;
-        const float* const ycol = p.y + gene_c;
-        const unsigned char* const ycolc = p.yc + gene_c;
-        const unsigned ldy_u = YC ? (unsigned)p.ldc : (unsigned)p.ldy;
-        auto count_at = [&](int sr) -> YV {
-            if constexpr (YC) return (unsigned)ycolc[(unsigned long long)(unsigned)sr * ldy_u];
-            else return ycol[(unsigned long long)(unsigned)sr * ldy_u];
-        };
-        auto row_clamped = [&](int tt) { const int rl = tt * kTR + l31; return rl < p.B ? rl : p.B - 1; };
-        auto load_srow = [&](int tt) { const int rlc = row_clamped(tt); return p.perm ? p.perm[cur + rlc] : (int)(cur + rlc); };
-        const __amdgpu_buffer_rsrc_t ha_rs = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<unsigned short*>(p.HA), 0, p.NT * (kHTile * 2), 0x00020000);
-        const int ha_lane = l31 * 128 + hi * 64;       // row l31, this lane half's 32 hidden units (4 K steps x 8)
-        u32x4 ha[4][3];                                // the whole forward A operand of a tile: 48 registers
-        auto load_ha = [&](int tt) {
-            const int so = tt * (kHTile * 2);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int q = 0; q < 3; ++q)
-                    ha[ks][q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ha_rs, ha_lane + q * 4096 + ks * 16, so, 0));
-        };
-        const int t16 = lane & 15, c8 = 4 * ((lane >> 4) & 1) + (t16 & 3);
-        int wtr[4];
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr)
-            wtr[rr] = hi * 2048 + (t16 >> 2) * 64 + ((((c8 >> 1) + rr) & 3) << 4) + ((c8 & 1) << 3);
-        auto w_tr = [&](int h, int q, int ks) {           // B operand of F: gene l31, k = 32 hi + 8 ks .. + 7
-            const unsigned char* b0 = Wimg + (h * 3 + q) * W_PIECE + ks * 512;
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (__attribute__((address_space(3))) s16x4*)(b0 + wtr[(2 * ks) & 3]));
-            const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (__attribute__((address_space(3))) s16x4*)(b0 + 256 + wtr[(2 * ks + 1) & 3]));
-            u32x4 o;
-            const u32x2 a = __builtin_bit_cast(u32x2, lo), b = __builtin_bit_cast(u32x2, hi4);
-            o[0] = a[0]; o[1] = a[1]; o[2] = b[0]; o[3] = b[1];
-            return o;
-        };
-
-        int t = s * kNPair + pr;
-        int srow_l = 0;
-        float sf_l = 1.f;
-        YV yc_[16];
-        auto load_y_all = [&](int srow_src) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) yc_[e] = count_at(__shfl(srow_src, rowmap(e, hi), 64));
-        };
-        if (t < p.NT) {
-            srow_l = load_srow(t);
-            sf_l = p.sf[srow_l];
-            load_ha(t);
-            load_y_all(srow_l);
-        }
-        float bias[NH];
-#pragma unroll
-        for (int h = 0; h < NH; ++h) bias[h] = Bs[h * 32 + l31];
-        const float thw = CONST_DISP ? Bs[NH * 32 + l31] : 0.f;
-        int it = 0;
-        for (; t < p.NT; t += tstep) {
-            ++it;
-            float* const Dt = Tl + (it & 1) * ST_TILE;
-            const int row0 = t * kTR;
-            const int tn = t + tstep < p.NT ? t + tstep : t;
-            const int srow_n = load_srow(tn);              // in flight during F and the dense pass
-            // ---- F: pre-activations, K = 64 as 4 steps of 16
-            f32x16 acc[NH];
-#pragma unroll
-            for (int h = 0; h < NH; ++h)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[h][e] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int h = 0; h < NH; ++h) {
-                    u32x4 bf[3] = {w_tr(h, 0, ks), w_tr(h, 1, ks), w_tr(h, 2, ks)};
-                    MFMA_X3(ha[ks], bf, acc[h])
-                }
-            TSTAMP(1)
-            wait_ge(f_done + (it & 1), it - 2);            // the consumer is through with this buffer's previous tile
-            TSTAMP(2)
-
-            // ---- Z on the accumulator registers: the y = 0 formulas densely, non-zero elements queued (their raw
-            // pre-activations parked in the D tile), evaluated 64 at a time and written over their slots
-            float lacc = 0.f;
-            int qn = 0;
-            auto z_sparse = [&](int q0, int cnt) {
-                const bool act = lane < cnt;
-                const unsigned e = Q[q0 + (act ? lane : 0)];
-                const int idx = e & 2047;
-                const int gq = (idx * 1986) >> 16;          // idx / 33 for idx < 1056
-                const int row = idx - gq * kLdS;
-                const float sfr = __shfl(sf_l, row, 64);
-                const int sr = __shfl(srow_l, row, 64);
-                const float am = Dt[idx];
-                const float ad = CONST_DISP ? Bs[NH * 32 + gq] : Dt[ST_PLANE + idx];
-                const float ap = HAS_PI ? Dt[PI_H * ST_PLANE + idx] : 0.f;
-                float yq = (float)(e >> 16);
-                if ((e >> 16) == 0xFFFFu) yq = YC ? escaped_count(p, sr, g0 + gq) : p.y[(long)sr * p.ldy + g0 + gq];
-                float o1, o2, o3 = 0.f, nll;
-                if (HAS_PI) {
-                    nll = zinb_nz_elem<CONST_DISP, YC>(am, ad, ap, sfr, yq, p.ridge, o1, o2, o3);
-                } else {
-                    float dmu = 0.f, dth = 0.f, dpi = 0.f;
-                    const Heads hd = head_acts<HAS_PI, CONST_DISP>(am, ad, ap, sfr);
-                    nll = nll_elem<HAS_PI, true, true, YC>(hd, yq, p.ridge, dmu, dth, dpi);
-                    o1 = dmu * hd.gm; o2 = dth * hd.gd;
-                }
-                lacc += act ? nll : 0.f;
-                if (act) {
-                    Dt[idx] = o1 * p.inv_n;
-                    const float od = o2 * p.inv_n;
-                    if (CONST_DISP) Dt[TH_P * ST_PLANE + idx] = od; else Dt[ST_PLANE + idx] = od;
-                    if (HAS_PI) Dt[PI_H * ST_PLANE + idx] = o3 * p.inv_n;
-                }
-            };
-            auto z_flush = [&](bool last) {
-                while (qn >= 64 || (last && qn > 0)) {
-                    const int c = qn < 64 ? qn : 64;
-                    wave_sync();
-                    z_sparse(qn - c, c);
-                    qn -= c;
-                }
-            };
-            // every pre-activation goes to the D tile first (48 LDS stores, no vector arithmetic): the queue pass reads the
-            // non-zero elements' inputs there, and the dense pass below needs no input register after its arithmetic
-#pragma unroll
-            for (int h = 0; h < NH; ++h)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) Dt[h * ST_PLANE + l31 * kLdS + rowmap(e, hi)] = acc[h][e] + bias[h];
-            auto z_dense = [&](auto fullv, auto grpc) {
-                constexpr bool FULLV = decltype(fullv)::value;
-                constexpr int grp = decltype(grpc)::value;
-                float o_m[kZU], o_d[kZU], o_p[kZU];
-                bool o_nz[kZU];
-#pragma unroll
-                for (int j = 0; j < kZU; ++j) {
-                    const int e = grp * kZU + j;
-                    const int row = rowmap(e, hi);
-                    const float i_am = acc[0][e] + bias[0];
-                    const float i_ad = CONST_DISP ? thw : acc[NH > 1 ? 1 : 0][e] + bias[NH > 1 ? 1 : 0];
-                    const float i_ap = HAS_PI ? acc[PI_H][e] + bias[PI_H] : 0.f;
-                    const bool valid = FULLV || ((row0 + row < p.B) && gvalid);
-                    const YV yj = yc_[e];
-                    bool nz;
-                    if constexpr (YC) nz = valid && yj != 0u;
-                    else nz = valid && (HAS_PI ? !(yj < kZeroThresh) : (yj != 0.f));
-                    const float sfr = __shfl(sf_l, row, 64);
-                    const float sc = valid ? p.inv_n : 0.f;
-                    if (HAS_PI) {
-                        float gmv, gdv, gpv;
-                        const float nll = zinb_zero_elem<CONST_DISP>(i_am, i_ad, i_ap, sfr, p.ridge, gmv, gdv, gpv);
-                        lacc += (valid && !nz) ? nll : 0.f;
-                        o_m[j] = gmv * sc; o_d[j] = gdv * sc; o_p[j] = gpv * sc;
-                    } else {
-                        float gmv, gdv;
-                        const float nll = nb_zero_elem<CONST_DISP>(i_am, i_ad, sfr, gmv, gdv);
-                        lacc += (valid && !nz) ? nll : 0.f;
-                        o_m[j] = gmv * sc; o_d[j] = gdv * sc; o_p[j] = 0.f;
-                    }
-                    o_nz[j] = nz;
-                }
-                // the four elements' arithmetic stays ONE interleaved block in front of the predicated stores (without this
-                // use the compiler sinks each element's gradient into its own `if (!nz)` branch: four dependent chains
-                // one after the other instead of side by side)
-                asm volatile("" :: "v"(o_m[0]), "v"(o_m[1]), "v"(o_m[2]), "v"(o_m[3]), "v"(o_d[0]), "v"(o_d[1]), "v"(o_d[2]),
-                             "v"(o_d[3]), "v"(o_p[0]), "v"(o_p[1]), "v"(o_p[2]), "v"(o_p[3]));
-#pragma unroll
-                for (int j = 0; j < kZU; ++j) {
-                    const int e = grp * kZU + j;
-                    const int row = rowmap(e, hi);
-                    const int idx = l31 * kLdS + row;
-                    const bool nz = o_nz[j];
-                    const unsigned long long m = __ballot(nz);
-                    const int slot = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                    if (nz) {
-                        const YV yj = yc_[e];
-                        unsigned y16;
-                        if constexpr (YC) y16 = yj == 255u ? 0xFFFFu : yj;
-                        else y16 = (yj < 65535.f && yj == floorf(yj)) ? (unsigned)yj : 0xFFFFu;
-                        Q[slot] = (unsigned)idx | (y16 << 16);
-                    } else {
-                        Dt[idx] = o_m[j];
-                        if (CONST_DISP) Dt[TH_P * ST_PLANE + idx] = o_d[j]; else Dt[ST_PLANE + idx] = o_d[j];
-                        if (HAS_PI) Dt[PI_H * ST_PLANE + idx] = o_p[j];
-                    }
-                    qn += __popcll(m);
-                }
-                z_flush(false);
-            };
-            auto z_all = [&](auto fullv) {
-                z_dense(fullv, std::integral_constant<int, 0>{});
-                z_dense(fullv, std::integral_constant<int, 1>{});
-                z_dense(fullv, std::integral_constant<int, 2>{});
-                z_dense(fullv, std::integral_constant<int, 3>{});
-            };
-            if (row0 + kTR <= p.B && g0 + kTG <= p.G) z_all(std::true_type{}); else z_all(std::false_type{});
-            TSTAMP(3)
-            // next tile's operands: in flight during the queue pass, the hand-over and the first products
-            const float sf_n = p.sf[srow_n];
-            load_ha(tn);
-            load_y_all(srow_n);
-            __builtin_amdgcn_sched_barrier(0);
-            z_flush(true);
-            dacc += (double)lacc;
-            signal(f_full + (it & 1), it);
-            srow_l = srow_n;
-            sf_l = sf_n;
-            TSTAMP(4)
-        }
-    }
-    // (the weight-gradient registers exist only in the consumers' nest: a producer joins the barriers of their tree)
-#pragma unroll
-    for (int i = 0; i < TAIL_BARRIERS; ++i) __syncthreads();
-    __syncthreads();
-    }   // work items (producer)
-    } else {
-#pragma unroll 1
-    for (int j = 0; j < nrounds; ++j) {
-    const int gb = j * p.npart + ((j & 1) ? p.npart - 1 - wq : wq);
-    int s = s_wg;
-    asm volatile("" : "+s"(s));
-    const int gt = p.tile_order ? p.tile_order[gb] : gb;
-    const int g0 = gt * kTG;
-    const int gene = g0 + l31;
-    const bool tile_ok = g0 < p.G;
-    const bool gvalid = gene < p.G;
-
-    item_prologue(g0, tile_ok);
-    if (tile_ok) {
-        // ================================================================== CONSUMER
-        f32x16 dW[NH][2];
-        float bsum[NH];
-        float thsum = 0.f;
-#pragma unroll
-        for (int h = 0; h < NH; ++h) {
-            bsum[h] = 0.f;
-#pragma unroll
-            for (int ib = 0; ib < 2; ++ib)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) dW[h][ib][e] = 0.f;
-        }
-        const __amdgpu_buffer_rsrc_t ht_rs = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<unsigned short*>(p.HT), 0, p.NT * (kHTile * 2), 0x00020000);
-        const int ht_lane = l31 * 64 + hi * 16;        // hidden unit l31 (+ 32 ib), rows of K-step half hi
-        auto load_ht = [&](int tt, int ks, u32x4 (&dst)[3][2]) {
-            const int so = tt * (kHTile * 2);
-#pragma unroll
-            for (int q = 0; q < 3; ++q)
-#pragma unroll
-                for (int ib = 0; ib < 2; ++ib)
-                    dst[q][ib] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                        ht_rs, ht_lane + q * 4096 + ib * 2048 + ks * 32, so, 0));
-        };
-        int wdr[2];
-#pragma unroll
-        for (int gs = 0; gs < 2; ++gs) wdr[gs] = l31 * 64 + (((2 * gs + hi + (l31 >> 2)) & 3) << 4);
-        auto w_dr = [&](int h, int q, int jb, int gs) {   // B operand of dH: hidden unit l31 + 32 jb, genes 16 gs + 8 hi ..
-            return *reinterpret_cast<const u32x4*>(Wimg + (h * 3 + q) * W_PIECE + jb * 2048 + wdr[gs]);
-        };
-        const long dh_tstride = (long)p.npart * (kTR * KT);
-        float* const dh_part = p.ws_dh + (long)(blockIdx.x / p.S) * (kTR * KT);
-        const int dh_lane = (4 * hi * KT + l31) * 4;
-        int it = 0;
-        for (int t = s * kNPair + pr; t < p.NT; t += tstep) {
-            ++it;
-            const float* const St = Tl + (it & 1) * ST_TILE;
-            u32x4 htb[2][3][2];
-            load_ht(t, 0, htb[0]);
-            f32x16 dHa[2];
-            const __amdgpu_buffer_rsrc_t dh_rs = __builtin_amdgcn_make_buffer_rsrc(
-                dh_part + (long)t * dh_tstride, 0, kTR * KT * 4, 0x00020000);
-            if (first_item) {
-#pragma unroll
-                for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) dHa[jb][e] = 0.f;
-            } else {
-#pragma unroll
-                for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const unsigned u = __builtin_amdgcn_raw_buffer_load_b32(
-                            dh_rs, dh_lane + (((rowmap(e, 0) * KT + jb * 32) * 4) & 4095), ((rowmap(e, 0) * KT + jb * 32) * 4) & ~4095, 0);
-                        dHa[jb][e] = __uint_as_float(u);
-                    }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            TSTAMP(5)
-            wait_ge(f_full + (it & 1), it);                // everything above is in flight while the producer finishes
-            TSTAMP(6)
-            // ---- dH[row, i] = sum_genes D[row, gene] W[i, gene]
-#pragma unroll
-            for (int h = 0; h < NH; ++h)
-#pragma unroll
-                for (int gs = 0; gs < 2; ++gs) {
-                    float dv[8];
-#pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) dv[jj] = St[h * ST_PLANE + (16 * gs + 8 * hi + jj) * kLdS + l31];
-                    u32x4 af[3];
-                    split8(dv, af);
-#pragma unroll
-                    for (int jb = 0; jb < 2; ++jb) {
-                        u32x4 bf[3] = {w_dr(h, 0, jb, gs), w_dr(h, 1, jb, gs), w_dr(h, 2, jb, gs)};
-                        MFMA_BWD(af, bf, dHa[jb])
-                    }
-                }
-#pragma unroll
-            for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const float v = dHa[jb][e];
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), dh_rs,
-                                                          dh_lane + (((rowmap(e, 0) * KT + jb * 32) * 4) & 4095),
-                                                          ((rowmap(e, 0) * KT + jb * 32) * 4) & ~4095, 0);
-                }
-            load_ht(t, 1, htb[1]);
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- dW[i, gene] += sum_rows H[row, i] D[row, gene]
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int h = 0; h < NH; ++h) {
-                    float dv[8];
-#pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) {
-                        dv[jj] = St[h * ST_PLANE + l31 * kLdS + rowmap(8 * ks + jj, hi)];
-                        bsum[h] += dv[jj];
-                    }
-                    u32x4 bf[3];
-                    split8(dv, bf);
-#pragma unroll
-                    for (int ib = 0; ib < 2; ++ib) {
-                        u32x4 af[3] = {htb[ks][0][ib], htb[ks][1][ib], htb[ks][2][ib]};
-                        MFMA_BWD(af, bf, dW[h][ib])
-                    }
-                }
-            if (CONST_DISP) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) thsum += St[TH_P * ST_PLANE + l31 * kLdS + rowmap(e, hi)];
-            }
-            signal(f_done + (it & 1), it);                 // (s_waitcnt lgkmcnt(0): every read of the tile has returned)
-            TSTAMP(7)
-        }
-        __syncthreads();                  // every wave is done with the weight image and the tiles of this item
-
-        // ---- dW / bias-gradient sums of the consumers: ordered tree through LDS (pair order)
-        float* red = lds + W_FLOATS;
-#pragma unroll
-        for (int step = 1; step < kNPair; step *= 2) {
-            const int slot = pr / (2 * step);
-            float* rs = red + (long)slot * NRED * 64 + lane;
-            if (pr % (2 * step) == step) {
-                int n = 0;
-#pragma unroll
-                for (int h = 0; h < NH; ++h)
-#pragma unroll
-                    for (int ib = 0; ib < 2; ++ib)
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) rs[(n++) * 64] = dW[h][ib][e];
-#pragma unroll
-                for (int h = 0; h < NH; ++h) rs[(n++) * 64] = bsum[h];
-                rs[(n++) * 64] = thsum;
-            }
-            __syncthreads();
-            if (pr % (2 * step) == 0 && pr + step < kNPair) {
-                int n = 0;
-#pragma unroll
-                for (int h = 0; h < NH; ++h)
-#pragma unroll
-                    for (int ib = 0; ib < 2; ++ib)
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) dW[h][ib][e] += rs[(n++) * 64];
-#pragma unroll
-                for (int h = 0; h < NH; ++h) bsum[h] += rs[(n++) * 64];
-                thsum += rs[(n++) * 64];
-            }
-            __syncthreads();
-        }
-        if (pr == 0) {
-        const bool direct = p.S == 1;
-        float* out = direct ? p.gW : p.ws_dw + (long)s * p.dw_stride;
-        const long ldo = direct ? p.ldg : p.ldws;
-        const bool cw = gene < p.plane;
-#pragma unroll
-        for (int h = 0; h < NH; ++h) {
-#pragma unroll
-            for (int ib = 0; ib < 2; ++ib)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int i = ib * 32 + rowmap(e, hi);
-                    if (cw && i < p.hL) out[(long)i * ldo + (long)h * p.plane + gene] = dW[h][ib][e];
-                }
-            const float bv = bsum[h] + __shfl_xor(bsum[h], 32, 64);
-            if (cw && hi == 0) out[(long)p.hL * ldo + (long)h * p.plane + gene] = bv;
-        }
-        if (CONST_DISP) {
-            const float tv = thsum + __shfl_xor(thsum, 32, 64);
-            if (direct) {
-                if (gvalid && hi == 0) {
-                    const float e = expf(p.theta_w[gene]);
-                    p.g_theta[gene] = (e >= 1e-3f && e <= 1e4f) ? tv * e : 0.f;
-                }
-            } else if (cw && hi == 0) {
-                out[(long)(p.hL + 1) * ldo + gene] = tv;
-            }
-        }
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < TAIL_BARRIERS; ++i) __syncthreads();
-    }
-    __syncthreads();
-    first_item = false;
-    }   // work items (consumer)
-    }
-
-    // ---- loss: producer wave -> pair slot -> one partial per workgroup (pair order)
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) dacc += __shfl_down(dacc, off, 64);
-    if (producer && lane == 0) lred[pr] = dacc;
-    __syncthreads();
-    if (tid == 0) {
-        double v = 0.0;
-        for (int w = 0; w < kNPair; ++w) v += lred[w];
-        if (*f_broken != 0) v = __builtin_nan("");
-        p.partials[blockIdx.x] = v;
-    }
-    (void)broken;
-#ifdef DCA_HEADS_TIMING
-    if (p.timing && lane == 0) {
-        long long* tp = p.timing + ((long)blockIdx.x * (2 * kNPair) + wave) * 10;
-        for (int i = 0; i < 8; ++i) tp[i] += tacc[i];
-        tp[8] = role;
-        tp[9] = (long long)__builtin_readcyclecounter() - t_entry;
-    }
-#endif
-}
-
 // gW[i, col] = sum_s ws[s][i][col], i = 0..hL (row hL = bias gradient), then the
 // ConstantDispersionLayer chain (dca/layers.py:17-21) on the per-gene theta sums.
 struct ReduceDwArgs {
@@ -1536,16 +919,8 @@ __global__ __launch_bounds__(256) void heads_reduce_both_kernel(ReduceDhArgs qh,
     else reduce_dw_body(qw, blockIdx.x - n_dh, gridDim.x - n_dh);
 }
 
-// Which persistent kernel serves batches of 5 row tiles and more: the wave-specialised one (default) or the round-2/3 form
-// in which every wave runs every phase (DCAHIP_HEADS_VARIANT=x3: kept for A/B measurements, same results to re-association).
-inline bool heads_use_ps() {
-    static const int v = [] { const char* e = getenv("DCAHIP_HEADS_VARIANT"); return (e && e[0] == 'x') ? 0 : 1; }();
-    return v != 0;
-}
-
 struct HeadsPlan {
     bool small;                          // one row tile: the four-wave kernel, one workgroup per gene tile
-    bool ps;                             // the wave-specialised persistent kernel (4 producer / consumer pairs per workgroup)
     int HLB, WR, S, NT, ntg, ngb, grid;
     int nitems, npart;                   // split-bf16 path: work items (S x gene tiles), dH partials per row tile
     long ldws, dw_stride, dw_bytes, dh_bytes, hs_bytes;
@@ -1575,15 +950,13 @@ bool make_heads_plan(int B, int hL, int G, long plane, int flags, HeadsPlan* out
     // at G = 20 000: B = 128 0.088 / 0.086 ms (kept on the four-wave kernel), 160: 0.100 / 0.104, 192: 0.103 / 0.121,
     // 224: 0.107 / 0.142 (profiles/r02z_heads_kernel_switch.txt)
     p.WR = p.NT >= kWr8MinNT ? kWR2 : 1;
-    p.ps = p.WR == kWR2 && heads_use_ps();
-    const int slots = p.ps ? kNPair : p.WR;          // row tiles a workgroup works on at a time
-    const int smax = (p.NT + slots - 1) / slots;
+    const int smax = (p.NT + p.WR - 1) / p.WR;
     double best = 1e300;
     p.S = 1;
     for (int S = 1; S <= smax && (long)S * p.ngb <= kMaxGrid; ++S) {
         const long items = (long)S * p.ngb;
         const long rounds = (items + kCUs - 1) / kCUs;
-        const int tiles = (p.NT + S * slots - 1) / (S * slots);
+        const int tiles = (p.NT + S * p.WR - 1) / (S * p.WR);
         const double cost = (double)rounds * (tiles + 0.75);
         if (cost < best - 1e-9) { best = cost; p.S = S; }
     }
@@ -1866,7 +1239,10 @@ __global__ __launch_bounds__(256) void heads_fused_small_kernel(HeadsArgs2 p) {
             const float ad = CONST_DISP ? Bs[NH * 32 + gq] : St[ST_PLANE + idx];
             const float ap = HAS_PI ? St[PI_H * ST_PLANE + idx] : 0.f;
             float yq = (float)(e >> 16);
-            if ((e >> 16) == 0xFFFFu) yq = YC ? escaped_count(p, sr, g0 + gq) : p.y[(long)sr * p.ldy + g0 + gq];
+            if (__ballot(act && (e >> 16) == 0xFFFFu)) {     // (see heads_fused_x3_kernel)
+                if (act && (e >> 16) == 0xFFFFu) yq = YC ? escaped_count(p, sr, g0 + gq) : p.y[(long)sr * p.ldy + g0 + gq];
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+            }
             float o1, o2, o3 = 0.f, nll;
             if (HAS_PI) {
                 nll = zinb_nz_elem<CONST_DISP>(am, ad, ap, sfr, yq, p.ridge, o1, o2, o3);
@@ -2012,7 +1388,6 @@ __global__ __launch_bounds__(64) void x3_product_kernel(const float* A, const fl
 template <bool P, bool C, bool YC>
 void launch_fused_x3(const HeadsPlan& pl, const HeadsArgs2& a, hipStream_t s) {
     if (pl.small) hipLaunchKernelGGL((heads_fused_small_kernel<P, C, YC>), dim3(pl.grid), dim3(256), 0, s, a);
-    else if (pl.ps) hipLaunchKernelGGL((heads_fused_ps_kernel<P, C, YC>), dim3(pl.grid), dim3(64 * 2 * kNPair), 0, s, a);
     else if (pl.WR == kWR2) hipLaunchKernelGGL((heads_fused_x3_kernel<P, C, kWR2, YC>), dim3(pl.grid), dim3(64 * kWR2), 0, s, a);
     else hipLaunchKernelGGL((heads_fused_x3_kernel<P, C, 1, YC>), dim3(pl.grid), dim3(64), 0, s, a);
 }

@@ -64,7 +64,10 @@ def run_single_step(eng, rows, lr=1e-3):
     eng.hist = torch.zeros(4, dtype=torch.float32, device=eng.dev)
     eng.cursor.zero_(); eng.acc.zero_()
     eng.set_lr(lr)
-    eng.train_step(B, rows_per_slot=B)
+    if eng.comm.dp:                       # data parallel with one rank: this rank holds the whole (global) batch
+        eng.train_step(B, B, [B], B)
+    else:
+        eng.train_step(B, rows_per_slot=B)
     if eng.dev.type == 'cuda':
         torch.cuda.synchronize()
     return float(eng.hist[0].item()), eng.get_grads(), eng.get_params()

@@ -203,3 +203,78 @@ def test_rccl_communicator_with_one_rank_runs_the_data_parallel_step(ae, n, B, h
         if k[0] == 'b' and k[1:].isdigit():
             continue                                                  # biases in front of BatchNorm: zero true gradient
         np.testing.assert_allclose(p_dp[k], p1[k], rtol=2e-3, atol=2e-3, err_msg=k)
+
+
+def _run_c4_shard_step(port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    os.environ.pop('DCA_AMD_DIST_BACKEND', None)
+    try:
+        from dca_amd import synth, prep
+        from dca_amd.engine import Engine
+        from dca_amd.ops import HipOps
+        from helpers import assert_grads_close, oracle_net, run_single_step
+        from oracle import net_np as N
+        comm = ddist.init_from_env(force=True)
+        assert comm.dp and comm.world == 1 and dist.get_backend() == 'nccl'
+        ops = HipOps()
+        n, G, hs, B, ae = 125000, 25000, (64, 32, 64), 4096, 'zinb'
+        dev = torch.device('cuda')
+        Y = synth.generate_counts_portable(n, G, seed=20260925, device=dev, row_offset=0)      # rank 0's rows of the 1M x 25k matrix
+        counts = prep.cell_counts(ops, Y, n, G)
+        sf = counts / counts.median()
+        X, norm = prep.transform(ops, Y, n, G, sf, True, True, return_norm=True)
+        p = N.init_params(ae, G, hs, batchnorm=True, seed=4, dtype=np.float64)
+        rng = np.random.RandomState(9)
+        for k in p:
+            if k[0] in 'bt':
+                p[k] = rng.normal(0, .1, p[k].shape)
+        p = {k: np.asarray(v, np.float32) for k, v in p.items()}
+        eng = Engine(ae, G, G, hs, True, 0.0, ops=ops, comm=comm)
+        eng.set_params(p)
+        eng.attach_device_data(X, Y, sf, norm=norm)
+        rows = np.random.RandomState(1).permutation(n)[:B]
+        rt = torch.as_tensor(rows).cuda()
+        Xr = X[rt][:, :G].cpu().numpy().astype(np.float64)
+        Yr = Y[rt][:, :G].cpu().numpy().astype(np.float64)
+        sfr = sf[rt].cpu().numpy().astype(np.float64)
+        zeros = float((Yr == 0).mean())
+        ref = oracle_net(ae, p, hs, True)
+        ref.row_threads = max(1, min(64, os.cpu_count() or 1))
+        rl, rg = ref.loss_and_grads(Xr, Yr, sfr)
+        comm.timer = {}
+        loss, g, newp = run_single_step(eng, rows)
+        spans = comm.timer_summary()
+        comm.timer = None
+        assert abs(loss - rl) < 1e-5 * abs(rl), (loss, rl)
+        assert_grads_close(g, rg)
+        q.put(('ok', dict(loss=loss, oracle=float(rl), zeros=zeros, fused=bool(eng.use_fused), calls={k: v[0] for k, v in spans.items()})))
+        dist.barrier()
+    except BaseException as e:
+        import traceback
+        q.put(('error', '%s: %s\n%s' % (type(e).__name__, e, traceback.format_exc())))
+        raise
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_c4_rank_shard_step_matches_oracle():
+    """BASELINE configs[3] (ZINB autoencoder on 1 000 000 x 25 000, data parallel over 8 GPUs) as ONE rank sees it: the
+    rank's shard of 125 000 cells x 25 000 genes resident in HBM (the portable generator: rows 0 .. 124 999 of the
+    matrix), 4 096 cells of it per step, the data-parallel step -- SyncBN exchanges, gradient buckets over a real RCCL
+    communicator of one rank (init_from_env(force=True) = DCA_AMD_DIST_FORCE) -- against the fp64 oracle of the reference
+    step (network.py:496-550 constant dispersion, loss.py:122-156) on the same gathered rows: loss to 1e-5, every gradient
+    to the tolerances of the single-GPU step tests."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    pr = ctx.Process(target=_run_c4_shard_step, args=(_free_port(), q))
+    pr.start()
+    got = q.get(timeout=900)
+    pr.join(timeout=60)
+    assert got[0] == 'ok', got[1]
+    assert pr.exitcode == 0
+    info = got[1]
+    print('C4 rank shard (125 000 x 25 000, batch 4 096, zinb): loss %.8f, fp64 oracle %.8f; zeros %.3f; exchanges %s'
+          % (info['loss'], info['oracle'], info['zeros'], info['calls']))
+    assert 0.90 < info['zeros'] < 0.96 and info['fused']
+    assert sum(info['calls'].values()) > 0

@@ -23,11 +23,13 @@ os.environ['ONLY_FUSED'] = '1'
 exec(open(os.path.join(ROOT, 'tools', 'bench_heads.py')).read())
 t = tim.cpu().numpy().reshape(-1, 10)
 t = t[t[:, 9] > 0]
+ps3 = os.environ.get('DCAHIP_HEADS_VARIANT', 'ps3') == 'ps3'
 for role, nme, fields in ((0, 'PRODUCER', [(0, 'item prologue (W split -> LDS) + barriers'), (1, 'F: 72 MFMA + weight operand reads'),
-                                           (2, 'wait: consumer done with the buffer'), (3, 'staging stores + dense likelihood'),
-                                           (4, 'next-tile loads, queue pass, hand-over')]),
-                          (1, 'CONSUMER', [(0, 'item prologue + barriers + dW tree / stores'), (5, 'operand + dH partial load issue'),
-                                           (6, 'wait: producer tile full'), (7, 'dH + dW: 144 MFMA, D splits, partial stores')])):
+                                           (2, 'wait: consumer(s) done with the tile'), (3, 'staging stores + dense likelihood'),
+                                           (4, 'partial / next-tile loads, queue pass, hand-over')] +
+                                          ([(5, 'dH: 72 MFMA, D split, partial stores')] if ps3 else [])),
+                          (1, 'CONSUMER', [(0, 'item prologue + barriers (+ dW tree) / stores'), (5, 'operand load issue'),
+                                           (6, 'wait: producer tile full'), (7, 'dW (ps3: one head, 24 MFMA) / dH + dW (ps)')])):
     r = t[t[:, 8] == role]
     if not len(r):
         continue
