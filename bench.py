@@ -39,15 +39,42 @@ MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32 MFMA peak
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (the headline 5 PF figure includes 2:1 sparsity)
 
 
+# Named workloads = BASELINE.json `configs`.  c3 is the configuration the metric is quoted on (and the default at every N:
+# "cells/sec training (ZINB AE, 68k x 20k) at 1/2/4/8 MI355X").  c4 / c5 are the two configurations north_star assigns to an
+# 8-GPU node: every rank holds ITS EIGHTH of the matrix (125 000 / 162 500 cells) whatever N is, so `--workload c4 --gpus 1`
+# measures exactly the per-GPU step an 8-GPU run starts from.
+WORKLOADS = {
+    'c3': dict(cells=68579, genes=20000, hidden='64,32,64', ae='zinb-conddisp', batch=4096, shard_of=None,
+               name='BASELINE configs[2]: ZINB-conddisp AE on 68k-PBMC-shaped synthetic (68 579 x 20 000)'),
+    'c4': dict(cells=1000000, genes=25000, hidden='64,32,64', ae='zinb', batch=4096, shard_of=8,
+               name='BASELINE configs[3]: ZINB AE on 1M cells x 25k genes synthetic, data-parallel 8 x MI355X'),
+    'c5': dict(cells=1300000, genes=25000, hidden='512,256,128,256,512', ae='zinb', batch=2048, shard_of=8,
+               name='BASELINE configs[4]: wide 512-256-128-256-512 ZINB AE on 1.3M-cell atlas-shaped synthetic, 8 GPUs'),
+}
+
+
+def source_sha():
+    """Fingerprint of the kernel sources (dca_amd/csrc): profiles/pmc_traffic.json carries the one it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, 'dca_amd', 'csrc')
+    for f in sorted(os.listdir(d)):
+        if f.endswith(('.hip', '.hpp', '.cpp')):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), 'rb').read())
+    return h.hexdigest()[:16]
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=0, help='timed steps; default: three epochs of the workload')
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--cells', type=int, default=68579)
-    ap.add_argument('--genes', type=int, default=20000)
-    ap.add_argument('--hidden', type=str, default='64,32,64')
-    ap.add_argument('--batch-size', type=int, default=4096, help='cells per GPU per step')
+    ap.add_argument('--workload', type=str, default='c3', choices=sorted(WORKLOADS), help='named BASELINE configuration')
+    ap.add_argument('--cells', type=int, default=0, help='(ad-hoc runs) override the workload')
+    ap.add_argument('--genes', type=int, default=0)
+    ap.add_argument('--hidden', type=str, default='')
+    ap.add_argument('--ae-type', type=str, default='')
+    ap.add_argument('--batch-size', type=int, default=0, help='cells per GPU per step')
     ap.add_argument('--graph', type=str, default='auto', choices=['auto', 'on', 'off'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
@@ -73,7 +100,7 @@ def kernel_model(name, B, G, hidden, nheads=3):
     return 'mfma', fl.get(name)
 
 
-def cpu_baseline(Xh, Yh, sfh, params, hidden, B, budget_s):
+def cpu_baseline(Xh, Yh, sfh, params, hidden, B, budget_s, ae_type='zinb-conddisp'):
     """Times the oracle's torch-CPU port of the training step (oracle/torch_ref.py) on the host:
     at the reference's default batch size 32 (train.py:37 -- also the CPU's best throughput)
     and at the batch size of the GPU run, on a bounded sample of the same matrix."""
@@ -86,7 +113,7 @@ def cpu_baseline(Xh, Yh, sfh, params, hidden, B, budget_s):
     X, Y, S = torch.as_tensor(Xh), torch.as_tensor(Yh), torch.as_tensor(sfh)
 
     def run(b, budget, max_steps):
-        net = TorchAE('zinb-conddisp', params, hidden, True, dtype=torch.float32)
+        net = TorchAE(ae_type, params, hidden, True, dtype=torch.float32)
         nb = max(n // b, 1)
         if b <= 256:
             net.train_step(X[:b], Y[:b], S[:b])               # warm-up
@@ -303,12 +330,23 @@ def main():
         if W == 1 and args.gpus > 1:
             raise SystemExit('bench.py --gpus %d must be launched with torch.distributed.run' % args.gpus)
     dev = torch.device('cuda', torch.cuda.current_device())
-    hidden = tuple(int(x) for x in args.hidden.split(','))
-    G, B = args.genes, args.batch_size
-    n_train_global = int(args.cells * 0.9)               # validation_split=0.1 tail is not trained on
-    t0, n_local = ddist.shard(n_train_global, W, rank)
-    n_local = n_train_global // W                         # equal shards (all-gather of stats)
-    n_val = args.cells - n_train_global if not multi else 0  # one GPU: the held-out rows sit behind the train rows
+    wl = dict(WORKLOADS[args.workload])
+    adhoc = bool(args.cells or args.genes or args.hidden or args.ae_type)
+    cells_total = args.cells or wl['cells']
+    G = args.genes or wl['genes']
+    hidden = tuple(int(x) for x in (args.hidden or wl['hidden']).split(','))
+    ae_type = args.ae_type or wl['ae']
+    B = args.batch_size or wl['batch']
+    shard_of = None if adhoc else wl['shard_of']
+    if shard_of:
+        # an 8-GPU configuration: this rank's eighth of the matrix, 90 % of it trained on (rank r holds rows r / 8 .. )
+        n_train_global = int(cells_total * 0.9)
+        n_local = n_train_global // shard_of
+        n_val = 0
+    else:
+        n_train_global = int(cells_total * 0.9)           # validation_split=0.1 tail is not trained on
+        n_local = n_train_global // W                     # equal shards (all-gather of stats)
+        n_val = cells_total - n_train_global if not multi else 0  # one GPU: the held-out rows sit behind the train rows
     n_store = n_local + n_val
 
     # ---- synthetic data, generated and normalised in HBM (not timed)
@@ -322,7 +360,7 @@ def main():
     med = (comm.all_gather(counts).flatten() if multi else counts).median()
     sf = counts / med
     X, norm = prep.transform(pops, Y, n_store, G, sf, True, True, comm if multi else None, return_norm=True)
-    eng = Engine('zinb-conddisp', G, G, hidden, True, 0.0, comm=comm)
+    eng = Engine(ae_type, G, G, hidden, True, 0.0, comm=comm)
     eng.init_params(0)
     # norm: how X was made from Y -> the engine keeps the counts as bytes and runs the first layer on the non-zero ones
     eng.attach_device_data(X, Y, sf, norm=norm)
@@ -466,18 +504,19 @@ def main():
         ksum = eng.prof.summary(); eng.prof = None
     kernels = []
     for name, st in ksum.items():
-        bound, work = kernel_model(name, B, G, hidden)
+        bound, work = kernel_model(name, B, G, hidden, nheads={'zinb-conddisp': 3, 'zinb': 2, 'nb-conddisp': 2, 'nb': 1}.get(ae_type, 3))
         ent = {'kernel': name, 'mean_ms': st['mean_ms'], 'share_of_step': st['total_ms'] / st['count'] / (1e3 * el / steps_timed)}
         if work:
             if bound == 'hbm':
                 ent.update(bound='hbm', achieved=work / (st['mean_ms'] * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit='GB/s')
             else:
-                ent.update(bound='mfma', achieved=work / (st['mean_ms'] * 1e-3) / 1e12, peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s')
-                # both denominators: the fp32-MFMA peak prices the algorithmic fp32 flops; the products execute as six bf16
-                # MFMAs per fp32 product, whose bound for the same result is the dense bf16 peak / 6 (a fraction above 1
-                # of the former is possible and means nothing more than that)
-                ent['peak_bf16_pipe_over_6'] = MFMA_BF16_PEAK_TFLOPS / 6.0
-                ent['frac_of_bf16_pipe_over_6'] = ent['achieved'] / (MFMA_BF16_PEAK_TFLOPS / 6.0)
+                # The products are computed as six bf16 MFMAs per fp32 product: the bound of the matrix pipe for THIS result is
+                # the dense bf16 peak / 6 -- `peak`.  (The fp32-MFMA peak, 157.3 TF/s, prices the same algorithmic flops on
+                # an instruction these kernels do not use and can exceed: kept as a secondary field only.)
+                ent.update(bound='mfma', achieved=work / (st['mean_ms'] * 1e-3) / 1e12, peak=MFMA_BF16_PEAK_TFLOPS / 6.0,
+                           unit='TFLOP/s')
+                ent['peak_fp32_mfma'] = MFMA_F32_PEAK_TFLOPS
+                ent['frac_of_fp32_mfma_peak'] = ent['achieved'] / MFMA_F32_PEAK_TFLOPS
             ent['frac'] = ent['achieved'] / ent['peak']
         kernels.append(ent)
     kernels.sort(key=lambda e: -e['mean_ms'])
@@ -495,20 +534,22 @@ def main():
                     'traffic_source': None,
                     'timing': 'HIP events around each launch, ' + ('isolated eager steps after the graph-replayed timed region' if use_graph else 'inside the timed region')}
             if e['bound'] == 'mfma':
-                # the two honest denominators: `peak` prices the algorithmic fp32 flops against the fp32-MFMA peak (what an
-                # fp32 result costs on this chip's matrix pipe); the kernel computes them as six bf16 products per fp32
-                # product on the bf16 pipe, whose bound for the SAME result is the dense bf16 peak / 6
-                roof['peak_bf16_pipe_over_6'] = MFMA_BF16_PEAK_TFLOPS / 6.0
-                roof['frac_of_bf16_pipe_over_6'] = e['achieved'] / (MFMA_BF16_PEAK_TFLOPS / 6.0)
-                roof['note'] = ('K-HEADS is bound by the SUM of its matrix and vector instruction cycles per SIMD '
-                                '(DESIGN.md 4.1): MfmaUtil 30 %, VALUBusy 54 % at 2.10 GHz (profiles/r03z_sq_counters_per_kernel.csv)')
+                roof['peak_note'] = ('dense bf16 MFMA peak / 6: the matrix-pipe bound of an fp32-accurate product computed as six '
+                                     'bf16 products; the fp32-MFMA peak is a secondary field')
+                roof['peak_fp32_mfma'] = e['peak_fp32_mfma']
+                roof['frac_of_fp32_mfma_peak'] = e['frac_of_fp32_mfma_peak']
             m = pmc.get(e['kernel'])
-            if m and m['shape']['B'] == B and m['shape']['G'] == G and m['shape']['hL'] == hidden[-1]:
-                roof['traffic'] = m['traffic_bytes']
-                roof['traffic_source'] = ('rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same kernel and shape '
-                                          '(profiles/pmc_traffic.json, profiles/r03_pmc_traffic/; %s): bytes per launch; '
-                                          'algorithmic HBM bytes %.0f' % (m.get('tree', 'tree not recorded'),
-                                                                          m['algorithmic_hbm_bytes']))
+            if m and m['shape']['B'] == B and m['shape']['G'] == G and m['shape']['hL'] == hidden[-1] and \
+                    m['shape'].get('ae_type', 'zinb-conddisp') == ae_type:
+                if m.get('source_sha') == source_sha():
+                    roof['traffic'] = m['traffic_bytes']
+                    roof['traffic_source'] = ('rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same kernel and shape on THIS '
+                                              'source tree (profiles/pmc_traffic.json, %s; sources %s): bytes per launch; algorithmic '
+                                              'HBM bytes %.0f' % (m.get('raw', 'raw files not recorded'), m['source_sha'],
+                                                                  m['algorithmic_hbm_bytes']))
+                else:
+                    roof['traffic_source'] = ('not attached: profiles/pmc_traffic.json was measured on kernel sources %s, this tree is '
+                                              '%s (tools/gpu_pmc_traffic.sh re-measures)' % (m.get('source_sha'), source_sha()))
             break
 
     extra = {}
@@ -519,15 +560,18 @@ def main():
 
     if rank == 0:
         out = {
-            'metric': 'cells/sec training (ZINB AE, 68k x 20k)',
+            'metric': 'cells/sec training (ZINB AE, 68k x 20k)' if args.workload == 'c3' and not adhoc else
+                      'cells/sec training (%s)' % (args.workload if not adhoc else 'ad-hoc shape'),
             'value': cells_timed / el, 'unit': 'cells/s', 'n_gpus': W, 'steps': steps_timed,
             'warmup': args.warmup, 'ms_per_step': 1e3 * el / steps_timed, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'zinb-conddisp autoencoder %s on synthetic %d x %d counts '
-                                   '(%s); train rows %d sharded over %d GPU(s)'
-                                   % ('-'.join(map(str, hidden)), args.cells, G,
-                                      'BASELINE configs[2]' if (args.cells, G, hidden) == (68579, 20000, (64, 32, 64))
-                                      else 'not a BASELINE shape: ad-hoc run', n_train_global, W),
+            'config': {'workload': ('%s [--workload %s]; %s autoencoder %s; ' % (wl['name'], args.workload, ae_type, '-'.join(map(str, hidden)))
+                                    if not adhoc else 'ad-hoc run (not a BASELINE shape): %s autoencoder %s on synthetic %d x %d; '
+                                    % (ae_type, '-'.join(map(str, hidden)), cells_total, G)) +
+                                   ('every rank holds its 1/%d of the matrix: %d train cells resident per GPU, %d GPU(s) running'
+                                    % (shard_of, n_local, W) if shard_of else
+                                    'train rows %d sharded over %d GPU(s)' % (n_train_global, W)),
+                       'workload_key': args.workload if not adhoc else 'adhoc',
                        'batch_per_gpu': B, 'global_batch': B * W, 'hidden': list(hidden),
                        'parallelism': 'dp%d' % W, 'launch': launch_desc,
                        'timed_region': ('%d consecutive steps of the fit loop (epochs of %d full batches of %d cells + one of %d), '
@@ -550,7 +594,7 @@ def main():
             p = eng.get_params()
             # host copy of a bounded sample of the same matrix; weights = current device weights
             out['cpu_baseline'] = cpu_baseline(X[:nb, :G].cpu().numpy(), Y[:nb, :G].cpu().numpy(),
-                                               sf[:nb].cpu().numpy(), p, hidden, B, args.cpu_seconds)
+                                               sf[:nb].cpu().numpy(), p, hidden, B, args.cpu_seconds, ae_type)
         else:
             out['cpu_baseline'] = None
         print(json.dumps(out), flush=True)

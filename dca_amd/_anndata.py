@@ -30,6 +30,26 @@ def _copy_matrix(X):
         return X.copy()
 
 
+class _CowView(np.ndarray):
+    """X of a select-everything subset: shares the parent's matrix until it is written to.  ``sub.X[...] = v`` copies the
+    matrix into the subset first (as a write through an anndata view does) and never reaches the parent; other in-place
+    operations (``sub.X += 1``) find the array read-only."""
+    _owner = None
+
+    def __array_finalize__(self, obj):
+        self._owner = None                      # slices / results of arithmetic are plain read-only views
+
+    def __setitem__(self, key, value):
+        own = self._owner
+        if own is None:
+            raise ValueError('assignment destination is a read-only view of the parent AnnData\'s matrix; assign through '
+                             'subset.X[...] = value (copies on write) or take subset.copy() first')
+        fresh = np.array(self, copy=True, subok=False)
+        fresh[key] = value
+        own._X = fresh
+        own.__dict__.pop('_dca_device', None)   # the device-resident tensors belong to the parent's matrix
+
+
 class _Raw:
     def __init__(self, X, var):
         self.X = X
@@ -137,9 +157,12 @@ class MiniAnnData:
             # (read-only, like a view that has not been written to: a write through the subset must not reach the parent)
             Xv = self._X
             if isinstance(Xv, np.ndarray):
-                Xv = Xv.view()
+                Xv = Xv.view(_CowView)
                 Xv.setflags(write=False)
             out = MiniAnnData(Xv, self.obs, self.var, dict(self.obsm), dict(self.uns), self._raw)
+            if isinstance(Xv, _CowView):
+                out._X = Xv                     # (the constructor's asarray keeps the subclass; the owner link is set here)
+                Xv._owner = out
             dd = getattr(self, '_dca_device', None)
             if dd is not None:
                 out._dca_device = dd

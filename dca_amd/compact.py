@@ -20,16 +20,27 @@ class CompactCounts:
         self.lutp = None        # [n, 64] x 8 bytes: f(k / fac[r]) for the counts k = 0 .. 63 as bf16 pieces (dcahip_enc0_lut)
 
     def with_input(self, fac, do_log, mean, std, ops=None):
-        """The same store with the description of the network input; with ops the per-cell table of the common counts is
-        made as well (the first-layer weight gradient looks its operand up there)."""
-        c = CompactCounts(self.Yc, self.ldc, self.ovf_ptr, self.ovf_col, self.ovf_val, fac, do_log, mean, std)
-        if ops is not None:
+        """The same store with the description of the network input (None when the store is too large for the sparse first
+        layer's 32-bit byte offsets).  The per-cell table of the common counts (512 B per cell) is made on the first use by
+        the weight-gradient kernel (ensure_lut): predict() never needs it."""
+        if ops is not None and self.Yc.shape[0] * self.ldc >= 2 ** 32:
+            if not CompactCounts._warned_32bit:
+                import sys
+                print('dca_amd: %d x %d counts exceed the 32-bit byte offsets of the sparse first layer: dense first layer'
+                      % (self.Yc.shape[0], self.ldc), file=sys.stderr)
+                CompactCounts._warned_32bit = True
+            return None
+        return CompactCounts(self.Yc, self.ldc, self.ovf_ptr, self.ovf_col, self.ovf_val, fac, do_log, mean, std)
+
+    _warned_32bit = False
+
+    def ensure_lut(self, ops):
+        """f(k / fac[r]) for the counts k = 0 .. 63 of every cell as bf16 pieces (dcahip_enc0_lut), once per store."""
+        if self.lutp is None:
             n = self.Yc.shape[0]
-            if n * self.ldc >= 2 ** 32:
-                return None                 # the kernels address the store with 32-bit byte offsets
-            c.lutp = torch.zeros(n, 64, 2, dtype=torch.int32, device=self.Yc.device)
-            ops.enc0_lut(fac, do_log, n, c.lutp)
-        return c
+            self.lutp = torch.zeros(n, 64, 2, dtype=torch.int32, device=self.Yc.device)
+            ops.enc0_lut(self.fac, self.do_log, n, self.lutp)
+        return self.lutp
 
 
 def build(ops, Y, n, G, chunk_rows=16384):

@@ -390,3 +390,47 @@ extern "C" int dcahost_parallel_copy(void* dst, const void* src, long nbytes, in
     for (auto& th : pool) th.join();
     return DCAHOST_OK;
 }
+
+// ---- exact content mark of a host matrix: every byte takes part (dca_amd/prep.py::DeviceData.matches decides with it
+// whether tensors left in HBM by normalize() still are the caller's adata.X -- the reference always feeds the current
+// adata.X, dca/network.py:188-211).  Fixed 4 MB pieces hashed independently (64-bit multiply-xorshift over 8-byte words)
+// and combined in piece order: the value does not depend on the thread count.  5.5 GB in ~0.1 s on the benchmark host.
+static unsigned long long hash_piece(const unsigned char* p, long n) {
+    unsigned long long h = 0x9E3779B97F4A7C15ULL ^ (unsigned long long)n;
+    long i = 0;
+    for (; i + 8 <= n; i += 8) {
+        unsigned long long w;
+        std::memcpy(&w, p + i, 8);
+        h = (h ^ w) * 0xD6E8FEB86659FD93ULL;
+        h ^= h >> 32;
+    }
+    unsigned long long w = 0;
+    if (i < n) { std::memcpy(&w, p + i, (size_t)(n - i)); h = (h ^ w) * 0xD6E8FEB86659FD93ULL; h ^= h >> 32; }
+    return h;
+}
+
+extern "C" unsigned long long dcahost_checksum(const void* data, long nbytes, int nthreads) {
+    if (!data || nbytes <= 0) return 0;
+    if (nthreads <= 0) {
+        nthreads = (int)std::thread::hardware_concurrency();
+        if (nthreads > 64) nthreads = 64;
+        if (nthreads < 1) nthreads = 1;
+    }
+    const long piece = 4L << 20;
+    const long npieces = (nbytes + piece - 1) / piece;
+    std::vector<unsigned long long> hs((size_t)npieces);
+    const unsigned char* base = static_cast<const unsigned char*>(data);
+    if (npieces < nthreads) nthreads = (int)npieces;
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nthreads; ++t)
+        pool.emplace_back([&, t] {
+            for (long i = t; i < npieces; i += nthreads) {
+                const long off = i * piece;
+                hs[(size_t)i] = hash_piece(base + off, off + piece > nbytes ? nbytes - off : piece);
+            }
+        });
+    for (auto& th : pool) th.join();
+    unsigned long long h = 0x243F6A8885A308D3ULL;
+    for (long i = 0; i < npieces; ++i) { h = (h ^ hs[(size_t)i]) * 0x9FB21C651E98DF25ULL; h ^= h >> 29; }
+    return h;
+}

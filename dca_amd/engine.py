@@ -495,18 +495,22 @@ class Engine:
         """Full training state after an epoch: parameters, RMSprop slots, BN moving statistics
         and the fit loop's scalars (epoch, lr, callback counters, history)."""
         import json
-        extra = {} if self.slot2 is None else {'slot2': self.slot2.cpu().numpy()}
+        T = self.lay.total
+        extra = {} if self.slot2 is None else {'slot2': self.slot2[:T].cpu().numpy()}     # (the flat buffers are padded to 4 x world)
         if self.m_sched is not None:
             extra['m_sched'] = self.m_sched.cpu().numpy()
-        if self.sharded_opt and self.comm.dp:      # every rank holds one shard of the slots: collect them
-            sh = self.flat_len // self.comm.world
-            self.ms.copy_(self.comm.all_gather(self.ms[self.comm.rank * sh:(self.comm.rank + 1) * sh]).reshape(-1))
-        T = self.lay.total
         np.savez(path, w=self.w[:T].cpu().numpy(), ms=self.ms[:T].cpu().numpy(), opt_iter=self.opt_iter.cpu().numpy(),
                  drop_iter=self.drop_iter.cpu().numpy(), **extra,
                  **{'mm%d' % i: t.cpu().numpy() for i, t in enumerate(self.mm)},
                  **{'mv%d' % i: t.cpu().numpy() for i, t in enumerate(self.mv)},
                  fit=np.frombuffer(json.dumps(fit_state).encode(), dtype=np.uint8))
+
+    def gather_optimizer_slots(self):
+        """Sharded optimizer (data parallel): every rank keeps only its shard of the RMSprop slots current; this collects
+        them on every rank.  A COLLECTIVE: every rank calls it (the fit loop does, before rank 0 alone writes a checkpoint)."""
+        if self.comm.dp and self._use_sharded_opt():
+            sh = self.flat_len // self.comm.world
+            self.ms.copy_(self.comm.all_gather(self.ms[self.comm.rank * sh:(self.comm.rank + 1) * sh]).reshape(-1))
 
     def load_state(self, path):
         import json
@@ -522,7 +526,7 @@ class Engine:
             if 'drop_iter' in z.files:
                 self.drop_iter.copy_(torch.as_tensor(z['drop_iter']))
             if self.slot2 is not None and 'slot2' in z.files:
-                self.slot2[:z['slot2'].shape[0]].copy_(torch.as_tensor(z['slot2']))
+                self.slot2[:T].copy_(torch.as_tensor(z['slot2'][:T]))          # (older checkpoints hold the padded length)
             for i in range(len(self.mm)):
                 self.mm[i].copy_(torch.as_tensor(z['mm%d' % i]))
                 self.mv[i].copy_(torch.as_tensor(z['mv%d' % i]))
@@ -582,12 +586,17 @@ class Engine:
             compact = _compact.build(ops, self.Y, self.Y.shape[0], lay.G_out)
         if compact is None:
             return                          # not a count matrix (check_counts=False on arbitrary data): fp32 path
-        self.cc = compact
-        # (the escapes of a batch -- counts >= 255 -- are corrected by one workgroup one after the other: a store with more
-        # than one escape in 1e5 counts is not count data of the kind this path is for and keeps the dense first layer)
+        # (counts >= 255 escape into a per-row list that K-HEADS scans linearly per escaped element, and that one workgroup
+        # walks for the first layer: read-count data with many large counts -- Smart-seq and the like -- keeps the fp32
+        # targets and the dense first layer.  Thresholds: one escape in 1e3 counts for K-HEADS' targets (the scan of a row's
+        # list then costs less than the bytes save), one in 1e5 for the sparse first layer.)
         n_esc = 0 if compact.ovf_col is None else int(compact.ovf_col.numel())
+        n_el = float(self.Y.shape[0]) * lay.G_out
+        if n_esc > 1e-3 * n_el:
+            return
+        self.cc = compact
         if norm is not None and lay.G_in == lay.G_out and ops.enc0_sparse_supported(lay.hidden[0]) \
-                and n_esc <= 1e-5 * self.Y.shape[0] * lay.G_out and os.environ.get('DCA_AMD_SPARSE_ENC0', '1') != '0':
+                and n_esc <= 1e-5 * n_el and os.environ.get('DCA_AMD_SPARSE_ENC0', '1') != '0':
             self.cc_in = compact.with_input(norm.get('fac'), norm.get('do_log', False), norm.get('mean'), norm.get('std'), ops=ops)
         self._sparse_workspaces()
 
@@ -1210,6 +1219,9 @@ class Engine:
             if i == 0:
                 with self._t('gemm_enc0_dW'):
                     if self._sparse_dw(B):
+                        if self.cc_in.lutp is None:              # the per-cell table of the common counts: first use only
+                            self._not_capturing('first use of the byte-store weight gradient')
+                            self.cc_in.ensure_lut(ops)
                         ops.enc0_dw_sparse(self.cc_in, self.perm, self.cursor, 0, B, Kp, h, self.dZ[0], self.ldh[0], gW, h,
                                            self.ws_enc0)
                     elif self._planes_enc0(B, True):

@@ -19,6 +19,7 @@ _SIGNATURES = {
     'dcahost_format_f32': (ctypes.c_long, [ctypes.c_void_p, ctypes.c_long, ctypes.c_char_p, ctypes.c_long]),
     'dcahost_format_f64': (ctypes.c_long, [ctypes.c_void_p, ctypes.c_long, ctypes.c_char_p, ctypes.c_long]),
     'dcahost_parallel_copy': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_int]),
+    'dcahost_checksum': (ctypes.c_ulonglong, [ctypes.c_void_p, ctypes.c_long, ctypes.c_int]),
     'dcahost_tsv_open': (ctypes.c_int, [ctypes.c_char_p, ctypes.c_char, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p),
                                         ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long),
                                         ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long)]),
@@ -168,3 +169,9 @@ def read_tsv(path, sep='\t', threads=0):
         return out, rows, cols
     finally:
         L.dcahost_tsv_close(h)
+
+
+def checksum(a, threads=0):
+    """Exact 64-bit content mark of a C-contiguous ndarray (every byte; dcahost_checksum)."""
+    a = np.ascontiguousarray(a)
+    return int(lib().dcahost_checksum(a.ctypes.data, a.nbytes, int(threads)))

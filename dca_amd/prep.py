@@ -36,13 +36,16 @@ class DeviceData:
 
 
 def fingerprint(X):
-    """Cheap content mark of a host matrix: shape + fp64 sums of ~64 evenly spaced rows and of the last row."""
-    n = X.shape[0]
-    rows = X[::max(1, n // 64)]
-    rows = rows.toarray() if hasattr(rows, 'toarray') else np.asarray(rows)
-    last = X[n - 1:n]
-    last = last.toarray() if hasattr(last, 'toarray') else np.asarray(last)
-    return (tuple(X.shape), float(rows.sum(dtype=np.float64)), float(last.sum(dtype=np.float64)))
+    """EXACT content mark of a host matrix: shape, dtype and a 64-bit hash of every byte (libdcahost, threaded: ~0.1 s for
+    the 5.5 GB benchmark matrix; sparse matrices: of their data / indices / indptr arrays).  An in-place edit of any element
+    between normalize() and train() / predict() changes it, and the resident tensors are then not used."""
+    from . import hostlib
+    if hasattr(X, 'toarray'):
+        Xc = X.tocsr() if hasattr(X, 'tocsr') else X
+        parts = [np.asarray(getattr(Xc, k)) for k in ('data', 'indices', 'indptr') if hasattr(Xc, k)]
+        return (tuple(X.shape), 'sparse') + tuple((str(p.dtype), hostlib.checksum(p)) for p in parts)
+    Xa = np.asarray(X)
+    return (tuple(Xa.shape), str(Xa.dtype), hostlib.checksum(Xa))
 
 
 def _r4(x):

@@ -310,6 +310,8 @@ def train(adata, network, output_dir=None, optimizer='RMSprop', learning_rate=No
     state_path = os.path.join(output_dir, 'train_state.npz') if output_dir is not None else None
 
     def on_epoch(epoch, h, st):
+        if checkpoint and output_dir is not None:
+            eng.gather_optimizer_slots()           # a collective with the sharded optimizer: every rank, before rank 0 writes
         if comm.rank != 0 or output_dir is None:
             return
         if save_weights:

@@ -62,6 +62,11 @@ long dcahost_format_f64(const double* v, long n, char* out, long cap);
  * matrices of predict() from the pinned staging buffers into the caller's arrays (dca/network.py:188-211, 395-405). */
 int dcahost_parallel_copy(void* dst, const void* src, long nbytes, int nthreads);
 
+/* Exact 64-bit content mark of nbytes bytes (every byte takes part; independent of nthreads): decides whether device
+ * tensors made from a host matrix still belong to it -- the reference always feeds the CURRENT adata.X
+ * (dca/network.py:188-211), so a resident copy may only be used while the host matrix is unchanged. */
+unsigned long long dcahost_checksum(const void* data, long nbytes, int nthreads);
+
 /* The count matrix of `dca <input> <outdir>` read natively (dca/io.py:59: sc.read(filename, first_column_names=True),
  * restated as pandas.read_csv(sep, index_col=0).values.astype(float32)): one header line of column names (with or
  * without a label for the name column), then one name + ncols numbers per line; '\n' or '\r\n' line ends, blank

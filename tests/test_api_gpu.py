@@ -109,3 +109,24 @@ def test_fused_predict_writer_writes_the_files_of_predict_then_write(tmp_path, a
     assert 'mean.tsv' in files and 'latent.tsv' in files and sorted(os.listdir(a)) == files
     for f in files:
         assert open(os.path.join(a, f), 'rb').read() == open(os.path.join(b, f), 'rb').read(), f
+
+
+def test_an_edit_of_adata_X_after_normalize_reaches_the_network():
+    """normalize() on the GPU leaves X / Y / size factors in HBM for train() and predict() (adata._dca_device).  The
+    reference always feeds the current adata.X (dca/network.py:188-211): when the caller edits the host matrix in place
+    after normalize() -- one element of one row -- the resident copy must not be used: the engine then holds the edited
+    values, and predict() answers for them."""
+    import torch
+    from dca_amd.train import train
+    ad = _prepared(n=400, G=90, seed=5)
+    assert getattr(ad, '_dca_device', None) is not None and ad._dca_device.matches(ad.X)
+    net = AE_types['zinb-conddisp'](input_size=ad.n_vars, hidden_size=(16, 4, 16))
+    net.seed = 0
+    net.build()
+    ad.X[123, 7] += np.float32(2.5)                      # row 123: not among the rows round 3's fingerprint sampled
+    assert not ad._dca_device.matches(ad.X)
+    train(ad, net, epochs=1, batch_size=32, verbose=False)
+    eng = net.engine
+    torch.cuda.synchronize()
+    assert float(eng.X[123, 7].item()) == float(ad.X[123, 7])      # the engine trained on the edited matrix
+    np.testing.assert_array_equal(eng.X[:, :ad.n_vars].cpu().numpy(), ad.X)

@@ -260,3 +260,60 @@ def test_shard_and_local_order():
     idx = np.array([5, 0, 9, 3, 7, 1, 8, 2, 6, 4])
     assert ddist.local_order(idx, 4, 3).tolist() == [1, 2, 0]        # 5, 6, 4 in visiting order
     assert ddist.local_order(idx, 0, 10).tolist() == idx.tolist()    # one rank: the reference order
+
+
+def _run_train_checkpoint(rank, world, port, outdir, sharded, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    os.environ['DCA_AMD_DP_SHARDED_OPT'] = '1' if sharded else '0'
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import pandas as pd
+        from conftest import synth_counts
+        from dca_amd import io
+        from dca_amd._anndata import AnnData
+        from dca_amd.network import AE_types, override_ops
+        from dca_amd.train import train
+        n, G = 64, 14
+        ad = AnnData(synth_counts(n, G, 2).astype(np.float32), obs=pd.DataFrame(index=['c%d' % i for i in range(n)]),
+                     var=pd.DataFrame(index=['g%d' % i for i in range(G)]))
+        ad = io.normalize(io.read_dataset(ad, test_split=False), device=False)
+        np.random.seed(5)
+        with override_ops(CpuRefOps):
+            net = AE_types['zinb-conddisp'](input_size=G, hidden_size=(6, 3, 6), comm=ddist.TorchDistComm())
+            net.seed = 0
+            net.build()
+            h = train(ad, net, output_dir=outdir, epochs=3, batch_size=16, verbose=False, checkpoint=True,
+                      early_stop=0, reduce_lr=0)
+        if rank == 0:
+            z = np.load(os.path.join(outdir, 'train_state.npz'))
+            q.put((h.history, z['ms'].copy(), z['w'].copy()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_checkpoints_of_the_sharded_optimizer_do_not_hang_and_hold_every_slot(tmp_path):
+    """train(checkpoint=True) on 2 ranks with the sharded optimizer (DCA_AMD_DP_SHARDED_OPT=1): every rank keeps only its
+    shard of the RMSprop slots current, so the checkpoint needs a gather -- a COLLECTIVE, which every rank must enter
+    (round 3: only rank 0 did, and the run hung at the end of the first epoch).  The checkpoint rank 0 writes then holds
+    the slots and parameters of the all-reduce run, bit for bit (two ranks: the same sums)."""
+    res = []
+    for sharded in (False, True):
+        ctx = mp.get_context('spawn')
+        q = ctx.Queue()
+        port = _free_port()
+        out = str(tmp_path / ('s%d' % sharded))
+        procs = [ctx.Process(target=_run_train_checkpoint, args=(r, 2, port, out, sharded, q)) for r in range(2)]
+        for pr in procs:
+            pr.start()
+        res.append(q.get(timeout=240))
+        for pr in procs:
+            pr.join(timeout=60)
+            assert pr.exitcode == 0
+    (h0, ms0, w0), (h1, ms1, w1) = res
+    assert h0 == h1
+    np.testing.assert_array_equal(w1, w0)
+    np.testing.assert_array_equal(ms1, ms0)
+    assert np.abs(ms0).max() > 0

@@ -56,3 +56,23 @@ def test_filters_and_switches():
         np.testing.assert_allclose(a.X, b.X, rtol=1e-5, atol=1e-6)
         np.testing.assert_array_equal(np.asarray(a.obs['size_factors'].values, np.float32),
                                       np.asarray(b.obs['size_factors'].values, np.float32))
+
+
+def test_resident_tensors_are_dropped_when_any_element_of_adata_X_changes():
+    """The reference always feeds the CURRENT adata.X (dca/network.py:188-211, dca/train.py:83-89).  normalize() leaves
+    tensors on the device and train() / predict() reuse them only while the host matrix still is the one they were made
+    from: an in-place edit of ONE element of ANY row (round 3's 64-row sample missed every other row) must be seen."""
+    y = synth_counts(1000, 40, 3)
+    with_ops = CpuRefOps()
+    ad, dd = prep.normalize_device(_adata(y), ops=with_ops, device='cpu')
+    assert dd.matches(ad.X)
+    for row in (1, 7, 501, 999):                        # rows the old sample (every 15th row + the last) did not contain, and one it did
+        x = ad.X
+        old = x[row, 3]
+        x[row, 3] = old + np.float32(1e-3)
+        assert not dd.matches(ad.X), row
+        x[row, 3] = old
+        assert dd.matches(ad.X)
+    # a different object with the same content still matches (anndata's setters copy), a different dtype does not
+    assert dd.matches(ad.X.copy())
+    assert not dd.matches(ad.X.astype(np.float64))
