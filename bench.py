@@ -257,6 +257,18 @@ class EpochRunner:
         return (full + 7) // 8 + (1 if self.n % self.B else 0)
 
 
+def _sclk():
+    """Current shader clock as rocm-smi prints it (None when the tool is not there)."""
+    import re
+    import subprocess
+    try:
+        out = subprocess.run(['rocm-smi', '--showclocks'], capture_output=True, text=True, timeout=20).stdout
+        m = re.search(r'sclk clock level[^(]*\((\d+)Mhz\)', out)
+        return int(m.group(1)) if m else None
+    except Exception:       # noqa: BLE001
+        return None
+
+
 def after_measurements(eng, args, B, n_train, n_val, G, dev, runner):
     """Same process, same resident matrix, after the timed region (one GPU): three individually timed epochs with the
     validation pass (SURVEY 8d's end-to-end figure), then the reference-default batch 32."""
@@ -305,13 +317,25 @@ def after_measurements(eng, args, B, n_train, n_val, G, dev, runner):
         ks = 8                               # steps per graph launch, as the fit loop replays them (dca_amd/train.py)
         g32k = capture_step(eng, b32, [b32], ks)
         g32k.replay()
-        new_order()
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        for _ in range(k32 // ks):
-            g32k.replay()
-        torch.cuda.synchronize(); el = time.perf_counter() - t0
+        # five runs of 400 steps; beside the time: what the host spent enqueueing the launches (the calls return long before the
+        # GPU is done: a host that needs as long as the GPU would starve it) and the shader clock before / after -- a box on
+        # which this step is slow (the driver measured 0.109 ms in round 2 and 0.180 in round 3; four boxes of round 4:
+        # 0.110-0.111, tools/b32_probe.py) then says why
+        runs, enq = [], []
+        clk0 = _sclk()
+        for _ in range(5):
+            new_order()
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(k32 // ks):
+                g32k.replay()
+            t1 = time.perf_counter()
+            torch.cuda.synchronize(); runs.append(time.perf_counter() - t0); enq.append(t1 - t0)
+        el = float(np.median(runs))
         out['batch32'] = {'ms_per_step': 1e3 * el / k32, 'cells_per_s': k32 * b32 / el, 'launches': launches,
-                          'steps': k32, 'launch': 'hipGraph replay, %d steps per graph' % ks}
+                          'steps': k32, 'launch': 'hipGraph replay, %d steps per graph' % ks,
+                          'ms_per_step_runs': [1e3 * r / k32 for r in runs],
+                          'host_enqueue_ms_per_graph_launch': 1e3 * float(np.median(enq)) / (k32 // ks),
+                          'gpu_ms_per_graph_launch': 1e3 * el / (k32 // ks), 'sclk_before_after': [clk0, _sclk()]}
     except Exception as e:
         out['batch32'] = {'error': str(e)}
     return out
@@ -447,7 +471,7 @@ def main():
             eng.train_step(B, B * W, counts, B)
         comm_ms = {k: {'calls_per_step': v[0] / 8, 'ms_per_step': v[1] / 8} for k, v in comm.timer_summary().items()}
         comm.timer = None
-        use_graph = args.graph != 'off' and os.environ.get('DCA_AMD_DP_GRAPH', '1') != '0' and getattr(comm, 'capturable', False)
+        use_graph = args.graph != 'off' and eng.cfg.dp_graph and getattr(comm, 'capturable', False)
         graphs = {}
         if use_graph:
             ok = 1.0

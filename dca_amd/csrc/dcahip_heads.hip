@@ -512,6 +512,9 @@ __global__ __launch_bounds__(64 * WR) void heads_fused_x3_kernel(HeadsArgs2 p) {
                     }
                     o_nz[j] = nz;
                 }
+                // (pinning the four elements' outputs here -- so that their arithmetic stays one interleaved block instead of
+                // being sunk into the `if (!nz)` branches below -- was measured: 0.888 / 0.876 ms against 0.868 / 0.864,
+                // profiles/notes/r04_heads_wave_specialised/README.md; the pass is bound by the vector pipe, not by latency)
 #pragma unroll
                 for (int j = 0; j < kZU; ++j) {
                     const int row = rowmap(grp * kZU + j, hi);

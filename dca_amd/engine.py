@@ -262,7 +262,7 @@ class ParamLayout:
 class Engine:
     def __init__(self, ae_type, input_size, output_size=None, hidden_size=(64, 32, 64),
                  batchnorm=True, ridge=0.0, ops=None, comm=None, device=None, activation='relu',
-                 hidden_dropout=0., input_dropout=0., dropout_seed=0, sharedpi=False):
+                 hidden_dropout=0., input_dropout=0., dropout_seed=0, sharedpi=False, config=None):
         if ae_type not in AE_HEADS:
             raise NotImplementedError('ae_type %r is not available on the MI355X path yet '
                                       '(supported: %s)' % (ae_type, ', '.join(AE_HEADS)))
@@ -271,6 +271,8 @@ class Engine:
             ops = HipOps()                              # raises without the HIP library / a GPU
         self.ops = ops
         self.comm = comm or SingleProcess()
+        from . import config as _config
+        self.cfg = config if config is not None else _config.current()      # every path decision below reads this
         self.dev = torch.device(device) if device is not None else (
             torch.device('cuda', torch.cuda.current_device()) if ops.device_type == 'cuda'
             else torch.device('cpu'))
@@ -298,8 +300,8 @@ class Engine:
         # data parallel, RMSprop: reduce-scatter of the gradient -> every rank clips and updates ITS shard of the
         # parameters (and keeps only that shard of the RMSprop slots current) -> all-gather of the parameters, instead of
         # all-reducing the whole gradient and updating everything everywhere.  Same bytes on the wire
-        # (2 (N-1)/N P either way), 1/N of the optimizer traffic per rank; DCA_AMD_DP_SHARDED_OPT=1 switches it on.
-        self.sharded_opt = self.comm.dp and os.environ.get('DCA_AMD_DP_SHARDED_OPT', '0') == '1'
+        # (2 (N-1)/N P either way), 1/N of the optimizer traffic per rank; EngineConfig.dp_sharded_opt switches it on.
+        self.sharded_opt = self.comm.dp and self.cfg.dp_sharded_opt
         self.mm = [torch.zeros(h, **f32) for h in lay.hidden] if batchnorm else []
         self.mv = [torch.ones(h, **f32) for h in lay.hidden] if batchnorm else []
         self.lr = torch.full((1,), 1e-3, **f32)
@@ -315,8 +317,8 @@ class Engine:
         self.hist = None
         self.prof = None            # EventProfiler or None
         # K-HEADS (heads forward + NLL + both backward products in one kernel) whenever the
-        # library supports the shape; DCA_AMD_FUSED_HEADS=0 forces the separate kernels
-        self.use_fused = os.environ.get('DCA_AMD_FUSED_HEADS', '1') != '0' and not (lay.shared or lay.fork or lay.elempi)
+        # library supports the shape (tests compare the two paths by setting this attribute)
+        self.use_fused = not (lay.shared or lay.fork or lay.elempi)
         self.sharedpi = bool(sharedpi) and lay.elempi       # ElementwiseDense(1): one scale / offset for all genes
         self.ws_elempi = torch.zeros(ops.elempi_workspace_doubles(lay.G_out), dtype=torch.float64, device=self.dev) \
             if lay.elempi else None
@@ -356,14 +358,14 @@ class Engine:
         # K-STACK at throughput batches: 'steps' = one launch per batch-wide dependency (9 launches instead of 22 for
         # the 64-32-64 stack), 'coop' = one cooperative launch per direction with grid barriers, 'off' = one launch per
         # operation.  Measured on the MI355X at 4096 rows (profiles/r03_stack_*): see DESIGN.md.
-        self.stack_mode = os.environ.get('DCA_AMD_STACK', 'steps')
+        self.stack_mode = self.cfg.stack
         # batch rows from which the byte-store kernels replace the dense first-layer GEMMs -- measured on the MI355X at
         # the benchmark shape (profiles/r03*_enc0_*): the weight gradient on the matrix pipe from the byte store ties the
         # dense TN GEMM at 4096 rows on the 68 579-cell matrix (0.149-0.154 vs 0.157 ms) and wins on a cache-resident one
         # (0.112 vs 0.150); the sparse forward (gathers of W0 rows from L2) loses to the dense NT GEMM at every batch
         # (0.160 vs 0.107 ms at 4096 rows) and stays off
-        self.sparse_fwd_min = int(os.environ.get('DCA_AMD_SPARSE_FWD_MIN', str(1 << 30)))
-        self.sparse_dw_min = int(os.environ.get('DCA_AMD_SPARSE_DW_MIN', '512'))
+        self.sparse_fwd_min = self.cfg.sparse_fwd_min
+        self.sparse_dw_min = self.cfg.sparse_dw_min
 
     def _t(self, name):
         return self.prof.section(name) if self.prof is not None else _NULL
@@ -579,7 +581,7 @@ class Engine:
         normalisation is known and input genes = output genes -- the sparse first layer."""
         self.cc = self.cc_in = None
         ops, lay = self.ops, self.lay
-        if self.Y is None or not hasattr(ops, 'counts_compact') or os.environ.get('DCA_AMD_COMPACT', '1') == '0':
+        if self.Y is None or not hasattr(ops, 'counts_compact'):
             return
         if compact is None:
             from . import compact as _compact
@@ -596,7 +598,7 @@ class Engine:
             return
         self.cc = compact
         if norm is not None and lay.G_in == lay.G_out and ops.enc0_sparse_supported(lay.hidden[0]) \
-                and n_esc <= 1e-5 * n_el and os.environ.get('DCA_AMD_SPARSE_ENC0', '1') != '0':
+                and n_esc <= 1e-5 * n_el:
             self.cc_in = compact.with_input(norm.get('fac'), norm.get('do_log', False), norm.get('mean'), norm.get('std'), ops=ops)
         self._sparse_workspaces()
 
@@ -861,7 +863,7 @@ class Engine:
                 and not (training and self.in_drop > 0.0) and not self._sparse_fwd(B, training))
 
     def _enc0_nt(self, B):
-        return self.W0T is not None and B >= 256 and os.environ.get('DCA_AMD_ENC0_NT', '1') != '0'
+        return self.W0T is not None and B >= self.cfg.enc0_nt_min
 
     def _wide_planes(self, B):
         """Throughput batches of a network whose heads run as separate kernels (decoder wider than 64 units): every large
@@ -870,25 +872,22 @@ class Engine:
         that contract over its rows and over its columns, so no transposed copies are kept."""
         lay = self.lay
         return (self.ws_heads is None and B >= 256 and hasattr(self.ops, 'gemm_p3') and not lay.fork and not lay.elempi
-                and not lay.shared and os.environ.get('DCA_AMD_WIDE_PLANES', '1') != '0')
+                and not lay.shared and self.cfg.wide_planes)
 
     def _wide_transposed(self, B):
         """The same networks without the planes path: transposed operand copies for K-GEMM's fast forms (see reserve)."""
-        return (self.ws_heads is None and B >= 256 and hasattr(self.ops, 'transpose') and not self._wide_planes(B)
-                and os.environ.get('DCA_AMD_WIDE_T', '1') != '0')
+        return self.ws_heads is None and B >= 256 and hasattr(self.ops, 'transpose') and not self._wide_planes(B)
 
     def _stack_small(self, B):
         """The whole hidden stack behind the first product in one launch (batch-normalised, every layer small)."""
         L = len(self.lay.hidden)
         return (self.lay.batchnorm and 2 <= L <= 4 and hasattr(self.ops, 'hidden_small_chain') and self._bn_small(B)
-                and all(self._layer_small(B, i) for i in range(1, L)) and self.lay.hidden[0] <= 64
-                and os.environ.get('DCA_AMD_SMALL_CHAIN', '1') != '0')
+                and all(self._layer_small(B, i) for i in range(1, L)) and self.lay.hidden[0] <= 64)
 
     def _stack_chain(self, B):
         """The backward of the whole hidden stack in ONE single-workgroup launch: batches of at most 64 rows (the
         reference's default 32) through small batch-normalised layers."""
-        return (self._stack_small(B) and B <= 64 and hasattr(self.ops, 'hidden_stack_bwd')
-                and os.environ.get('DCA_AMD_BWD_CHAIN', '1') != '0')
+        return self._stack_small(B) and B <= 64 and hasattr(self.ops, 'hidden_stack_bwd') and self.cfg.bwd_chain
 
     def _stack_coop(self, B):
         """The hidden stack in one cooperative launch per direction (K-STACK): one GPU, batch norm on, every layer at

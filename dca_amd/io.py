@@ -116,7 +116,7 @@ def scale(adata):
 def read_text(filename, first_column_names=True):
     """Stand-in for sc.read(path, first_column_names=True) on TSV/CSV (io.py:59)."""
     sep = ',' if filename.endswith('.csv') else '\t'
-    if first_column_names and os.environ.get('DCA_AMD_NATIVE_READ', '1') != '0':
+    if first_column_names:
         native = _read_text_native(filename, sep)
         if native is not None:
             return native
@@ -193,7 +193,8 @@ def read_dataset(adata, transpose=False, test_split=False, copy=False, check_cou
 
 
 def _device_prep_available():
-    if os.environ.get('DCA_AMD_DEVICE_PREP', '1') == '0':
+    from . import config as _config
+    if not _config.current().device_prep:
         return False
     try:
         import torch

@@ -52,7 +52,7 @@ _stage_cache = {}
 def _staging(want, cols, chunk, pinned):
     """Two staging buffers [chunk, cols] per requested output, page-locked when a GPU is present.  ONE set is kept
     between calls (locking pages costs about as much as copying them): a call with other shapes drops it first, and
-    DCA_AMD_KEEP_STAGING=0 releases the page-locked memory at the end of every predict()."""
+    (The page-locked memory is kept for the life of the process: locking pages costs about as much as copying them.)"""
     keys = {k: (k, chunk, cols[k], pinned) for k in want}
     if any(key not in _stage_cache for key in keys.values()) or len(_stage_cache) != len(keys):
         _stage_cache.clear()
@@ -189,7 +189,7 @@ class Autoencoder():
         """One inference pass over all cells; returns host arrays for the requested outputs."""
         eng = self.engine
         if chunk is None:       # rows per device -> host chunk: 2 page-locked staging buffers of this many rows per output
-            chunk = int(os.environ.get('DCA_AMD_PREDICT_CHUNK', '1024'))
+            chunk = eng.cfg.predict_chunk if hasattr(eng, 'cfg') else 1024
         n = adata.n_obs
         X = adata.X
         sf = np.asarray(adata.obs['size_factors'].values, dtype=np.float32)
@@ -223,7 +223,7 @@ class Autoencoder():
             for k in want:
                 _host_copy(outs[k][start:start + rows], stage[k][slot][:rows].numpy())
 
-        trace = os.environ.get('DCA_AMD_PREDICT_TRACE')
+        trace = False                       # (set by hand when looking at the predict loop: prints its three time shares)
         import time as _time
         t_launch = t_drain = 0.0
         t_all = _time.perf_counter()
@@ -246,8 +246,6 @@ class Autoencoder():
         if trace:
             print('dca: predict trace: %d cells, outputs %s: enqueue %.2f s, wait + host copies %.2f s, loop total %.2f s'
                   % (n, sorted(want), t_launch, t_drain, _time.perf_counter() - t_all))
-        if os.environ.get('DCA_AMD_KEEP_STAGING', '1') == '0':
-            _stage_cache.clear()
         return outs
 
     def predict(self, adata, mode='denoise', return_info=False, copy=False):
@@ -306,7 +304,7 @@ class Autoencoder():
             native = False
         fusable = (native and eng.dev.type == 'cuda' and hasattr(eng.ops, 'transpose') and lay.G_out >= 256 and head_keys
                    and not (lay.shared or lay.fork or lay.elempi) and mode in ('denoise', 'full')
-                   and len(genes) == lay.G_out and os.environ.get('DCA_AMD_FUSED_WRITE', '1') != '0')
+                   and len(genes) == lay.G_out and getattr(eng, 'cfg', None) is not None and eng.cfg.fused_write)
         if not fusable:
             self.predict(adata, mode=mode, return_info=True)
             self.write(adata, file_path, mode=mode, colnames=colnames)

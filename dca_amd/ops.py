@@ -111,6 +111,7 @@ class HipOps:
     def enc0_dw_sparse(self, c, perm, cursor, row_base, B, G, H1, dZ, ldz, gW, ldg, ws):
         """gW [G + 1, ldg] = [X^T dZ ; colsum dZ] with X described by the compact counts c (its normalisation fields)."""
         p = hip.ptr
+        c.ensure_lut(self)                   # the per-cell table of the common counts: made on the first call for this store
         hip.check(self.L.dcahip_enc0_dw_sparse(p(c.Yc), c.ldc, p(c.ovf_ptr), p(c.ovf_col), p(c.ovf_val), p(c.fac),
                                                int(c.do_log), p(c.lutp), p(c.mean), p(c.std), p(perm), p(cursor), int(row_base),
                                                B, G, H1, p(dZ), ldz, p(gW), ldg, p(ws), ws.numel() * ws.element_size(),

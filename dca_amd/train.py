@@ -178,17 +178,20 @@ class _StepRunner:
     the device idles ~9 us between two graph launches, 6 % of a batch-32 step (profiles/r02w_batch32_step_trace.txt).
     Data parallel: the RCCL exchanges of the step are captured with it (every rank replays the same sequence of
     collectives; an eager data-parallel step is host-bound: ~45 launches + 8 collectives took 2.17 ms against 1.25 ms of
-    kernels, profiles/r03_dp_one_rank.txt).  DCA_AMD_DP_GRAPH=0 keeps the data-parallel steps eager; a capture that raises
+    kernels, profiles/r03_dp_one_rank.txt).  EngineConfig.dp_graph = False keeps the data-parallel steps eager; a capture that raises
     does the same for the rest of the run (a capture executes nothing, so ranks that did capture stay in step)."""
-
-    GRAPH_STEPS = int(os.environ.get('DCA_AMD_GRAPH_STEPS', '8'))
 
     def __init__(self, eng, use_graph):
         self.eng = eng
+        cfg = getattr(eng, 'cfg', None)
+        if cfg is None:
+            from . import config as _config
+            cfg = _config.current()
+        self.GRAPH_STEPS = cfg.graph_steps
         if use_graph is None:
-            use_graph = os.environ.get('DCA_AMD_GRAPH', '1') != '0'
+            use_graph = True
         self.use_graph = bool(use_graph) and eng.ops.device_type == 'cuda' and \
-            (not eng.comm.dp or (getattr(eng.comm, 'capturable', False) and os.environ.get('DCA_AMD_DP_GRAPH', '1') != '0'))
+            (not eng.comm.dp or (getattr(eng.comm, 'capturable', False) and cfg.dp_graph))
         self.graphs = {}
 
     def _capture(self, args, k):
