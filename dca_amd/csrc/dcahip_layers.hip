@@ -201,15 +201,35 @@ __device__ __forceinline__ void merge_entries_wg(const float* entries, const flo
 
 __global__ __launch_bounds__(256) void moments_combine_kernel(const float* entries,
                                                               const float* counts, int E, int H,
-                                                              float* out) {
+                                                              float* out, int Bfallback = 0) {
     __shared__ double smd[512];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     double n, mean, m2;
-    merge_entries_wg(entries, counts, E, H, c, 0, smd, n, mean, m2);
+    merge_entries_wg(entries, counts, E, H, c, Bfallback, smd, n, mean, m2);
     if (threadIdx.x < 64 && c < H) {
         out[c] = (float)mean;
         out[H + c] = (float)m2;
     }
+}
+
+// out[2][H] = sum over E partial pairs [E][2][H], in entry order (K-STACK's backward sums of one rank, ahead of the all-reduce)
+// (dbeta: this rank's LOCAL share of d beta = its own sum of dy -- the gradient bucket is summed over the ranks afterwards)
+__global__ __launch_bounds__(64) void stack_sums_combine_kernel(const float* part, int E, int H, float* out, float* dbeta) {
+    const int c = threadIdx.x;
+    if (c >= H) return;
+    float v1 = 0.f, v2 = 0.f;
+    for (int e0 = 0; e0 < E; e0 += 8) {
+        float a1[8], a2[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long eo = (long)(e0 + u < E ? e0 + u : E - 1) * 2;
+            a1[u] = part[(eo + 0) * H + c]; a2[u] = part[(eo + 1) * H + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (e0 + u < E) { v1 += a1[u]; v2 += a2[u]; }
+    }
+    out[c] = v1; out[H + c] = v2;
+    if (dbeta) dbeta[c] = v1;
 }
 
 struct BnApplyArgs {
@@ -1428,6 +1448,9 @@ struct StepFwdArgs {
     float momentum, eps;
     const float* part_in;               // [nwg][2][H] (mean, M2) of layer i (unused with stats_only)
     float* part_out;                    // [nwg][2][H'] of layer i + 1 (stats_only: of layer i)
+    // data parallel (SyncBN): the statistics of layer i come from outside instead -- one (mean, M2) entry per RANK with
+    // its row count, gathered between two launches (dcahip_hidden_stack_fwd_sync); the row partition stays this rank's
+    const float* ext_in; const float* ext_counts; int ext_E;
 };
 
 __global__ __launch_bounds__(256) void stack_fwd_step_kernel(StepFwdArgs a) {
@@ -1453,11 +1476,14 @@ __global__ __launch_bounds__(256) void stack_fwd_step_kernel(StepFwdArgs a) {
     float out_z[kStepRows / 4];
     int Hs = H;                                            // width of the layer whose block statistics this launch writes
     if (!a.stats_only) {
+        const float* const ein = a.ext_in ? a.ext_in : a.part_in;      // whose statistics: every rank's, or this launch grid's
+        const float* const cnt = a.ext_in ? a.ext_counts : nullptr;
+        const int Em = a.ext_in ? a.ext_E : E;
         float pm[32], pq[32];
 #pragma unroll
         for (int u = 0; u < 32; ++u) {
-            const long eo = (long)(ty + 4 * u < E ? ty + 4 * u : E - 1) * 2;
-            pm[u] = a.part_in[(eo + 0) * H + cc]; pq[u] = a.part_in[(eo + 1) * H + cc];
+            const long eo = (long)(ty + 4 * u < Em ? ty + 4 * u : Em - 1) * 2;
+            pm[u] = ein[(eo + 0) * H + cc]; pq[u] = ein[(eo + 1) * H + cc];
         }
         const SmallLayer& N = a.nxt;
         const int K = H, HN = N.W ? N.H : 0;
@@ -1470,16 +1496,16 @@ __global__ __launch_bounds__(256) void stack_fwd_step_kernel(StepFwdArgs a) {
 #pragma unroll
         for (int u = 0; u < 32; ++u) {
             const int e = ty + 4 * u;
-            const double ne = (e < E && c < H) ? entry_count(nullptr, e, E, a.B) : 0.0;
+            const double ne = (e < Em && c < H) ? entry_count(cnt, e, Em, a.B) : 0.0;
             n += ne; sw += ne * (double)pm[u]; sq += ne > 0.0 ? (double)pq[u] + ne * (double)pm[u] * (double)pm[u] : 0.0;
         }
-        for (int e0 = ty + 128; e0 < E; e0 += 128) {       // (more than 128 blocks: further batches)
+        for (int e0 = ty + 128; e0 < Em; e0 += 128) {      // (more than 128 entries: further batches)
 #pragma unroll 4
             for (int u = 0; u < 32; ++u) {
                 const int e = e0 + 4 * u;
-                if (e < E && c < H) {
-                    const double ne = entry_count(nullptr, e, E, a.B);
-                    const double me = (double)a.part_in[((long)e * 2 + 0) * H + cc], qe = (double)a.part_in[((long)e * 2 + 1) * H + cc];
+                if (e < Em && c < H) {
+                    const double ne = entry_count(cnt, e, Em, a.B);
+                    const double me = (double)ein[((long)e * 2 + 0) * H + cc], qe = (double)ein[((long)e * 2 + 1) * H + cc];
                     n += ne; sw += ne * me; sq += qe + ne * me * me;
                 }
             }
@@ -1564,6 +1590,7 @@ struct StepBwdArgs {
     const float* part_in;               // [nwg][2][H] sums of layer i (unused with sums_only)
     float* part_out;                    // sums of the layer below (sums_only: of layer i)
     float* gwp;                         // [nwg][65][64] weight-gradient partials of layer i
+    const float* ext_in;                // data parallel: [2][H] sums of layer i over every rank (all-reduced between two launches)
 };
 
 __global__ __launch_bounds__(256) void stack_bwd_step_kernel(StepBwdArgs a) {
@@ -1599,11 +1626,13 @@ __global__ __launch_bounds__(256) void stack_bwd_step_kernel(StepBwdArgs a) {
         if (c < H && ty == 0) { a.part_out[((long)wg * 2 + 0) * H + c] = t1; a.part_out[((long)wg * 2 + 1) * H + c] = t2; }
         return;
     }
+    const float* const ein = a.ext_in ? a.ext_in : a.part_in;
+    const int Em = a.ext_in ? 1 : E;
     float p1[16], p2[16];                                  // the first 64 blocks' sums (the rest in further batches below)
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
-        const long eo = (long)(ty + 4 * u < E ? ty + 4 * u : E - 1) * 2;
-        p1[u] = a.part_in[(eo + 0) * H + cc]; p2[u] = a.part_in[(eo + 1) * H + cc];
+        const long eo = (long)(ty + 4 * u < Em ? ty + 4 * u : Em - 1) * 2;
+        p1[u] = ein[(eo + 0) * H + cc]; p2[u] = ein[(eo + 1) * H + cc];
     }
     const bool has_low = a.low.Hact != nullptr;
     const int K = has_low ? L.K : 0;
@@ -1621,21 +1650,21 @@ __global__ __launch_bounds__(256) void stack_bwd_step_kernel(StepBwdArgs a) {
     // ---- the two batch sums, every block the same order
     float v1 = 0.f, v2 = 0.f;
 #pragma unroll
-    for (int u = 0; u < 16; ++u) if (ty + 4 * u < E && c < H) { v1 += p1[u]; v2 += p2[u]; }
+    for (int u = 0; u < 16; ++u) if (ty + 4 * u < Em && c < H) { v1 += p1[u]; v2 += p2[u]; }
 #pragma unroll 1
-    for (int e0 = ty + 64; e0 < E; e0 += 64) {
+    for (int e0 = ty + 64; e0 < Em; e0 += 64) {
         float q1[16], q2[16];
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
-            const long eo = (long)(e0 + 4 * u < E ? e0 + 4 * u : E - 1) * 2;
-            q1[u] = a.part_in[(eo + 0) * H + cc]; q2[u] = a.part_in[(eo + 1) * H + cc];
+            const long eo = (long)(e0 + 4 * u < Em ? e0 + 4 * u : Em - 1) * 2;
+            q1[u] = ein[(eo + 0) * H + cc]; q2[u] = ein[(eo + 1) * H + cc];
         }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) if (e0 + 4 * u < E && c < H) { v1 += q1[u]; v2 += q2[u]; }
+        for (int u = 0; u < 16; ++u) if (e0 + 4 * u < Em && c < H) { v1 += q1[u]; v2 += q2[u]; }
     }
     v1 = wg_rowlane_sum(v1, smf);
     v2 = wg_rowlane_sum(v2, smf);
-    if (wg == 0 && ty == 0 && c < H && L.dbeta) L.dbeta[c] = v1;
+    if (wg == 0 && ty == 0 && c < H && L.dbeta && !a.ext_in) L.dbeta[c] = v1;     // (all-rank sums: d beta stays the local share)
     const float m1 = v1 / a.n_total, m2 = v2 / a.n_total;
 #pragma unroll
     for (int j = 0; j < kStepRows / 4; ++j) {
@@ -2288,6 +2317,84 @@ extern "C" int dcahip_hidden_stack_fwd(const dcahip_small_layer* layers, int n, 
         return (int)hipGetLastError();
     }
     hipLaunchKernelGGL(hidden_stack_fwd_kernel, dim3(a.nwg), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return (int)hipGetLastError();
+}
+
+// ---- K-STACK between the exchanges of a data-parallel step (SyncBN): ONE step per call, the statistics of the step's input
+// layer handed in as one entry per rank, the statistics of the layer the step makes merged over this rank's row blocks into
+// `stat_out` ([2][H]: mean, M2) for the all-gather that follows.  Rows per workgroup: the step kernels' 32.
+extern "C" int dcahip_hidden_stack_step_blocks(int B) { return B > 0 ? stack_workgroups(B, kStepRows) : 0; }
+
+extern "C" int dcahip_hidden_stack_fwd_sync(const dcahip_small_layer* layers, int n, int B, float momentum, float eps, int act,
+                                            int step, const float* ext_entries, const float* ext_counts, int ext_E,
+                                            float* stat_out, void* workspace, long workspace_bytes, void* stream) {
+    if (!layers || n < 1 || n > kStackMaxLayers || B <= 0 || B > kStackMaxWG * kStackRows || !workspace) return DCAHIP_EINVAL;
+    if (workspace_bytes < dcahip_hidden_stack_workspace_bytes(n, B) || !al16(workspace) || step < 0 || step > n) return DCAHIP_EINVAL;
+    if (step > 0 && (!ext_entries || !ext_counts || ext_E <= 0)) return DCAHIP_EINVAL;
+    const int nwg = stack_workgroups(B, kStepRows);
+    if (nwg > kStackMaxPhaseWG) return DCAHIP_EINVAL;
+    SmallLayer l[kStackMaxLayers];
+    for (int i = 0; i < n; ++i) {
+        const dcahip_small_layer& q = layers[i];
+        if (q.H <= 0 || q.H > 64 || !q.Hout || !q.moving_mean || !q.moving_var || !q.Z) return DCAHIP_EINVAL;
+        if (i > 0 && (!q.W || q.K != layers[i - 1].H)) return DCAHIP_EINVAL;
+        l[i] = SmallLayer{q.W, q.ldw, q.bias, q.K, q.H, q.beta, q.moving_mean, q.moving_var, q.Z, q.ldz, q.xhat, q.ldx,
+                          q.Hout, q.ldh, q.inv_std};
+    }
+    float* part = reinterpret_cast<float*>(static_cast<char*>(workspace) + 256);
+    StepFwdArgs q{};
+    const int i = step == 0 ? 0 : step - 1;
+    q.cur = l[i];
+    if (step > 0 && i + 1 < n) q.nxt = l[i + 1];
+    q.B = B; q.act = act; q.nwg = nwg; q.stats_only = step == 0; q.momentum = momentum; q.eps = eps;
+    q.part_in = part + (long)i * nwg * 2 * 64;
+    const int made = step == 0 ? 0 : i + 1;                       // the layer whose block statistics this launch writes
+    q.part_out = part + (long)made * nwg * 2 * 64;
+    if (step > 0) { q.ext_in = ext_entries; q.ext_counts = ext_counts; q.ext_E = ext_E; }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(stack_fwd_step_kernel, dim3(nwg), dim3(256), 0, st, q);
+    if (made < n && stat_out) {
+        const int Hm = l[made].H;
+        hipLaunchKernelGGL(moments_combine_kernel, dim3((Hm + 63) / 64), dim3(256), 0, st,
+                           (const float*)q.part_out, (const float*)nullptr, nwg, Hm, stat_out, B);
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int dcahip_hidden_stack_bwd_sync(const dcahip_stack_bwd_layer* layers, int n, int B, float n_total, int act,
+                                            float* dZ0, long ldz0, int step, const float* ext_sums, float* sums_out,
+                                            void* workspace, long workspace_bytes, void* stream) {
+    if (!layers || n < 1 || n > kStackMaxLayers || B <= 0 || B > kStackMaxWG * kStackRows || !dZ0 || !workspace) return DCAHIP_EINVAL;
+    if (workspace_bytes < dcahip_hidden_stack_workspace_bytes(n, B) || !al16(workspace) || step < 0 || step > n) return DCAHIP_EINVAL;
+    if (step > 0 && !ext_sums) return DCAHIP_EINVAL;
+    const int nwg = stack_workgroups(B, kStepRows);
+    if (nwg > kStackMaxPhaseWG) return DCAHIP_EINVAL;
+    StackBwdLayer l[kStackMaxLayers];
+    for (int i = 0; i < n; ++i) {
+        const dcahip_stack_bwd_layer& q = layers[i];
+        if (q.H <= 0 || q.H > 64 || !q.Hact || !q.xhat || !q.inv_std || !q.dH) return DCAHIP_EINVAL;
+        if (i > 0 && (!q.W || !q.Hprev || !q.gW || q.K != layers[i - 1].H || q.K > 64)) return DCAHIP_EINVAL;
+        l[i] = StackBwdLayer{q.W, q.ldw, q.K, q.H, q.Hact, q.ldh, q.xhat, q.ldx, q.inv_std, q.Hprev, q.ldp, q.gW, q.ldg,
+                             q.dbeta, q.dH, q.lddh};
+    }
+    float* part = reinterpret_cast<float*>(static_cast<char*>(workspace) + 256);
+    float* gwp = part + (long)n * nwg * 2 * 64;
+    StepBwdArgs q{};
+    const int i = step == 0 ? n - 1 : n - step;
+    q.cur = l[i];
+    if (step > 0 && i > 0) q.low = l[i - 1];
+    q.B = B; q.act = act; q.nwg = nwg; q.sums_only = step == 0; q.n_total = n_total;
+    q.dZ0 = dZ0; q.ldz0 = ldz0;
+    q.part_in = part + (long)i * nwg * 2 * 64;
+    const int made = step == 0 ? i : i - 1;                       // the layer whose block sums this launch writes (-1: none)
+    q.part_out = part + (long)(made >= 0 ? made : 0) * nwg * 2 * 64;
+    q.gwp = gwp + (long)i * nwg * 65 * 64;
+    if (step > 0) q.ext_in = ext_sums;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(stack_bwd_step_kernel, dim3(nwg), dim3(256), 0, st, q);
+    if (made >= 0 && sums_out)
+        hipLaunchKernelGGL(stack_sums_combine_kernel, dim3(1), dim3(64), 0, st, (const float*)q.part_out, nwg, l[made].H, sums_out,
+                           l[made].dbeta);
     return (int)hipGetLastError();
 }
 

@@ -668,6 +668,7 @@ class Engine:
         self.part = [torch.zeros(max(R, self.comm.world) * 2 * h, **f32) for h in lay.hidden]
         self.bpart = [torch.zeros(R * 2 * h, **f32) for h in lay.hidden]
         self.stat_local = [torch.zeros(2 * h, **f32) for h in lay.hidden]
+        self.bsum = [torch.zeros(2 * h, **f32) for h in lay.hidden]      # SyncBN backward: [sum dy | sum dy xhat] per layer
         self.counts_world = torch.zeros(self.comm.world, **f32)
         self._counts_world_key = None
         self._counts_local, self._counts_world = {}, {}
@@ -799,6 +800,23 @@ class Engine:
             else:
                 ops.sgemm(0, 0, B, h, K, self.Hcur[i - 1], self.ldh[i - 1], Wi, h, self.Z[i],
                           self.ldh[i], bias=bi, ws=self.ws)
+            if training and i == 0 and self._stack_sync(B):
+                # data parallel: one K-STACK step per launch, the (mean, M2) of every rank gathered between two launches
+                entries = [self._chain_entry(j) for j in range(len(lay.hidden))]
+                n, Wd = len(entries), self.comm.world
+                ops.hidden_stack_fwd_sync(entries, B, BN_MOMENTUM, BN_EPS, self.act, 0, None, None, 0, self.stat_local[0],
+                                          self.ws_stack)
+                self.comm.all_gather_into(self.part[0][:Wd * 2 * lay.hidden[0]], self.stat_local[0], name='all_gather_small')
+                for st in range(1, n + 1):
+                    ops.hidden_stack_fwd_sync(entries, B, BN_MOMENTUM, BN_EPS, self.act, st, self.part[st - 1], counts, Wd,
+                                              self.stat_local[st] if st < n else None, self.ws_stack)
+                    if st < n:
+                        self.comm.all_gather_into(self.part[st][:Wd * 2 * lay.hidden[st]], self.stat_local[st],
+                                                  name='all_gather_small')
+                for j, hj in enumerate(lay.hidden):
+                    self.Hcur[j] = self.H[j]
+                    K = hj
+                break
             if training and i == 0 and self._stack_coop(B):
                 # throughput batches: batch norm + activation of this layer and the whole stack behind it in ONE cooperative
                 # launch (K-STACK: workgroups own row blocks, exchange the batch statistics through grid barriers)
@@ -897,6 +915,16 @@ class Engine:
                 and hasattr(self.ops, 'hidden_stack_fwd') and self.ws_stack is not None
                 and 1 <= len(lay.hidden) <= 8 and max(lay.hidden) <= 64 and not self._bn_small(B)
                 and B <= self.ops.hidden_stack_max_rows and self.stack_mode != 'off')
+
+    def _stack_sync(self, B):
+        """Data parallel: the hidden stack as K-STACK's one-step launches with the SyncBN exchange BETWEEN two launches (the
+        statistics of every rank enter the next step as one entry per rank) instead of one launch per operation.  A rank
+        with an empty batch takes the per-operation path, which issues the same collectives in the same order."""
+        lay = self.lay
+        return (self.comm.dp and B > 0 and lay.batchnorm and not self.prelu and not self.has_dropout
+                and hasattr(self.ops, 'hidden_stack_fwd_sync') and self.ws_stack is not None
+                and 1 <= len(lay.hidden) <= 8 and max(lay.hidden) <= 64 and B <= self.ops.hidden_stack_max_rows
+                and self._stack_rows(B) == 32 and self.stack_mode != 'off' and self.comm.world <= 128)
 
     def _stack_rows(self, B):
         """Rows per workgroup of the one-step launches."""
@@ -1154,7 +1182,8 @@ class Engine:
         # ---- backward: hidden stack
         L = len(lay.hidden)
         chain = self._stack_chain(B)
-        coop = chain or self._stack_coop(B)
+        sync = self._stack_sync(B)
+        coop = chain or sync or self._stack_coop(B)
         if coop:
             layers = []
             for i, h in enumerate(lay.hidden):
@@ -1164,7 +1193,20 @@ class Engine:
                     d.update(W=lay.view(w, 'W%d' % i), ldw=h, K=lay.hidden[i - 1], Hprev=self.H[i - 1], ldp=self.ldh[i - 1],
                              gW=lay.view(g, 'W%d' % i), ldg=h)
                 layers.append(d)
-            if chain:
+            if sync:
+                # data parallel: the two batch sums of a layer all-reduced between two launches; d beta stays the local share
+                ops.hidden_stack_bwd_sync(layers, B, float(Bg), self.act, self.dZ[0], self.ldh[0], 0, None, self.bsum[L - 1],
+                                          self.ws_stack)
+                comm.all_reduce_sum(self.bsum[L - 1])
+                for st in range(1, L + 1):
+                    i = L - st
+                    ops.hidden_stack_bwd_sync(layers, B, float(Bg), self.act, self.dZ[0], self.ldh[0], st, self.bsum[i],
+                                              self.bsum[i - 1] if i > 0 else None, self.ws_stack)
+                    if i > 0:
+                        comm.all_reduce_sum(self.bsum[i - 1])
+                ops.hidden_stack_bwd(layers, B, float(Bg), self.act, self.dZ[0], self.ldh[0], self.ws_stack,
+                                     rows_per_wg=32, steps=(L + 1, L + 1))
+            elif chain:
                 ops.hidden_stack_bwd(layers, B, float(Bg), self.act, self.dZ[0], self.ldh[0], None, rows_per_wg=64)
             elif self.stack_mode == 'coop' and B <= 256 * 64:
                 ops.hidden_stack_bwd(layers, B, float(Bg), self.act, self.dZ[0], self.ldh[0], self.ws_stack, rows_per_wg=64)

@@ -156,6 +156,11 @@ _SIGNATURES = {
                                            _c.c_int, _c.c_int, _c.c_int, _vp, _c.c_long, _vp]),
     'dcahip_hidden_stack_bwd': (_c.c_int, [_c.POINTER(StackBwdLayer), _c.c_int, _c.c_int, _c.c_float, _c.c_int,
                                            _f32p, _c.c_long, _c.c_int, _c.c_int, _c.c_int, _vp, _c.c_long, _vp]),
+    'dcahip_hidden_stack_step_blocks': (_c.c_int, [_c.c_int]),
+    'dcahip_hidden_stack_fwd_sync': (_c.c_int, [_c.POINTER(SmallLayer), _c.c_int, _c.c_int, _c.c_float, _c.c_float, _c.c_int,
+                                                _c.c_int, _f32p, _f32p, _c.c_int, _f32p, _vp, _c.c_long, _vp]),
+    'dcahip_hidden_stack_bwd_sync': (_c.c_int, [_c.POINTER(StackBwdLayer), _c.c_int, _c.c_int, _c.c_float, _c.c_int,
+                                                _f32p, _c.c_long, _c.c_int, _f32p, _f32p, _vp, _c.c_long, _vp]),
     'dcahip_counts_compact_ld': (_c.c_long, [_c.c_int]),
     'dcahip_counts_compact': (_c.c_int, [_f32p, _c.c_long, _c.c_int, _c.c_int, _vp, _c.c_long, _i32p, _vp]),
     'dcahip_enc0_sparse_supported': (_c.c_int, [_c.c_int]),

@@ -268,6 +268,40 @@ class HipOps:
                                                  0 if ws is None else ws.numel() * ws.element_size(),
                                                  hip.stream()), 'hidden_stack_bwd')
 
+    # ---- K-STACK between the exchanges of a data-parallel step (SyncBN): one step per call
+    def _small_layers(self, layers):
+        arr = (hip.SmallLayer * len(layers))()
+        for q, d in zip(arr, layers):
+            for k in ('W', 'bias', 'beta', 'moving_mean', 'moving_var', 'Z', 'xhat', 'Hout', 'inv_std'):
+                setattr(q, k, hip.ptr(d.get(k)))
+            for k in ('ldw', 'K', 'H', 'ldz', 'ldx', 'ldh'):
+                setattr(q, k, int(d.get(k, 0)))
+        return arr
+
+    def _bwd_layers(self, layers):
+        arr = (hip.StackBwdLayer * len(layers))()
+        for q, d in zip(arr, layers):
+            for k in ('W', 'Hact', 'xhat', 'inv_std', 'Hprev', 'gW', 'dbeta', 'dH'):
+                setattr(q, k, hip.ptr(d.get(k)))
+            for k in ('ldw', 'K', 'H', 'ldh', 'ldx', 'ldp', 'ldg', 'lddh'):
+                setattr(q, k, int(d.get(k, 0)))
+        return arr
+
+    def hidden_stack_fwd_sync(self, layers, B, momentum, eps, act, step, ext_entries, ext_counts, ext_E, stat_out, ws):
+        """Step `step` of the forward pass with the input layer's statistics from every rank (ext_entries [E, 2, H],
+        ext_counts [E]); stat_out [2, H'] <- this rank's (mean, M2) of the layer made."""
+        arr = self._small_layers(layers)
+        hip.check(self.L.dcahip_hidden_stack_fwd_sync(arr, len(layers), B, momentum, eps, int(act), int(step),
+                                                      hip.ptr(ext_entries), hip.ptr(ext_counts), int(ext_E), hip.ptr(stat_out),
+                                                      hip.ptr(ws), ws.numel() * ws.element_size(), hip.stream()),
+                  'hidden_stack_fwd_sync')
+
+    def hidden_stack_bwd_sync(self, layers, B, n_total, act, dZ0, ldz0, step, ext_sums, sums_out, ws):
+        arr = self._bwd_layers(layers)
+        hip.check(self.L.dcahip_hidden_stack_bwd_sync(arr, len(layers), B, float(n_total), int(act), hip.ptr(dZ0), ldz0,
+                                                      int(step), hip.ptr(ext_sums), hip.ptr(sums_out), hip.ptr(ws),
+                                                      ws.numel() * ws.element_size(), hip.stream()), 'hidden_stack_bwd_sync')
+
     def dense_bn_bwd_small(self, dH, ldd, Hact, ldh, xhat, ldx, inv_std, Hp, ldp, W, ldw, B, K, H, batchnorm, n_total, act,
                            gW, ldg, dbeta, dHp, lddp):
         p = hip.ptr

@@ -343,6 +343,26 @@ int dcahip_hidden_stack_fwd(const dcahip_small_layer* layers, int n, int B, floa
 int dcahip_hidden_stack_bwd(const dcahip_stack_bwd_layer* layers, int n, int B, float n_total, int act,
                             float* dZ0, long ldz0, int rows_per_wg, int first_step, int last_step,
                             void* workspace, long workspace_bytes, void* stream);
+
+/* K-STACK inside a data-parallel step (SyncBN; dca/network.py:127-128 BatchNormalization with the statistics of the GLOBAL
+ * batch): ONE step per call (the steps of dcahip_hidden_stack_fwd / _bwd at 32 rows per workgroup) with the batch-wide
+ * quantity of the step's input layer handed in from outside and the one the step produces merged over this rank's row
+ * blocks for the exchange that follows:
+ *   forward, step s = 0..n: s = 0 only measures layer 0; s >= 1 normalises layer s - 1 with ext_entries [ext_E][2][H]
+ *     (mean, M2 per rank) and ext_counts [ext_E] (rows per rank), applies the activation, multiplies by the next layer's
+ *     kernel; stat_out [2][H'] <- (mean, M2) of this rank's rows of the layer made (all-gather it; NULL after the last).
+ *   backward, step s = 0..n: s = 0 only sums the top layer; s >= 1 handles layer n - s with ext_sums [2][H] (sum dy,
+ *     sum dy xhat over ALL ranks, all-reduced); sums_out [2][K] <- this rank's sums of the layer below (all-reduce them),
+ *     whose first half is also stored as that layer's LOCAL d beta.  The weight-gradient reduction is step n + 1 of
+ *     dcahip_hidden_stack_bwd (rows_per_wg = 32), unchanged.
+ * dcahip_hidden_stack_step_blocks(B): workgroups (= row blocks) of these launches. */
+int dcahip_hidden_stack_step_blocks(int B);
+int dcahip_hidden_stack_fwd_sync(const dcahip_small_layer* layers, int n, int B, float momentum, float eps, int act,
+                                 int step, const float* ext_entries, const float* ext_counts, int ext_E,
+                                 float* stat_out, void* workspace, long workspace_bytes, void* stream);
+int dcahip_hidden_stack_bwd_sync(const dcahip_stack_bwd_layer* layers, int n, int B, float n_total, int act,
+                                 float* dZ0, long ldz0, int step, const float* ext_sums, float* sums_out,
+                                 void* workspace, long workspace_bytes, void* stream);
 int dcahip_bn_relu_train_small(const float* Z, long ldz, int B, int H, const float* beta,
                                float* moving_mean, float* moving_var, float momentum, float eps,
                                int act, float* Hout, long ldh, float* xhat, long ldx,
