@@ -51,6 +51,7 @@ class EngineConfig:
     graph_steps: int = 8                    # consecutive training steps per hipGraph launch (fit loop and bench)
     sparse_dw_min: int = 512                # batch rows from which the first layer's weight gradient reads the byte store
     sparse_fwd_min: int = 1 << 30           # ... and its forward product (never: the gathers of W0 rows lose to the dense GEMM)
+    lut_fwd_min: int = 1024                 # ... and from which its forward product does, on the matrix pipe (32 / 64 units)
     enc0_nt_min: int = 256                  # batch rows from which the first product runs in the NT form on a transposed W0
     predict_chunk: int = 1024               # rows per device -> host chunk of predict()
 

@@ -460,10 +460,16 @@ __global__ __launch_bounds__(256) void enc0_c0_kernel(C0Args a) {
     __syncthreads();
     if (!is_last) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    {                                                    // the partials in a fixed order: phases of blocks, then the phases
+        double v = 0.0;
+        for (unsigned k = ph; k < gridDim.x; k += nph)
+            v += __hip_atomic_load(a.part + (long)k * a.H1 + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        red[tid] = v;
+    }
+    __syncthreads();
     if (tid < a.H1) {
         double v = 0.0;
-        for (unsigned k = 0; k < gridDim.x; ++k)
-            v += __hip_atomic_load(a.part + (long)k * a.H1 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int k = 0; k < nph; ++k) v += red[k * a.H1 + tid];
         a.beff[tid] = (a.bias ? a.bias[tid] : 0.f) - (float)v;
     }
     if (tid == 0) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -575,6 +581,256 @@ __global__ __launch_bounds__(256) void enc0_fwd_kernel(FwArgs a) {
         float* dst = a.Z + (long)c * a.ldz + 4 * lane;
         *reinterpret_cast<float4*>(dst) = make_float4(acc.x + b.x, acc.y + b.y, acc.z + b.z, acc.w + b.w);
     }
+}
+
+// ------------------------------------------------------------------------------------------------- forward on the matrix pipe
+// Z0 = L (W0 / std) + b_eff as a dense product whose A operand is LOOKED UP from the byte store (the mirror image of
+// enc0_dw): a wave owns 32 batch rows (one per lane and K half) and all H1 columns; K = the genes, 128 per super step:
+// the two lanes of a row load its 128 consecutive count bytes (one cache line, requested a super step ahead and touched
+// two ahead: the rows are gathered, every line is a DRAM access of its own and the loop is otherwise latency bound),
+// consumed as two macro steps of 64 genes (4 K steps of 8 bytes per lane each).  Every byte indexes the cell's table of
+// pre-split values (counts 0 .. 31 from LDS, one padded table row per batch row so that equal counts of different
+// rows fall into different banks; larger counts take the formula -- a wave-uniform branch that is rare on count data).
+// The B operand (W0 / std as three bf16 pieces in MFMA order, written once per call by enc0_wsplit) is shared by the
+// workgroup's 8 waves through LDS, one 64-gene tile at a time, double buffered.  The genes are cut into chunks (one
+// partial per chunk, added in order by enc0_fwd_reduce): fixed order everywhere, deterministic.
+constexpr int kFlRows = 256;        // batch rows per workgroup (8 waves x 32)
+constexpr int kFlMS = 64;           // genes per macro step (one tile of split W0 in LDS); two macro steps = one super step
+constexpr int kFlLut = 32;          // table entries per cell held in LDS
+constexpr int kFlLutLd = 33;        // their row stride (entries)
+constexpr int fl_ms_elems(int H1) { return 3 * (H1 / 32) * 4 * 2 * 32 * 8; }   // bf16 elements of one macro step of split W0
+
+// W0 [G, ldw] (/ std) -> WP [macro step][piece][column tile][K step][k half][32 columns][8 genes] bf16; K step ks of
+// macro step ms holds genes 128 (ms / 2) + 64 half + 32 (ms % 2) + 8 ks + j (the bytes a lane holds); zero beyond G.  With a mean: the
+// macro step's share of the bias correction, C0P [macro step][H1] = sum_g (mean[g] / std[g]) W0[g, :] in fp64.
+template <int H1>
+__global__ __launch_bounds__(256) void enc0_wsplit_kernel(const float* W, long ldw, const float* mean, const float* stdv,
+                                                          int G, unsigned short* WP, double* C0P) {
+    constexpr int NTL = H1 / 32;
+    __shared__ double red[8][32];
+    const int ms = blockIdx.x, t = blockIdx.y, u = threadIdx.x;      // one (macro step, column tile) per workgroup
+    const int col = u & 31, hi = (u >> 5) & 1, ks = u >> 6;
+    const int gb = (ms >> 1) * (2 * kFlMS) + 64 * hi + 32 * (ms & 1) + 8 * ks;
+    float w[8], sd[8], mu[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int g = gb + j;
+        w[j] = g < G ? W[(long)g * ldw + 32 * t + col] : 0.f;
+        sd[j] = (stdv && g < G) ? stdv[g] : 1.f;
+        mu[j] = (mean && g < G) ? mean[g] : 0.f;
+    }
+    double c0 = 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (mean) c0 += (double)(stdv ? __fdiv_rn(mu[j], sd[j]) : mu[j]) * (double)w[j];
+        if (stdv) w[j] = __fdiv_rn(w[j], sd[j]);
+    }
+    u32x4 p[3];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        unsigned a, b, c;
+        split_pair(w[2 * jj], w[2 * jj + 1], a, b, c);
+        p[0][jj] = a; p[1][jj] = b; p[2][jj] = c;
+    }
+    u32x4* out = reinterpret_cast<u32x4*>(WP + (long)ms * fl_ms_elems(H1));
+#pragma unroll
+    for (int q = 0; q < 3; ++q) out[((q * NTL + t) * 4 + ks) * 64 + hi * 32 + col] = p[q];
+    if (!mean) return;
+    red[ks * 2 + hi][col] = c0;
+    __syncthreads();
+    if (u < 32) {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v += red[k][u];
+        C0P[(long)ms * H1 + 32 * t + u] = v;
+    }
+}
+
+struct FlArgs {
+    Compact c;
+    const float* fac; int do_log;
+    const uint2* lutp;              // [n, kLut]
+    const int* perm; const long long* cursor; long row_base;
+    int B, G;
+    const unsigned short* WP;       // [n_ms][fl_ms_elems]
+    const double* C0P;              // [n_ms][H1] shares of the bias correction, or NULL
+    float* P; long Bp;              // [chunks][Bp][H1] partial products
+    int n_ms, ms_per;               // macro steps in all / per gene chunk
+};
+
+template <int H1>
+__global__ __launch_bounds__(512) void enc0_fwd_lut_kernel(FlArgs a) {
+    constexpr int NTL = H1 / 32, MSE = fl_ms_elems(H1), UNITS = MSE / 8, UPT = (UNITS + 511) / 512;
+    __shared__ __attribute__((aligned(16))) uint2 lutl[kFlRows * kFlLutLd];
+    __shared__ __attribute__((aligned(16))) unsigned short wl[2][MSE];
+    __shared__ int srows[kFlRows];
+    __shared__ float csum[H1];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rg0 = blockIdx.x * kFlRows;
+    const int ms0 = blockIdx.y * a.ms_per, ms1 = min(a.n_ms, ms0 + a.ms_per);
+    if (tid < kFlRows) {
+        const long long cur = (a.cursor ? *a.cursor : 0) + a.row_base;
+        const int r = min(rg0 + tid, a.B - 1);
+        srows[tid] = a.perm ? a.perm[cur + r] : (int)(cur + r);
+    } else if (tid < kFlRows + H1) {       // this chunk's share of -sum_g (mean / std) W0[g, :]: where its partial starts
+        double v = 0.0;
+        if (a.C0P)
+            for (int ms = ms0; ms < ms1; ++ms) v += a.C0P[(long)ms * H1 + tid - kFlRows];
+        csum[tid - kFlRows] = (float)(-v);
+    }
+    __syncthreads();
+    for (int u = tid; u < kFlRows * (kFlLut / 2); u += 512) {
+        const int row = u / (kFlLut / 2), seg = u % (kFlLut / 2);
+        const u32x4 v = *reinterpret_cast<const u32x4*>(a.lutp + (long)srows[row] * kLut + seg * 2);
+        lutl[row * kFlLutLd + seg * 2] = make_uint2(v[0], v[1]);
+        lutl[row * kFlLutLd + seg * 2 + 1] = make_uint2(v[2], v[3]);
+    }
+    const int myrow = wave * 32 + l31;
+    const long sr = srows[myrow];
+    const float facr = a.fac ? a.fac[sr] : 1.f;
+    const unsigned char* const yrow = a.c.yc + sr * a.c.ldc + 64 * hi;
+    const uint2* const lp = lutl + myrow * kFlLutLd;
+    f32x16 acc[NTL];
+#pragma unroll
+    for (int t = 0; t < NTL; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = csum[32 * t + l31];
+    u32x4 cq[4], cn[4], wr[UPT];
+    // every load of the loop is unconditional (addresses clamped, results selected): the loads of a step then form one
+    // straight queue -- tile first, counts after -- and the wait before the tile's LDS store leaves the counts in flight
+    const int ss_last = a.n_ms / 2 - 1;
+    auto codes_ok = [&](int ss, int i) __attribute__((always_inline)) {
+        return (long)min(ss, ss_last) * (2 * kFlMS) + 16 * i + 64 * hi + 16 <= a.c.ldc;
+    };
+    auto load_codes = [&](int ss, u32x4 (&c)[4]) __attribute__((always_inline)) {        // raw: take_codes masks them
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            c[i] = *reinterpret_cast<const u32x4*>(yrow + (codes_ok(ss, i) ? (long)min(ss, ss_last) * (2 * kFlMS) + 16 * i : -64L * hi));
+    };
+    auto take_codes = [&](int ss, const u32x4 (&c)[4]) __attribute__((always_inline)) {   // the first use of the loaded bytes
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool ok = codes_ok(ss, i);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cq[i][k] = ok ? c[i][k] : 0u;
+        }
+    };
+    auto load_w = [&](int ms) __attribute__((always_inline)) {
+        const u32x4* src = reinterpret_cast<const u32x4*>(a.WP + (long)min(ms, a.n_ms - 1) * MSE);
+#pragma unroll
+        for (int i = 0; i < UPT; ++i)
+            if ((i + 1) * 512 <= UNITS || tid + i * 512 < UNITS) wr[i] = src[tid + i * 512];
+    };
+    auto store_w = [&](int b) __attribute__((always_inline)) {
+        u32x4* dst = reinterpret_cast<u32x4*>(wl[b]);
+#pragma unroll
+        for (int i = 0; i < UPT; ++i)
+            if ((i + 1) * 512 <= UNITS || tid + i * 512 < UNITS) dst[tid + i * 512] = wr[i];
+    };
+    using Half0 = std::integral_constant<int, 0>;
+    using Half1 = std::integral_constant<int, 1>;
+    if (ms0 < ms1) { load_codes(ms0 >> 1, cn); load_w(ms0); store_w(0); take_codes(ms0 >> 1, cn); }
+    // one macro step (half h of its super step; tile h of the LDS pair: ms0 is even)
+    auto step = [&](auto half, int ms) __attribute__((always_inline)) {
+        constexpr int h = decltype(half)::value, b = h;
+        __syncthreads();                    // tile b (and, the first time, the tables) is in LDS; everyone is done with tile b ^ 1
+        load_w(ms + 1);                     // (past the chunk's end: a tile nobody reads)
+        if (h == 0) load_codes((ms >> 1) + 1, cn);
+        const unsigned short* wt = wl[b] + (hi * 32 + l31) * 8;
+        // the macro step's 32 values of this lane: all lookups first (one LDS round trip), then the products
+        const unsigned d[8] = {cq[2 * h][0], cq[2 * h][1], cq[2 * h][2], cq[2 * h][3],
+                               cq[2 * h + 1][0], cq[2 * h + 1][1], cq[2 * h + 1][2], cq[2 * h + 1][3]};
+        unsigned lo[32], hx[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const uint2 e = lp[(d[i >> 2] >> (8 * (i & 3))) & (unsigned)(kFlLut - 1)];
+            lo[i] = e.x; hx[i] = e.y;
+        }
+        const unsigned big = (((d[0] | d[1]) | (d[2] | d[3])) | ((d[4] | d[5]) | (d[6] | d[7]))) & 0xe0e0e0e0u;
+        if (__ballot(big != 0u)) {          // rare: counts beyond the table take the formula itself, one at a time
+            unsigned bad = 0u;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) bad |= (((d[i >> 2] >> (8 * (i & 3) + 5)) & 7u) != 0u ? 1u : 0u) << i;
+#pragma unroll 1
+            while (__ballot(bad != 0u)) {
+                const bool on = bad != 0u;
+                const int i = on ? __builtin_ctz(bad) : 0;
+                bad &= bad - 1u;
+                unsigned dw = d[0];
+#pragma unroll
+                for (int q = 1; q < 8; ++q) dw = (i >> 2) == q ? d[q] : dw;
+                const unsigned code = (dw >> (8 * (i & 3))) & 255u;
+                float val = (float)code;
+                if (__ballot(on && code == 255u)) {     // an escape: the count itself from the row's overflow list
+                    if (on && code == 255u) val = escaped_count(a.c, sr, (ms >> 1) * (2 * kFlMS) + 64 * hi + 32 * h + i);
+                }
+                float x = a.fac ? __fdiv_rn(val, facr) : val;
+                if (a.do_log) x = log1pf(x);
+                const uint2 e = split_entry(x);
+#pragma unroll
+                for (int k = 0; k < 32; ++k)
+                    if (on && i == k) { lo[k] = e.x; hx[k] = e.y; }
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            u32x4 A[3];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                A[0][jj] = __builtin_amdgcn_perm(lo[8 * ks + 2 * jj + 1], lo[8 * ks + 2 * jj], 0x05040100u);
+                A[1][jj] = __builtin_amdgcn_perm(lo[8 * ks + 2 * jj + 1], lo[8 * ks + 2 * jj], 0x07060302u);
+                A[2][jj] = __builtin_amdgcn_perm(hx[8 * ks + 2 * jj + 1], hx[8 * ks + 2 * jj], 0x05040100u);
+            }
+#pragma unroll
+            for (int t = 0; t < NTL; ++t) {
+                u32x4 Bf[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    Bf[q] = *reinterpret_cast<const u32x4*>(wt + (((q * NTL + t) * 4 + ks) * 2) * 32 * 8);
+                MFMA_X3(A, Bf, acc[t])
+            }
+        }
+        store_w(b ^ 1);
+    };
+#pragma unroll 1
+    for (int ms = ms0; ms < ms1; ms += 2) {
+        step(Half0{}, ms);
+        step(Half1{}, ms + 1);
+        take_codes((ms >> 1) + 1, cn);
+    }
+    float* const dst = a.P + ((long)blockIdx.y * a.Bp + rg0 + wave * 32) * H1;
+#pragma unroll
+    for (int t = 0; t < NTL; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dst[(long)rowmap(e, hi) * H1 + 32 * t + l31] = acc[t][e];
+}
+
+// Z[r, :] = b_eff + the chunk partials in order
+__global__ __launch_bounds__(256) void enc0_fwd_reduce_kernel(const float* P, long Bp, int nsk, const float* beff, int B,
+                                                              int H1, float* Z, long ldz) {
+    const int hq = H1 >> 2;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)B * hq) return;
+    const int r = (int)(idx / hq), j = (int)(idx - (long)r * hq) * 4;
+    float4 v = beff ? *reinterpret_cast<const float4*>(beff + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < nsk; ++k) {
+        const float4 t = *reinterpret_cast<const float4*>(P + ((long)k * Bp + r) * H1 + j);
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    *reinterpret_cast<float4*>(Z + (long)r * ldz + j) = v;
+}
+
+inline bool fl_width_ok(int H1) { return H1 == 32 || H1 == 64; }
+inline int fl_row_groups(int B) { return (B + kFlRows - 1) / kFlRows; }
+inline int fl_n_ms(int G) { return 2 * ((G + 2 * kFlMS - 1) / (2 * kFlMS)); }        // whole super steps
+// gene chunks (whole super steps): about one workgroup per CU in all
+inline int fl_ms_per(int B, int G) {
+    int nsk = 256 / fl_row_groups(B);
+    if (nsk > 32) nsk = 32;
+    if (nsk < 1) nsk = 1;
+    const int n_ss = fl_n_ms(G) / 2;
+    return 2 * ((n_ss + nsk - 1) / nsk);
 }
 
 inline bool width_ok(int H1) { return H1 == 16 || H1 == 32 || H1 == 64 || H1 == 128 || H1 == 256; }
@@ -710,5 +966,51 @@ extern "C" int dcahip_enc0_fwd_sparse(const unsigned char* Yc, long ldc, const i
         case 128: hipLaunchKernelGGL(enc0_fwd_kernel<128>, grid, dim3(256), 0, s, f); break;
         default: hipLaunchKernelGGL(enc0_fwd_kernel<256>, grid, dim3(256), 0, s, f); break;
     }
+    return (int)hipGetLastError();
+}
+
+// workspace: WP | C0P | P
+extern "C" long dcahip_enc0_fwd_lut_workspace_bytes(int B, int G, int H1) {
+    if (!fl_width_ok(H1) || B <= 0 || G <= 0) return 0;
+    const int ms_per = fl_ms_per(B, G), n_ms = fl_n_ms(G);
+    const long nsk = (n_ms + ms_per - 1) / ms_per, Bp = (long)fl_row_groups(B) * kFlRows;
+    return r16((long)n_ms * fl_ms_elems(H1) * 2) + r16((long)n_ms * H1 * 8) + r16(nsk * Bp * H1 * 4);
+}
+
+extern "C" int dcahip_enc0_fwd_lut(const unsigned char* Yc, long ldc, const int* ovf_ptr, const int* ovf_col,
+                                   const float* ovf_val, const float* fac, int do_log, const void* lutp, const float* mean,
+                                   const float* stdv, const int* perm, const long long* cursor, long row_base,
+                                   int B, int G, int H1, const float* W, long ldw, const float* bias,
+                                   float* Z, long ldz, void* workspace, long workspace_bytes, void* stream) {
+    if (!fl_width_ok(H1) || B <= 0 || G <= 0 || !Yc || !lutp || (ldc & 15) || ldc < G || !W || ldw < H1 || !Z || (ldz & 3) ||
+        ldz < H1 || (reinterpret_cast<uintptr_t>(Z) & 15) || (reinterpret_cast<uintptr_t>(workspace) & 15) || !workspace)
+        return DCAHIP_EINVAL;
+    if (workspace_bytes < dcahip_enc0_fwd_lut_workspace_bytes(B, G, H1)) return DCAHIP_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    char* wsb = static_cast<char*>(workspace);
+    const int ms_per = fl_ms_per(B, G), n_ms = fl_n_ms(G);
+    const int nsk = (n_ms + ms_per - 1) / ms_per;
+    const long Bp = (long)fl_row_groups(B) * kFlRows;
+    unsigned short* WP = reinterpret_cast<unsigned short*>(wsb);
+    double* C0P = reinterpret_cast<double*>(wsb + r16((long)n_ms * fl_ms_elems(H1) * 2));
+    float* P = reinterpret_cast<float*>(reinterpret_cast<char*>(C0P) + r16((long)n_ms * H1 * 8));
+    FlArgs f;
+    f.c = Compact{Yc, ldc, ovf_ptr, ovf_col, ovf_val};
+    f.fac = fac; f.do_log = do_log; f.lutp = static_cast<const uint2*>(lutp);
+    f.perm = perm; f.cursor = cursor; f.row_base = row_base; f.B = B; f.G = G;
+    f.WP = WP; f.C0P = mean ? C0P : nullptr; f.P = P; f.Bp = Bp; f.n_ms = n_ms; f.ms_per = ms_per;
+    const dim3 grid((unsigned)fl_row_groups(B), (unsigned)nsk);
+    if (H1 == 32) {
+        hipLaunchKernelGGL(enc0_wsplit_kernel<32>, dim3((unsigned)n_ms, 1), dim3(256), 0, s, W, ldw, mean, stdv, G, WP, C0P);
+        hipLaunchKernelGGL(enc0_fwd_lut_kernel<32>, grid, dim3(512), 0, s, f);
+    } else {
+        hipLaunchKernelGGL(enc0_wsplit_kernel<64>, dim3((unsigned)n_ms, 2), dim3(256), 0, s, W, ldw, mean, stdv, G, WP, C0P);
+        hipLaunchKernelGGL(enc0_fwd_lut_kernel<64>, grid, dim3(512), 0, s, f);
+    }
+    int rc = (int)hipGetLastError();
+    if (rc) return rc;
+    const long total = (long)B * (H1 / 4);
+    hipLaunchKernelGGL(enc0_fwd_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, P, Bp, nsk,
+                       bias, B, H1, Z, ldz);
     return (int)hipGetLastError();
 }

@@ -353,7 +353,7 @@ class Engine:
         # compact counts (dca_amd/compact.py): K-HEADS reads its targets from the byte store (cc); with the input
         # normalisation known (cc_in) the first Dense layer works on the non-zero counts only (K-SPARSE)
         self.cc = self.cc_in = None
-        self.ws_enc0 = self.ws_enc0f = None
+        self.ws_enc0 = self.ws_enc0f = self.ws_enc0l = None
         self.ws_stack = None
         # K-STACK at throughput batches: 'steps' = one launch per batch-wide dependency (9 launches instead of 22 for
         # the 64-32-64 stack), 'coop' = one cooperative launch per direction with grid barriers, 'off' = one launch per
@@ -612,9 +612,20 @@ class Engine:
         if self.ws_enc0f is None:
             self.ws_enc0f = torch.zeros(ops.enc0_fwd_sparse_workspace_bytes(lay.hidden[0]) // 4 + 4,
                                         dtype=torch.float32, device=self.dev)
+        if self.Bmax >= self.cfg.lut_fwd_min:
+            # the matrix-pipe forward from the byte store: its partials grow with rows x gene chunks -- the largest over
+            # the batch sizes this engine can be handed
+            need = max(ops.enc0_fwd_lut_workspace_bytes(min(b, self.Bmax), lay.G_in, lay.hidden[0])
+                       for b in range(256, self.Bmax + 256, 256))
+            if need and (self.ws_enc0l is None or self.ws_enc0l.numel() * 4 < need):
+                self.ws_enc0l = torch.zeros(need // 4 + 4, dtype=torch.float32, device=self.dev)
 
     def _sparse_fwd(self, B, training):
         return (self.cc_in is not None and self.ws_enc0f is not None and B >= self.sparse_fwd_min
+                and not (training and self.in_drop > 0.0))
+
+    def _lut_fwd(self, B, training):
+        return (self.cc_in is not None and self.ws_enc0l is not None and B >= self.cfg.lut_fwd_min
                 and not (training and self.in_drop > 0.0))
 
     def _sparse_dw(self, B):
@@ -743,7 +754,15 @@ class Engine:
         for i, h in enumerate(lay.hidden):
             Wi = lay.view(w, 'W%d' % i); bi = lay.view(w, 'b%d' % i)
             if i == 0:
-                if self._sparse_fwd(B, training):
+                if self._lut_fwd(B, training):
+                    # K-SPARSE on the matrix pipe: the input looked up from the byte store (x = (log1p(y / fac) - mean) / std
+                    # never read: 1 byte per count instead of 4, no transposed kernel)
+                    gather = rows_from[0] == 'perm'
+                    with self._t('gemm_enc0_fwd'):
+                        ops.enc0_fwd_lut(self.cc_in, self.perm if gather else None, self.cursor if gather else None,
+                                         0 if gather else rows_from[1], B, K, h, Wi, h, bi, self.Z[0], self.ldh[0],
+                                         self.ws_enc0l)
+                elif self._sparse_fwd(B, training):
                     # K-SPARSE: the product over the non-zero counts of the batch rows (x = (log1p(y / fac) - mean) / std)
                     gather = rows_from[0] == 'perm'
                     with self._t('gemm_enc0_fwd'):
@@ -878,7 +897,8 @@ class Engine:
 
     def _planes_enc0(self, B, training):
         return (self.pl is not None and 'X' in self.pl and self._wide_planes(B) and B <= self.pl['X'].shape[1]
-                and not (training and self.in_drop > 0.0) and not self._sparse_fwd(B, training))
+                and not (training and self.in_drop > 0.0) and not self._sparse_fwd(B, training)
+                and not self._lut_fwd(B, training))
 
     def _enc0_nt(self, B):
         return self.W0T is not None and B >= self.cfg.enc0_nt_min

@@ -173,6 +173,10 @@ _SIGNATURES = {
     'dcahip_enc0_fwd_sparse': (_c.c_int, [_vp, _c.c_long, _i32p, _i32p, _f32p, _f32p, _c.c_int, _f32p, _f32p, _i32p, _i64p,
                                           _c.c_long, _c.c_int, _c.c_int, _c.c_int, _f32p, _c.c_long, _f32p, _f32p, _c.c_long,
                                           _vp, _c.c_long, _vp]),
+    'dcahip_enc0_fwd_lut_workspace_bytes': (_c.c_long, [_c.c_int, _c.c_int, _c.c_int]),
+    'dcahip_enc0_fwd_lut': (_c.c_int, [_vp, _c.c_long, _i32p, _i32p, _f32p, _f32p, _c.c_int, _vp, _f32p, _f32p, _i32p, _i64p,
+                                       _c.c_long, _c.c_int, _c.c_int, _c.c_int, _f32p, _c.c_long, _f32p, _f32p, _c.c_long,
+                                       _vp, _c.c_long, _vp]),
     'dcahip_heads_fused_compact': (_c.c_int, [_f32p, _c.c_long, _f32p, _c.c_long, _f32p, _c.c_long, _f32p,
                                               _f32p, _c.c_long, _vp, _c.c_long, _i32p, _i32p, _f32p, _f32p, _i32p, _i64p,
                                               _c.c_int, _c.c_int, _c.c_int, _c.c_float, _c.c_float, _c.c_int, _f32p,

@@ -125,6 +125,19 @@ class HipOps:
                                                 B, G, H1, p(W), ldw, p(bias), p(Z), ldz, p(ws),
                                                 ws.numel() * ws.element_size(), hip.stream()), 'enc0_fwd_sparse')
 
+    def enc0_fwd_lut_workspace_bytes(self, B, G, H1):
+        """0: this first-layer width is not taken by the matrix-pipe forward."""
+        return int(self.L.dcahip_enc0_fwd_lut_workspace_bytes(B, G, H1))
+
+    def enc0_fwd_lut(self, c, perm, cursor, row_base, B, G, H1, W, ldw, bias, Z, ldz, ws):
+        """Z [B, ldz] = X W + bias on the matrix pipe, X looked up from the byte store; ws zero-initialised once."""
+        p = hip.ptr
+        c.ensure_lut(self)
+        hip.check(self.L.dcahip_enc0_fwd_lut(p(c.Yc), c.ldc, p(c.ovf_ptr), p(c.ovf_col), p(c.ovf_val), p(c.fac),
+                                             int(c.do_log), p(c.lutp), p(c.mean), p(c.std), p(perm), p(cursor), int(row_base),
+                                             B, G, H1, p(W), ldw, p(bias), p(Z), ldz, p(ws),
+                                             ws.numel() * ws.element_size(), hip.stream()), 'enc0_fwd_lut')
+
     # ------------------------------------------------------------------ gemm
     def sgemm_workspace_bytes(self, ta, tb, M, N, K, colsum_row=False, split_k=0):
         return self.L.dcahip_sgemm_workspace_bytes(int(ta), int(tb), M, N, K, int(colsum_row), split_k)

@@ -586,6 +586,20 @@ int dcahip_enc0_fwd_sparse(const unsigned char* Yc, long ldc, const int* ovf_ptr
                            const float* stdv, const int* perm, const long long* cursor, long row_base,
                            int B, int G, int H1, const float* W, long ldw, const float* bias,
                            float* Z, long ldz, void* workspace, long workspace_bytes, void* stream);
+/*
+ * The same product on the matrix pipe for large batches (H1 = 32 or 64; 0 workspace bytes = width not taken): the A
+ * operand is looked up from the byte store through lutp (dcahip_enc0_lut of the same cells: counts 0 .. 31 from the
+ * table, larger ones and escapes by the formula), W / std is split into bf16 pieces once per call, six bf16 products per
+ * fp32 product as dcahip_sgemm, gene chunks added in a fixed order: deterministic.  workspace >=
+ * dcahip_enc0_fwd_lut_workspace_bytes(B, G, H1), 16-byte aligned, any content; n_cells * ldc must stay below 2^32 (lutp).
+ * Replaces Dense(hidden_size[0]) of dca/network.py:124-126 on the input of dca/io.py:88-111.
+ */
+long dcahip_enc0_fwd_lut_workspace_bytes(int B, int G, int H1);
+int dcahip_enc0_fwd_lut(const unsigned char* Yc, long ldc, const int* ovf_ptr, const int* ovf_col,
+                        const float* ovf_val, const float* fac, int do_log, const void* lutp, const float* mean,
+                        const float* stdv, const int* perm, const long long* cursor, long row_base,
+                        int B, int G, int H1, const float* W, long ldw, const float* bias,
+                        float* Z, long ldz, void* workspace, long workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -27,6 +27,7 @@ def counts_with_escapes(n, G, seed, big=True):
     if big:                                    # counts at and beyond the escape code, several per row, first / last column
         rng = np.random.RandomState(seed)
         y[0, 0] = 255; y[0, G - 1] = 254; y[min(1, n - 1), G // 2] = 70000
+        y[2 % n, 1 % G] = 31; y[2 % n, 2 % G] = 32; y[3 % n, 5 % G] = 200; y[n - 1, G - 2] = 63; y[n - 1, G - 1] = 64   # table edges
         for r in rng.randint(0, n, 6):
             y[r, rng.randint(0, G, 3)] = rng.randint(255, 5000, 3)
     return y
@@ -95,6 +96,8 @@ CASES = [
     (300, 1000, 64, True, True, True, True, False),
     (1100, 130, 64, False, True, False, True, False),
     (64, 77, 32, True, False, True, False, False),
+    (4101, 3000, 64, True, True, True, True, True),       # several macro steps per gene chunk of the matrix-pipe forward
+    (600, 2050, 32, False, True, True, True, True),
 ]
 
 
@@ -142,6 +145,18 @@ def test_sparse_first_layer_vs_numpy(ops, B, G, H1, gather, use_fac, do_log, sca
     torch.cuda.synchronize()
     err = np.abs(Zd.cpu().numpy() - Z_ref)
     assert (err <= 1e-6 * Z_abs + 1e-30).all(), float((err / Z_abs).max())
+    # ---- the same product on the matrix pipe (looked-up operand), where the width is taken; twice, bit for bit
+    nb = ops.enc0_fwd_lut_workspace_bytes(B, G, H1)
+    assert (nb > 0) == (H1 in (32, 64))
+    if nb:
+        wsl = torch.full((nb // 4 + 4,), float("nan"), device="cuda")
+        Zl = torch.full((B, H1), 7.0, device='cuda'); Zl2 = torch.full((B, H1), 3.0, device='cuda')
+        ops.enc0_fwd_lut(cc, dperm, dcur, base, B, G, H1, dW_, H1, db_, Zl, H1, wsl)
+        ops.enc0_fwd_lut(cc, dperm, dcur, base, B, G, H1, dW_, H1, db_, Zl2, H1, wsl)
+        torch.cuda.synchronize()
+        err = np.abs(Zl.cpu().numpy() - Z_ref)
+        assert (err <= 1e-6 * Z_abs + 1e-30).all(), float((err / Z_abs).max())
+        assert torch.equal(Zl, Zl2)
     # ---- weight + bias gradient
     if not ops.enc0_sparse_supported(H1):
         return

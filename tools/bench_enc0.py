@@ -56,6 +56,13 @@ for B in (32, 128, 512, 1024, 2048, 4096, 8192):
     def fwd_sp():
         ops.enc0_fwd_sparse(cc, perm, cur, 0, B, G, h, W0, h, W0[G], Z2, h, wsf)
 
+    nbl = ops.enc0_fwd_lut_workspace_bytes(B, G, h)
+    wsl = torch.zeros(max(nbl, 16) // 4 + 4, device=dev)
+    Z3 = torch.zeros(B, h, device=dev)
+
+    def fwd_lut():
+        ops.enc0_fwd_lut(cc, perm, cur, 0, B, G, h, W0, h, W0[G], Z3, h, wsl)
+
     def dw_tn():
         ops.sgemm(1, 0, G, h, B, X, ldx, dZ, h, gW, h, perm=perm, cursor=cur, colsum_row=True, ws=ws)
 
@@ -63,8 +70,11 @@ for B in (32, 128, 512, 1024, 2048, 4096, 8192):
         ops.enc0_dw_sparse(cc, perm, cur, 0, B, G, h, dZ, h, gW2, h, wsd)
 
     t = {'fwd dense NN': timeit(fwd_nn), 'fwd dense NT+transpose': timeit(fwd_nt) if B >= 256 else float('nan'),
-         'fwd sparse': timeit(fwd_sp), 'dW dense TN': timeit(dw_tn), 'dW sparse': timeit(dw_sp)}
+         'fwd sparse': timeit(fwd_sp), 'fwd lut': timeit(fwd_lut) if nbl else float('nan'), 'dW dense TN': timeit(dw_tn), 'dW sparse': timeit(dw_sp)}
     fwd_nn(); fwd_sp(); dw_tn(); dw_sp(); torch.cuda.synchronize()
     ez = (Z - Z2).abs().max().item() / Z.abs().max().item()
+    if nbl:
+        fwd_lut(); torch.cuda.synchronize()
+        ez = max(ez, (Z - Z3).abs().max().item() / Z.abs().max().item())
     eg = (gW - gW2).abs().max().item() / gW.abs().max().item()
     print('B=%5d  ' % B + '  '.join('%s %.4f ms' % kv for kv in t.items()) + '   max diff fwd %.1e dW %.1e' % (ez, eg), flush=True)
