@@ -665,6 +665,7 @@ __global__ __launch_bounds__(512) void enc0_fwd_lut_kernel(FlArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned short wl[2][MSE];
     __shared__ int srows[kFlRows];
     __shared__ float csum[H1];
+    __shared__ double cpart[512 / H1][H1];
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rg0 = blockIdx.x * kFlRows;
@@ -673,18 +674,29 @@ __global__ __launch_bounds__(512) void enc0_fwd_lut_kernel(FlArgs a) {
         const long long cur = (a.cursor ? *a.cursor : 0) + a.row_base;
         const int r = min(rg0 + tid, a.B - 1);
         srows[tid] = a.perm ? a.perm[cur + r] : (int)(cur + r);
-    } else if (tid < kFlRows + H1) {       // this chunk's share of -sum_g (mean / std) W0[g, :]: where its partial starts
+    }
+    {                                       // this chunk's share of -sum_g (mean / std) W0[g, :], macro steps spread over the threads
+        const int col = tid % H1, part = tid / H1;
         double v = 0.0;
         if (a.C0P)
-            for (int ms = ms0; ms < ms1; ++ms) v += a.C0P[(long)ms * H1 + tid - kFlRows];
-        csum[tid - kFlRows] = (float)(-v);
+            for (int ms = ms0 + part; ms < ms1; ms += 512 / H1) v += a.C0P[(long)ms * H1 + col];
+        cpart[part][col] = v;
     }
     __syncthreads();
-    for (int u = tid; u < kFlRows * (kFlLut / 2); u += 512) {
-        const int row = u / (kFlLut / 2), seg = u % (kFlLut / 2);
-        const u32x4 v = *reinterpret_cast<const u32x4*>(a.lutp + (long)srows[row] * kLut + seg * 2);
-        lutl[row * kFlLutLd + seg * 2] = make_uint2(v[0], v[1]);
-        lutl[row * kFlLutLd + seg * 2 + 1] = make_uint2(v[2], v[3]);
+    if (tid < H1) {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < 512 / H1; ++k) v += cpart[k][tid];
+        csum[tid] = (float)(-v);            // (read after the loop's barriers)
+    }
+    // the table rows of the workgroup's cells: requested here, stored behind the first counts / tile requests below (one
+    // round trip to memory for the whole prologue instead of three)
+    constexpr int NU = kFlRows * (kFlLut / 2) / 512;
+    u32x4 lv[NU];
+#pragma unroll
+    for (int k = 0; k < NU; ++k) {
+        const int u = tid + 512 * k;
+        lv[k] = *reinterpret_cast<const u32x4*>(a.lutp + (long)srows[u / (kFlLut / 2)] * kLut + (u % (kFlLut / 2)) * 2);
     }
     const int myrow = wave * 32 + l31;
     const long sr = srows[myrow];
@@ -695,7 +707,7 @@ __global__ __launch_bounds__(512) void enc0_fwd_lut_kernel(FlArgs a) {
 #pragma unroll
     for (int t = 0; t < NTL; ++t)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[t][e] = csum[32 * t + l31];
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
     u32x4 cq[4], cn[4], wr[UPT];
     // every load of the loop is unconditional (addresses clamped, results selected): the loads of a step then form one
     // straight queue -- tile first, counts after -- and the wait before the tile's LDS store leaves the counts in flight
@@ -730,7 +742,14 @@ __global__ __launch_bounds__(512) void enc0_fwd_lut_kernel(FlArgs a) {
     };
     using Half0 = std::integral_constant<int, 0>;
     using Half1 = std::integral_constant<int, 1>;
-    if (ms0 < ms1) { load_codes(ms0 >> 1, cn); load_w(ms0); store_w(0); take_codes(ms0 >> 1, cn); }
+    if (ms0 < ms1) { load_codes(ms0 >> 1, cn); load_w(ms0); }
+#pragma unroll
+    for (int k = 0; k < NU; ++k) {
+        const int u = tid + 512 * k, row = u / (kFlLut / 2), seg = u % (kFlLut / 2);
+        lutl[row * kFlLutLd + seg * 2] = make_uint2(lv[k][0], lv[k][1]);
+        lutl[row * kFlLutLd + seg * 2 + 1] = make_uint2(lv[k][2], lv[k][3]);
+    }
+    if (ms0 < ms1) { store_w(0); take_codes(ms0 >> 1, cn); }
     // one macro step (half h of its super step; tile h of the LDS pair: ms0 is even)
     auto step = [&](auto half, int ms) __attribute__((always_inline)) {
         constexpr int h = decltype(half)::value, b = h;
@@ -799,11 +818,14 @@ __global__ __launch_bounds__(512) void enc0_fwd_lut_kernel(FlArgs a) {
         step(Half1{}, ms + 1);
         take_codes((ms >> 1) + 1, cn);
     }
+    if (ms0 >= ms1) __syncthreads();        // (an empty chunk never passed a barrier after csum was written)
     float* const dst = a.P + ((long)blockIdx.y * a.Bp + rg0 + wave * 32) * H1;
 #pragma unroll
-    for (int t = 0; t < NTL; ++t)
+    for (int t = 0; t < NTL; ++t) {
+        const float c0 = csum[32 * t + l31];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) dst[(long)rowmap(e, hi) * H1 + 32 * t + l31] = acc[t][e];
+        for (int e = 0; e < 16; ++e) dst[(long)rowmap(e, hi) * H1 + 32 * t + l31] = acc[t][e] + c0;
+    }
 }
 
 // Z[r, :] = b_eff + the chunk partials in order

@@ -300,6 +300,7 @@ def test_full_size_step_matches_oracle(ops, c3, B):
     loss, g, newp = run_single_step(eng, rows)
     assert eng.ws_heads is not None                          # K-HEADS ran
     assert eng._sparse_dw(B) == (B >= 512) and eng._stack_coop(B) == (B > 64)
+    assert eng._lut_fwd(B, True) == (B >= eng.cfg.lut_fwd_min)      # the first product from the byte store on the matrix pipe
     assert abs(loss - rl) < 1e-5 * abs(rl), (loss, rl)
     assert_grads_close(g, rg)
     for i in range(len(hs)):
