@@ -621,7 +621,11 @@ __global__ __launch_bounds__(64 * WR) void heads_fused_x3_kernel(HeadsArgs2 p) {
                 // offset, immediates -- 32 separate 64-bit addresses would not fit the register file
                 const __amdgpu_buffer_rsrc_t dh_rs = __builtin_amdgcn_make_buffer_rsrc(
                     dh_part + (long)t * dh_tstride, 0, kTR * KT * 4, 0x00020000);
+#ifdef DCA_EXP_NODHLOAD      // experiment (wrong results): every item starts its dH partial from zero -- prices the load's exposed latency
+                if (true) {
+#else
                 if (first_item) {
+#endif
 #pragma unroll
                     for (int jb = 0; jb < 2; ++jb)
 #pragma unroll

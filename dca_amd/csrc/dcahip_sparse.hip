@@ -146,6 +146,7 @@ __global__ __launch_bounds__(256) void enc0_lut_kernel(const float* fac, int do_
 constexpr int kKS = 16;             // batch rows per K step
 constexpr int kDwWaves = 8;         // waves (32-gene tiles) per workgroup: 256 genes
 constexpr int kDwRB = 64;           // batch rows a workgroup holds in LDS at a time (4 K steps)
+constexpr int kDwMaxRS = 2048;      // batch rows per row split at most (their storage rows sit in LDS)
 constexpr int kCodeLd = 272;        // row stride of the count tile in LDS (256 + 16: rows 8 apart sit 32 banks apart)
 constexpr int dz_step_elems(int H1) { return 3 * (H1 / 32) * 2 * 32 * 8; }   // bf16 elements of one K step of split dZ
 
@@ -197,6 +198,8 @@ struct DwArgs {
     int RS;                         // batch rows per split (multiple of the row block)
 };
 
+constexpr int kDwLut = kLut;        // table entries per cell held in LDS: all of them (with 32, one block in two waits for a wave in the formula path)
+
 template <int H1>
 __global__ __launch_bounds__(64 * kDwWaves) void enc0_dw_kernel(DwArgs a) {
     constexpr int NTL = H1 / 32;
@@ -206,13 +209,17 @@ __global__ __launch_bounds__(64 * kDwWaves) void enc0_dw_kernel(DwArgs a) {
     constexpr int NT = 64 * kDwWaves;
     constexpr int DZ_UNITS = NKS * KSE * 2 / 16;         // 16-byte units of the block's split dZ
     constexpr int DZ_PER = (DZ_UNITS + NT - 1) / NT;
-    constexpr int LUT_PER = RB * (kLut / 2) / NT;        // 16-byte units of the table rows per thread
-    static_assert(RB * 16 == 2 * NT && RB * (kLut / 2) == LUT_PER * NT && NT % (kLut / 2) == 0, "tile units per thread");
-    __shared__ __attribute__((aligned(16))) unsigned short dzp[NKS * KSE];
-    __shared__ __attribute__((aligned(16))) uint2 lutl[RB * kLut];
-    __shared__ __attribute__((aligned(16))) unsigned char codes[RB * kCodeLd];
-    __shared__ float rfac[RB];
-    __shared__ int srows[RB];
+    constexpr int LSEG = kDwLut / 2;                     // 16-byte units of one table row
+    constexpr int LUT_PER = RB * LSEG / NT;              // ... of the block's table rows per thread
+    constexpr int NBUF = H1 <= 64 ? 2 : 1;               // LDS tiles of a block: double buffered where they fit
+    constexpr int GK = H1 <= 64 ? NKS : 1;               // K steps whose lookups are issued together (registers)
+    static_assert(RB * 16 == 2 * NT && RB * LSEG == LUT_PER * NT && NT % LSEG == 0, "tile units per thread");
+    __shared__ __attribute__((aligned(16))) unsigned short dzp[NBUF][NKS * KSE];
+    __shared__ __attribute__((aligned(16))) uint2 lutl[NBUF][RB * kDwLut];
+    __shared__ __attribute__((aligned(16))) unsigned char codes[NBUF][RB * kCodeLd];
+    __shared__ float rfac[NBUF][RB];
+    __shared__ int srows[NBUF][RB];
+    __shared__ int srow_all[kDwMaxRS];                   // storage rows of the split's batch rows
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -233,38 +240,35 @@ __global__ __launch_bounds__(64 * kDwWaves) void enc0_dw_kernel(DwArgs a) {
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 
     // ---- the loader: every thread moves fixed pieces of a block -- two 16-byte units of the count tile (rows tid / 16
-    // and 32 + tid / 16), one of the table rows (row tid / 8), DZ_PER of the split dZ, and (tid < RB) one row's divisor.
-    // The pieces of block i + 1 are requested before block i is computed and written to LDS after it.
+    // and 32 + tid / 16), LUT_PER of the table rows, DZ_PER of the split dZ, and (tid < RB) one row's divisor.
+    // Block i is computed from LDS buffer i % NBUF while the pieces of block i + 1 (requested during block i - 1, in
+    // registers) are written to the other buffer behind the products and block i + 2 is requested: ONE barrier per block
+    // (with a single buffer: a second one between the products and the writes).
     const int crow = tid >> 4, cseg = tid & 15;
-    constexpr int LROWS = NT / (kLut / 2);               // table rows one pass of the workgroup covers
-    const int lrow = tid / (kLut / 2), lseg = tid % (kLut / 2);
+    constexpr int LROWS = NT / LSEG;                     // table rows one pass of the workgroup covers
+    const int lrow = tid / LSEG, lseg = tid % LSEG;
     const bool cseg_ok = gbase + cseg * 16 < a.c.ldc;
+    // the storage rows of the split come from LDS: a storage row fetched from memory and carried in a register to the
+    // next block's requests made the compiler wait for EVERY request in flight before a block's products (the copy of a
+    // loaded register waits for the whole in-order load queue)
+    for (int i = tid; i < re - rb; i += NT) srow_all[i] = a.srowb[rb + i];
+    __syncthreads();
     auto srow_of = [&](int rg0, int row) __attribute__((always_inline)) {               // storage row of the block's row (clamped inside the split)
         const int r = rg0 + row;
-        return a.srowb[r < re ? r : re - 1];
+        return srow_all[(r < re ? r : re - 1) - rb];
     };
-    // Pipeline: the count tiles (the only reads that come from HBM: 256 B per gathered row) are requested TWO blocks ahead
-    // into the register pair the deposit of the current block has just emptied; the table rows and the split dZ (L2) one
-    // block ahead; the storage rows of a block one step before its first request.
-    int sc0, sc1;                                        // storage rows of the count pieces to request next (block + 2)
-    int sr_l[LUT_PER], sr_t;                             // storage rows of the table / divisor pieces of block + 1
-    u32x4 cq[2][2], r_l[LUT_PER], r_dz[DZ_PER];
+    u32x4 cq[2], r_l[LUT_PER], r_dz[DZ_PER];
     float r_fac = 1.f;
     int r_srow = 0;
-    auto rows_counts = [&](int rg0) __attribute__((always_inline)) { sc0 = srow_of(rg0, crow); sc1 = srow_of(rg0, 32 + crow); };
-    auto rows_others = [&](int rg0) __attribute__((always_inline)) {
+    auto request = [&](int rg0) __attribute__((always_inline)) {
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        const int sc0 = srow_of(rg0, crow), sc1 = srow_of(rg0, 32 + crow);
+        int sr_l[LUT_PER];
 #pragma unroll
         for (int i = 0; i < LUT_PER; ++i) sr_l[i] = srow_of(rg0, lrow + i * LROWS);
-        sr_t = srow_of(rg0, tid < RB ? tid : 0);
-    };
-    auto request_counts = [&](auto slot, int rg0) __attribute__((always_inline)) {
-        constexpr int S = decltype(slot)::value;
-        const u32x4 z = {0u, 0u, 0u, 0u};
-        cq[S][0] = (cseg_ok && rg0 + crow < re) ? *reinterpret_cast<const u32x4*>(a.c.yc + (long)sc0 * a.c.ldc + gbase + cseg * 16) : z;
-        cq[S][1] = (cseg_ok && rg0 + 32 + crow < re) ? *reinterpret_cast<const u32x4*>(a.c.yc + (long)sc1 * a.c.ldc + gbase + cseg * 16) : z;
-    };
-    auto request_others = [&](int rg0) __attribute__((always_inline)) {
-        const u32x4 z = {0u, 0u, 0u, 0u};
+        const int sr_t = srow_of(rg0, tid < RB ? tid : 0);
+        cq[0] = (cseg_ok && rg0 + crow < re) ? *reinterpret_cast<const u32x4*>(a.c.yc + (long)sc0 * a.c.ldc + gbase + cseg * 16) : z;
+        cq[1] = (cseg_ok && rg0 + 32 + crow < re) ? *reinterpret_cast<const u32x4*>(a.c.yc + (long)sc1 * a.c.ldc + gbase + cseg * 16) : z;
 #pragma unroll
         for (int i = 0; i < LUT_PER; ++i) r_l[i] = *reinterpret_cast<const u32x4*>(a.lutp + (long)sr_l[i] * kLut + lseg * 2);
         const int ks0 = rg0 / kKS;
@@ -278,90 +282,104 @@ __global__ __launch_bounds__(64 * kDwWaves) void enc0_dw_kernel(DwArgs a) {
         r_fac = a.fac ? a.fac[sr_t] : 1.f;
         r_srow = sr_t;
     };
-    auto deposit = [&](auto slot) __attribute__((always_inline)) {
-        constexpr int S = decltype(slot)::value;
-        *reinterpret_cast<u32x4*>(codes + crow * kCodeLd + cseg * 16) = cq[S][0];
-        *reinterpret_cast<u32x4*>(codes + (32 + crow) * kCodeLd + cseg * 16) = cq[S][1];
+    auto deposit = [&](auto bufc) __attribute__((always_inline)) {
+        constexpr int b = decltype(bufc)::value;
+        *reinterpret_cast<u32x4*>(codes[b] + crow * kCodeLd + cseg * 16) = cq[0];
+        *reinterpret_cast<u32x4*>(codes[b] + (32 + crow) * kCodeLd + cseg * 16) = cq[1];
 #pragma unroll
-        for (int i = 0; i < LUT_PER; ++i) *reinterpret_cast<u32x4*>(lutl + (lrow + i * LROWS) * kLut + lseg * 2) = r_l[i];
+        for (int i = 0; i < LUT_PER; ++i) *reinterpret_cast<u32x4*>(lutl[b] + (lrow + i * LROWS) * kDwLut + lseg * 2) = r_l[i];
 #pragma unroll
         for (int i = 0; i < DZ_PER; ++i) {
             const int u = tid + i * NT;
-            if (u < DZ_UNITS) reinterpret_cast<u32x4*>(dzp)[u] = r_dz[i];
+            if (u < DZ_UNITS) reinterpret_cast<u32x4*>(dzp[b])[u] = r_dz[i];
         }
-        if (tid < RB) { rfac[tid] = r_fac; srows[tid] = r_srow; }
+        if (tid < RB) { rfac[b][tid] = r_fac; srows[b][tid] = r_srow; }
     };
 
-    using Slot0 = std::integral_constant<int, 0>;
-    using Slot1 = std::integral_constant<int, 1>;
+    using Buf0 = std::integral_constant<int, 0>;
+    using Buf1 = std::integral_constant<int, NBUF - 1>;
     if (rb < re) {
-        rows_counts(rb); rows_others(rb);
-        request_counts(Slot0{}, rb); request_others(rb);
-        if (rb + RB < re) { rows_counts(rb + RB); request_counts(Slot1{}, rb + RB); rows_others(rb + RB); }
-        if (rb + 2 * RB < re) rows_counts(rb + 2 * RB);
+        request(rb);
+        deposit(Buf0{});
+        if (rb + RB < re) request(rb + RB);
     }
-    auto block = [&](auto slot, int rg0) __attribute__((always_inline)) {
-        const int nrow = min(RB, re - rg0);
-        __syncthreads();                    // everyone is done with the previous block
-        deposit(slot);
-        __syncthreads();
-        if (rg0 + 2 * RB < re) { request_counts(slot, rg0 + 2 * RB); if (rg0 + 3 * RB < re) rows_counts(rg0 + 3 * RB); }
-        if (rg0 + RB < re) { request_others(rg0 + RB); if (rg0 + 2 * RB < re) rows_others(rg0 + 2 * RB); }
-        if (!wave_on) return;
+    auto block = [&](auto bufc, auto nextc, int rg0) __attribute__((always_inline)) {
+        constexpr int b = decltype(bufc)::value;
+        __syncthreads();                    // block rg0 is in buffer b; everyone is done with the block before it
+        if (wave_on) {
+            // all lookups of GK K steps first (two LDS round trips for the group instead of two per step), then their
+            // products.  Rows beyond the split's end hold zero counts (table entry 0 = 0): their K steps add nothing.
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-            if (ks * kKS >= nrow) break;
-            const int rl0 = ks * kKS + 8 * hi;           // this lane's 8 rows of the step
-            const unsigned char* cp = codes + rl0 * kCodeLd + wave * 32 + l31;
-            unsigned code[8];
+          for (int kg = 0; kg < NKS; kg += GK) {
+            unsigned code[GK * 8], lo[GK * 8], hx[GK * 8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) code[j] = cp[j * kCodeLd];
-            unsigned lo[8], hx[8];
-            const uint2* lp = lutl + rl0 * kLut;
+            for (int ks = 0; ks < GK; ++ks) {
+                const unsigned char* cp = codes[b] + ((kg + ks) * kKS + 8 * hi) * kCodeLd + wave * 32 + l31;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const unsigned idx = code[j] < (unsigned)(kLut - 1) ? code[j] : (unsigned)(kLut - 1);
-                const uint2 e = lp[j * kLut + idx];
-                lo[j] = e.x; hx[j] = e.y;
+                for (int j = 0; j < 8; ++j) code[ks * 8 + j] = cp[j * kCodeLd];
             }
-            const unsigned any = (code[0] | code[1] | code[2]) | (code[3] | code[4] | code[5]) | (code[6] | code[7]);
-            if (__ballot(any >= (unsigned)kLut)) {       // rare: counts beyond the table take the formula itself
+            unsigned any = 0u;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    if (__ballot(code[j] >= (unsigned)kLut)) {
-                        float val = (float)code[j];
-                        if (__ballot(code[j] == 255u)) {            // an escape: the count itself from the row's overflow list
-                            if (code[j] == 255u) val = escaped_count(a.c, srows[rl0 + j], gene);
-                        }
-                        float x = a.fac ? __fdiv_rn(val, rfac[rl0 + j]) : val;
-                        if (a.do_log) x = log1pf(x);
-                        const uint2 e = split_entry(x);
-                        if (code[j] >= (unsigned)kLut) { lo[j] = e.x; hx[j] = e.y; }
+            for (int i = 0; i < GK * 8; ++i) {
+                const unsigned idx = code[i] < (unsigned)(kDwLut - 1) ? code[i] : (unsigned)(kDwLut - 1);
+                const uint2 e = lutl[b][((kg + (i >> 3)) * kKS + 8 * hi + (i & 7)) * kDwLut + idx];
+                lo[i] = e.x; hx[i] = e.y;
+                any |= code[i];
+            }
+            if (__ballot(any >= (unsigned)kDwLut)) {         // rare: counts beyond the table take the formula itself, one at a time
+                unsigned bad = 0u;
+#pragma unroll
+                for (int i = 0; i < GK * 8; ++i) bad |= (code[i] >= (unsigned)kDwLut ? 1u : 0u) << i;
+#pragma unroll 1
+                while (__ballot(bad != 0u)) {
+                    const bool on = bad != 0u;
+                    const int i = on ? __builtin_ctz(bad) : 0;
+                    bad &= bad - 1u;
+                    unsigned ci = code[0];
+#pragma unroll
+                    for (int k = 1; k < GK * 8; ++k) ci = i == k ? code[k] : ci;
+                    const int rl = (kg + (i >> 3)) * kKS + 8 * hi + (i & 7);
+                    float val = (float)ci;
+                    if (__ballot(on && ci == 255u)) {        // an escape: the count itself from the row's overflow list
+                        if (on && ci == 255u) val = escaped_count(a.c, srows[b][rl], gene);
                     }
+                    float x = a.fac ? __fdiv_rn(val, rfac[b][rl]) : val;
+                    if (a.do_log) x = log1pf(x);
+                    const uint2 e = split_entry(x);
+#pragma unroll
+                    for (int k = 0; k < GK * 8; ++k)
+                        if (on && i == k) { lo[k] = e.x; hx[k] = e.y; }
                 }
             }
-            u32x4 A[3];
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                A[0][jj] = __builtin_amdgcn_perm(lo[2 * jj + 1], lo[2 * jj], 0x05040100u);
-                A[1][jj] = __builtin_amdgcn_perm(lo[2 * jj + 1], lo[2 * jj], 0x07060302u);
-                A[2][jj] = __builtin_amdgcn_perm(hx[2 * jj + 1], hx[2 * jj], 0x05040100u);
+            for (int ks = 0; ks < GK; ++ks) {
+                u32x4 A[3];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    A[0][jj] = __builtin_amdgcn_perm(lo[8 * ks + 2 * jj + 1], lo[8 * ks + 2 * jj], 0x05040100u);
+                    A[1][jj] = __builtin_amdgcn_perm(lo[8 * ks + 2 * jj + 1], lo[8 * ks + 2 * jj], 0x07060302u);
+                    A[2][jj] = __builtin_amdgcn_perm(hx[8 * ks + 2 * jj + 1], hx[8 * ks + 2 * jj], 0x05040100u);
+                }
+                const unsigned short* bstep = dzp[b] + (kg + ks) * KSE + (hi * 32 + l31) * 8;
+#pragma unroll
+                for (int t = 0; t < NTL; ++t) {
+                    u32x4 Bf[3];
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+                        Bf[q] = *reinterpret_cast<const u32x4*>(bstep + ((q * NTL + t) * 2) * 32 * 8);
+                    MFMA_X3(A, Bf, acc[t])
+                }
             }
-            const unsigned short* bstep = dzp + ks * KSE + (hi * 32 + l31) * 8;
-#pragma unroll
-            for (int t = 0; t < NTL; ++t) {
-                u32x4 Bf[3];
-#pragma unroll
-                for (int q = 0; q < 3; ++q)
-                    Bf[q] = *reinterpret_cast<const u32x4*>(bstep + ((q * NTL + t) * 2) * 32 * 8);
-                MFMA_X3(A, Bf, acc[t])
-            }
+          }
         }
+        if (NBUF == 1) __syncthreads();     // a single buffer: everyone is done reading it
+        if (rg0 + RB < re) deposit(nextc);  // the next block (in registers since the previous step) behind the products
+        if (rg0 + 2 * RB < re) request(rg0 + 2 * RB);
     };
 #pragma unroll 1
     for (int rg0 = rb; rg0 < re; rg0 += 2 * RB) {
-        block(Slot0{}, rg0);
-        if (rg0 + RB < re) block(Slot1{}, rg0 + RB);
+        block(Buf0{}, Buf1{}, rg0);
+        if (rg0 + RB < re) block(Buf1{}, Buf0{}, rg0 + RB);
     }
     if (blockIdx.x == 0 && tid < H1) {                   // column sums of this split's rows: its K steps in order
         float s = 0.f;
@@ -766,30 +784,33 @@ __global__ __launch_bounds__(512) void enc0_fwd_lut_kernel(FlArgs a) {
             const uint2 e = lp[(d[i >> 2] >> (8 * (i & 3))) & (unsigned)(kFlLut - 1)];
             lo[i] = e.x; hx[i] = e.y;
         }
-        const unsigned big = (((d[0] | d[1]) | (d[2] | d[3])) | ((d[4] | d[5]) | (d[6] | d[7]))) & 0xe0e0e0e0u;
-        if (__ballot(big != 0u)) {          // rare: counts beyond the table take the formula itself, one at a time
-            unsigned bad = 0u;
+        // rare: counts beyond the table take the formula itself, one at a time -- checked per K step (8 values of the lane):
+        // about one macro step in two has such a count somewhere in the workgroup and everyone waits for that wave at
+        // the next barrier, so the repair touches 8 registers, not 32
 #pragma unroll
-            for (int i = 0; i < 32; ++i) bad |= (((d[i >> 2] >> (8 * (i & 3) + 5)) & 7u) != 0u ? 1u : 0u) << i;
+        for (int ks = 0; ks < 4; ++ks) {
+            if (__ballot(((d[2 * ks] | d[2 * ks + 1]) & 0xe0e0e0e0u) != 0u)) {
+                unsigned bad = 0u;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bad |= (((d[2 * ks + (j >> 2)] >> (8 * (j & 3) + 5)) & 7u) != 0u ? 1u : 0u) << j;
 #pragma unroll 1
-            while (__ballot(bad != 0u)) {
-                const bool on = bad != 0u;
-                const int i = on ? __builtin_ctz(bad) : 0;
-                bad &= bad - 1u;
-                unsigned dw = d[0];
+                while (__ballot(bad != 0u)) {
+                    const bool on = bad != 0u;
+                    const int j = on ? __builtin_ctz(bad) : 0;
+                    bad &= bad - 1u;
+                    const unsigned dw = (j >> 2) ? d[2 * ks + 1] : d[2 * ks];
+                    const unsigned code = (dw >> (8 * (j & 3))) & 255u;
+                    float val = (float)code;
+                    if (__ballot(on && code == 255u)) {     // an escape: the count itself from the row's overflow list
+                        if (on && code == 255u) val = escaped_count(a.c, sr, (ms >> 1) * (2 * kFlMS) + 64 * hi + 32 * h + 8 * ks + j);
+                    }
+                    float x = a.fac ? __fdiv_rn(val, facr) : val;
+                    if (a.do_log) x = log1pf(x);
+                    const uint2 e = split_entry(x);
 #pragma unroll
-                for (int q = 1; q < 8; ++q) dw = (i >> 2) == q ? d[q] : dw;
-                const unsigned code = (dw >> (8 * (i & 3))) & 255u;
-                float val = (float)code;
-                if (__ballot(on && code == 255u)) {     // an escape: the count itself from the row's overflow list
-                    if (on && code == 255u) val = escaped_count(a.c, sr, (ms >> 1) * (2 * kFlMS) + 64 * hi + 32 * h + i);
+                    for (int k = 0; k < 8; ++k)
+                        if (on && j == k) { lo[8 * ks + k] = e.x; hx[8 * ks + k] = e.y; }
                 }
-                float x = a.fac ? __fdiv_rn(val, facr) : val;
-                if (a.do_log) x = log1pf(x);
-                const uint2 e = split_entry(x);
-#pragma unroll
-                for (int k = 0; k < 32; ++k)
-                    if (on && i == k) { lo[k] = e.x; hx[k] = e.y; }
             }
         }
 #pragma unroll
@@ -867,6 +888,8 @@ inline int dw_splits(int B, int G, int H1) {
     if (ns > maxs) ns = maxs;
     if (ns > 16) ns = 16;
     if (ns < 1) ns = 1;
+    const int need = (B + kDwMaxRS - 1) / kDwMaxRS;       // a split's storage rows sit in LDS
+    if (ns < need) ns = need;
     return ns;
 }
 inline int dw_rows_per_split(int B, int ns, int H1) {

@@ -3,6 +3,10 @@ import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+if os.environ.get('DCA_AMD_LIB'):
+    from dca_amd import build as _b
+    _b.LIB = os.environ['DCA_AMD_LIB']
+    _b.needs_build = lambda: False
 from dca_amd import synth, prep, compact
 from dca_amd.ops import HipOps
 ops = HipOps()
