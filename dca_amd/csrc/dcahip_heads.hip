@@ -311,6 +311,9 @@ __global__ __launch_bounds__(64 * WR) void heads_fused_x3_kernel(HeadsArgs2 p) {
         const unsigned char* const ycolc = p.yc + gene_c;
         const unsigned ldy_u = YC ? (unsigned)p.ldc : (unsigned)p.ldy;
         auto count_at = [&](int sr) -> YV {
+#ifdef DCA_EXP_YCACHED       // experiment (wrong results): every count from the same 8 storage rows -- always cache hits: prices the count loads' latency
+            sr &= 7;
+#endif
             if constexpr (YC) return (unsigned)ycolc[(unsigned long long)(unsigned)sr * ldy_u];
             else return ycol[(unsigned long long)(unsigned)sr * ldy_u];
         };
