@@ -169,7 +169,7 @@ def capture_step(eng, b, counts, k=1, rows_per_slot=None, b_global=None):
         g = torch.cuda.CUDAGraph()
     st = torch.cuda.Stream(); st.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(st):
-        with torch.cuda.graph(g, stream=st):
+        with torch.cuda.graph(g, stream=st, capture_error_mode='thread_local'):     # (RCCL's watchdog thread: see train.py::_StepRunner._capture)
             for _ in range(k):
                 eng.train_step(b, b if b_global is None else b_global, counts, rows_per_slot or b)
     torch.cuda.current_stream().wait_stream(st)

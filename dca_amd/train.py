@@ -198,8 +198,11 @@ class _StepRunner:
         g = torch.cuda.CUDAGraph()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
+        # thread-local capture mode: RCCL's watchdog thread polls the events of earlier (eager) collectives with
+        # hipEventQuery; under the default global mode that call from ANOTHER thread is illegal while this one captures --
+        # it invalidates the capture and kills the watchdog (seen once in ~10 runs of the one-rank RCCL test)
         with torch.cuda.stream(s):
-            with torch.cuda.graph(g, stream=s):
+            with torch.cuda.graph(g, stream=s, capture_error_mode='thread_local'):
                 for _ in range(k):
                     self.eng.train_step(*args)
         torch.cuda.current_stream().wait_stream(s)
