@@ -50,8 +50,8 @@ class EngineConfig:
     # ---- measured constants (no environment variable; DESIGN.md holds the measurements)
     graph_steps: int = 8                    # consecutive training steps per hipGraph launch (fit loop and bench)
     sparse_dw_min: int = 512                # batch rows from which the first layer's weight gradient reads the byte store
-    sparse_fwd_min: int = 1 << 30           # ... and its forward product (never: the gathers of W0 rows lose to the dense GEMM)
-    lut_fwd_min: int = 1024                 # ... and from which its forward product does, on the matrix pipe (32 / 64 units)
+    lut_fwd_min: int = 1024                 # ... and its forward product (looked-up operand on the matrix pipe; 32 / 64 units)
+    sparse_fwd_min: int = 1 << 30           # the forward over the non-zero counts only (never: its gathers of W0 rows lose to the dense GEMM)
     enc0_nt_min: int = 256                  # batch rows from which the first product runs in the NT form on a transposed W0
     predict_chunk: int = 1024               # rows per device -> host chunk of predict()
 
