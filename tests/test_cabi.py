@@ -64,3 +64,65 @@ def test_heads_kernel_stays_inside_its_scratch_budget():
             seen += 1
             assert s <= (128 if 'ELi8E' in n else 32), (n, s)
     assert seen == 16         # {zinb, nb} x {conditional, constant dispersion} x {8 waves, 1 wave} x {fp32 counts, byte store}
+
+
+def _lib():
+    from dca_amd import build
+    L = ctypes.CDLL(build.build_hip(verbose=False))
+    for n in ('dcahip_enc0_fwd_lut_workspace_bytes', 'dcahip_enc0_dw_sparse_workspace_bytes'):
+        getattr(L, n).restype = ctypes.c_long
+        getattr(L, n).argtypes = [ctypes.c_int] * 3
+    return L
+
+
+def test_first_layer_plans_are_pure_functions_of_the_shape():
+    """Host side of K-SPARSE (no launch): the matrix-pipe forward takes 32 / 64 units only and says so with 0 bytes; its
+    workspace holds the split weights, the per-tile bias shares and one partial per gene chunk of whole 128-gene super steps;
+    the weight gradient cuts the batch into splits of at most 2 048 rows (their storage rows sit in LDS)."""
+    L = _lib()
+    r16 = lambda x: (x + 15) // 16 * 16
+    for H1 in (16, 128, 256, 0):
+        assert L.dcahip_enc0_fwd_lut_workspace_bytes(4096, 20000, H1) == 0
+    assert L.dcahip_enc0_fwd_lut_workspace_bytes(0, 20000, 64) == 0 and L.dcahip_enc0_fwd_lut_workspace_bytes(64, 0, 64) == 0
+    for B, G, H1 in ((4096, 20000, 64), (281, 20000, 64), (1024, 25000, 32), (70000, 130, 64), (300, 64, 32)):
+        n_ms = 2 * ((G + 127) // 128)
+        rgs = (B + 255) // 256
+        nsk = max(1, min(32, 256 // rgs))
+        ms_per = 2 * ((n_ms // 2 + nsk - 1) // nsk)
+        chunks = (n_ms + ms_per - 1) // ms_per
+        tile = 3 * (H1 // 32) * 4 * 2 * 32 * 8 * 2
+        want = r16(n_ms * tile) + r16(n_ms * H1 * 8) + r16(chunks * rgs * 256 * H1 * 4)
+        assert L.dcahip_enc0_fwd_lut_workspace_bytes(B, G, H1) == want, (B, G, H1)
+    # weight gradient: [splits][Gs][H1] partials + column sums ...: the number of splits follows from the size
+    def splits(B, G, H1):
+        groups = (G + 255) // 256
+        ns = max(1, min(16, 256 // groups, (B + 63) // 64))
+        return max(ns, (B + 2047) // 2048)
+    for B, G, H1 in ((4096, 20000, 64), (65536, 20000, 64), (40000, 2000, 32), (512, 25000, 128)):
+        ns, Gs, steps = splits(B, G, H1), (G + 255) // 256 * 256, (B + 15) // 16
+        dz = 3 * (H1 // 32) * 2 * 32 * 8
+        want = r16((ns * Gs * H1 + ns * H1) * 4) + r16(steps * H1 * 4) + r16(steps * dz * 2) + r16(B * 4)
+        assert L.dcahip_enc0_dw_sparse_workspace_bytes(B, G, H1) == want, (B, G, H1)
+        assert (B + ns - 1) // ns <= 2048
+    assert L.dcahip_enc0_dw_sparse_workspace_bytes(4096, 20000, 16) == 0
+
+
+def test_first_layer_kernels_stay_inside_their_budget():
+    """The byte-store kernels of the first layer run one 8-wave workgroup per CU: no scratch, LDS <= 160 KiB."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    src = os.path.join(ROOT, 'dca_amd', 'csrc', 'dcahip_sparse.hip')
+    out = subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-I' + os.path.join(ROOT, 'include'),
+                          '--cuda-device-only', '-c', src, '-o', os.devnull, '-Rpass-analysis=kernel-resource-usage'],
+                         capture_output=True, text=True, check=True).stderr
+    names = re.findall(r'Function Name: (\S+)', out)
+    scratch = [int(x) for x in re.findall(r'ScratchSize \[bytes/lane\]: (\d+)', out)]
+    lds = [int(x) for x in re.findall(r'LDS Size \[bytes/block\]: (\d+)', out)]
+    assert len(names) == len(scratch) == len(lds)
+    seen = 0
+    for n, s, l in zip(names, scratch, lds):
+        if 'enc0_dw_kernel' in n or 'enc0_fwd_lut_kernel' in n:
+            seen += 1
+            assert s == 0 and l <= 163840, (n, s, l)
+    assert seen == 5          # weight gradient at 32 / 64 / 128 units, forward at 32 / 64
