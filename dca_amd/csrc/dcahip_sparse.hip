@@ -15,15 +15,23 @@
 //
 // Kernels
 //   counts_compact      fp32 counts -> bytes (+ the number of values that are not counts / that need the escape)
-//   enc0_dw             weight gradient: a WAVE owns 16 genes x a range of batch rows.  Per 256 rows: the counts of the
-//                       strip are read once (16 B per lane and row), per gene the non-zero rows are compacted into an LDS
-//                       queue (ballot + mbcnt), converted 64 at a time (escape, / fac, log1p) and accumulated by groups of
-//                       H1/4 lanes -- one queue entry per group and iteration, four columns per lane, dZ0 rows from L2.
-//                       Fixed order everywhere: deterministic.  One partial per row split; enc0_dw_finish adds them and
-//                       applies mean / std and writes the bias gradient row.
+//   enc0_lut            per cell: f(k / fac) for the counts k = 0 .. 63 as three bf16 pieces -- both products below LOOK
+//                       their operand up instead of dividing, taking logarithms and splitting
+//   enc0_split_dz, enc0_dw, enc0_dw_finish
+//                       weight gradient on the matrix pipe: a wave owns 32 genes x all H1 columns, K = the batch rows; the
+//                       counts of a 64-row block go through an LDS tile (a lane needs 8 rows of ONE gene), the rows'
+//                       tables and the pre-split dZ are staged with them, double buffered.  One partial per row split;
+//                       the finish adds them, applies mean / std and writes the bias-gradient row.  Deterministic.
+//   enc0_wsplit, enc0_fwd_lut, enc0_fwd_reduce
+//                       forward on the matrix pipe (batches from 1 024 rows, 32 / 64 units): a wave owns 32 batch rows, one
+//                       per lane -- each lane reads ITS row's bytes straight from memory, looks them up in its row's table
+//                       (LDS, resident for the whole kernel); W0 / std pre-split into MFMA-ordered tiles shared by the
+//                       workgroup; K = the genes in 16 chunks whose partials are added in order.  Deterministic.
 //   enc0_c0             b_eff = b0 - sum_g (mean / std) W0[g, :] (fp64 partials, finished by the last-arriving workgroup)
-//   enc0_fwd            forward: a wave owns one batch row; 1 KB of counts per load, byte positions compacted into the
-//                       queue, entries converted 64 at a time (x = L / std[g]) and accumulated against gathered W0 rows.
+//   enc0_fwd            forward over the non-zero counts only (vector pipe): a wave owns one batch row; 1 KB of counts per
+//                       load, byte positions compacted into a queue, entries converted 64 at a time (x = L / std[g]) and
+//                       accumulated against gathered W0 rows.  Slower than the dense GEMM at every batch size; kept for
+//                       the widths the matrix-pipe forward does not take, off by default.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -97,9 +105,10 @@ __global__ __launch_bounds__(256) void counts_compact_kernel(const float* Y, lon
 //     sum_c x[c, g] dZ[c, :] = (sum_c L[c, g] dZ[c, :] - mean[g] colsum(dZ)) / std[g],   L = f(y / fac[c])
 // A wave owns a 32-gene tile and all H1 columns; K = the batch rows, 16 per step.  The A operand (32 genes x 16 rows
 // of L as three bf16 pieces) is LOOKED UP, not computed: 8 byte loads of counts per lane and step, each the index
-// into the cell's table of pre-split values lutp[cell][count] (counts 0 .. 15; larger ones take the formula -- a
-// wave-uniform branch that is rare on count data; an escape byte looks its count up in the row's overflow list there).  The B operand (dZ as three bf16 pieces, laid out
-// for the MFMA by enc0_split_dz once per call) is shared by the workgroup's 8 waves through LDS, 128 rows at a time.
+// into the cell's table of pre-split values lutp[cell][count] (counts 0 .. 63; larger ones take the formula -- a
+// wave-uniform branch that is rare on count data; an escape byte looks its count up in the row's overflow list there).
+// The B operand (dZ as three bf16 pieces, laid out for the MFMA by enc0_split_dz once per call) is shared by the
+// workgroup's 8 waves through LDS, 64 rows at a time.
 // Six bf16 products per fp32 product, fp32 accumulation (the arithmetic of K-HEADS / K-GEMM); fixed order.
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using bf16x2v = __attribute__((ext_vector_type(2))) __bf16;
