@@ -313,6 +313,15 @@ def test_full_size_step_matches_oracle(ops, c3, B):
     want = ref.predict(c3['X'][:256, :G].cpu().numpy().astype(np.float64), c3['sf'][:256].cpu().numpy().astype(np.float64))
     for k in ('mean', 'dispersion', 'dropout', 'latent'):
         np.testing.assert_allclose(out[k].cpu().numpy(), want[k], rtol=2e-3, atol=2e-4, err_msg=k)
+    if B == 4096:
+        # a 1 024-cell chunk of consecutive storage rows (predict()'s chunk size): the first product now comes from the byte
+        # store on the matrix pipe, rows by range instead of through the permutation
+        assert eng._lut_fwd(1024, False)
+        got = {k: v.cpu().numpy().copy() for k, v in eng.predict_chunk(3000, 1024, {'mean', 'latent'}).items()}
+        torch.cuda.synchronize()
+        want = ref.predict(c3['X'][3000:4024, :G].cpu().numpy().astype(np.float64), c3['sf'][3000:4024].cpu().numpy().astype(np.float64))
+        for k in ('mean', 'latent'):
+            np.testing.assert_allclose(got[k], want[k], rtol=2e-3, atol=2e-4, err_msg=k)
 
 
 def test_full_size_step_fused_equals_separate(ops, c3):
