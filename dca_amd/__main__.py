@@ -1,7 +1,7 @@
 """Command line of the reference (``dca input outputdir [flags]``, dca/__main__.py:18-154) on the
 MI355X path: same positionals, flag names, defaults and output files.  The option table below
 restates the reference's flag set; ``--hyper*`` runs dca_amd/hyper.py (the search space and outputs of
-dca/hyper.py with random proposals instead of hyperopt's TPE); ``--tensorboard`` is accepted for
+dca/hyper.py with hyperopt's TPE restated in dca_amd/tpe.py); ``--tensorboard`` is accepted for
 command-line compatibility and ignored.
 """
 import argparse

@@ -49,7 +49,8 @@ def test_cli_end_to_end(tmp_path):
 
 
 def test_cli_hyper_search(tmp_path):
-    """dca --hyper (dca/hyper.py): the reference's space, random proposals, best.json + trials.pickle."""
+    """dca --hyper (dca/hyper.py): the reference's space, TPE proposals (random while fewer than 20 trials have finished:
+    tests/test_tpe_cpu.py holds the algorithm), best.json + trials.pickle."""
     import json
     import pickle
     from dca_amd import hyper as H
