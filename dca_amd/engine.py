@@ -17,7 +17,6 @@ Layout of the three head matrices: one [h_L, nheads*Gp] weight block ([mean | di
 Gp = G rounded up to 4) so the heads are ONE GEMM forward and TWO backward.
 """
 import math
-import os
 
 import numpy as np
 import torch

@@ -9,7 +9,6 @@ are bit-identical to the reference's.
 Works on real ``anndata.AnnData`` objects when anndata is installed and on the bundled
 MiniAnnData otherwise.
 """
-import os
 import pickle
 
 import numpy as np

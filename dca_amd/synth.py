@@ -11,7 +11,6 @@ Used by bench.py / smoke() / the full-size property tests: the datasets named in
 BASELINE.json are synthetic by definition and too large to be shipped or built on the host
 (1M x 25k fp32 = 100 GB).  torch is the allocator and RNG here -- plumbing, not the timed path.
 """
-import math
 
 import torch
 
