@@ -120,3 +120,43 @@ def test_a_refused_capture_leaves_the_data_parallel_run_eager_and_complete(capsy
     r, caps = make_runner(eng, fail_on=0)
     with pytest.raises(RuntimeError):
         r.run(32, 32, [32], 32, n=12)
+
+
+def test_captures_are_thread_local(monkeypatch):
+    """_StepRunner._capture itself, with torch's graph objects replaced: the capture must run in thread-local error mode
+    (RCCL's watchdog thread polls the events of earlier collectives; under the global mode that call from another thread
+    invalidates a capture in progress), on a side stream that waits for / is waited for by the current one."""
+    import contextlib
+    import torch
+    seen = {}
+
+    class G:
+        pass
+
+    class S:
+        def wait_stream(self, other):
+            seen.setdefault('waits', []).append('side')
+
+    class Cur:
+        def wait_stream(self, other):
+            seen.setdefault('waits', []).append('current')
+
+    @contextlib.contextmanager
+    def fake_graph(g, stream=None, capture_error_mode='global', **kw):
+        seen['mode'], seen['stream'] = capture_error_mode, stream
+        yield
+
+    @contextlib.contextmanager
+    def fake_stream(s):
+        yield
+
+    monkeypatch.setattr(torch.cuda, 'CUDAGraph', G)
+    monkeypatch.setattr(torch.cuda, 'Stream', S)
+    monkeypatch.setattr(torch.cuda, 'current_stream', lambda: Cur())
+    monkeypatch.setattr(torch.cuda, 'graph', fake_graph)
+    monkeypatch.setattr(torch.cuda, 'stream', fake_stream)
+    eng = FakeEngine(dp=True)
+    r = T._StepRunner(eng, True)
+    g = r._capture((32, 64, [32, 32], 32), 3)
+    assert isinstance(g, G) and seen['mode'] == 'thread_local' and isinstance(seen['stream'], S)
+    assert seen['waits'] == ['side', 'current'] and [e[0] for e in eng.log] == ['step'] * 3
