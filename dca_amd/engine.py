@@ -21,6 +21,8 @@ import math
 import numpy as np
 import torch
 
+from . import prep as _prep
+
 BN_MOMENTUM = 0.99   # keras BatchNormalization defaults (network.py:127-128)
 BN_EPS = 1e-3
 RMS_RHO = 0.9        # tf.keras RMSprop defaults (train.py:54-57)
@@ -553,11 +555,11 @@ class Engine:
             e = min(n, s + chunk_rows)
             xs = X[s:e]
             xs = xs.toarray() if hasattr(xs, 'toarray') else np.asarray(xs)
-            self.X[s:e, :lay.G_in] = torch.as_tensor(np.ascontiguousarray(xs, dtype=np.float32)).to(self.dev)
+            self.X[s:e, :lay.G_in] = _prep.host_chunk_tensor(xs).to(self.dev)
             if Y is not None:
                 ys = Y[s:e]
                 ys = ys.toarray() if hasattr(ys, 'toarray') else np.asarray(ys)
-                self.Y[s:e, :lay.G_out] = torch.as_tensor(np.ascontiguousarray(ys, dtype=np.float32)).to(self.dev)
+                self.Y[s:e, :lay.G_out] = _prep.host_chunk_tensor(ys).to(self.dev)
         sfv = np.ones(n, np.float32) if sf is None else np.asarray(sf, dtype=np.float32).reshape(-1)
         self.sf = torch.as_tensor(sfv).to(self.dev)
         self._set_tile_order()

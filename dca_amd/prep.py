@@ -17,6 +17,22 @@ import numpy as np
 import torch
 
 
+def host_chunk_tensor(a):
+    """A host chunk as a CPU tensor for the upload (read only here).  A read-only array (a select-everything subset of the
+    AnnData stand-in shares its parent's matrix that way) is wrapped through a writeable VIEW: torch warns about -- and
+    would misbehave on writes through -- non-writeable arrays, and nothing is written through this tensor."""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if not a.flags.writeable:
+        v = a.view()
+        try:
+            v.flags.writeable = True
+            a = v
+        except ValueError:                  # the owner itself is read only (a memory map opened 'r', say): copy the chunk
+            a = a.copy()
+    return torch.from_numpy(a)
+
+
+
 class DeviceData:
     """Preprocessed tensors resident on the device: X [n, ldx] (network input), Y [n, ldy]
     (raw counts, the loss target), sf [n]."""
@@ -78,7 +94,7 @@ def _upload(X, dev, chunk_rows=2048):
             e = min(n, s + 8192)
             xs = X[s:e]
             xs = xs.toarray() if hasattr(xs, 'toarray') else np.asarray(xs)
-            out[s:e, :G] = torch.as_tensor(np.ascontiguousarray(xs, dtype=np.float32)).to(dev)
+            out[s:e, :G] = host_chunk_tensor(xs).to(dev)
         return out
     from . import hostlib
     chunk_rows = min(chunk_rows, n)
