@@ -22,7 +22,7 @@ class CompactCounts:
     def with_input(self, fac, do_log, mean, std, ops=None):
         """The same store with the description of the network input (None when the store is too large for the sparse first
         layer's 32-bit byte offsets).  The per-cell table of the common counts (512 B per cell) is made on the first use by
-        the weight-gradient kernel (ensure_lut): predict() never needs it."""
+        a training step's first-layer kernels (ensure_lut): a predict-only run never builds it."""
         if ops is not None and self.Yc.shape[0] * self.ldc >= 2 ** 32:
             if not CompactCounts._warned_32bit:
                 import sys

@@ -626,8 +626,10 @@ class Engine:
                 and not (training and self.in_drop > 0.0))
 
     def _lut_fwd(self, B, training):
+        # inference takes this form only once the per-cell tables exist (training made them): a predict-only run keeps the
+        # dense product instead of building 512 B of tables per cell for no gain at its chunk size
         return (self.cc_in is not None and self.ws_enc0l is not None and B >= self.cfg.lut_fwd_min
-                and not (training and self.in_drop > 0.0))
+                and not (training and self.in_drop > 0.0) and (training or self.cc_in.lutp is not None))
 
     def _sparse_dw(self, B):
         return (self.cc_in is not None and self.ws_enc0 is not None and B >= self.sparse_dw_min and self.in_drop == 0.0)
