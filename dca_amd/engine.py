@@ -371,6 +371,11 @@ class Engine:
     def _t(self, name):
         return self.prof.section(name) if self.prof is not None else _NULL
 
+    @property
+    def _dhl(self):
+        """Where the heads' backward writes the gradient of their input (a sink when the input is the data itself)."""
+        return self.dH[-1] if self.lay.hidden else self.dHin0
+
     # ------------------------------------------------------------------ parameters
     def init_params(self, seed=0, init='glorot_uniform'):
         """Dense kernels from the named Keras initialiser (network.py:57 default glorot_uniform; every
@@ -598,7 +603,7 @@ class Engine:
         if n_esc > 1e-3 * n_el:
             return
         self.cc = compact
-        if norm is not None and lay.G_in == lay.G_out and ops.enc0_sparse_supported(lay.hidden[0]) \
+        if norm is not None and lay.hidden and lay.G_in == lay.G_out and ops.enc0_sparse_supported(lay.hidden[0]) \
                 and n_esc <= 1e-5 * n_el:
             self.cc_in = compact.with_input(norm.get('fac'), norm.get('do_log', False), norm.get('mean'), norm.get('std'), ops=ops)
         self._sparse_workspaces()
@@ -671,6 +676,10 @@ class Engine:
             if self.prelu else None
         self.Hcur = list(self.H)
         self.Xb = None                                  # input-dropout batch, allocated on first use
+        # hidden_size=(): the heads are Dense layers on the input itself (the reference's own fixture scripts fit
+        # exactly that network, data/test-biochemists-zinb.py:10-19) -- the gathered minibatch and a sink for its gradient
+        self.Hin0 = torch.zeros(B, _r4(lay.G_in), **f32) if not lay.hidden else None
+        self.dHin0 = torch.zeros(B, _r4(lay.G_in), **f32) if not lay.hidden else None
         self.dH = [torch.zeros(B, l, **f32) for l in self.ldh]
         self.dZ = [torch.zeros(B, l, **f32) for l in self.ldh]
         self.A = torch.zeros(B, lay.ldA, **f32)
@@ -702,10 +711,10 @@ class Engine:
                 need = max(need, ops.sgemm_workspace_bytes(0, 0, b, nc, lay.hL))
                 need = max(need, ops.sgemm_workspace_bytes(1, 0, lay.hL, nc, b, True))
                 need = max(need, ops.sgemm_workspace_bytes(0, 1, b, lay.hL, nc))
-        nb = ops.heads_fused_workspace_bytes(B, lay.hidden[-1], lay.G_out, lay.Gp, self.flags) if self.use_fused else 0
+        nb = ops.heads_fused_workspace_bytes(B, lay.hL, lay.G_out, lay.Gp, self.flags) if self.use_fused else 0
         self.ws_heads = torch.zeros(nb // 4, **f32) if nb > 0 else None
         self.W0T = self.WhT = self.HT = self.XT = self.dZT = None
-        if hasattr(ops, 'transpose') and B >= 256:
+        if hasattr(ops, 'transpose') and B >= 256 and lay.hidden:
             self.W0T = torch.zeros(lay.hidden[0], _r4(lay.G_in), **f32)
             for b in cand:
                 need = max(need, ops.sgemm_workspace_bytes(0, 1, b, lay.hidden[0], lay.G_in))
@@ -742,7 +751,7 @@ class Engine:
                                ops.gemm_p3_workspace_bytes(lay.G_in, lay.hidden[0], b, True))
         self.ws = torch.zeros(max(need // 4, 4), **f32)
         self.ws_stack = None
-        if hasattr(ops, 'hidden_stack_fwd') and max(lay.hidden) <= 64 and len(lay.hidden) <= 8:
+        if hasattr(ops, 'hidden_stack_fwd') and lay.hidden and max(lay.hidden) <= 64 and len(lay.hidden) <= 8:
             nb = ops.hidden_stack_workspace_bytes(len(lay.hidden), min(B, ops.hidden_stack_max_rows))
             self.ws_stack = torch.zeros(nb // 4 + 4, **f32) if nb > 0 else None
         self._sparse_workspaces()
@@ -754,6 +763,15 @@ class Engine:
         lay, ops = self.lay, self.ops
         w = self.w
         K = lay.G_in
+        if not lay.hidden:
+            # no hidden layer: the heads read the minibatch of the input (network.py:98-99 input dropout applies)
+            if rows_from[0] == 'perm':
+                ops.dropout_apply(self.X, self.ldx, self.perm, self.cursor, B, K, self.in_drop if training else 0.0,
+                                  self.drop_seed, self.drop_iter, INPUT_DROPOUT_LAYER, self.row0, self.Hin0, self.ldx)
+                self._hl = (self.Hin0, self.ldx)
+            else:
+                self._hl = (self.X[rows_from[1]:], self.ldx)
+            return K
         for i, h in enumerate(lay.hidden):
             Wi = lay.view(w, 'W%d' % i); bi = lay.view(w, 'b%d' % i)
             if i == 0:
@@ -913,11 +931,12 @@ class Engine:
         that contract over its rows and over its columns, so no transposed copies are kept."""
         lay = self.lay
         return (self.ws_heads is None and B >= 256 and hasattr(self.ops, 'gemm_p3') and not lay.fork and not lay.elempi
-                and not lay.shared and self.cfg.wide_planes)
+                and not lay.shared and self.cfg.wide_planes and bool(lay.hidden))
 
     def _wide_transposed(self, B):
         """The same networks without the planes path: transposed operand copies for K-GEMM's fast forms (see reserve)."""
-        return self.ws_heads is None and B >= 256 and hasattr(self.ops, 'transpose') and not self._wide_planes(B)
+        return (self.ws_heads is None and B >= 256 and hasattr(self.ops, 'transpose') and not self._wide_planes(B)
+                and bool(self.lay.hidden))
 
     def _stack_small(self, B):
         """The whole hidden stack behind the first product in one launch (batch-normalised, every layer small)."""
@@ -1009,17 +1028,17 @@ class Engine:
         Wh, bh = lay.view(self.w, 'Wh'), lay.view(self.w, 'bh')
         with self._t('gemm_heads_fwd'):
             if self.pl is not None and self._wide_planes(B) and B <= self.pl['H'].shape[1]:
-                ops.split_planes(self.Hcur[-1], self.ldh[-1], B, lay.hL, self.pl['H'])
+                ops.split_planes(self._hl[0], self._hl[1], B, lay.hL, self.pl['H'])
                 ops.split_planes(Wh, lay.NH, lay.hL, lay.NH, self.pl['Wh'])
                 ops.gemm_p3(0, 0, B, lay.NH, _r16(lay.hL), self.pl['H'], self.pl['Wh'], self.A, lay.ldA, bias=bh, ws=self.ws)
             elif self.WhT is not None and B >= 256:
                 ops.transpose(Wh, lay.NH, lay.hL, lay.NH, self.WhT, self.WhT.shape[1])
                 for c0, nc, h0 in self._head_blocks():
-                    ops.sgemm(0, 1, B, nc, lay.hL, self.Hcur[-1][:, h0:], self.ldh[-1], self.WhT[c0:], self.WhT.shape[1],
+                    ops.sgemm(0, 1, B, nc, lay.hL, self._hl[0][:, h0:], self._hl[1], self.WhT[c0:], self.WhT.shape[1],
                               self.A[:, c0:], lay.ldA, bias=bh[c0:], ws=self.ws)
             else:
                 for c0, nc, h0 in self._head_blocks():
-                    ops.sgemm(0, 0, B, nc, lay.hL, self.Hcur[-1][:, h0:], self.ldh[-1], Wh[:, c0:], lay.NH,
+                    ops.sgemm(0, 0, B, nc, lay.hL, self._hl[0][:, h0:], self._hl[1], Wh[:, c0:], lay.NH,
                               self.A[:, c0:], lay.ldA, bias=bh[c0:], ws=self.ws)
         if lay.elempi:               # m = -(Dense output) in place; dropout logit = k m + c
             ops.elempi_fwd(self._plane(self.A, 'mean'), lay.ldA, lay.view(self.w, 'pi_k'), lay.view(self.w, 'pi_c'),
@@ -1191,13 +1210,13 @@ class Engine:
         KL = self._hidden_forward(B, ('perm',), True, self.counts_world)
         if self.ws_heads is not None:
             with self._t('heads_fused'):
-                ops.heads_fused(self.Hcur[-1], self.ldh[-1], lay.view(w, 'Wh'), lay.NH,
+                ops.heads_fused(self._hl[0], self._hl[1], lay.view(w, 'Wh'), lay.NH,
                                     lay.view(w, 'bh'), lay.Gp,
                                     lay.view(w, 'theta_w') if lay.const_disp else None, self.Y,
                                     self.ldy, self.sf, self.perm, self.cursor, B, KL, lay.G_out,
                                     self.ridge, inv_n, self.flags, lay.view(g, 'Wh'), lay.NH,
                                     lay.view(g, 'theta_w') if lay.const_disp else None,
-                                    self.dH[-1], self.ldh[-1], self.partials, self.ws_heads,
+                                    self._dhl, self._hl[1], self.partials, self.ws_heads,
                                     tile_order=self.tile_order, loss_out=g[lay.P:], **self._heads_compact())
         else:
             self._heads_backward_unfused(B, KL, inv_n)
@@ -1330,18 +1349,18 @@ class Engine:
             if lay.const_disp:
                 ops.colsum_chain(self.Dth, self.ldD, B, lay.G_out, lay.view(w, 'theta_w'), lay.view(g, 'theta_w'))
             with self._t('gemm_heads_dH'):
-                ops.gemm_p3(0, 1, B, lay.hL, _r16(lay.NH), self.pl['D'], self.pl['Wh'], self.dH[-1], self.ldh[-1], ws=self.ws)
+                ops.gemm_p3(0, 1, B, lay.hL, _r16(lay.NH), self.pl['D'], self.pl['Wh'], self._dhl, self._hl[1], ws=self.ws)
             return
         with self._t('gemm_heads_dW'):
             if self.HT is not None and B >= 256:
                 hin = self.HT.shape[0]
-                ops.transpose(self.Hcur[-1], self.ldh[-1], B, hin, self.HT, self.ldb_t)
+                ops.transpose(self._hl[0], self._hl[1], B, hin, self.HT, self.ldb_t)
                 for c0, nc, h0 in self._head_blocks():
                     ops.sgemm(0, 0, lay.hL, nc, B, self.HT[h0:], self.ldb_t, self.D[:, c0:], self.ldD,
                               gWh[:, c0:], lay.NH, colsum_row=True, ws=self.ws)
             else:
                 for c0, nc, h0 in self._head_blocks():      # colsum_row: the bias gradient lands in row hL = 'bh'
-                    ops.sgemm(1, 0, lay.hL, nc, B, self.Hcur[-1][:, h0:], self.ldh[-1], self.D[:, c0:], self.ldD,
+                    ops.sgemm(1, 0, lay.hL, nc, B, self._hl[0][:, h0:], self._hl[1], self.D[:, c0:], self.ldD,
                               gWh[:, c0:], lay.NH, colsum_row=True, ws=self.ws)
         if lay.const_disp:
             ops.colsum_chain(self.Dth, self.ldD, B, lay.G_out, lay.view(w, 'theta_w'),
@@ -1349,7 +1368,7 @@ class Engine:
         with self._t('gemm_heads_dH'):
             for c0, nc, h0 in self._head_blocks():
                 ops.sgemm(0, 1, B, lay.hL, nc, self.D[:, c0:], self.ldD, Wh[:, c0:], lay.NH,
-                          self.dH[-1][:, h0:], self.ldh[-1], ws=self.ws)
+                          self._dhl[:, h0:], self._hl[1], ws=self.ws)
 
     def _reduce_bwd_sums(self, i, E, h, dbeta_local):
         """SyncBN backward: local chunk sums -> one [2h] vector (its first half = this rank's d beta, stored) -> all-reduce;

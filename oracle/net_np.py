@@ -233,7 +233,7 @@ class OracleAE:
             self.hidden_dropout = self.hidden_dropout[:self.center + 1] + [self.hidden_dropout[-1]]
         self.batchnorm = batchnorm
         self.ridge = ridge
-        self.dtype = params['W0'].dtype
+        self.dtype = params['W0' if 'W0' in params else 'W_mean'].dtype      # (no hidden layer: the heads read the input)
         self.row_threads = 0                                # > 1: likelihood of large batches on a thread pool
         # {layer: boolean [B, h]}: evaluate ReLU layers on a GIVEN linear piece (unit active where True) instead of the sign
         # of this evaluation's own pre-activation.  A test of an fp32 implementation at sizes where some of its millions of
