@@ -908,6 +908,7 @@ class Engine:
                 cur = self.HD[i]
             self.Hcur[i] = cur
             K = h
+        self._hl = (self.Hcur[-1], self.ldh[-1])        # what the heads read
         return K
 
     def _planes_nll(self, B):

@@ -394,3 +394,33 @@ def test_prelu_oracle_finite_differences_and_engine_parity(batchnorm):
     want = oracle_net(ae, p, hs, batchnorm, activation='PReLU').predict(X[:8], sf[:8])
     np.testing.assert_allclose(out['mean'].numpy()[:, :G], want['mean'], rtol=2e-4)
     np.testing.assert_allclose(out['latent'].numpy(), want['latent'], rtol=2e-4, atol=1e-5)
+
+
+def test_reseeded_epoch_harness_on_the_oracle_backed_ops():
+    """tests/helpers.py::run_reseeded_epoch (the GPU suite walks a whole C3 epoch with it, every step restarted from the
+    fp64 oracle's state) on the oracle-backed ops at a small size: an engine whose arithmetic IS the oracle's fp32 twin must
+    pass every per-step statement -- and a step taken from a perturbed state must fail them (the harness has teeth)."""
+    import torch
+    from helpers import run_reseeded_epoch
+    from oracle.torch_ref import TorchAE
+    n, G, hs, B = 150, 60, (16, 8, 16), 32
+    X, Y, sf, p = make_problem(n, G, hs, 'zinb-conddisp', True, seed=4)
+    eng = make_engine(CpuRefOps(), 'zinb-conddisp', G, hs, True, 0.0, p, X, Y, sf)
+    tnet = TorchAE('zinb-conddisp', p, hs, True, dtype=torch.float64)
+    order = np.random.RandomState(1).permutation(n)
+    r = run_reseeded_epoch(eng, tnet, order, B)
+    assert len(r['loss_eng']) == 5                                    # 4 x 32 + 22
+    assert np.abs(r['loss_eng'] / r['loss_or'] - 1).max() < 2e-6
+    assert r['grad_viol'].sum() == 0 and r['grad_err'].max() < 1.0
+    assert r['upd_err'].max() < 1.0 and r['ms_err'].max() < 1.0 and r['bn_err'].max() < 1.0
+    # teeth: the same oracle against an engine that applies a different learning rate / sees other weights
+    tnet2 = TorchAE('zinb-conddisp', p, hs, True, dtype=torch.float64)
+    eng2 = make_engine(CpuRefOps(), 'zinb-conddisp', G, hs, True, 0.0, p, X, Y, sf)
+    real_step = eng2.train_step
+
+    def bad_step(b, **kw):
+        eng2.w[5] += 0.05                                            # one first-layer weight off before the step
+        return real_step(b, **kw)
+    eng2.train_step = bad_step
+    r2 = run_reseeded_epoch(eng2, tnet2, order, B)
+    assert r2['grad_viol'].sum() > 0 or np.abs(r2['loss_eng'] / r2['loss_or'] - 1).max() > 2e-6

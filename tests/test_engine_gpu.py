@@ -608,3 +608,51 @@ def test_single_workgroup_backward_chain_equals_the_per_layer_kernels(ops, hs, B
         assert_grads_close(g1, {k: np.asarray(v, np.float64) for k, v in g0.items()}, rtol=2e-4, atol_scale=2e-6, skip=zero_b)
         for k in p0:
             np.testing.assert_allclose(p1[k], p0[k], rtol=2e-4, atol=2e-6)
+
+
+def test_c3_whole_epoch_every_step_from_the_oracle_state(ops, c3_portable):
+    """The statement about the WHOLE C3 epoch that the chaos cannot blur: all 1 929 steps of batch 32 -- the
+    25-row last batch included -- of zinb-conddisp 64-32-64 on the 68 579 x 20 000 matrix (train.py:91-98: first 61 721 cells,
+    numpy-shuffled), EVERY step started from the fp64 oracle's parameters, RMSprop accumulators and batch-norm moving
+    statistics, the oracle (oracle/torch_ref.py in fp64, on this box's host cores) taking the same step on the engine's own
+    device-resident inputs.  Held, at every step: the batch loss to 2e-6 relative; every gradient element to the single-step
+    tolerance (2e-3 relative + 2e-5 of its tensor's largest; tests/helpers.py::run_reseeded_epoch); clipvalue + RMSprop of
+    the engine's own gradient to 2e-6 of the update; the moving statistics to 1e-5.  The free-running form of the same
+    epoch is test_c3_whole_epoch_matches_oracle above.  DCA_AMD_TEST_RESEED_STEPS=n walks only the first n and the last
+    2 steps (timing trials)."""
+    import os
+    import time
+    from dca_amd.engine import Engine
+    from helpers import run_reseeded_epoch
+    from oracle.torch_ref import TorchAE
+    c = c3_portable
+    n, G, B = c['n'], c['G'], c['B']
+    n_train = int(n * 0.9)
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    p = {k: np.asarray(v, np.float32) for k, v in N.init_params('zinb-conddisp', G, (64, 32, 64), batchnorm=True, seed=0).items()}
+    eng = Engine('zinb-conddisp', G, G, (64, 32, 64), True, 0.0, ops=ops)
+    eng.set_params(p)
+    eng.attach_device_data(c['X'], c['Y'], c['sf'], norm=c['norm'])
+    assert eng.cc is not None                                       # the product path: targets from the byte store
+    tnet = TorchAE('zinb-conddisp', p, (64, 32, 64), True, dtype=torch.float64)
+    order = np.arange(n_train)
+    np.random.RandomState(5).shuffle(order)
+    limit = int(os.environ.get('DCA_AMD_TEST_RESEED_STEPS', '0'))
+    if limit:                                                       # the head of the epoch + its partial last batch
+        tail = n_train - (n_train // B) * B
+        order = np.r_[order[:limit * B], order[-(B + tail):]]
+    t0 = time.time()
+    r = run_reseeded_epoch(eng, tnet, order, B, report_every=400)
+    steps = len(r['loss_eng'])
+    rel = np.abs(r['loss_eng'] / r['loss_or'] - 1)
+    print('C3 epoch, every step from the oracle state: %d steps in %.0f s; batch loss |rel| max %.2e (step %d), median %.1e; '
+          'gradient elements outside the single-step tolerance: %d, worst error / tolerance %.2f; optimizer error / tolerance '
+          '%.2f (accumulators %.2f); moving statistics %.2f; epoch loss %.8f vs oracle %.8f'
+          % (steps, time.time() - t0, rel.max(), int(rel.argmax()), np.median(rel), int(r['grad_viol'].sum()),
+             r['grad_err'].max(), r['upd_err'].max(), r['ms_err'].max(), r['bn_err'].max(),
+             r['loss_eng'].mean(), r['loss_or'].mean()))
+    assert limit or steps == 1929
+    assert rel.max() < 2e-6, (int(rel.argmax()), float(rel.max()))
+    assert r['grad_viol'].sum() == 0, (int(r['grad_viol'].sum()), float(r['grad_err'].max()), int(r['grad_err'].argmax()))
+    assert r['upd_err'].max() < 1.0 and r['ms_err'].max() < 1.0, (float(r['upd_err'].max()), float(r['ms_err'].max()))
+    assert r['bn_err'].max() < 1.0, float(r['bn_err'].max())
