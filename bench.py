@@ -46,10 +46,17 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (the headline 5 PF figure
 WORKLOADS = {
     'c3': dict(cells=68579, genes=20000, hidden='64,32,64', ae='zinb-conddisp', batch=4096, shard_of=None,
                name='BASELINE configs[2]: ZINB-conddisp AE on 68k-PBMC-shaped synthetic (68 579 x 20 000)'),
-    'c4': dict(cells=1000000, genes=25000, hidden='64,32,64', ae='zinb', batch=4096, shard_of=8,
+    # c4 / c5 run the THREE-head network (ae 'zinb-conddisp', dca/network.py:366-393: the CLI's default --type, and the one
+    # SURVEY 8 sizes these configurations by: P = 6 479 416 / 51.6 M parameters); c4z / c5z are the two-head sibling with a
+    # per-gene dispersion (ae 'zinb', dca/network.py:496-550) on the same shapes
+    'c4': dict(cells=1000000, genes=25000, hidden='64,32,64', ae='zinb-conddisp', batch=4096, shard_of=8,
                name='BASELINE configs[3]: ZINB AE on 1M cells x 25k genes synthetic, data-parallel 8 x MI355X'),
-    'c5': dict(cells=1300000, genes=25000, hidden='512,256,128,256,512', ae='zinb', batch=2048, shard_of=8,
+    'c5': dict(cells=1300000, genes=25000, hidden='512,256,128,256,512', ae='zinb-conddisp', batch=2048, shard_of=8,
                name='BASELINE configs[4]: wide 512-256-128-256-512 ZINB AE on 1.3M-cell atlas-shaped synthetic, 8 GPUs'),
+    'c4z': dict(cells=1000000, genes=25000, hidden='64,32,64', ae='zinb', batch=4096, shard_of=8,
+                name='configs[3] shape, constant-dispersion ZINB (two heads)'),
+    'c5z': dict(cells=1300000, genes=25000, hidden='512,256,128,256,512', ae='zinb', batch=2048, shard_of=8,
+                name='configs[4] shape, constant-dispersion ZINB (two heads)'),
 }
 
 
@@ -612,6 +619,9 @@ def main():
                        **extra},
             'loss_first': loss_first, 'loss_last': loss_last,
             'roofline': roof, 'kernels': kernels,
+            # the reference-default batch (dca/train.py:37) and the end-to-end epoch once more at the top level (records that
+            # prune `config` keep them)
+            'batch32': extra.get('batch32'), 'epoch': extra.get('epoch'),
         }
         if not args.no_cpu_baseline and not multi:
             nb = min(n_local, max(B, 4 * B))
