@@ -205,7 +205,7 @@ def test_rccl_communicator_with_one_rank_runs_the_data_parallel_step(ae, n, B, h
         np.testing.assert_allclose(p_dp[k], p1[k], rtol=2e-3, atol=2e-3, err_msg=k)
 
 
-def _run_c4_shard_step(port, q):
+def _run_c4_shard_step(port, q, ae='zinb'):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
     os.environ.pop('DCA_AMD_DIST_BACKEND', None)
     try:
@@ -217,7 +217,7 @@ def _run_c4_shard_step(port, q):
         comm = ddist.init_from_env(force=True)
         assert comm.dp and comm.world == 1 and dist.get_backend() == 'nccl'
         ops = HipOps()
-        n, G, hs, B, ae = 125000, 25000, (64, 32, 64), 4096, 'zinb'
+        n, G, hs, B = 125000, 25000, (64, 32, 64), 4096
         dev = torch.device('cuda')
         Y = synth.generate_counts_portable(n, G, seed=20260925, device=dev, row_offset=0)      # rank 0's rows of the 1M x 25k matrix
         counts = prep.cell_counts(ops, Y, n, G)
@@ -258,23 +258,25 @@ def _run_c4_shard_step(port, q):
             dist.destroy_process_group()
 
 
-def test_c4_rank_shard_step_matches_oracle():
+@pytest.mark.parametrize('ae', ['zinb-conddisp', 'zinb'])
+def test_c4_rank_shard_step_matches_oracle(ae):
     """BASELINE configs[3] (ZINB autoencoder on 1 000 000 x 25 000, data parallel over 8 GPUs) as ONE rank sees it: the
     rank's shard of 125 000 cells x 25 000 genes resident in HBM (the portable generator: rows 0 .. 124 999 of the
     matrix), 4 096 cells of it per step, the data-parallel step -- SyncBN exchanges, gradient buckets over a real RCCL
     communicator of one rank (init_from_env(force=True) = DCA_AMD_DIST_FORCE) -- against the fp64 oracle of the reference
-    step (network.py:496-550 constant dispersion, loss.py:122-156) on the same gathered rows: loss to 1e-5, every gradient
-    to the tolerances of the single-GPU step tests."""
+    step on the same gathered rows: loss to 1e-5, every gradient to the tolerances of the single-GPU step tests.  Both
+    readings of "ZINB AE": the three-head network SURVEY 8 sizes the configuration by (network.py:366-393, P = 6 479 416) and
+    the constant-dispersion sibling (network.py:496-550)."""
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    pr = ctx.Process(target=_run_c4_shard_step, args=(_free_port(), q))
+    pr = ctx.Process(target=_run_c4_shard_step, args=(_free_port(), q, ae))
     pr.start()
     got = q.get(timeout=900)
     pr.join(timeout=60)
     assert got[0] == 'ok', got[1]
     assert pr.exitcode == 0
     info = got[1]
-    print('C4 rank shard (125 000 x 25 000, batch 4 096, zinb): loss %.8f, fp64 oracle %.8f; zeros %.3f; exchanges %s'
-          % (info['loss'], info['oracle'], info['zeros'], info['calls']))
+    print('C4 rank shard (125 000 x 25 000, batch 4 096, %s): loss %.8f, fp64 oracle %.8f; zeros %.3f; exchanges %s'
+          % (ae, info['loss'], info['oracle'], info['zeros'], info['calls']))
     assert 0.90 < info['zeros'] < 0.96 and info['fused']
     assert sum(info['calls'].values()) > 0
