@@ -929,8 +929,17 @@ __global__ __launch_bounds__(256) void heads_reduce_both_kernel(ReduceDhArgs qh,
     else reduce_dw_body(qw, blockIdx.x - n_dh, gridDim.x - n_dh);
 }
 
+#include "heads_p4.inc"
+
+// Row tiles from which the pipelined one-wave-per-SIMD kernel (heads_p4.inc) takes the launch: NEVER in the product --
+// measured on the MI355X it loses to the 8-wave kernel at every batch size (C3, 4 096 rows: 1.23 vs 0.81 ms;
+// profiles/r05c_heads_p4_ab.txt, per-phase cycles in profiles/r05c_heads_p4_timing.txt, why in DESIGN.md 4.1).
+// dcahip_heads_set_p4_min_tiles moves the threshold: the parity tests run both kernels on one build.
+int g_p4_min_nt = 1 << 30;
+
 struct HeadsPlan {
     bool small;                          // one row tile: the four-wave kernel, one workgroup per gene tile
+    bool p4;                             // the pipelined four-wave kernel (one wave per SIMD)
     int HLB, WR, S, NT, ntg, ngb, grid;
     int nitems, npart;                   // split-bf16 path: work items (S x gene tiles), dH partials per row tile
     long ldws, dw_stride, dw_bytes, dh_bytes, hs_bytes;
@@ -943,7 +952,8 @@ inline int x3_resident(int WR) { return WR == 1 ? 3 * kCUs : kCUs; }
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // a pure function of the shape: row slots per workgroup, batch splits, workspace layout
-bool make_heads_plan(int B, int hL, int G, long plane, int flags, HeadsPlan* out) {
+bool make_heads_plan(int B, int hL, int G, long plane, int flags, HeadsPlan* out, int p4_min_nt = -1) {
+    if (p4_min_nt < 0) p4_min_nt = g_p4_min_nt;
     if (flags & (DCAHIP_NLL_POISSON | DCAHIP_NLL_MSE)) return false;     // NB / ZINB family only
     if (B <= 0 || G <= 0 || hL <= 0 || hL > 64 || plane < G || (plane & 3) || plane > ((G + 31) & ~31)) return false;
     if (B > (1 << 22)) return false;                 // H is addressed through a 32-bit buffer resource (B x 64 floats)
@@ -960,14 +970,19 @@ bool make_heads_plan(int B, int hL, int G, long plane, int flags, HeadsPlan* out
     // at G = 20 000: B = 128 0.088 / 0.086 ms (kept on the four-wave kernel), 160: 0.100 / 0.104, 192: 0.103 / 0.121,
     // 224: 0.107 / 0.142 (profiles/r02z_heads_kernel_switch.txt)
     p.WR = p.NT >= kWr8MinNT ? kWR2 : 1;
+    p.p4 = has_pi && p.NT >= kWr8MinNT && p.NT >= p4_min_nt;
+    if (p.p4) p.WR = kWR4;
     const int smax = (p.NT + p.WR - 1) / p.WR;
     double best = 1e300;
     p.S = 1;
+    // per work item: the weight prologue and the reduce (0.75 tile times); the pipelined kernel also fills and drains its
+    // three-stage pipeline (two more iterations of about a third of the work each)
+    const double item_cost = p.p4 ? 1.75 : 0.75;
     for (int S = 1; S <= smax && (long)S * p.ngb <= kMaxGrid; ++S) {
         const long items = (long)S * p.ngb;
         const long rounds = (items + kCUs - 1) / kCUs;
         const int tiles = (p.NT + S * p.WR - 1) / (S * p.WR);
-        const double cost = (double)rounds * (tiles + 0.75);
+        const double cost = (double)rounds * (tiles + item_cost);
         if (cost < best - 1e-9) { best = cost; p.S = S; }
     }
     p.nitems = p.S * p.ngb;
@@ -1397,6 +1412,9 @@ __global__ __launch_bounds__(64) void x3_product_kernel(const float* A, const fl
 
 template <bool P, bool C, bool YC>
 void launch_fused_x3(const HeadsPlan& pl, const HeadsArgs2& a, hipStream_t s) {
+    if constexpr (P) {
+        if (pl.p4) { hipLaunchKernelGGL((heads_fused_p4_kernel<C, YC>), dim3(pl.grid), dim3(64 * kWR4), 0, s, a); return; }
+    }
     if (pl.small) hipLaunchKernelGGL((heads_fused_small_kernel<P, C, YC>), dim3(pl.grid), dim3(256), 0, s, a);
     else if (pl.WR == kWR2) hipLaunchKernelGGL((heads_fused_x3_kernel<P, C, kWR2, YC>), dim3(pl.grid), dim3(64 * kWR2), 0, s, a);
     else hipLaunchKernelGGL((heads_fused_x3_kernel<P, C, 1, YC>), dim3(pl.grid), dim3(64), 0, s, a);
@@ -1411,13 +1429,21 @@ extern "C" long dcahip_heads_fused_workspace_bytes(int B, int hL, int G, long pl
     if (!make_heads_plan(B, hL, G, plane, flags, &p)) return 0;
     long need = 0;
     for (int nt = 1; nt <= p.NT; ++nt) {
-        HeadsPlan q;
         const int b = nt * kTR < B ? nt * kTR : B;
-        if (!make_heads_plan(b, hL, G, plane, flags, &q)) continue;
-        const long n = q.dw_bytes + q.dh_bytes + q.hs_bytes;
-        if (n > need) need = n;
+        for (int p4_min : {1, 1 << 30}) {           // whichever kernel the threshold (dcahip_heads_set_p4_min_tiles) picks later
+            HeadsPlan q;
+            if (!make_heads_plan(b, hL, G, plane, flags, &q, p4_min)) continue;
+            const long n = q.dw_bytes + q.dh_bytes + q.hs_bytes;
+            if (n > need) need = n;
+        }
     }
     return need;
+}
+
+extern "C" int dcahip_heads_set_p4_min_tiles(int nt) {
+    const int old = g_p4_min_nt;
+    if (nt > 0) g_p4_min_nt = nt;
+    return old;
 }
 
 extern "C" int dcahip_x3_product_32x32(const float* A, const float* B, float* C, int K, void* stream) {

@@ -251,6 +251,119 @@ __device__ __forceinline__ float zinb_zero_elem(float am, float ad, float ap, fl
     return nll;
 }
 
+// ---- zinb_zero_elem cut into nine stages of about ten vector instructions each: the pipelined K-HEADS kernel
+// (heads_p4.inc) issues one stage (for four elements) beside every chain of six matrix instructions.  Same operations in
+// the same order as zinb_acts + zinb_zero_elem above (the comments there apply); the state between two stages is ZS.
+struct ZS {
+    float am, ad, ap, sf;                  // inputs: pre-activations, size factor
+    float e, mu, gm;                       // mean head
+    float ex, u, s, theta, gd;             // dispersion head
+    float ex2, s2, pi, omp;                // dropout head
+    float mue, rden, t, logq, tl, z, D, nll, invD, oz, dmu, dth, dpi;
+    float g_m, g_d, g_p;                   // outputs: d nll / d (a_mean, a_disp, a_pi), unscaled; nll
+};
+
+template <bool CONST_DISP, int K>
+__device__ __forceinline__ void zinb_zero_stage(ZS& q, float ridge) {
+    if constexpr (K == 0) {
+        q.e = fexp_raw(q.am);                                                     // network.py:38
+        const float ec = __builtin_amdgcn_fmed3f(q.e, 1e-5f, 1e6f);
+        q.mu = ec * q.sf;                                                         // layers.py:85
+        q.gm = ec == q.e ? q.mu : 0.f;
+        if (CONST_DISP) {                                                         // layers.py:21
+            q.theta = __builtin_amdgcn_fmed3f(fexp_raw(q.ad), 1e-3f, 1e4f);
+            q.gd = 1.f;
+        } else {
+            q.ex = fexp_raw(-fabsf(q.ad));                                        // network.py:39
+        }
+    } else if constexpr (K == 1) {
+        if (!CONST_DISP) {
+            q.u = 1.f + q.ex;
+            q.s = frcp(q.u);
+            q.theta = fmaf(q.ex - (q.u - 1.f), q.s, flog_fast(q.u));             // log1p(ex), finished in stage 2
+        }
+        q.ex2 = fexp_raw(-fabsf(q.ap));
+    } else if constexpr (K == 2) {
+        if (!CONST_DISP) {
+            const float sp = fmaxf(q.ad, 0.f) + q.theta;
+            q.theta = __builtin_amdgcn_fmed3f(sp, 1e-4f, 1e4f);                   // <= 1e4 < kThetaMax
+            q.gd = q.theta == sp ? (q.ad >= 0.f ? q.s : q.ex * q.s) : 0.f;
+        }
+        q.s2 = frcp(1.f + q.ex2);
+    } else if constexpr (K == 3) {
+        const float es2 = q.ex2 * q.s2;
+        q.pi = q.ap >= 0.f ? q.s2 : es2;
+        q.omp = q.ap >= 0.f ? es2 : q.s2;
+        q.mue = q.mu + kEps;                                                      // zero_case, loss.py:136-137
+        q.rden = frcp(q.theta + q.mue);
+        q.t = q.mue * frcp(q.theta);
+    } else if constexpr (K == 4) {
+        const float u2 = 1.f + q.t;
+        q.logq = -fmaf(q.t - (u2 - 1.f), q.theta * q.rden, flog_fast(u2));
+        q.tl = q.theta * q.logq;
+        q.z = fexp_raw(q.tl);
+    } else if constexpr (K == 5) {
+        q.D = fmaf(q.omp, q.z, q.pi) + kEps;
+        q.nll = -flog_fast(q.D);
+        q.invD = frcp(q.D);
+        q.oz = q.omp * q.z * q.invD;
+        q.dmu = q.oz * q.theta * q.rden;
+    } else if constexpr (K == 6) {
+        const float t = q.t;
+        const float fs = -t * t * (0.5f - t * (2.f / 3.f - t * (0.75f - t * (0.8f - t * (5.f / 6.f)))));
+        const float fl = fmaf(q.mue, q.rden, q.logq);
+        q.dth = -q.oz * (t < 0.03125f ? fs : fl);
+    } else if constexpr (K == 7) {
+        const float tl = q.tl;
+        const float ser = tl * fmaf(tl, fmaf(tl, 1.f / 6.f, 0.5f), 1.f);
+        float dpi = (tl > -0.015625f ? ser : q.z - 1.f) * q.invD;                 // -(1 - z) / D
+        q.dpi = fmaf(2.f * ridge, q.pi, dpi);                                     // loss.py:139-140
+        q.nll = fmaf(ridge * q.pi, q.pi, q.nll);
+    } else {
+        q.g_m = q.dmu * q.gm;
+        q.g_d = q.dth * q.gd;
+        q.g_p = q.dpi * q.pi * q.omp;
+    }
+}
+
+// The values a stage hands to the later ones, redefined by an empty asm: the instruction selector orders pure arithmetic by
+// register pressure and would sink every stage to the point where the element's results are stored; a pinned value has to
+// exist WHERE the pin stands in program order, so stage K stays between the pins of stage K - 1 and its own.  No code.
+#define ZPIN1(a) asm volatile("" : "+v"(a))
+#define ZPIN4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+template <bool CONST_DISP, int K>
+__device__ __forceinline__ void zinb_zero_pin(ZS& q) {
+    if constexpr (K == 0) {
+        if (CONST_DISP) { ZPIN4(q.mu, q.gm, q.ap, q.theta); ZPIN1(q.gd); }
+        else { ZPIN4(q.mu, q.gm, q.ap, q.ex); ZPIN1(q.ad); }
+    } else if constexpr (K == 1) {
+        ZPIN4(q.mu, q.gm, q.ap, q.ex2);
+        if (CONST_DISP) { ZPIN1(q.theta); ZPIN1(q.gd); } else { ZPIN4(q.ad, q.ex, q.s, q.theta); }
+    } else if constexpr (K == 2) {
+        ZPIN4(q.mu, q.gm, q.theta, q.gd);
+        ZPIN1(q.ap); ZPIN1(q.ex2); ZPIN1(q.s2);
+    } else if constexpr (K == 3) {
+        ZPIN4(q.gm, q.theta, q.gd, q.pi);
+        ZPIN4(q.omp, q.mue, q.rden, q.t);
+    } else if constexpr (K == 4) {
+        ZPIN4(q.gm, q.theta, q.gd, q.pi);
+        ZPIN4(q.omp, q.mue, q.rden, q.t);
+        ZPIN1(q.logq); ZPIN1(q.tl); ZPIN1(q.z);
+    } else if constexpr (K == 5) {
+        ZPIN4(q.gm, q.gd, q.pi, q.omp);
+        ZPIN4(q.mue, q.rden, q.t, q.logq);
+        ZPIN4(q.tl, q.z, q.nll, q.invD);
+        ZPIN1(q.oz); ZPIN1(q.dmu);
+    } else if constexpr (K == 6) {
+        ZPIN4(q.gm, q.gd, q.pi, q.omp);
+        ZPIN4(q.tl, q.z, q.nll, q.invD);
+        ZPIN1(q.dmu); ZPIN1(q.dth);
+    } else if constexpr (K == 7) {
+        ZPIN4(q.gm, q.gd, q.pi, q.omp);
+        ZPIN4(q.dmu, q.dth, q.dpi, q.nll);
+    }
+}
+
 // The y = 0 element of the plain NB likelihood (loss.py:87-88 with y = 0: t1 = 0, t2 = theta log1p(mu / tp)).
 template <bool CONST_DISP>
 __device__ __forceinline__ float nb_zero_elem(float am, float ad, float sf, float& g_m, float& g_d) {

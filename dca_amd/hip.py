@@ -71,6 +71,7 @@ _SIGNATURES = {
                                       _f32p, _f32p, _c.c_long, _f64p, _c.POINTER(_c.c_int), _vp,
                                       _c.c_long, _vp]),
     'dcahip_heads_tile_order_len': (_c.c_int, [_c.c_int]),
+    'dcahip_heads_set_p4_min_tiles': (_c.c_int, [_c.c_int]),
     'dcahip_x3_product_32x32': (_c.c_int, [_f32p, _f32p, _f32p, _c.c_int, _vp]),
     'dcahip_heads_fused_ordered': (_c.c_int, [_f32p, _c.c_long, _f32p, _c.c_long, _f32p, _c.c_long, _f32p,
                                               _f32p, _c.c_long, _f32p, _i32p, _i64p, _c.c_int, _c.c_int,

@@ -66,6 +66,10 @@ class HipOps:
     def x3_product_32x32(self, A, B, C, K):
         hip.check(self.L.dcahip_x3_product_32x32(hip.ptr(A), hip.ptr(B), hip.ptr(C), K, hip.stream()), "x3_product_32x32")
 
+    def heads_set_p4_min_tiles(self, nt):
+        """Row tiles from which K-HEADS takes its pipelined four-wave kernel (returns the previous value)."""
+        return int(self.L.dcahip_heads_set_p4_min_tiles(int(nt)))
+
     def heads_tile_order_len(self, G):
         return int(self.L.dcahip_heads_tile_order_len(G))
 

@@ -163,6 +163,13 @@ int dcahip_x3_product_32x32(const float* A, const float* B, float* C, int K, voi
  * tile's 32 count columns) removes the imbalance: measured 15 % between the two tiles of a workgroup in file order,
  * 8 % of the kernel.  NULL = identity (what dcahip_heads_fused passes). */
 int dcahip_heads_tile_order_len(int G);
+
+/* K-HEADS has two persistent kernels for batches of 160 rows and more: eight waves per workgroup (two per SIMD, the phases of
+ * a row tile one after the other) and four waves (one per SIMD) that overlap the three phases of consecutive row tiles
+ * inside each wave (dca_amd/csrc/heads_p4.inc).  Launches with at least `nt` 32-row tiles take the second form; returns the
+ * previous value; nt <= 0 only reads it.  Results are the same sums in the same orders either way (tests run both).
+ * No reference call site: a launch-shape switch for measurements and tests. */
+int dcahip_heads_set_p4_min_tiles(int nt);
 int dcahip_heads_fused_ordered(const float* H, long ldh, const float* Wh, long ldw, const float* bh,
                                long plane, const float* theta_w,
                                const float* y, long ldy, const float* sf,

@@ -10,7 +10,12 @@
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
+#ifdef ACC_AGPR
+#define MFMA(acc, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b))
+#else
 #define MFMA(acc, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
+#endif
+#define PKFMA(x, c, d) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(x) : "v"(c), "v"(d))
 #define FMA(x, c, d) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x) : "v"(c), "v"(d))
 #define EXP(x) asm volatile("v_exp_f32 %0, %0" : "+v"(x))
 #define MED3(x, c, d) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(x) : "v"(c), "v"(d))
@@ -18,8 +23,16 @@ using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 #define MUL(x, c) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x) : "v"(c))
 #define CVT(x, y) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(x) : "v"(y))
 
+using f32x2 = __attribute__((ext_vector_type(2))) float;
 template <int MODE> __device__ __forceinline__ void filler(int j, float (&v)[8], float c, float d) {
     float& x = v[j & 7];
+    if (MODE == 3) {
+        f32x2 pv = {v[(2 * j) & 6], v[((2 * j) & 6) + 1]};
+        const f32x2 pc = {c, c}, pd = {d, d};
+        PKFMA(pv, pc, pd);
+        v[(2 * j) & 6] = pv[0]; v[((2 * j) & 6) + 1] = pv[1];
+        return;
+    }
     if (MODE == 0) FMA(x, c, d);
     else if (MODE == 2) EXP(x);
     else {
@@ -113,6 +126,20 @@ template <int MODE, bool CHAIN, int NT> void sweep(const char* label) {
 }
 
 int main() {
+#ifdef ACC_AGPR
+    printf("==== accumulators in AGPRs\n");
+#endif
+    printf("== packed fma fillers (one v_pk_fma_f32 = two lanes' worth), one wave per SIMD, then two\n");
+    sweep<3, false, 256>("pk_fma fillers");
+    sweep<3, false, 512>("pk_fma fillers");
+    printf("== plain fma fillers, two waves per SIMD in-wave, then cross-wave\n");
+    sweep<0, false, 512>("fma fillers");
+    run<5, 0, false, 512>("fma, cross-wave", 1, 1);
+    run<8, 0, false, 512>("fma, cross-wave", 1, 1);
+    run<13, 0, false, 512>("fma, cross-wave", 1, 1);
+    run<13, 0, false, 512>("  fma fillers alone on waves 4-7", 0, 1);
+    run<13, 2, false, 512>("exp, cross-wave", 1, 1);
+    run<13, 2, false, 512>("  exp fillers alone on waves 4-7", 0, 1);
     printf("== one wave per SIMD, interleaved in the wave\n");
     sweep<0, false, 256>("fma fillers");
     sweep<1, false, 256>("mixed fillers");
