@@ -430,7 +430,11 @@ __global__ __launch_bounds__(64 * WR) void heads_fused_x3_kernel(HeadsArgs2 p) {
 #endif
         int tile_no = wave >> 2;
         for (; t < p.NT; t += tstep) {
-#ifndef DCA_EXP_NOPRIO
+#if defined(DCA_EXP_PRIO_MFMA)
+            __builtin_amdgcn_s_setprio(2);           // experiment: the matrix phases outrank the partner's likelihood phase
+#elif defined(DCA_EXP_PRIO_Z)
+            __builtin_amdgcn_s_setprio(0);
+#elif !defined(DCA_EXP_NOPRIO)
             if (WR == 8) { if ((tile_no++) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
 #endif
             TSTAMP(0)
@@ -473,6 +477,11 @@ __global__ __launch_bounds__(64 * WR) void heads_fused_x3_kernel(HeadsArgs2 p) {
             TSTAMP(3)
 
             // ---- Z: element-wise likelihood and gradient (dense y = 0 pass + compacted non-zero pass)
+#if defined(DCA_EXP_PRIO_MFMA)
+            __builtin_amdgcn_s_setprio(0);
+#elif defined(DCA_EXP_PRIO_Z)
+            __builtin_amdgcn_s_setprio(2);
+#endif
             float lacc = 0.f;
             int qn = 0;
             auto z_dense = [&](auto fullv, int grp, const YV (&yv)[kZU]) {
@@ -609,6 +618,11 @@ __global__ __launch_bounds__(64 * WR) void heads_fused_x3_kernel(HeadsArgs2 p) {
             dacc += (double)lacc;
             const float sf_n = p.sf[srow_n];
             wave_sync();
+#if defined(DCA_EXP_PRIO_MFMA)
+            __builtin_amdgcn_s_setprio(2);
+#elif defined(DCA_EXP_PRIO_Z)
+            __builtin_amdgcn_s_setprio(0);
+#endif
             TSTAMP(4)
 
             // ---- dH[row, i] = sum_genes D[row, gene] W[i, gene]: A = D read transposed from the staging tile

@@ -126,3 +126,61 @@ def test_first_layer_kernels_stay_inside_their_budget():
             seen += 1
             assert s == 0 and l <= 163840, (n, s, l)
     assert seen == 5          # weight gradient at 32 / 64 / 128 units, forward at 32 / 64
+
+
+def _blocks_with_matrix_instructions(asm, kernel_substr):
+    """(kernel name, basic block label, matrix instructions, scratch instructions) of every basic block of the kernels whose
+    mangled name contains kernel_substr and that holds a matrix instruction."""
+    out, cur_kernel, cur_block, n_m, n_s = [], None, None, 0, 0
+
+    def flush():
+        if cur_kernel is not None and n_m:
+            out.append((cur_kernel, cur_block, n_m, n_s))
+    for ln in asm.split('\n'):
+        t = ln.strip()
+        m = re.match(r'^(_Z\w+):', ln)
+        if m:
+            flush()
+            cur_kernel = m.group(1) if kernel_substr in m.group(1) else None
+            cur_block, n_m, n_s = 'entry', 0, 0
+            continue
+        if cur_kernel is None:
+            continue
+        m = re.match(r'^(\.LBB\d+_\d+):', t)
+        if m or t.startswith(('s_cbranch', 's_branch', 's_endpgm')):
+            flush()
+            cur_block, n_m, n_s = (m.group(1) if m else cur_block + "'"), 0, 0
+            if t.startswith('s_endpgm'):
+                cur_kernel = None
+            continue
+        if t.startswith('v_mfma'):
+            n_m += 1
+        elif t.startswith('scratch_'):
+            n_s += 1
+    flush()
+    return out
+
+
+def test_matrix_loops_of_the_product_kernels_are_spill_free():
+    """A spill reload inside a loop of matrix instructions waits for every request in flight (and a lone wave per SIMD has
+    nothing to hide it behind): no basic block that issues MFMAs may touch scratch -- the wide networks' plane GEMM
+    (gemm_p3w_kernel: its 308-320 B/lane of scratch sit in the epilogue), the byte-store first-layer kernels and the 8-wave
+    K-HEADS kernels (the product instantiations over the byte store: at most the 2 scratch instructions of the tile loop the
+    round-4 review counted)."""
+    import shutil
+    import subprocess
+    import tempfile
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    budget = {'dcahip_gemm.hip': ('gemm_p3w_kernel', 0), 'dcahip_sparse.hip': ('enc0_', 0),
+              'dcahip_heads.hip': ('heads_fused_x3_kernelILb1ELb0ELi8ELb1E', 2)}
+    for src, (sub, allowed) in budget.items():
+        with tempfile.TemporaryDirectory() as td:
+            out = os.path.join(td, 'k.s')
+            subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-I' + os.path.join(ROOT, 'include'),
+                            '--cuda-device-only', '-S', os.path.join(ROOT, 'dca_amd', 'csrc', src), '-o', out],
+                           capture_output=True, text=True, check=True)
+            blocks = _blocks_with_matrix_instructions(open(out).read(), sub)
+        assert blocks, (src, sub)
+        assert sum(b[2] for b in blocks) >= 24, (src, sub)
+        bad = [(k[-48:], b, m, s) for k, b, m, s in blocks if s > allowed]
+        assert not bad, (src, bad[:5])
