@@ -44,6 +44,10 @@ class _CowView(np.ndarray):
         if own is None:
             raise ValueError('assignment destination is a read-only view of the parent AnnData\'s matrix; assign through '
                              'subset.X[...] = value (copies on write) or take subset.copy() first')
+        if own._X is not self:
+            # this reference already triggered the copy: later writes through it belong to the subset's own matrix
+            own._X[key] = value
+            return
         fresh = np.array(self, copy=True, subok=False)
         fresh[key] = value
         own._X = fresh

@@ -586,13 +586,17 @@ class Engine:
         """Compact byte store of the resident counts (built here unless given) for K-HEADS and -- when the input
         normalisation is known and input genes = output genes -- the sparse first layer."""
         self.cc = self.cc_in = None
+        self.cc_verdict = None              # False: these counts do not take the byte store (a full pass over Y found that out)
         ops, lay = self.ops, self.lay
         if self.Y is None or not hasattr(ops, 'counts_compact'):
             return
+        if compact is False:
+            return                          # an earlier attach found these counts unfit for the byte store (train.py keeps the verdict)
         if compact is None:
             from . import compact as _compact
             compact = _compact.build(ops, self.Y, self.Y.shape[0], lay.G_out)
         if compact is None:
+            self.cc_verdict = False
             return                          # not a count matrix (check_counts=False on arbitrary data): fp32 path
         # (counts >= 255 escape into a per-row list that K-HEADS scans linearly per escaped element, and that one workgroup
         # walks for the first layer: read-count data with many large counts -- Smart-seq and the like -- keeps the fp32
@@ -601,6 +605,7 @@ class Engine:
         n_esc = 0 if compact.ovf_col is None else int(compact.ovf_col.numel())
         n_el = float(self.Y.shape[0]) * lay.G_out
         if n_esc > 1e-3 * n_el:
+            self.cc_verdict = False
             return
         self.cc = compact
         if norm is not None and lay.hidden and lay.G_in == lay.G_out and ops.enc0_sparse_supported(lay.hidden[0]) \
@@ -778,6 +783,9 @@ class Engine:
                 if self._lut_fwd(B, training):
                     # K-SPARSE on the matrix pipe: the input looked up from the byte store (x = (log1p(y / fac) - mean) / std
                     # never read: 1 byte per count instead of 4, no transposed kernel)
+                    if self.cc_in.lutp is None:          # the per-cell table of the common counts: first use only, never in a capture
+                        self._not_capturing('first use of the byte-store forward')
+                        self.cc_in.ensure_lut(ops)
                     gather = rows_from[0] == 'perm'
                     with self._t('gemm_enc0_fwd'):
                         ops.enc0_fwd_lut(self.cc_in, self.perm if gather else None, self.cursor if gather else None,

@@ -201,7 +201,7 @@ class Autoencoder():
         if dd is not None and dd.n == n and dd.G == lay_G(eng) and dd.X.device == eng.dev and dd.matches(X):
             # K-PREP's tensors are still in HBM and still ARE adata.X
             eng.attach_device_data(dd.X, dd.Y, dd.sf, norm=dd.norm, compact=dd.compact)
-            dd.compact = eng.cc
+            dd.compact = eng.cc if eng.cc is not None else (False if getattr(eng, 'cc_verdict', None) is False else None)
         else:
             eng.load_data(X, None, sf)
         chunk = min(chunk, n)
@@ -309,7 +309,7 @@ class Autoencoder():
         dd = getattr(adata, '_dca_device', None)
         if dd is not None and dd.n == n and dd.G == lay_G(eng) and dd.X.device == eng.dev and dd.matches(adata.X):
             eng.attach_device_data(dd.X, dd.Y, dd.sf, norm=dd.norm, compact=dd.compact)
-            dd.compact = eng.cc
+            dd.compact = eng.cc if eng.cc is not None else (False if getattr(eng, 'cc_verdict', None) is False else None)
         else:
             eng.load_data(adata.X, None, sf)
         print('dca: Calculating low dimensional representations...')

@@ -55,13 +55,24 @@ def fingerprint(X):
     """EXACT content mark of a host matrix: shape, dtype and a 64-bit hash of every byte (libdcahost, threaded: ~0.1 s for
     the 5.5 GB benchmark matrix; sparse matrices: of their data / indices / indptr arrays).  An in-place edit of any element
     between normalize() and train() / predict() changes it, and the resident tensors are then not used."""
-    from . import hostlib
+    def mark(a):
+        a = np.ascontiguousarray(a)
+        try:
+            from . import hostlib
+            return hostlib.checksum(a)
+        except (OSError, RuntimeError, AttributeError):          # no native host library (no compiler on the host): slower, same guarantee
+            import hashlib
+            return hashlib.blake2b(a.view(np.uint8).reshape(-1), digest_size=8).hexdigest()
     if hasattr(X, 'toarray'):
-        Xc = X.tocsr() if hasattr(X, 'tocsr') else X
-        parts = [np.asarray(getattr(Xc, k)) for k in ('data', 'indices', 'indptr') if hasattr(Xc, k)]
-        return (tuple(X.shape), 'sparse') + tuple((str(p.dtype), hostlib.checksum(p)) for p in parts)
+        # the arrays of the matrix' OWN format (no conversion; the format name is part of the mark: equal matrices in
+        # another format or index order do not match, which only costs a re-upload)
+        fmt = getattr(X, 'format', type(X).__name__)
+        parts = [np.asarray(getattr(X, k)) for k in ('data', 'indices', 'indptr', 'row', 'col', 'offsets') if hasattr(X, k)]
+        if not parts:
+            parts = [np.asarray(X.tocsr().data)]
+        return (tuple(X.shape), 'sparse', fmt) + tuple((str(p.dtype), mark(p)) for p in parts)
     Xa = np.asarray(X)
-    return (tuple(Xa.shape), str(Xa.dtype), hostlib.checksum(Xa))
+    return (tuple(Xa.shape), str(Xa.dtype), mark(Xa))
 
 
 def _r4(x):

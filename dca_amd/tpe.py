@@ -122,8 +122,10 @@ class TPE:
         return [p for _, p, _ in below], [p for _, p, _ in above]
 
     def suggest(self, history):
+        # hyperopt's start-up phase counts every trial on record, failed ones included (tpe.suggest: len(trials.trials) <
+        # n_startup_jobs); the posteriors below then use the successful ones -- with none of them yet, stay random
         n_ok = sum(1 for _, l in history if l is not None and np.isfinite(l))
-        if n_ok < self.n_startup:
+        if len(history) < self.n_startup or n_ok == 0:
             return self.random()
         below, above = self.split(history)
         out = {}

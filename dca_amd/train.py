@@ -301,7 +301,7 @@ def train(adata, network, output_dir=None, optimizer='RMSprop', learning_rate=No
             dd.n == n and dd.G == X.shape[1] == eng.lay.G_in == eng.lay.G_out and \
             dd.X.device == eng.dev and dd.matches(X):
         eng.attach_device_data(dd.X, dd.Y, dd.sf, norm=dd.norm, compact=dd.compact)      # K-PREP left the tensors in HBM
-        dd.compact = eng.cc
+        dd.compact = eng.cc if eng.cc is not None else (False if eng.cc_verdict is False else None)
     elif comm.world == 1:
         eng.load_data(X, Y, sf)
     else:

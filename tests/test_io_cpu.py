@@ -156,3 +156,19 @@ def test_parallel_host_copy():
     small = np.arange(10, dtype=np.float32); out = np.empty_like(small)
     hostlib.parallel_copy(out, small)
     np.testing.assert_array_equal(out, small)
+
+
+def test_copy_on_write_subset_keeps_every_write_through_one_reference():
+    """A select-everything subset shares its parent's matrix until written to; TWO writes through one held reference both land
+    in the subset's own copy (the second used to rebuild the copy from the parent and lose the first), the parent stays."""
+    import numpy as np
+    import pandas as pd
+    from dca_amd._anndata import AnnData
+    a = AnnData(np.arange(12, dtype=np.float32).reshape(3, 4), obs=pd.DataFrame(index=list('abc')),
+                var=pd.DataFrame(index=list('wxyz')))
+    sub = a[np.ones(3, bool)]
+    x = sub.X
+    x[0, 0] = 100.0
+    x[1, 1] = 200.0
+    assert sub.X[0, 0] == 100.0 and sub.X[1, 1] == 200.0
+    assert a.X[0, 0] == 0.0 and a.X[1, 1] == 5.0
