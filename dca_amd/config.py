@@ -18,6 +18,7 @@ Tested combinations (tests/, all against the same oracle numbers):
                                             test_step_runner_cpu.py
   device_prep = False                       test_prep_gpu.py (host path == K-PREP)
   fused_write = False                       test_api_gpu.py::test_fused_predict_writer_writes_the_files_of_predict_then_write
+  small_dw = True                           test_sparse_gpu.py::test_small_batch_weight_gradient_from_the_byte_store (engine step, both forms)
 Engine attributes a test sets directly instead (no knob): use_fused (K-HEADS vs separate kernels:
 test_fused_and_separate_heads_agree_stepwise, test_full_size_step_fused_equals_separate).
 """
@@ -47,6 +48,10 @@ class EngineConfig:
     device_prep: bool = True                # DCA_AMD_DEVICE_PREP
     # the command line's predict + write as one streaming pass (gene x cell blocks formatted while the next one computes)
     fused_write: bool = True                # DCA_AMD_FUSED_WRITE
+    # batches of at most 64 rows (the reference default 32): the first layer's weight gradient over the non-zero counts of the
+    # byte store in one launch instead of the rank-B update through the GEMM.  OFF: measured on the MI355X at G = 20 000, batch
+    # 32, the launch is bound by its memory round trips (11.2 us) and loses to the GEMM's 7.4 us (profiles/r05g_b32_*)
+    small_dw: bool = False                  # DCA_AMD_SMALL_DW
     # ---- measured constants (no environment variable; DESIGN.md holds the measurements)
     graph_steps: int = 8                    # consecutive training steps per hipGraph launch (fit loop and bench)
     sparse_dw_min: int = 512                # batch rows from which the first layer's weight gradient reads the byte store
@@ -57,7 +62,7 @@ class EngineConfig:
 
     _ENV = {'stack': 'DCA_AMD_STACK', 'bwd_chain': 'DCA_AMD_BWD_CHAIN', 'wide_planes': 'DCA_AMD_WIDE_PLANES',
             'dp_sharded_opt': 'DCA_AMD_DP_SHARDED_OPT', 'dp_graph': 'DCA_AMD_DP_GRAPH', 'device_prep': 'DCA_AMD_DEVICE_PREP',
-            'fused_write': 'DCA_AMD_FUSED_WRITE'}
+            'fused_write': 'DCA_AMD_FUSED_WRITE', 'small_dw': 'DCA_AMD_SMALL_DW'}
 
     @classmethod
     def from_env(cls):

@@ -906,6 +906,98 @@ inline int dw_rows_per_split(int B, int ns, int H1) {
 }
 inline long r16(long x) { return (x + 15) / 16 * 16; }
 
+
+// ------------------------------------------------------------------------------------------------- small batches
+// The first layer's weight gradient at the reference's default batch (32 rows, dca/train.py:37; up to 64 here) straight
+// from the byte store: dW0[g, :] = (sum over the batch rows with a NON-ZERO count of f(y / fac) dZ[r, :] - mean[g] colsum(dZ)) / std[g]
+// -- about two terms per gene at 93 % zeros -- instead of a rank-32 update through the GEMM (14 us + a split-K reduce at
+// G = 20 000).  A group of 16 lanes owns one gene (lane t: hidden units 4 t .. 4 t + 3: one 16-byte store), a workgroup
+// kGenesSmall genes; dZ, its column sums, the storage rows and the per-cell divisors sit in LDS.  fp32 FMAs in row order:
+// deterministic.  Row G of gW = colsum(dZ) (the bias gradient, as dcahip_sgemm's colsum_row).  The kernel is bound by
+// memory round trips and instruction fetch, not by work: the workgroup requests its 16 x B count bytes in one round trip into
+// LDS and walks them in ONE compact loop body (measured at G = 20 000, batch 32: four genes per group with eight requests in
+// flight 44 us; all 32 requests at once but unrolled bodies with libm's log1pf 35 us, with the fast logarithm 22 us; the GEMM
+// + split-K reduce it replaces 19 us).
+constexpr int kSmallRows = 64;
+constexpr int kGenesSmall = 16;          // per workgroup: one gene per group of 16 lanes
+
+struct DwSmallArgs {
+    Compact c;
+    const float* fac; int do_log;
+    const float* mean; const float* stdv;
+    const int* perm; const long long* cursor; long row_base;
+    int B, G, H1;
+    const float* dZ; long ldz;
+    float* gW; long ldg;
+};
+
+__global__ __launch_bounds__(256) void enc0_dw_small_kernel(DwSmallArgs a) {
+    __shared__ __attribute__((aligned(16))) float dz[kSmallRows * 64];
+    __shared__ float cs[64];
+    __shared__ int srow[kSmallRows];
+    __shared__ float rfac[kSmallRows];
+    __shared__ unsigned char codes[kSmallRows][kGenesSmall];
+    const int tid = threadIdx.x;
+    const long cur = a.cursor ? (long)*a.cursor : 0;
+    const int H4 = a.H1 >> 2;
+    const int g0 = blockIdx.x * kGenesSmall;
+    // every request of the workgroup in ONE memory round trip behind the row indices: thread (row, gene) takes the count
+    // byte of its pair straight away (its row index from memory, not from LDS), rows 0 .. 15, then 16 .. 31, ...
+    {
+        const int gl = tid & 15;
+        const int gene = g0 + gl < a.G ? g0 + gl : a.G - 1;
+        for (int r = tid >> 4; r < a.B; r += 16) {
+            const long rr = cur + a.row_base + r;
+            const int sr = a.perm ? a.perm[rr] : (int)rr;
+            codes[r][gl] = a.c.yc[(unsigned long long)(unsigned)sr * (unsigned long long)a.c.ldc + gene];
+            if (gl == 0) { srow[r] = sr; rfac[r] = a.fac ? 1.f / a.fac[sr] : 1.f; }
+        }
+    }
+    for (int i = tid; i < a.B * 16; i += 256) {
+        const int r = i >> 4, q = i & 15;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q < H4) v = *reinterpret_cast<const float4*>(a.dZ + (long)r * a.ldz + 4 * q);
+        *reinterpret_cast<float4*>(dz + r * 64 + 4 * q) = v;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        float v = 0.f;
+        for (int r = 0; r < a.B; ++r) v += dz[r * 64 + tid];
+        cs[tid] = v;
+    }
+    __syncthreads();
+    const int t = tid & 15, grp = tid >> 4;
+    if (blockIdx.x == 0 && tid < H4)           // the bias gradient
+        *reinterpret_cast<float4*>(a.gW + (long)a.G * a.ldg + 4 * tid) = *reinterpret_cast<const float4*>(cs + 4 * tid);
+    const int gene = g0 + grp;
+    if (t >= H4 || gene >= a.G) return;
+    const float4 c4 = *reinterpret_cast<const float4*>(cs + 4 * t);
+    const float m = a.mean ? a.mean[gene] : 0.f;
+    const float sd = a.stdv ? a.stdv[gene] : 1.f;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 1
+    for (int r = 0; r < a.B; ++r) {             // (one compact body: the unrolled form spent its time fetching instructions)
+        const unsigned code = codes[r][grp];
+        if (code == 0u) continue;
+        float val = (float)code;
+        if (code == 255u) val = escaped_count(a.c, srow[r], gene);
+        float L = val * rfac[r];
+        if (a.do_log) {
+            // log1p on the transcendental unit (v_log_f32, 1 ulp) with Kahan's exact-ratio correction of the rounded 1 + L:
+            // ~2e-7 relative for the arguments counts produce (L >= 1 / fac)
+            const float u = 1.f + L, d1 = u - 1.f;
+            const float lg = __builtin_amdgcn_logf(u) * 0.69314718055994531f;
+            L = d1 == 0.f ? L : lg * (L * __builtin_amdgcn_rcpf(d1));
+        }
+        const float4 d = *reinterpret_cast<const float4*>(dz + r * 64 + 4 * t);
+        acc.x = fmaf(L, d.x, acc.x); acc.y = fmaf(L, d.y, acc.y); acc.z = fmaf(L, d.z, acc.z); acc.w = fmaf(L, d.w, acc.w);
+    }
+    const float is = 1.f / sd;
+    float4 o;
+    o.x = (acc.x - m * c4.x) * is; o.y = (acc.y - m * c4.y) * is; o.z = (acc.z - m * c4.z) * is; o.w = (acc.w - m * c4.w) * is;
+    *reinterpret_cast<float4*>(a.gW + (long)gene * a.ldg + 4 * t) = o;
+}
+
 }  // namespace
 
 extern "C" long dcahip_counts_compact_ld(int G) { return ((long)G + 15) / 16 * 16; }
@@ -917,6 +1009,21 @@ extern "C" int dcahip_counts_compact(const float* Y, long ldy, int n, int G, uns
     const long total = (long)n * (ldc >> 4);
     hipLaunchKernelGGL(counts_compact_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        Y, ldy, n, G, Yc, ldc, status);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dcahip_enc0_dw_small_max_rows(void) { return kSmallRows; }
+
+extern "C" int dcahip_enc0_dw_small(const unsigned char* Yc, long ldc, const int* ovf_ptr, const int* ovf_col,
+                                    const float* ovf_val, const float* fac, int do_log, const float* mean, const float* stdv,
+                                    const int* perm, const long long* cursor, long row_base, int B, int G, int H1,
+                                    const float* dZ, long ldz, float* gW, long ldg, void* stream) {
+    if (!Yc || !dZ || !gW || B <= 0 || B > kSmallRows || G <= 0 || H1 <= 0 || H1 > 64 || (H1 & 3) || ldc < G || ldz < H1 || ldg < H1 ||
+        (ldz & 3) || (ldg & 3) || ((reinterpret_cast<uintptr_t>(dZ) | reinterpret_cast<uintptr_t>(gW)) & 15))
+        return DCAHIP_EINVAL;
+    DwSmallArgs a{Compact{Yc, ldc, ovf_ptr, ovf_col, ovf_val}, fac, do_log, mean, stdv, perm, cursor, row_base, B, G, H1, dZ, ldz, gW, ldg};
+    hipLaunchKernelGGL(enc0_dw_small_kernel, dim3((unsigned)((G + kGenesSmall - 1) / kGenesSmall)), dim3(256), 0,
+                       (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
 

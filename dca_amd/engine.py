@@ -608,8 +608,9 @@ class Engine:
             self.cc_verdict = False
             return
         self.cc = compact
-        if norm is not None and lay.hidden and lay.G_in == lay.G_out and ops.enc0_sparse_supported(lay.hidden[0]) \
-                and n_esc <= 1e-5 * n_el:
+        if norm is not None and lay.hidden and lay.G_in == lay.G_out and n_esc <= 1e-5 * n_el and \
+                (ops.enc0_sparse_supported(lay.hidden[0]) or (hasattr(ops, 'enc0_dw_small') and lay.hidden[0] <= 64
+                                                               and lay.hidden[0] % 4 == 0)):
             self.cc_in = compact.with_input(norm.get('fac'), norm.get('do_log', False), norm.get('mean'), norm.get('std'), ops=ops)
         self._sparse_workspaces()
 
@@ -643,6 +644,13 @@ class Engine:
 
     def _sparse_dw(self, B):
         return (self.cc_in is not None and self.ws_enc0 is not None and B >= self.sparse_dw_min and self.in_drop == 0.0)
+
+    def _small_dw(self, B):
+        """Small batches (the reference's default 32): the first layer's weight gradient over the non-zero counts of the
+        byte store in one launch, instead of the rank-B update through the GEMM + its split-K reduce."""
+        lay = self.lay
+        return (self.cc_in is not None and self.in_drop == 0.0 and self.cfg.small_dw and hasattr(self.ops, 'enc0_dw_small')
+                and 0 < B <= self.ops.enc0_dw_small_max_rows and lay.hidden[0] <= 64 and lay.hidden[0] % 4 == 0)
 
     def _set_tile_order(self):
         """K-HEADS: which 32-gene tiles share a workgroup.  A workgroup lasts as long as its slower tile and the
@@ -1310,7 +1318,9 @@ class Engine:
             gW = lay.view(g, 'W%d' % i)
             if i == 0:
                 with self._t('gemm_enc0_dW'):
-                    if self._sparse_dw(B):
+                    if self._small_dw(B):
+                        ops.enc0_dw_small(self.cc_in, self.perm, self.cursor, 0, B, Kp, h, self.dZ[0], self.ldh[0], gW, h)
+                    elif self._sparse_dw(B):
                         if self.cc_in.lutp is None:              # the per-cell table of the common counts: first use only
                             self._not_capturing('first use of the byte-store weight gradient')
                             self.cc_in.ensure_lut(ops)

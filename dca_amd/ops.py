@@ -121,6 +121,18 @@ class HipOps:
                                                B, G, H1, p(dZ), ldz, p(gW), ldg, p(ws), ws.numel() * ws.element_size(),
                                                hip.stream()), 'enc0_dw_sparse')
 
+    @property
+    def enc0_dw_small_max_rows(self):
+        return int(self.L.dcahip_enc0_dw_small_max_rows())
+
+    def enc0_dw_small(self, c, perm, cursor, row_base, B, G, H1, dZ, ldz, gW, ldg):
+        """gW [G + 1, ldg] = X^T dZ (+ column sums of dZ in row G) for a batch of at most enc0_dw_small_max_rows rows, X
+        read from the byte store (non-zero counts only)."""
+        p = hip.ptr
+        hip.check(self.L.dcahip_enc0_dw_small(p(c.Yc), c.ldc, p(c.ovf_ptr), p(c.ovf_col), p(c.ovf_val), p(c.fac),
+                                              int(c.do_log), p(c.mean), p(c.std), p(perm), p(cursor), int(row_base),
+                                              B, G, H1, p(dZ), ldz, p(gW), ldg, hip.stream()), 'enc0_dw_small')
+
     def enc0_fwd_sparse(self, c, perm, cursor, row_base, B, G, H1, W, ldw, bias, Z, ldz, ws):
         """Z [B, ldz] = X W + bias; ws: zero-initialised once, private to this call site."""
         p = hip.ptr

@@ -575,6 +575,16 @@ int dcahip_enc0_sparse_supported(int H1);
  * three bf16 pieces the matrix products use ({p0 | p1 << 16, p2}) -- made once per dataset, so that the weight gradient
  * LOOKS UP its operand instead of dividing, taking logarithms and splitting (counts beyond 63 take the formula). */
 int dcahip_enc0_lut(const float* fac, int do_log, int n, void* lutp, void* stream);
+/* The same weight (+ bias) gradient for SMALL batches (B <= dcahip_enc0_dw_small_max_rows() = 64; the reference's default
+ * batch is 32, dca/train.py:37), any first-layer width H1 <= 64 that is a multiple of 4: one pass over the batch's count bytes,
+ * fp32 FMAs over the non-zero counts in row order (deterministic), no workspace, no table:
+ *   gW[g, :] = (sum_r f(y[r, g] / fac[r]) dZ[r, :] - mean[g] colsum(dZ)) / stdv[g],   gW[G, :] = colsum(dZ).
+ * dZ, gW 16-byte aligned, ldz / ldg multiples of 4.  Replaces the same autodiff as dcahip_enc0_dw_sparse. */
+int dcahip_enc0_dw_small_max_rows(void);
+int dcahip_enc0_dw_small(const unsigned char* Yc, long ldc, const int* ovf_ptr, const int* ovf_col, const float* ovf_val,
+                         const float* fac, int do_log, const float* mean, const float* stdv, const int* perm,
+                         const long long* cursor, long row_base, int B, int G, int H1, const float* dZ, long ldz,
+                         float* gW, long ldg, void* stream);
 long dcahip_enc0_dw_sparse_workspace_bytes(int B, int G, int H1);
 int dcahip_enc0_dw_sparse(const unsigned char* Yc, long ldc, const int* ovf_ptr, const int* ovf_col,
                           const float* ovf_val, const float* fac, int do_log, const void* lutp, const float* mean,

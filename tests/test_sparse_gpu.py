@@ -268,3 +268,83 @@ def test_step_with_compact_counts_matches_oracle(ops, ae_type, B):
     loss2, g2, _ = run_single_step(eng2, rows)
     assert abs(loss - loss2) < 2e-6 * abs(loss2)
     assert_grads_close(g, {k: np.asarray(v, np.float64) for k, v in g2.items()}, rtol=5e-4, atol_scale=5e-6, skip=zero_b)
+
+
+@pytest.mark.parametrize('B,G,H1,gather,use_fac,do_log,scale,esc', [
+    (32, 200, 64, True, True, True, True, False), (32, 20000, 64, True, True, True, True, True), (25, 333, 64, True, True, True, True, True),
+    (64, 77, 32, False, True, True, False, True), (1, 50, 64, True, True, True, True, False), (33, 90, 16, True, False, False, False, True),
+    (40, 130, 48, False, True, False, True, False)])
+def test_small_batch_weight_gradient_kernel_vs_numpy(ops, B, G, H1, gather, use_fac, do_log, scale, esc):
+    """dcahip_enc0_dw_small: the first layer's weight + bias gradient of a batch of at most 64 rows (the reference's default
+    32, its 25-row last batch of C3, a single row) over the non-zero counts of the byte store, against fp64 numpy on the
+    dense input: |err| <= 1e-6 of the summed magnitudes, the bias row to 2e-6; a second launch reproduces every bit."""
+    rng = np.random.RandomState(B + G + H1)
+    n = B + 9
+    Y = counts_with_escapes(n, G, B + G, big=esc)
+    fac = (rng.lognormal(0, 0.4, n)).astype(np.float32).astype(np.float64) if use_fac else None
+    L = dense_input(Y, fac, do_log, None, None)
+    mean = L.mean(0).astype(np.float32).astype(np.float64) if scale else None
+    std = np.maximum(L.std(0, ddof=1), 1e-3).astype(np.float32).astype(np.float64) if scale else None
+    X = dense_input(Y, fac, do_log, mean, std)
+    if gather:
+        perm = rng.permutation(n)[:B + 3].astype(np.int32); cur = 3
+        rows = perm[cur:cur + B]
+    else:
+        perm = None; cur = 4
+        rows = np.arange(cur, cur + B)
+    dZ = rng.normal(0, 1e-3, (B, H1)).astype(np.float32).astype(np.float64)
+    gW_ref = X[rows].T @ dZ
+    Lr = L[rows] / (std[None, :] if scale else 1.0)
+    gW_abs = np.abs(Lr).T @ np.abs(dZ)
+    if scale:
+        gW_abs = gW_abs + np.abs(mean / std)[:, None] * np.abs(dZ).sum(0)[None, :]
+    _, cc = build_compact(ops, Y)
+    cc = cc.with_input(dev(fac) if use_fac else None, do_log, dev(mean) if scale else None, dev(std) if scale else None, ops=ops)
+    dperm = torch.as_tensor(perm).cuda() if perm is not None else None
+    dcur = torch.tensor([cur if gather else 0], dtype=torch.int64, device='cuda')
+    base = 0 if gather else cur
+    assert B <= ops.enc0_dw_small_max_rows
+    gWd = torch.full((G + 1, H1), 7.0, device='cuda')
+    ops.enc0_dw_small(cc, dperm, dcur, base, B, G, H1, dev(dZ), H1, gWd, H1)
+    torch.cuda.synchronize()
+    got = gWd.cpu().numpy()
+    err = np.abs(got[:G] - gW_ref)
+    assert (err <= 1e-6 * gW_abs + 1e-12 * np.abs(dZ).max()).all(), float((err / np.maximum(gW_abs, 1e-30)).max())
+    np.testing.assert_allclose(got[G], dZ.sum(0), rtol=0, atol=2e-6 * np.abs(dZ).sum(0).max())
+    gW2 = torch.zeros_like(gWd)
+    ops.enc0_dw_small(cc, dperm, dcur, base, B, G, H1, dev(dZ), H1, gW2, H1)
+    assert torch.equal(gW2, gWd)
+
+
+@pytest.mark.parametrize('B', [32, 25])
+def test_small_batch_weight_gradient_from_the_byte_store(ops, B, monkeypatch):
+    """One training step at the reference's default batch with the first layer's weight gradient from the byte store
+    (EngineConfig.small_dw; off in the product: it measured slower) and through the GEMM: same loss, gradients within the single-step tolerance of each
+    other and of the fp64 oracle."""
+    from dca_amd import prep
+    from dca_amd.engine import Engine
+    n, G, hs = 300, 1000, (64, 32, 64)
+    _, Yh, _, p = make_problem(n, G, hs, 'zinb-conddisp', True, seed=21)
+    Yh = np.minimum(Yh, 200.0)                   # (no escapes: the byte-store first layer takes stores with at most 1e-5 of them)
+    Gp = (G + 3) // 4 * 4
+    Y = torch.zeros(n, Gp, device='cuda'); Y[:, :G] = dev(Yh)
+    counts = prep.cell_counts(ops, Y, n, G)
+    sf = counts / counts.median()
+    X, norm = prep.transform(ops, Y, n, G, sf, True, True, return_norm=True)
+    rows = np.random.RandomState(3).permutation(n)[:B]
+    rt = torch.as_tensor(rows).cuda()
+    ref = oracle_net('zinb-conddisp', p, hs, True)
+    rl, rg = ref.loss_and_grads(X[rt][:, :G].cpu().numpy().astype(np.float64), Yh[rows].astype(np.float64),
+                                sf[rt].cpu().numpy().astype(np.float64))
+    res = {}
+    for on in ('1', '0'):
+        monkeypatch.setenv('DCA_AMD_SMALL_DW', on)
+        eng = Engine('zinb-conddisp', G, G, hs, True, 0.0, ops=ops)
+        eng.set_params(p)
+        eng.attach_device_data(X, Y, sf, norm=norm)
+        eng.reserve(B)
+        assert eng._small_dw(B) == (on == '1')
+        res[on] = run_single_step(eng, rows)
+        assert abs(res[on][0] - rl) < 1e-5 * abs(rl)
+        assert_grads_close(res[on][1], rg)
+    np.testing.assert_allclose(res['1'][1]['W0'], res['0'][1]['W0'], rtol=2e-4, atol=2e-6 * np.abs(res['0'][1]['W0']).max())
