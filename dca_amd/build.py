@@ -17,7 +17,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(CSRC, 'libdcahip.so')
 SOURCES = ['dcahip_zinb.hip', 'dcahip_gemm.hip', 'dcahip_layers.hip', 'dcahip_heads.hip', 'dcahip_prep.hip', 'dcahip_opt.hip',
-           'dcahip_dropout.hip', 'dcahip_sparse.hip']
+           'dcahip_dropout.hip', 'dcahip_sparse.hip', 'dcahip_peer.hip']
 HEADERS = ['zinb_math.hpp', 'heads_p4.inc']
 ARCH = 'gfx950'
 HOST_LIB = os.path.join(CSRC, 'libdcahost.so')

@@ -18,6 +18,8 @@ Tested combinations (tests/, all against the same oracle numbers):
                                             test_step_runner_cpu.py
   device_prep = False                       test_prep_gpu.py (host path == K-PREP)
   fused_write = False                       test_api_gpu.py::test_fused_predict_writer_writes_the_files_of_predict_then_write
+  dp_peer_exchange = True                   test_dp_gpu.py::test_peer_exchange_two_processes_on_one_gpu (raw exchanges, then a fit == the
+                                            library-collective fit, bit for bit)
   small_dw = True                           test_sparse_gpu.py::test_small_batch_weight_gradient_from_the_byte_store (engine step, both forms)
 Engine attributes a test sets directly instead (no knob): use_fused (K-HEADS vs separate kernels:
 test_fused_and_separate_heads_agree_stepwise, test_full_size_step_fused_equals_separate).
@@ -44,6 +46,9 @@ class EngineConfig:
     dp_sharded_opt: bool = False            # DCA_AMD_DP_SHARDED_OPT
     # data parallel: capture the steps (RCCL exchanges included) into hipGraphs
     dp_graph: bool = True                   # DCA_AMD_DP_GRAPH
+    # data parallel: the SyncBN exchanges (<= 2 h floats each) as one kernel launch over IPC-mapped peer buffers (K-PEER)
+    # instead of RCCL calls; off until a multi-GPU node has measured it (functionally proven with two processes on one GPU)
+    dp_peer_exchange: bool = False          # DCA_AMD_DP_PEER
     # io.normalize on the GPU (K-PREP) when one is present
     device_prep: bool = True                # DCA_AMD_DEVICE_PREP
     # the command line's predict + write as one streaming pass (gene x cell blocks formatted while the next one computes)
@@ -62,7 +67,7 @@ class EngineConfig:
 
     _ENV = {'stack': 'DCA_AMD_STACK', 'bwd_chain': 'DCA_AMD_BWD_CHAIN', 'wide_planes': 'DCA_AMD_WIDE_PLANES',
             'dp_sharded_opt': 'DCA_AMD_DP_SHARDED_OPT', 'dp_graph': 'DCA_AMD_DP_GRAPH', 'device_prep': 'DCA_AMD_DEVICE_PREP',
-            'fused_write': 'DCA_AMD_FUSED_WRITE', 'small_dw': 'DCA_AMD_SMALL_DW'}
+            'fused_write': 'DCA_AMD_FUSED_WRITE', 'small_dw': 'DCA_AMD_SMALL_DW', 'dp_peer_exchange': 'DCA_AMD_DP_PEER'}
 
     @classmethod
     def from_env(cls):

@@ -25,12 +25,27 @@ class TorchDistComm:
         self.group = group
         self.world = dist.get_world_size(group)
         # the exchanges may be captured into hipGraphs with the step only over RCCL (gloo stages through the host)
-        self.capturable = dist.get_backend(group) == 'nccl'
+        self.capturable = dist.get_backend(group) == 'nccl'          # (K-PEER's launches are capturable whatever the backend)
         self.rank = dist.get_rank(group)
         # a second communicator (its own RCCL stream) for the bulk gradient bucket: on the main
         # one it would queue the small SyncBN exchanges of the backward pass behind 15 MB
         self.bulk = dist.new_group(ranks=list(range(dist.get_world_size())) if group is None else None) \
             if group is None else group
+
+    # K-PEER (dca_amd/peer.py): the small fp32 exchanges (SyncBN statistics) as one kernel launch over IPC-mapped buffers
+    # instead of a library call; None = the library's collectives (the default: EngineConfig.dp_peer_exchange)
+    peer = None
+
+    def enable_peer_exchange(self, nmax):
+        """Collective.  Small float32 device tensors (<= nmax elements) of all_gather_into(name='all_gather_small') and
+        all_reduce_sum go through dcahip_peer_exchange from here on."""
+        from .peer import PeerExchange
+        if self.peer is None or self.peer.nmax < nmax:
+            self.peer = PeerExchange(self.rank, self.world, nmax, group=self.group)
+        return self.peer
+
+    def _peer_takes(self, t, n):
+        return (self.peer is not None and t.is_cuda and t.dtype == torch.float32 and 0 < n <= self.peer.nmax and t.is_contiguous())
 
     # every exchange can be timed: with .timer = {} the communicator brackets each call (and each wait for an
     # asynchronous one) with events on the compute stream -- what the stream spends there is the EXPOSED communication
@@ -81,6 +96,10 @@ class TorchDistComm:
         return out
 
     def all_reduce_sum(self, t):
+        if self._peer_takes(t, t.numel()):
+            with self._Span(self, 'peer_reduce_small', t):
+                self.peer.reduce(t)
+            return t
         with self._Span(self, 'all_reduce_%s' % ('small' if t.numel() <= 4096 else 'bucket'), t):
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
@@ -113,6 +132,10 @@ class TorchDistComm:
         """out = concatenation of every rank's shard (shard may be a slice of out)."""
         src = shard.clone() if shard.data_ptr() >= out.data_ptr() and \
             shard.data_ptr() < out.data_ptr() + out.numel() * out.element_size() else shard
+        if name == 'all_gather_small' and self._peer_takes(src, src.numel()) and out.is_contiguous():
+            with self._Span(self, 'peer_gather_small', out):
+                self.peer.gather(out, src)
+            return out
         with self._Span(self, name, out):
             dist.all_gather_into_tensor(out, src, group=self.group)
         return out

@@ -303,6 +303,10 @@ class Engine:
         # all-reducing the whole gradient and updating everything everywhere.  Same bytes on the wire
         # (2 (N-1)/N P either way), 1/N of the optimizer traffic per rank; EngineConfig.dp_sharded_opt switches it on.
         self.sharded_opt = self.comm.dp and self.cfg.dp_sharded_opt
+        if self.comm.dp and self.cfg.dp_peer_exchange and batchnorm and hasattr(self.comm, 'enable_peer_exchange') \
+                and self.dev.type == 'cuda' and self.lay.hidden:
+            # (collective: every rank builds its engine with the same configuration)
+            self.comm.enable_peer_exchange(2 * max(self.lay.hidden))
         self.mm = [torch.zeros(h, **f32) for h in lay.hidden] if batchnorm else []
         self.mv = [torch.ones(h, **f32) for h in lay.hidden] if batchnorm else []
         self.lr = torch.full((1,), 1e-3, **f32)

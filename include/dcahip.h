@@ -618,6 +618,22 @@ int dcahip_enc0_fwd_lut(const unsigned char* Yc, long ldc, const int* ovf_ptr, c
                         int B, int G, int H1, const float* W, long ldw, const float* bias,
                         float* Z, long ldz, void* workspace, long workspace_bytes, void* stream);
 
+/*
+ * K-PEER (dca_amd/csrc/dcahip_peer.hip): the small exchanges of the data-parallel step without a library call.
+ *   slots[q], flags[q]: device arrays of `world` pointers to every rank's exchange buffers (rank's own: its local
+ *   allocation; the others: mapped with hipIpcOpenMemHandle), each dcahip_peer_slot_bytes(world, nmax) /
+ *   dcahip_peer_flag_bytes(world) bytes, zero-initialised once.  epoch: one device counter per communicator, 0 at the start,
+ *   advanced by every call (all ranks call in the same order).  reduce = 0: out [world * n] = concatenation of the ranks'
+ *   vectors (all-gather); reduce = 1: out [n] = their sum in rank order (all-reduce; out may be local).  A peer that does
+ *   not arrive within max_spin polls sets *status |= 1 and the call returns what it has (the caller checks status at its
+ *   next synchronisation).  Asynchronous on `stream`; one workgroup.  Replaces torch.distributed.all_gather_into_tensor /
+ *   all_reduce on <= nmax floats (SyncBN statistics); no reference call site (the reference is single-process).
+ */
+long dcahip_peer_slot_bytes(int world, int nmax);
+long dcahip_peer_flag_bytes(int world);
+int dcahip_peer_exchange(const float* local, int n, float* const* slots, unsigned* const* flags, int rank, int world, int nmax,
+                         unsigned long long* epoch, float* out, int reduce, int* status, long max_spin, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -280,3 +280,104 @@ def test_c4_rank_shard_step_matches_oracle(ae):
           % (ae, info['loss'], info['oracle'], info['zeros'], info['calls']))
     assert 0.90 < info['zeros'] < 0.96 and info['fused']
     assert sum(info['calls'].values()) > 0
+
+
+def _run_peer(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), DCA_AMD_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    try:
+        from dca_amd.engine import Engine
+        from dca_amd.peer import PeerExchange
+        from dca_amd.train import fit_engine
+        comm = ddist.init_from_env()
+        dev = torch.device('cuda')
+        # ---- raw exchanges: gathers and reductions of several lengths, 60 epochs, then the same inside a hipGraph
+        px = PeerExchange(rank, world, 128)
+        bad = 0
+        for e in range(60):
+            n = (1, 7, 64, 128)[e % 4]
+            local = (torch.arange(n, device=dev, dtype=torch.float32) * 0.25 + 1000.0 * (rank + 1) + e)
+            out = torch.full((world * n,), -1.0, device=dev)
+            px.gather(out, local)
+            want = torch.cat([torch.arange(n, device=dev, dtype=torch.float32) * 0.25 + 1000.0 * (r + 1) + e for r in range(world)])
+            bad += int((out != want).sum().item())
+            t = local.clone()
+            px.reduce(t)
+            bad += int((t != want.view(world, n).sum(0)).sum().item())
+        px.check()
+        g = torch.cuda.CUDAGraph()
+        src = torch.zeros(16, device=dev); dst = torch.zeros(world * 16, device=dev); red = torch.zeros(16, device=dev)
+        s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            with torch.cuda.graph(g, stream=s, capture_error_mode='thread_local'):
+                px.gather(dst, src)
+                red.copy_(src)
+                px.reduce(red)
+        torch.cuda.current_stream().wait_stream(s)
+        for k in range(3):
+            src.fill_(float(10 * k + rank + 1))
+            g.replay()
+            torch.cuda.synchronize()
+            want = torch.cat([torch.full((16,), float(10 * k + r + 1), device=dev) for r in range(world)])
+            bad += int((dst != want).sum().item()) + int((red != want.view(world, 16).sum(0)).sum().item())
+        px.check()
+        px.close()
+        # ---- the data-parallel fit with the SyncBN exchanges through K-PEER against the library's collectives
+        n, G, hs, ae, B, epochs, seed = 300, 150, (64, 32, 64), 'zinb-conddisp', 64, 2, 17
+        X, Y, sf, p = make_problem(n, G, hs, ae, True, seed=3)
+        n_train = int(n * 0.9); n_val = n - n_train
+        t0, nt = ddist.shard(n_train, world, rank); v0, nv = ddist.shard(n_val, world, rank)
+        rows = np.r_[np.arange(t0, t0 + nt), n_train + np.arange(v0, v0 + nv)]
+        res = []
+        for peer in ('0', '1'):
+            os.environ['DCA_AMD_DP_PEER'] = peer
+            eng = Engine(ae, G, G, hs, True, 0.0, comm=comm)
+            assert (comm.peer is not None) == (peer == '1')
+            eng.set_params(p)
+            eng.load_data(X[rows], Y[rows], sf[rows])
+            comm.timer = {}
+            h = fit_engine(eng, n_train, n_val, nt, nv, t0, epochs=epochs, batch_size=B,
+                           shuffle_rng=np.random.RandomState(seed), reduce_lr=1, early_stop=0)
+            calls = {k: v[0] for k, v in comm.timer_summary().items()}
+            comm.timer = None
+            if comm.peer is not None:
+                comm.peer.check()
+            res.append((h.history, eng.get_params(), calls))
+        if rank == 0:
+            q.put(('ok', bad, res))
+        dist.barrier()
+    except BaseException as e:
+        import traceback
+        q.put(('error', '%s: %s\n%s' % (type(e).__name__, e, traceback.format_exc()), None))
+        raise
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_peer_exchange_two_processes_on_one_gpu():
+    """K-PEER (dcahip_peer_exchange: peer stores into IPC-mapped slots + flags, no library call) with two processes sharing this
+    GPU: 60 gathers and 60 reductions of 1 .. 128 floats give exactly the expected vectors, eagerly and replayed from a hipGraph;
+    then a two-epoch data-parallel fit whose SyncBN exchanges go through K-PEER (EngineConfig.dp_peer_exchange) equals the fit
+    over the library's collectives BIT FOR BIT (two ranks: the sum a + b has one order) -- and did use the peer path."""
+    W = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_run_peer, args=(r, W, port, q)) for r in range(W)]
+    for pr in procs:
+        pr.start()
+    got = q.get(timeout=600)
+    for pr in procs:
+        pr.join(timeout=120)
+    assert got[0] == 'ok', got[1]
+    assert all(pr.exitcode == 0 for pr in procs)
+    _, bad, res = got
+    assert bad == 0
+    (h0, p0, c0), (h1, p1, c1) = res
+    assert h0 == h1, (h0, h1)
+    for k in p0:
+        assert np.array_equal(p0[k], p1[k]), k
+    assert c1.get('peer_gather_small', 0) > 0 and c1.get('peer_reduce_small', 0) > 0 and 'all_gather_small' not in c1
+    assert c0.get('all_gather_small', 0) > 0 and 'peer_gather_small' not in c0
+    print('K-PEER fit == collective fit; exchanges per fit: %s' % c1)
