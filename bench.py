@@ -66,7 +66,7 @@ def source_sha():
     h = hashlib.sha256()
     d = os.path.join(ROOT, 'dca_amd', 'csrc')
     for f in sorted(os.listdir(d)):
-        if f.endswith(('.hip', '.hpp', '.cpp')):
+        if f.endswith(('.hip', '.hpp', '.cpp', '.inc')):
             h.update(f.encode()); h.update(open(os.path.join(d, f), 'rb').read())
     return h.hexdigest()[:16]
 
