@@ -40,7 +40,10 @@ class TorchDistComm:
         """Collective.  Small float32 device tensors (<= nmax elements) of all_gather_into(name='all_gather_small') and
         all_reduce_sum go through dcahip_peer_exchange from here on."""
         from .peer import PeerExchange
-        if self.peer is None or self.peer.nmax < nmax:
+        if self.peer is not None and self.peer.nmax < nmax:
+            self.peer.close()
+            self.peer = None
+        if self.peer is None:
             self.peer = PeerExchange(self.rank, self.world, nmax, group=self.group)
         return self.peer
 

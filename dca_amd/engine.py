@@ -317,6 +317,7 @@ class Engine:
         self.clip = 5.0                                   # train.py:37 clip_grad
         self.ldD = lay.ldA + (lay.Gp if lay.const_disp else 0)
         self.Bmax = 0
+        self._hl = None             # (tensor, leading dimension) the heads read: the last hidden layer's output, or the input batch
         self.X = self.Y = self.sf = self.perm = None
         self.tile_order = None
         self.hist = None

@@ -134,6 +134,8 @@ def fit_engine(eng, n_train_global, n_val_global, nt_local, nv_local, t0_global,
         if W > 1:
             comm.all_reduce_sum(eng.acc[1:])
         acc = eng.acc.cpu().numpy()                            # the one host sync per epoch
+        if getattr(comm, 'peer', None) is not None:
+            comm.peer.check()                                  # K-PEER: a rank that never arrived at an exchange fails the fit here
         loss = float(acc[0]) / n_train_global
         hist.history['loss'].append(loss)
         hist.history['lr'].append(lr)
