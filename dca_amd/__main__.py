@@ -13,7 +13,7 @@ _OPTIONS = [
     (('-t', '--transpose'), dict(dest='transpose', action='store_true', help='input is cell x gene (default: gene x cell)')),
     (('--testsplit',), dict(dest='testsplit', action='store_true', help='hold one fold out as a test set')),
     (('--type',), dict(type=str, default='nb-conddisp', help='autoencoder type (see dca_amd.network.AE_types)')),
-    (('--threads',), dict(type=int, default=None, help='ignored on the GPU path (sized TensorFlow CPU pools in the reference)')),
+    (('--threads',), dict(type=int, default=None, help='host threads of the native host stages (the reference sized TensorFlow CPU pools with it; the step runs on the GPU)')),
     (('-b', '--batchsize'), dict(type=int, default=32, help='batch size (default: 32)')),
     (('--sizefactors',), dict(dest='sizefactors', action='store_true', help='normalise means by library size (default)')),
     (('--nosizefactors',), dict(dest='sizefactors', action='store_false')),

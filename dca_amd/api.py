@@ -45,8 +45,8 @@ def dca(adata,
     """Deep count autoencoder (DCA) API -- see dca/api.py:46-144 of the reference for the full
     parameter documentation; every parameter keeps its meaning.
 
-    ``threads`` sized TensorFlow's CPU pools in the reference (train.py:41-48); it is accepted
-    and has no effect here.  ``random_state`` seeds python / numpy exactly as api.py:150-153 does
+    ``threads`` sized TensorFlow's CPU pools in the reference (train.py:41-48); here it sizes the host thread pools of the
+    native host stages (staging copies, checksums, result writers) -- the training step runs on the GPU.  ``random_state`` seeds python / numpy exactly as api.py:150-153 does
     (the per-epoch shuffles consume the numpy global stream like Keras did) and additionally the
     glorot-uniform weight initialisation (TensorFlow's stream is not reproducible outside TF).
     """

@@ -63,6 +63,17 @@ def names_need_quoting(names):
     return any(ch in s for s in map(str, names) for ch in ('\t', '"', '\n', '\r'))
 
 
+DEFAULT_THREADS = 0          # 0: one per hardware thread (the library's own caps apply)
+
+
+def set_threads(n):
+    """Host threads of every native host stage from here on (result writers, input parser, staging copies, checksums): what
+    the reference's ``threads`` argument sized for TensorFlow's CPU pools (dca/train.py:41-48) sizes here.  None / 0: all."""
+    global DEFAULT_THREADS
+    DEFAULT_THREADS = max(0, int(n or 0))
+    return DEFAULT_THREADS
+
+
 def write_tsv(path, matrix, rownames=None, colnames=None, threads=0):
     """matrix: 2-D float32 / float64 ndarray with ANY strides (a transposed view costs nothing);
     rownames / colnames: sequences or None."""
@@ -77,7 +88,7 @@ def write_tsv(path, matrix, rownames=None, colnames=None, threads=0):
     rn, _keep_r = _names(rownames, nr)
     cn, _keep_c = _names(colnames, nc)
     fn = lib().dcahost_write_tsv_f32 if m.dtype == np.float32 else lib().dcahost_write_tsv_f64
-    rc = fn(os.fsencode(path), m.ctypes.data, nr, nc, rs, cs, rn, cn, int(threads))
+    rc = fn(os.fsencode(path), m.ctypes.data, nr, nc, rs, cs, rn, cn, int(threads or DEFAULT_THREADS))
     if rc == -2:
         err = ctypes.get_errno()
         raise OSError(err, os.strerror(err), str(path))
@@ -105,7 +116,7 @@ class TsvStream:
         assert v.shape[0] == 0 or v.strides[1] == 4
         ld = v.strides[0] // 4 if v.shape[0] > 1 else max(self.ncols, v.shape[1])
         rn, _keep = _names(rownames, v.shape[0]) if self.index else (None, None)
-        rc = lib().dcahost_tsv_stream_rows_f32(self.h, v.ctypes.data, v.shape[0], ld, rn, int(threads))
+        rc = lib().dcahost_tsv_stream_rows_f32(self.h, v.ctypes.data, v.shape[0], ld, rn, int(threads or DEFAULT_THREADS))
         if rc != 0:
             raise OSError(ctypes.get_errno(), 'dcahost_tsv_stream_rows_f32 failed (%d)' % rc)
 
@@ -139,7 +150,7 @@ def format_values(values):
 def parallel_copy(dst, src, threads=0):
     """dst[...] = src for two C-contiguous numpy arrays of equal byte size, on several host threads."""
     assert dst.flags['C_CONTIGUOUS'] and src.flags['C_CONTIGUOUS'] and dst.nbytes == src.nbytes
-    rc = lib().dcahost_parallel_copy(dst.ctypes.data, src.ctypes.data, dst.nbytes, threads)
+    rc = lib().dcahost_parallel_copy(dst.ctypes.data, src.ctypes.data, dst.nbytes, int(threads or DEFAULT_THREADS))
     if rc != 0:
         raise RuntimeError('dcahost_parallel_copy failed (%d)' % rc)
 
@@ -151,7 +162,7 @@ def read_tsv(path, sep='\t', threads=0):
     L = lib()
     h = ctypes.c_void_p()
     n, g, rb, cb = ctypes.c_long(), ctypes.c_long(), ctypes.c_long(), ctypes.c_long()
-    rc = L.dcahost_tsv_open(os.fsencode(path), sep.encode('ascii'), int(threads), ctypes.byref(h), ctypes.byref(n),
+    rc = L.dcahost_tsv_open(os.fsencode(path), sep.encode('ascii'), int(threads or DEFAULT_THREADS), ctypes.byref(h), ctypes.byref(n),
                             ctypes.byref(g), ctypes.byref(rb), ctypes.byref(cb))
     if rc != 0:
         return None
@@ -174,4 +185,4 @@ def read_tsv(path, sep='\t', threads=0):
 def checksum(a, threads=0):
     """Exact 64-bit content mark of a C-contiguous ndarray (every byte; dcahost_checksum)."""
     a = np.ascontiguousarray(a)
-    return int(lib().dcahost_checksum(a.ctypes.data, a.nbytes, int(threads)))
+    return int(lib().dcahost_checksum(a.ctypes.data, a.nbytes, int(threads or DEFAULT_THREADS)))

@@ -269,12 +269,16 @@ def train(adata, network, output_dir=None, optimizer='RMSprop', learning_rate=No
           early_stop=15, batch_size=32, clip_grad=5., save_weights=False,
           validation_split=0.1, tensorboard=False, verbose=True, threads=None,
           **kwds):
-    """Signature and defaults of dca/train.py:35-39.  ``threads`` (TF CPU pools) and
-    ``tensorboard`` have no meaning on the GPU path and are accepted and ignored; optimizers:
+    """Signature and defaults of dca/train.py:35-39.  ``threads`` sized TensorFlow's CPU pools in the reference
+    (train.py:41-48); here it sizes the host thread pools of the native host stages (staging copies, checksums, result
+    writers: dca_amd/hostlib.py) -- the step itself runs on the GPU.  ``tensorboard`` is accepted and ignored; optimizers:
     SGD, RMSprop, Adagrad, Adadelta, Adam, Adamax, Nadam (Keras defaults)."""
     eng = network.engine
     if eng is None:
         raise RuntimeError('network.build() must be called before train()')
+    if threads:
+        from . import hostlib
+        hostlib.set_threads(threads)
     # train.py:54-57: opt.__dict__[optimizer](lr=learning_rate, clipvalue=clip_grad), the optimizer's
     # own default learning rate when none is given
     eng.set_optimizer(optimizer)

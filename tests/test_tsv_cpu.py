@@ -155,3 +155,23 @@ def test_streamed_writer_writes_the_bytes_of_the_one_shot_writer(tmp_path):
     with hostlib.TsvStream(str(tmp_path / 'b.tsv'), 211, colnames=cn, index=True) as st:
         st.rows(padded[:10], rn[:10]); st.rows(padded[10:11], rn[10:11]); st.rows(padded[11:11], []); st.rows(padded[11:], rn[11:], threads=3)
     assert (tmp_path / 'a.tsv').read_bytes() == (tmp_path / 'b.tsv').read_bytes()
+
+
+def test_threads_argument_sizes_the_host_pools(tmp_path):
+    """`threads` of dca() / train() / the CLI (dca/train.py:41-48 sized TensorFlow's CPU pools with it) becomes the default
+    thread count of the native host stages; the files are the same bytes whatever the count."""
+    import numpy as np
+    from dca_amd import hostlib
+    m = np.random.RandomState(0).rand(300, 40).astype(np.float32)
+    old = hostlib.DEFAULT_THREADS
+    try:
+        outs = []
+        for n in (1, 3, 0):
+            assert hostlib.set_threads(n) == n
+            p = tmp_path / ('t%d.tsv' % n)
+            hostlib.write_tsv(str(p), m)
+            outs.append(p.read_bytes())
+            assert hostlib.checksum(m) == hostlib.checksum(m, threads=2)
+        assert outs[0] == outs[1] == outs[2]
+    finally:
+        hostlib.set_threads(old)
