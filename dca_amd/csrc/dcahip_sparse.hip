@@ -36,6 +36,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <type_traits>
+#include <utility>
 #include "dcahip.h"
 
 namespace {
@@ -115,6 +116,7 @@ using bf16x2v = __attribute__((ext_vector_type(2))) __bf16;
 using f32x2v = __attribute__((ext_vector_type(2))) float;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0)
 // the six products of one K = 16 step, small terms first (index 0 = leading piece)
@@ -209,6 +211,20 @@ struct DwArgs {
 
 constexpr int kDwLut = kLut;        // table entries per cell held in LDS: all of them (with 32, one block in two waits for a wave in the formula path)
 
+// Workgroups are dealt to the eight XCDs round-robin by their linear index, and each XCD has its own L2.  The weight-gradient
+// kernels want the workgroups of ONE row split (same table rows, same dZ pieces, all gene groups) behind the same L2: this
+// gives workgroup L the (group, split) cell that keeps each XCD on a contiguous range of the split-major order.
+__device__ __forceinline__ void xcd_cell(int& bx, int& by) {
+#ifdef DCA_EXP_NO_XCD_MAP
+    bx = blockIdx.x; by = blockIdx.y;
+#else
+    const int total = gridDim.x * gridDim.y, L = blockIdx.x + blockIdx.y * gridDim.x;
+    const int q = total >> 3, r = total & 7, x = L & 7;
+    const int cell = x * q + (x < r ? x : r) + (L >> 3);
+    bx = cell % (int)gridDim.x; by = cell / (int)gridDim.x;
+#endif
+}
+
 template <int H1>
 __global__ __launch_bounds__(64 * kDwWaves) void enc0_dw_kernel(DwArgs a) {
     constexpr int NTL = H1 / 32;
@@ -233,10 +249,12 @@ __global__ __launch_bounds__(64 * kDwWaves) void enc0_dw_kernel(DwArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
-    const int split = blockIdx.y;
+    int bx, by;
+    xcd_cell(bx, by);
+    const int split = by;
     const int rb = split * a.RS;
     const int re = min(a.B, rb + a.RS);
-    const int gbase = blockIdx.x * (32 * kDwWaves);
+    const int gbase = bx * (32 * kDwWaves);
     const int g0 = gbase + wave * 32;
     const bool wave_on = g0 < a.G;
     const int gene = g0 + l31;
@@ -390,7 +408,7 @@ __global__ __launch_bounds__(64 * kDwWaves) void enc0_dw_kernel(DwArgs a) {
         block(Buf0{}, Buf1{}, rg0);
         if (rg0 + RB < re) block(Buf1{}, Buf0{}, rg0 + RB);
     }
-    if (blockIdx.x == 0 && tid < H1) {                   // column sums of this split's rows: its K steps in order
+    if (bx == 0 && tid < H1) {                           // column sums of this split's rows: its K steps in order
         float s = 0.f;
         for (int ks = rb / kKS; ks * kKS < re; ++ks) s += a.Spp[(long)ks * H1 + tid];
         a.Sp[(long)split * H1 + tid] = s;
@@ -402,6 +420,362 @@ __global__ __launch_bounds__(64 * kDwWaves) void enc0_dw_kernel(DwArgs a) {
         for (int e = 0; e < 16; ++e)
             a.P[((long)split * a.Gs + g0 + rowmap(e, hi)) * H1 + 32 * t + l31] = acc[t][e];
 }
+
+// ---- second form of the weight gradient (64 first-layer units): operands staged global -> LDS directly into a deep ring,
+// a software pipeline over the K steps, the two waves of a SIMD out of phase.  What changed against enc0_dw_kernel above and why
+// (its counters: MfmaUtil 25 %, 46 % of a wave's cycles at s_waitcnt, 343 vector + 103 LDS instructions per 48 matrix
+// instructions; each block ran barrier -> counts -> table entries -> products with every LDS round trip exposed, both waves of
+// a SIMD in the same phase -- profiles/r05k_*, r05l_*):
+//   * a wave owns TWO 32-gene tiles (a workgroup 512 genes): the dZ fragments of a K step are read from LDS once for both,
+//     the table rows and dZ of a batch row are fetched by half as many workgroups;
+//   * a stage is ONE K step (16 batch rows: their counts, table rows and split dZ, 22.25 KB); six stages in a ring filled by
+//     global_load_lds_dwordx4 (no staging registers, no LDS store pass) FIVE steps ahead, retired with a counted
+//     s_waitcnt vmcnt; one barrier per step.  (Four stages -- two workgroups of four waves per CU -- were measured: the two
+//     steps of lead do not cover the memory round trip, 46 % of the wave cycles at the vmcnt wait.)
+//   * software pipeline over the steps: in step k a wave requests step k + 5, reads the counts of step k + 1, the table
+//     entries of step k (its counts arrived during step k - 1) and the dZ fragments of step k, and issues the 24 matrix
+//     instructions of step k - 1: every LDS round trip stands behind matrix work;
+//   * waves 0..3 read first and multiply second, waves 4..7 (the other wave of each SIMD) multiply first: one wave's matrix
+//     instructions run while the other addresses, reads and repacks;
+//   * all LDS reads of the loop are written as instructions (lds_read_*): the compiler does not know which LDS bytes a
+//     global_load_lds writes and puts s_waitcnt vmcnt(0) in front of every LDS read it generates itself (measured with plain
+//     reads: the ring stands still for a memory round trip per step).
+// Same operands, same six products, same summation order over the rows of a split as the first form (the split count differs:
+// dw2_splits): results agree to the association of the split sums.
+constexpr int kD2Waves = 8;
+constexpr int kD2MT = 2;                                   // 32-gene tiles per wave
+constexpr int kD2Genes = kD2Waves * kD2MT * 32;            // 512 genes per workgroup
+constexpr int kD2RB = kKS;                                 // rows per split are a multiple of this
+constexpr int kD2MaxRS = 1024;                             // batch rows per split at most (their storage rows sit in LDS)
+constexpr int kD2Stages = 6;
+constexpr int kD2Lead = kD2Stages - 1;                     // a request goes into the stage the step before the current one used
+constexpr int kD2LutB = kKS * kLut * 8;                    // 8192: 16 table rows of 512 bytes
+constexpr int kD2DzB = dz_step_elems(64) * 2;              // 6144: one K step of split dZ
+constexpr int kD2CodeChunk = 1024 + 32;                    // two count rows of 512 bytes land as one chunk; rows 8 apart sit 32 banks apart
+constexpr int kD2CodeB = 8 * kD2CodeChunk;                 // 8448
+constexpr int kD2StageB = kD2LutB + kD2DzB + kD2CodeB;     // 22784
+
+// LDS reads as instructions (the caller waits: s_waitcnt lgkmcnt tied to the destinations)
+template <int OFF> __device__ __forceinline__ void lds_read_u8(unsigned& r, unsigned ad) { asm volatile("ds_read_u8 %0, %1 offset:%2" : "=v"(r) : "v"(ad), "n"(OFF)); }
+template <int OFF> __device__ __forceinline__ void lds_read_b64(u32x2& r, unsigned ad) { asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r) : "v"(ad), "n"(OFF)); }
+template <int OFF> __device__ __forceinline__ void lds_read_b128(u32x4& r, unsigned ad) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(ad), "n"(OFF)); }
+template <int... I, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
+#ifdef DCA_DW_TIMING
+__device__ long long* g_dw_timing = nullptr;         // [workgroup][8]: clock at kernel entry, after the prologue, after the loop, at the end (wave 0) + realtime at entry / end
+#define DWSTAMP(i) if (g_dw_timing && tid == 0) g_dw_timing[(blockIdx.x + blockIdx.y * gridDim.x) * 8 + (i)] = (i) >= 4 ? (long long)__builtin_amdgcn_s_memrealtime() : (long long)__builtin_readcyclecounter();
+#else
+#define DWSTAMP(i)
+#endif
+__global__ __launch_bounds__(64 * kD2Waves) __attribute__((amdgpu_waves_per_eu(2, 2))) void enc0_dw2_kernel(DwArgs a) {
+    constexpr int H1 = 64, NTL = 2;
+    constexpr int KSE = dz_step_elems(H1);
+    constexpr int NT = 64 * kD2Waves;
+    static_assert(kLut == 64 && kKS == 16 && kD2DzB == 6 * 1024 && kD2Waves == 8, "chunks of the loader");
+    __shared__ __attribute__((aligned(16))) unsigned char ring[kD2Stages * kD2StageB];
+    __shared__ int srow_all[kD2MaxRS];
+    __shared__ float fac_all[kD2MaxRS];                    // size factors of the split's rows (the formula path)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    DWSTAMP(0) DWSTAMP(4)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    int bx, by;
+    xcd_cell(bx, by);
+    const int split = by;
+    const int rb = split * a.RS;
+    const int re = min(a.B, rb + a.RS);
+    const int gbase = bx * kD2Genes;
+    const int g0 = gbase + wave * (32 * kD2MT);
+
+    f32x16 acc[kD2MT][NTL];
+#pragma unroll
+    for (int m = 0; m < kD2MT; ++m)
+#pragma unroll
+        for (int t = 0; t < NTL; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[m][t][e] = 0.f;
+
+    // storage rows of the split's rows; entries up to the end of the last K step repeat the last row (its dZ rows are zero
+    // beyond B: enc0_split_dz_kernel)
+    const int nrows = re > rb ? re - rb : 0;           // (a split behind the end of the batch is empty: it writes zero partials)
+    const int nsteps = (nrows + kKS - 1) / kKS;
+    for (int i = tid; i < nsteps * kKS; i += NT) {
+        const int sr = a.srowb[rb + (i < nrows ? i : nrows - 1)];
+        srow_all[i] = sr;
+        fac_all[i] = a.fac ? a.fac[sr] : 1.f;
+    }
+    // count bytes of genes behind the end of a stored row are never loaded: those places of the ring stay zero
+    for (int i = tid; i < kD2Stages * kD2CodeB / 16; i += NT) {
+        const int st = i / (kD2CodeB / 16), u = i % (kD2CodeB / 16);
+        *reinterpret_cast<u32x4*>(ring + st * kD2StageB + kD2LutB + kD2DzB + u * 16) = u32x4{0u, 0u, 0u, 0u};
+    }
+    __syncthreads();
+
+    // ---- the loader: a wave instruction moves 1 KB (lane-linear in LDS).  Per step 8 chunks of table rows and 8 of counts
+    // (rows 2 wave and 2 wave + 1 of the step, one of each per wave) and 6 of split dZ (waves 0..5).
+    const unsigned ring_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)ring;
+    const unsigned srow_base = (unsigned)(size_t)(__attribute__((address_space(3))) int*)srow_all;
+    const int ks_first = rb / kKS;
+    const bool cseg_ok = gbase + l31 * 16 < a.c.ldc;
+    const bool three = wave < 6;                           // requests of this wave per step: 3 or 2
+    const unsigned sr_ad = srow_base + (unsigned)(2 * wave + hi) * 4u;
+    auto issue_srow = [&](int k, int& s0) __attribute__((always_inline)) {   // storage row of batch row 2 wave + hi of step k
+        asm volatile("ds_read_b32 %0, %1" : "=v"(s0) : "v"(sr_ad + (unsigned)k * (kKS * 4u)));
+    };
+    auto request = [&](int k, int stage, int s0) __attribute__((always_inline)) {
+        unsigned char* st = ring + stage * kD2StageB;
+        const unsigned char* lut = reinterpret_cast<const unsigned char*>(a.lutp);
+        const unsigned char* dz = reinterpret_cast<const unsigned char*>(a.DZP + (long)(ks_first + k) * KSE);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(lut + (long)s0 * (kLut * 8) + l31 * 16),
+                                         (__attribute__((address_space(3))) void*)(st + wave * 1024), 16, 0, 0);
+        if (cseg_ok)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.c.yc + (long)s0 * a.c.ldc + gbase + l31 * 16),
+                                             (__attribute__((address_space(3))) void*)(st + kD2LutB + kD2DzB + wave * kD2CodeChunk), 16, 0, 0);
+        if (three)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dz + wave * 1024 + lane * 16),
+                                             (__attribute__((address_space(3))) void*)(st + kD2LutB + wave * 1024), 16, 0, 0);
+    };
+    // own requests of all steps but the `newer` newest have landed
+    auto retire = [&](int newer) __attribute__((always_inline)) {
+        if (newer <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (three) {
+            if (newer == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else if (newer == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        } else {
+            if (newer == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else if (newer == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        }
+    };
+
+    // ---- the stages of a K step: counts -> table entries -> six products per (gene tile, dZ tile)
+    const unsigned code_off = ring_base + kD2LutB + kD2DzB + (4 * hi) * kD2CodeChunk + wave * (32 * kD2MT) + l31;   // row 8 hi + j: chunk 4 hi + j / 2, row j % 2 of it
+    const unsigned lut_off = ring_base + 8 * hi * (kLut * 8);
+    const unsigned dz_off = ring_base + kD2LutB + (hi * 32 + l31) * 16;
+    auto issue_counts = [&](int stage, unsigned (&code)[kD2MT][8]) __attribute__((always_inline)) {
+        const unsigned ad = code_off + (unsigned)stage * kD2StageB;
+        static_for<kD2MT * 8>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int m = decltype(ic)::value >> 3, j = decltype(ic)::value & 7;
+            lds_read_u8<(j >> 1) * kD2CodeChunk + (j & 1) * 512 + 32 * m>(code[m][j], ad);      // gene g0 + 32 m + l31
+        });
+    };
+    // (a count beyond the table reads past its row -- still inside the ring: the value is replaced below)
+    auto issue_entries = [&](int stage, const unsigned (&code)[kD2MT][8], u32x2 (&ent)[kD2MT][8]) __attribute__((always_inline)) {
+        const unsigned ad = lut_off + (unsigned)stage * kD2StageB;
+        static_for<kD2MT * 8>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int m = decltype(ic)::value >> 3, j = decltype(ic)::value & 7;
+            lds_read_b64<j * kLut * 8>(ent[m][j], ad + code[m][j] * 8u);
+        });
+    };
+    auto issue_dz = [&](int stage, u32x4 (&Bf)[NTL][3]) __attribute__((always_inline)) {
+        const unsigned ad = dz_off + (unsigned)stage * kD2StageB;
+        static_for<NTL * 3>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int t = decltype(ic)::value / 3, q = decltype(ic)::value % 3;
+            lds_read_b128<(q * NTL + t) * 1024>(Bf[t][q], ad);
+        });
+    };
+    // rare: counts beyond the table take the formula itself -- only the (tile, row) places some lane of the wave needs, one at
+    // a time; count, size factor and storage row come from LDS (a workgroup that holds a highly expressed gene comes here in
+    // most steps, and all its waves wait at the barrier meanwhile: each visit cost ~3300 cycles with select chains over the
+    // register arrays and global loads -- those workgroups ran 25 % longer than the others, profiles/r05n_*)
+    const unsigned fac_base = (unsigned)(size_t)(__attribute__((address_space(3))) float*)fac_all;
+#ifdef DCA_DW_TIMING
+    int n_visits = 0, n_places = 0;
+#endif
+    auto beyond_table = [&](int k, int stage, const unsigned (&code)[kD2MT][8], u32x2 (&ent)[kD2MT][8]) __attribute__((always_inline)) {
+        unsigned places = 0u;
+        static_for<kD2MT * 8>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int q = decltype(ic)::value;
+            if (__ballot(code[q >> 3][q & 7] >= (unsigned)kLut)) places |= 1u << q;
+        });
+#ifdef DCA_DW_TIMING
+        n_visits += 1; n_places += __builtin_popcount(places);
+#endif
+#pragma unroll 1
+        while (places) {
+            const int q = __builtin_ctz(places);
+            places &= places - 1u;
+            const int m = q >> 3, j = q & 7;
+            const unsigned ro = (unsigned)(k * kKS + 8 * hi + j) * 4u;
+            unsigned c; float fc; int srow;
+            asm volatile("ds_read_u8 %0, %1" : "=v"(c) : "v"(code_off + (unsigned)(stage * kD2StageB + (j >> 1) * kD2CodeChunk + (j & 1) * 512 + 32 * m)));
+            asm volatile("ds_read_b32 %0, %1" : "=v"(fc) : "v"(fac_base + ro));
+            asm volatile("ds_read_b32 %0, %1" : "=v"(srow) : "v"(srow_base + ro));
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c), "+v"(fc), "+v"(srow));
+            const bool on = c >= (unsigned)kLut;
+            float val = (float)c;
+            if (__ballot(on && c == 255u)) { if (on && c == 255u) val = escaped_count(a.c, srow, g0 + 32 * m + l31); }
+            float x = a.fac ? __fdiv_rn(val, fc) : val;
+            if (a.do_log) x = log1pf(x);
+            const uint2 e = split_entry(x);
+            static_for<kD2MT * 8>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int Q = decltype(ic)::value;
+                if (q == Q) {                                   // (uniform: one of the sixteen runs)
+                    ent[Q >> 3][Q & 7][0] = on ? e.x : ent[Q >> 3][Q & 7][0];
+                    ent[Q >> 3][Q & 7][1] = on ? e.y : ent[Q >> 3][Q & 7][1];
+                }
+            });
+        }
+    };
+#define DCA_TIE8(x, m) "+v"(x[m][0]), "+v"(x[m][1]), "+v"(x[m][2]), "+v"(x[m][3]), "+v"(x[m][4]), "+v"(x[m][5]), "+v"(x[m][6]), "+v"(x[m][7])
+#define DCA_TIE_ACC "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1])
+
+    if (nsteps > 0) {
+        u32x4 A0[kD2MT][3], A1[kD2MT][3], B0[NTL][3], B1[NTL][3];
+        unsigned c0[kD2MT][8], c1[kD2MT][8];
+        u32x2 ent[kD2MT][8];
+        int s0 = 0;
+#pragma unroll
+        for (int m = 0; m < kD2MT; ++m)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) A0[m][q] = u32x4{0u, 0u, 0u, 0u};        // (step "-1": zero products)
+#pragma unroll
+        for (int t = 0; t < NTL; ++t)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) B0[t][q] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int k = 0; k < kD2Lead; ++k)
+            if (k < nsteps) {
+                issue_srow(k, s0);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(s0));
+                request(k, k, s0);
+            }
+        if (kD2Lead < nsteps) issue_srow(kD2Lead, s0);
+        retire(min(kD2Lead, nsteps) - 2);               // steps 0 and 1 have landed (mine)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        issue_counts(0, c0);
+        int sk = 0;                                       // stage of step k
+        DWSTAMP(1)
+        // One matrix instruction of the six-product scheme: product PR (0..5, small terms first) of gene tile M with dZ tile T.
+        // The accumulator is tied to an (empty) instruction statement behind it: the compiler keeps the matrix instruction
+        // between the LDS / vector work written before and after it.
+#define DCA_MF(Ap, Bp, M, T, PR) { constexpr int PA_[6] = {2, 1, 0, 1, 0, 0}, PB_[6] = {0, 1, 2, 0, 1, 0}; \
+            acc[M][T] = MFMA16(Ap[M][PA_[PR]], Bp[T][PB_[PR]], acc[M][T]); asm volatile("" : "+v"(acc[M][T])); }
+        // step k: cK = its counts (requested in the step before), Ap / Bp = table entries / dZ fragments of step k - 1; leaves
+        // the counts of step k + 1 in cN, the operands of step k in An / Bk.  A wave's vector and LDS instructions ride behind
+        // its OWN matrix instructions (about five per matrix instruction are free, tools/microbench/mfma_valu_interleave.hip);
+        // the other wave of the SIMD does not hide them (measured: the two waves' times add).
+        auto step = [&](int k, unsigned (&cK)[kD2MT][8], unsigned (&cN)[kD2MT][8], u32x4 (&Ap)[kD2MT][3], u32x4 (&An)[kD2MT][3],
+                        u32x4 (&Bp)[NTL][3], u32x4 (&Bk)[NTL][3]) __attribute__((always_inline)) {
+            const int sn = sk + 1 == kD2Stages ? 0 : sk + 1, sp = sk == 0 ? kD2Stages - 1 : sk - 1;
+            asm volatile("s_waitcnt lgkmcnt(0)" : DCA_TIE8(cK, 0), DCA_TIE8(cK, 1), "+v"(s0));
+            if (k + kD2Lead < nsteps) request(k + kD2Lead, sp, s0);   // into the stage of step k - 1: everyone read it before the barrier
+            unsigned any = 0u;
+#pragma unroll
+            for (int m = 0; m < kD2MT; ++m)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) any |= cK[m][j];
+            // ---- gene tile 0 of step k - 1, behind it: the table entries and dZ fragments of step k
+            const unsigned ead = lut_off + (unsigned)sk * kD2StageB, dad = dz_off + (unsigned)sk * kD2StageB;
+            static_for<12>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value, T = i & 1, PR = i >> 1;
+                DCA_MF(Ap, Bp, 0, T, PR)
+                if constexpr (i < 8) {                    // entries of (tile, row) places 2 i and 2 i + 1
+                    constexpr int q0 = 2 * i, q1 = 2 * i + 1;
+                    lds_read_b64<(q0 & 7) * kLut * 8>(ent[q0 >> 3][q0 & 7], ead + cK[q0 >> 3][q0 & 7] * 8u);
+                    lds_read_b64<(q1 & 7) * kLut * 8>(ent[q1 >> 3][q1 & 7], ead + cK[q1 >> 3][q1 & 7] * 8u);
+                } else if constexpr (i < 11) {            // dZ fragments 2 (i - 8) and 2 (i - 8) + 1
+                    constexpr int f0 = 2 * (i - 8), f1 = f0 + 1;
+                    lds_read_b128<((f0 % 3) * NTL + f0 / 3) * 1024>(Bk[f0 / 3][f0 % 3], dad);
+                    lds_read_b128<((f1 % 3) * NTL + f1 / 3) * 1024>(Bk[f1 / 3][f1 % 3], dad);
+                } else {
+                    if (k + 1 + kD2Lead < nsteps) issue_srow(k + 1 + kD2Lead, s0);
+                }
+            });
+            asm volatile("s_waitcnt lgkmcnt(0)" : DCA_TIE8(ent, 0), DCA_TIE8(ent, 1), "+v"(s0));
+            asm volatile("" : "+v"(Bk[0][0]), "+v"(Bk[0][1]), "+v"(Bk[0][2]), "+v"(Bk[1][0]), "+v"(Bk[1][1]), "+v"(Bk[1][2]));
+            if (__ballot(any >= (unsigned)kLut)) beyond_table(k, sk, cK, ent);
+            // ---- gene tile 1 of step k - 1, behind it: the operands of step k from its entries, the counts of step k + 1
+            const unsigned cad = code_off + (unsigned)sn * kD2StageB;
+            static_for<12>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value, T = i & 1, PR = i >> 1;
+                DCA_MF(Ap, Bp, 1, T, PR)
+                if constexpr (i < 8) {                    // counts of places 2 i, 2 i + 1 of step k + 1 (behind the last step: a stale stage, not used)
+                    constexpr int q0 = 2 * i, q1 = 2 * i + 1;
+                    lds_read_u8<((q0 & 7) >> 1) * kD2CodeChunk + (q0 & 1) * 512 + 32 * (q0 >> 3)>(cN[q0 >> 3][q0 & 7], cad);
+                    lds_read_u8<((q1 & 7) >> 1) * kD2CodeChunk + (q1 & 1) * 512 + 32 * (q1 >> 3)>(cN[q1 >> 3][q1 & 7], cad);
+                }
+                {                                         // two of the 24 operand registers of step k
+                    constexpr int M = i / 6, Q = (i % 6) / 2, J0 = (i & 1) * 2;
+#pragma unroll
+                    for (int jj = J0; jj < J0 + 2; ++jj) {
+                        const unsigned e1 = ent[M][2 * jj + 1][Q == 2 ? 1 : 0], e0 = ent[M][2 * jj][Q == 2 ? 1 : 0];
+                        An[M][Q][jj] = __builtin_amdgcn_perm(e1, e0, Q == 1 ? 0x07060302u : 0x05040100u);
+                    }
+                    if constexpr ((i & 1) == 1) asm volatile("" : "+v"(An[M][Q]));
+                }
+            });
+            retire(min(k + kD2Lead, nsteps - 1) - (k + 2));   // step k + 2 has landed (mine); the LDS reads of stage sk are in registers
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            sk = sn;
+        };
+        int k = 0;
+#pragma unroll 1
+        for (; k + 1 < nsteps; k += 2) {
+            step(k, c0, c1, A0, A1, B0, B1);
+            step(k + 1, c1, c0, A1, A0, B1, B0);
+        }
+        if (k < nsteps) {
+            step(k, c0, c1, A0, A1, B0, B1);
+            asm volatile("s_waitcnt lgkmcnt(0)" : DCA_TIE8(c1, 0), DCA_TIE8(c1, 1));
+#pragma unroll
+            for (int m = 0; m < kD2MT; ++m)
+#pragma unroll
+                for (int t = 0; t < NTL; ++t) { MFMA_X3(A1[m], B1[t], acc[m][t]) }
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" : DCA_TIE8(c0, 0), DCA_TIE8(c0, 1));
+#pragma unroll
+            for (int m = 0; m < kD2MT; ++m)
+#pragma unroll
+                for (int t = 0; t < NTL; ++t) { MFMA_X3(A0[m], B0[t], acc[m][t]) }
+        }
+#undef DCA_MF
+        DWSTAMP(2)
+#ifdef DCA_DW_TIMING
+        if (g_dw_timing && lane == 0 && n_visits) {
+            atomicAdd((unsigned long long*)&g_dw_timing[(blockIdx.x + blockIdx.y * gridDim.x) * 8 + 6], (unsigned long long)n_visits);
+            atomicAdd((unsigned long long*)&g_dw_timing[(blockIdx.x + blockIdx.y * gridDim.x) * 8 + 7], (unsigned long long)n_places);
+        }
+#endif
+    }
+#undef DCA_TIE8
+#undef DCA_TIE_ACC
+    if (bx == 0 && tid < H1) {                           // column sums of this split's rows: its K steps in order
+        float sum = 0.f;
+        for (int ks = rb / kKS; ks * kKS < re; ++ks) sum += a.Spp[(long)ks * H1 + tid];
+        a.Sp[(long)split * H1 + tid] = sum;
+    }
+#pragma unroll
+    for (int m = 0; m < kD2MT; ++m)
+#pragma unroll
+        for (int t = 0; t < NTL; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                a.P[((long)split * a.Gs + g0 + 32 * m + rowmap(e, hi)) * H1 + 32 * t + l31] = acc[m][t][e];
+    DWSTAMP(3) DWSTAMP(5)
+}
+
+// splits of the batch for the second form: one workgroup per CU (256 slots), at least one 32-row block each, at most
+// kD2MaxRS rows each
+inline int dw2_splits(int B, int G) {
+    const int groups = (G + kD2Genes - 1) / kD2Genes;
+    int ns = 256 / groups;
+    const int maxs = (B + kD2RB - 1) / kD2RB;
+    if (ns > maxs) ns = maxs;
+    if (ns > 16) ns = 16;
+    if (ns < 1) ns = 1;
+    const int need = (B + kD2MaxRS - 1) / kD2MaxRS;
+    if (ns < need) ns = need;
+    return ns;
+}
+inline int dw2_rows_per_split(int B, int ns) { return (((B + ns - 1) / ns) + kD2RB - 1) / kD2RB * kD2RB; }
 
 struct DwFinishArgs {
     const float* P; long Gs; const float* Sp; int NS;
@@ -890,7 +1264,15 @@ inline bool width_ok(int H1) { return H1 == 16 || H1 == 32 || H1 == 64 || H1 == 
 inline bool dw_width_ok(int H1) { return H1 == 32 || H1 == 64 || H1 == 128; }
 
 // row splits: as many workgroups as are resident at once (or just below): one round
+// 64 units: the ring form (enc0_dw2_kernel) from kD2MinRows batch rows up (below, its longer prologue and the 512-gene
+// workgroups cost more than the pipeline saves: tools/ab_enc0_dw.py); dcahip_enc0_dw_set_form(0 / 2) forces the first / the
+// ring form at every size (A/B runs, tests)
+constexpr int kD2MinRows = 1024;
+int g_dw_form = 1;
+inline bool dw_second_form(int H1, int B) { return H1 == 64 && (g_dw_form == 2 || (g_dw_form == 1 && B >= kD2MinRows)); }
+
 inline int dw_splits(int B, int G, int H1) {
+    if (dw_second_form(H1, B)) return dw2_splits(B, G);
     const int groups = (G + 32 * kDwWaves - 1) / (32 * kDwWaves);
     int ns = 256 / groups;                               // one 8-wave workgroup per CU (registers)
     const int maxs = (B + kDwRB - 1) / kDwRB;
@@ -902,6 +1284,7 @@ inline int dw_splits(int B, int G, int H1) {
     return ns;
 }
 inline int dw_rows_per_split(int B, int ns, int H1) {
+    if (dw_second_form(H1, B)) return dw2_rows_per_split(B, ns);
     return (((B + ns - 1) / ns) + kDwRB - 1) / kDwRB * kDwRB;
 }
 inline long r16(long x) { return (x + 15) / 16 * 16; }
@@ -1039,10 +1422,22 @@ extern "C" int dcahip_enc0_lut(const float* fac, int do_log, int n, void* lutp, 
 // workspace: P [NS][Gs][H1] | Sp [NS][H1] | Spp [steps][H1] | DZP [steps][...] bf16
 extern "C" long dcahip_enc0_dw_sparse_workspace_bytes(int B, int G, int H1) {
     if (!dw_width_ok(H1) || B <= 0 || G <= 0) return 0;
-    const int ns = dw_splits(B, G, H1);
-    const long Gs = ((long)G + 255) / 256 * 256;
+    // (sufficient for either form of the 64-unit kernel: the form can be switched between the query and the launch)
+    int ns = dw_splits(B, G, H1);
+    if (H1 == 64) { const int n2 = dw2_splits(B, G); if (n2 > ns) ns = n2; const int old = g_dw_form; g_dw_form = 0; const int n1 = dw_splits(B, G, H1); g_dw_form = old; if (n1 > ns) ns = n1; }
+    const long Gs = ((long)G + 511) / 512 * 512;
     const long steps = (B + kKS - 1) / kKS;
     return r16(((long)ns * Gs * H1 + (long)ns * H1) * 4) + r16(steps * H1 * 4) + r16(steps * (long)dz_step_elems(H1) * 2) + r16((long)B * 4);
+}
+
+
+#ifdef DCA_DW_TIMING
+extern "C" void dcahip_enc0_dw_set_timing(long long* buf) { hipMemcpyToSymbol(HIP_SYMBOL(g_dw_timing), &buf, sizeof(buf)); }
+#endif
+extern "C" int dcahip_enc0_dw_set_form(int form) {
+    const int old = g_dw_form;
+    if (form == 0 || form == 1 || form == 2) g_dw_form = form;
+    return old;
 }
 
 extern "C" int dcahip_enc0_dw_sparse(const unsigned char* Yc, long ldc, const int* ovf_ptr, const int* ovf_col,
@@ -1055,7 +1450,8 @@ extern "C" int dcahip_enc0_dw_sparse(const unsigned char* Yc, long ldc, const in
         return DCAHIP_EINVAL;
     if (workspace_bytes < dcahip_enc0_dw_sparse_workspace_bytes(B, G, H1)) return DCAHIP_EINVAL;
     const int ns = dw_splits(B, G, H1);
-    const long Gs = ((long)G + 255) / 256 * 256;
+    if (dw_second_form(H1, B) && dw_rows_per_split(B, ns, H1) > kD2MaxRS) return DCAHIP_EINVAL;
+    const long Gs = ((long)G + 511) / 512 * 512;
     const long steps = (B + kKS - 1) / kKS;
     char* wsb = static_cast<char*>(workspace);
     DwArgs a;
@@ -1077,7 +1473,11 @@ extern "C" int dcahip_enc0_dw_sparse(const unsigned char* Yc, long ldc, const in
             hipLaunchKernelGGL(enc0_dw_kernel<32>, grid, block, 0, s, a); break;
         case 64:
             hipLaunchKernelGGL(enc0_split_dz_kernel<64>, dim3((unsigned)steps), dim3(256), 0, s, dZ, ldz, B, perm, cursor, row_base, DZP, Spp, srowb);
-            hipLaunchKernelGGL(enc0_dw_kernel<64>, grid, block, 0, s, a); break;
+            if (dw_second_form(H1, B))
+                hipLaunchKernelGGL(enc0_dw2_kernel, dim3((unsigned)((G + kD2Genes - 1) / kD2Genes), (unsigned)ns), dim3(64 * kD2Waves), 0, s, a);
+            else
+                hipLaunchKernelGGL(enc0_dw_kernel<64>, grid, block, 0, s, a);
+            break;
         default:
             hipLaunchKernelGGL(enc0_split_dz_kernel<128>, dim3((unsigned)steps), dim3(256), 0, s, dZ, ldz, B, perm, cursor, row_base, DZP, Spp, srowb);
             hipLaunchKernelGGL(enc0_dw_kernel<128>, grid, block, 0, s, a); break;

@@ -121,6 +121,11 @@ class HipOps:
                                                B, G, H1, p(dZ), ldz, p(gW), ldg, p(ws), ws.numel() * ws.element_size(),
                                                hip.stream()), 'enc0_dw_sparse')
 
+    def enc0_dw_set_form(self, form):
+        """Which kernel the 64-unit byte-store weight gradient takes (1, default: the ring kernel from 1024 rows up; 0: always the
+        first kernel; 2: always the ring kernel); returns the previous."""
+        return int(self.L.dcahip_enc0_dw_set_form(int(form)))
+
     @property
     def enc0_dw_small_max_rows(self):
         return int(self.L.dcahip_enc0_dw_small_max_rows())

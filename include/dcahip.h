@@ -586,6 +586,13 @@ int dcahip_enc0_dw_small(const unsigned char* Yc, long ldc, const int* ovf_ptr, 
                          const long long* cursor, long row_base, int B, int G, int H1, const float* dZ, long ldz,
                          float* gW, long ldg, void* stream);
 long dcahip_enc0_dw_sparse_workspace_bytes(int B, int G, int H1);
+/* The 64-unit weight gradient has two kernels (csrc/dcahip_sparse.hip): enc0_dw_kernel (counts through an LDS tile, lookups
+ * and products of a 64-row block between two barriers) and enc0_dw2_kernel (512 genes per workgroup, operands staged
+ * global -> LDS into a six-stage ring five K steps ahead, a wave's LDS / vector work behind its own matrix instructions).
+ * form 1 (default): the ring kernel from 1024 batch rows up, the first kernel below; 0: always the first; 2: always the ring
+ * kernel.  Returns the previous form; other values only read it.  Same products, same row order inside a split; the number
+ * of splits differs.  A switch for A/B runs and the parity tests of both; no reference call site. */
+int dcahip_enc0_dw_set_form(int form);
 int dcahip_enc0_dw_sparse(const unsigned char* Yc, long ldc, const int* ovf_ptr, const int* ovf_col,
                           const float* ovf_val, const float* fac, int do_log, const void* lutp, const float* mean,
                           const float* stdv, const int* perm, const long long* cursor, long row_base,

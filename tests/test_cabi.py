@@ -93,17 +93,26 @@ def test_first_layer_plans_are_pure_functions_of_the_shape():
         tile = 3 * (H1 // 32) * 4 * 2 * 32 * 8 * 2
         want = r16(n_ms * tile) + r16(n_ms * H1 * 8) + r16(chunks * rgs * 256 * H1 * 4)
         assert L.dcahip_enc0_fwd_lut_workspace_bytes(B, G, H1) == want, (B, G, H1)
-    # weight gradient: [splits][Gs][H1] partials + column sums ...: the number of splits follows from the size
+    # weight gradient: [splits][Gs][H1] partials + column sums ...: the number of splits follows from the size.  The 64-unit
+    # gradient has two kernels with different split counts (dcahip_enc0_dw_set_form); the workspace covers either
     def splits(B, G, H1):
         groups = (G + 255) // 256
         ns = max(1, min(16, 256 // groups, (B + 63) // 64))
         return max(ns, (B + 2047) // 2048)
-    for B, G, H1 in ((4096, 20000, 64), (65536, 20000, 64), (40000, 2000, 32), (512, 25000, 128)):
-        ns, Gs, steps = splits(B, G, H1), (G + 255) // 256 * 256, (B + 15) // 16
+
+    def splits2(B, G):                        # the ring form: 512 genes per workgroup, one workgroup per CU
+        groups = (G + 511) // 512
+        ns = max(1, min(16, 256 // groups, (B + 15) // 16))
+        return max(ns, (B + 1023) // 1024)
+    for B, G, H1 in ((4096, 20000, 64), (65536, 20000, 64), (40000, 2000, 32), (512, 25000, 128), (300, 77, 64)):
+        ns = max(splits(B, G, H1), splits2(B, G)) if H1 == 64 else splits(B, G, H1)
+        Gs, steps = (G + 511) // 512 * 512, (B + 15) // 16
         dz = 3 * (H1 // 32) * 2 * 32 * 8
         want = r16((ns * Gs * H1 + ns * H1) * 4) + r16(steps * H1 * 4) + r16(steps * dz * 2) + r16(B * 4)
         assert L.dcahip_enc0_dw_sparse_workspace_bytes(B, G, H1) == want, (B, G, H1)
-        assert (B + ns - 1) // ns <= 2048
+        assert (B + splits(B, G, H1) - 1) // splits(B, G, H1) <= 2048
+        if H1 == 64:
+            assert ((B + splits2(B, G) - 1) // splits2(B, G) + 15) // 16 * 16 <= 1024 or B > 16 * 1024
     assert L.dcahip_enc0_dw_sparse_workspace_bytes(4096, 20000, 16) == 0
 
 
@@ -122,10 +131,10 @@ def test_first_layer_kernels_stay_inside_their_budget():
     assert len(names) == len(scratch) == len(lds)
     seen = 0
     for n, s, l in zip(names, scratch, lds):
-        if 'enc0_dw_kernel' in n or 'enc0_fwd_lut_kernel' in n:
+        if 'enc0_dw_kernel' in n or 'enc0_dw2_kernel' in n or 'enc0_fwd_lut_kernel' in n:
             seen += 1
             assert s == 0 and l <= 163840, (n, s, l)
-    assert seen == 5          # weight gradient at 32 / 64 / 128 units, forward at 32 / 64
+    assert seen == 6          # weight gradient at 32 / 64 / 128 units + the ring form at 64, forward at 32 / 64
 
 
 def _blocks_with_matrix_instructions(asm, kernel_substr):

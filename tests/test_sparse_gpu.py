@@ -160,18 +160,24 @@ def test_sparse_first_layer_vs_numpy(ops, B, G, H1, gather, use_fac, do_log, sca
     # ---- weight + bias gradient
     if not ops.enc0_sparse_supported(H1):
         return
-    gWd = torch.full((G + 1, H1), 7.0, device='cuda')
-    ws = torch.full((ops.enc0_dw_sparse_workspace_bytes(B, G, H1) // 4 + 4,), float('nan'), device='cuda')
-    ops.enc0_dw_sparse(cc, dperm, dcur, base, B, G, H1, ddZ, H1, gWd, H1, ws)
-    torch.cuda.synchronize()
-    got = gWd.cpu().numpy()
-    err = np.abs(got[:G] - gW_ref)
-    assert (err <= 1e-6 * gW_abs + 1e-30).all(), float((err / np.maximum(gW_abs, 1e-30)).max())
-    np.testing.assert_allclose(got[G], dZ.sum(0), rtol=0, atol=2e-6 * np.abs(dZ).sum(0).max())
-    # deterministic: a second launch reproduces every bit
-    gW2 = torch.zeros_like(gWd)
-    ops.enc0_dw_sparse(cc, dperm, dcur, base, B, G, H1, ddZ, H1, gW2, H1, ws)
-    assert torch.equal(gW2, gWd)
+    # (64 units: both kernels at every size -- the library itself takes the ring kernel from 1024 rows up)
+    for form in ((0, 2) if H1 == 64 else (1,)):
+        prev = ops.enc0_dw_set_form(form)
+        try:
+            gWd = torch.full((G + 1, H1), 7.0, device='cuda')
+            ws = torch.full((ops.enc0_dw_sparse_workspace_bytes(B, G, H1) // 4 + 4,), float('nan'), device='cuda')
+            ops.enc0_dw_sparse(cc, dperm, dcur, base, B, G, H1, ddZ, H1, gWd, H1, ws)
+            torch.cuda.synchronize()
+            got = gWd.cpu().numpy()
+            err = np.abs(got[:G] - gW_ref)
+            assert (err <= 1e-6 * gW_abs + 1e-30).all(), (form, float((err / np.maximum(gW_abs, 1e-30)).max()))
+            np.testing.assert_allclose(got[G], dZ.sum(0), rtol=0, atol=2e-6 * np.abs(dZ).sum(0).max())
+            # deterministic: a second launch reproduces every bit
+            gW2 = torch.zeros_like(gWd)
+            ops.enc0_dw_sparse(cc, dperm, dcur, base, B, G, H1, ddZ, H1, gW2, H1, ws)
+            assert torch.equal(gW2, gWd), form
+        finally:
+            ops.enc0_dw_set_form(prev)
 
 
 @pytest.mark.parametrize('flags', [1, 3, 0, 2])
