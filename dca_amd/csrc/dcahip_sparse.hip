@@ -455,7 +455,9 @@ constexpr int kD2CodeChunk = 1024 + 32;                    // two count rows of 
 constexpr int kD2CodeB = 8 * kD2CodeChunk;                 // 8448
 constexpr int kD2StageB = kD2LutB + kD2DzB + kD2CodeB;     // 22784
 
-// LDS reads as instructions (the caller waits: s_waitcnt lgkmcnt tied to the destinations)
+// LDS reads as instructions.  The destination is written when the data arrives, not where the statement stands: EVERY
+// destination must appear in a tie ("+v") of an s_waitcnt statement before it dies -- a destination the compiler considers dead
+// is handed to another value and overwritten by the late data (seen: the last step's storage-row read landing in `any`).
 template <int OFF> __device__ __forceinline__ void lds_read_u8(unsigned& r, unsigned ad) { asm volatile("ds_read_u8 %0, %1 offset:%2" : "=v"(r) : "v"(ad), "n"(OFF)); }
 template <int OFF> __device__ __forceinline__ void lds_read_b64(u32x2& r, unsigned ad) { asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r) : "v"(ad), "n"(OFF)); }
 template <int OFF> __device__ __forceinline__ void lds_read_b128(u32x4& r, unsigned ad) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(ad), "n"(OFF)); }
@@ -587,7 +589,7 @@ __global__ __launch_bounds__(64 * kD2Waves) __attribute__((amdgpu_waves_per_eu(2
 #ifdef DCA_DW_TIMING
     int n_visits = 0, n_places = 0;
 #endif
-    auto beyond_table = [&](int k, int stage, const unsigned (&code)[kD2MT][8], u32x2 (&ent)[kD2MT][8]) __attribute__((always_inline)) {
+    auto beyond_table = [&](int k, int stage, const unsigned (&code)[kD2MT][8], u32x2 (&ent)[kD2MT][8], unsigned any_dbg) __attribute__((always_inline)) {
         unsigned places = 0u;
         static_for<kD2MT * 8>([&](auto ic) __attribute__((always_inline)) {
             constexpr int q = decltype(ic)::value;
@@ -595,6 +597,16 @@ __global__ __launch_bounds__(64 * kD2Waves) __attribute__((amdgpu_waves_per_eu(2
         });
 #ifdef DCA_DW_TIMING
         n_visits += 1; n_places += __builtin_popcount(places);
+        if (places == 0u && g_dw_timing) {                 // (must not happen) leave the evidence: step, lane's sixteen counts packed
+            unsigned long long pk0 = 0ull, pk1 = 0ull;
+            for (int q = 0; q < 8; ++q) { pk0 |= (unsigned long long)(code[0][q] & 0xffu) << (8 * q); pk1 |= (unsigned long long)(code[1][q] & 0xffu) << (8 * q); }
+            unsigned mx = 0u;
+            for (int q = 0; q < 16; ++q) mx |= code[q >> 3][q & 7];
+            if (any_dbg >= (unsigned)kLut) {
+                long long* d = g_dw_timing + 4096 * 8;
+                d[0] = k; d[1] = (long long)pk0; d[2] = (long long)pk1; d[3] = lane + 1000 * wave; d[4] = mx; d[5] = any_dbg;
+            }
+        }
 #endif
 #pragma unroll 1
         while (places) {
@@ -611,7 +623,18 @@ __global__ __launch_bounds__(64 * kD2Waves) __attribute__((amdgpu_waves_per_eu(2
             float val = (float)c;
             if (__ballot(on && c == 255u)) { if (on && c == 255u) val = escaped_count(a.c, srow, g0 + 32 * m + l31); }
             float x = a.fac ? __fdiv_rn(val, fc) : val;
+#ifdef DCA_EXP_DW2_LIBM_LOG
             if (a.do_log) x = log1pf(x);
+#else
+            // log1p on the transcendental unit (v_log_f32, 1 ulp) with Kahan's exact-ratio correction of the rounded 1 + x:
+            // ~2e-7 relative for x >= 64 / fac (the library's log1pf -- the table's formula -- costs this path ~1100 more
+            // cycles per visit, with the whole workgroup waiting at the barrier: profiles/r05q_*)
+            if (a.do_log) {
+                const float u = 1.f + x, d1 = u - 1.f;
+                const float lg = __builtin_amdgcn_logf(u) * 0.69314718055994531f;
+                x = d1 == 0.f ? x : lg * (x * __builtin_amdgcn_rcpf(d1));
+            }
+#endif
             const uint2 e = split_entry(x);
             static_for<kD2MT * 8>([&](auto ic) __attribute__((always_inline)) {
                 constexpr int Q = decltype(ic)::value;
@@ -645,7 +668,7 @@ __global__ __launch_bounds__(64 * kD2Waves) __attribute__((amdgpu_waves_per_eu(2
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(s0));
                 request(k, k, s0);
             }
-        if (kD2Lead < nsteps) issue_srow(kD2Lead, s0);
+        issue_srow(min(kD2Lead, nsteps - 1), s0);
         retire(min(kD2Lead, nsteps) - 2);               // steps 0 and 1 have landed (mine)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -664,18 +687,18 @@ __global__ __launch_bounds__(64 * kD2Waves) __attribute__((amdgpu_waves_per_eu(2
         auto step = [&](int k, unsigned (&cK)[kD2MT][8], unsigned (&cN)[kD2MT][8], u32x4 (&Ap)[kD2MT][3], u32x4 (&An)[kD2MT][3],
                         u32x4 (&Bp)[NTL][3], u32x4 (&Bk)[NTL][3]) __attribute__((always_inline)) {
             const int sn = sk + 1 == kD2Stages ? 0 : sk + 1, sp = sk == 0 ? kD2Stages - 1 : sk - 1;
+            // (counts of this step, dZ fragments of the last one, storage row of the next request: all LDS reads so far)
             asm volatile("s_waitcnt lgkmcnt(0)" : DCA_TIE8(cK, 0), DCA_TIE8(cK, 1), "+v"(s0));
-            if (k + kD2Lead < nsteps) request(k + kD2Lead, sp, s0);   // into the stage of step k - 1: everyone read it before the barrier
+            asm volatile("" : "+v"(Bp[0][0]), "+v"(Bp[0][1]), "+v"(Bp[0][2]), "+v"(Bp[1][0]), "+v"(Bp[1][1]), "+v"(Bp[1][2]));
             unsigned any = 0u;
-#pragma unroll
-            for (int m = 0; m < kD2MT; ++m)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) any |= cK[m][j];
-            // ---- gene tile 0 of step k - 1, behind it: the table entries and dZ fragments of step k
+            // ---- gene tile 0 of step k - 1, behind it: the request of step k + 5, the table entries and dZ fragments of step k
             const unsigned ead = lut_off + (unsigned)sk * kD2StageB, dad = dz_off + (unsigned)sk * kD2StageB;
             static_for<12>([&](auto ic) __attribute__((always_inline)) {
                 constexpr int i = decltype(ic)::value, T = i & 1, PR = i >> 1;
                 DCA_MF(Ap, Bp, 0, T, PR)
+                if constexpr (i == 0) {
+                    if (k + kD2Lead < nsteps) request(k + kD2Lead, sp, s0);   // into the stage of step k - 1: everyone read it before the barrier
+                }
                 if constexpr (i < 8) {                    // entries of (tile, row) places 2 i and 2 i + 1
                     constexpr int q0 = 2 * i, q1 = 2 * i + 1;
                     lds_read_b64<(q0 & 7) * kLut * 8>(ent[q0 >> 3][q0 & 7], ead + cK[q0 >> 3][q0 & 7] * 8u);
@@ -685,12 +708,17 @@ __global__ __launch_bounds__(64 * kD2Waves) __attribute__((amdgpu_waves_per_eu(2
                     lds_read_b128<((f0 % 3) * NTL + f0 / 3) * 1024>(Bk[f0 / 3][f0 % 3], dad);
                     lds_read_b128<((f1 % 3) * NTL + f1 / 3) * 1024>(Bk[f1 / 3][f1 % 3], dad);
                 } else {
-                    if (k + 1 + kD2Lead < nsteps) issue_srow(k + 1 + kD2Lead, s0);
+                    issue_srow(min(k + 1 + kD2Lead, nsteps - 1), s0);
+#pragma unroll
+                    for (int m = 0; m < kD2MT; ++m)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) any |= cK[m][j];
                 }
             });
-            asm volatile("s_waitcnt lgkmcnt(0)" : DCA_TIE8(ent, 0), DCA_TIE8(ent, 1), "+v"(s0));
-            asm volatile("" : "+v"(Bk[0][0]), "+v"(Bk[0][1]), "+v"(Bk[0][2]), "+v"(Bk[1][0]), "+v"(Bk[1][1]), "+v"(Bk[1][2]));
-            if (__ballot(any >= (unsigned)kLut)) beyond_table(k, sk, cK, ent);
+            // the sixteen entries are in registers (LDS reads return in order: the six dZ fragments and the storage row
+            // behind them may still be in flight -- they are waited for at the top of the next step)
+            asm volatile("s_waitcnt lgkmcnt(7)" : DCA_TIE8(ent, 0), DCA_TIE8(ent, 1));
+            if (__ballot(any >= (unsigned)kLut)) beyond_table(k, sk, cK, ent, any);
             // ---- gene tile 1 of step k - 1, behind it: the operands of step k from its entries, the counts of step k + 1
             const unsigned cad = code_off + (unsigned)sn * kD2StageB;
             static_for<12>([&](auto ic) __attribute__((always_inline)) {
@@ -724,13 +752,15 @@ __global__ __launch_bounds__(64 * kD2Waves) __attribute__((amdgpu_waves_per_eu(2
         }
         if (k < nsteps) {
             step(k, c0, c1, A0, A1, B0, B1);
-            asm volatile("s_waitcnt lgkmcnt(0)" : DCA_TIE8(c1, 0), DCA_TIE8(c1, 1));
+            asm volatile("s_waitcnt lgkmcnt(0)" : DCA_TIE8(c1, 0), DCA_TIE8(c1, 1), "+v"(s0));
+            asm volatile("" : "+v"(B1[0][0]), "+v"(B1[0][1]), "+v"(B1[0][2]), "+v"(B1[1][0]), "+v"(B1[1][1]), "+v"(B1[1][2]));
 #pragma unroll
             for (int m = 0; m < kD2MT; ++m)
 #pragma unroll
                 for (int t = 0; t < NTL; ++t) { MFMA_X3(A1[m], B1[t], acc[m][t]) }
         } else {
-            asm volatile("s_waitcnt lgkmcnt(0)" : DCA_TIE8(c0, 0), DCA_TIE8(c0, 1));
+            asm volatile("s_waitcnt lgkmcnt(0)" : DCA_TIE8(c0, 0), DCA_TIE8(c0, 1), "+v"(s0));
+            asm volatile("" : "+v"(B0[0][0]), "+v"(B0[0][1]), "+v"(B0[0][2]), "+v"(B0[1][0]), "+v"(B0[1][1]), "+v"(B0[1][2]));
 #pragma unroll
             for (int m = 0; m < kD2MT; ++m)
 #pragma unroll

@@ -29,12 +29,15 @@ wsd = torch.zeros(ops.enc0_dw_sparse_workspace_bytes(B, G, h) // 4 + 4, device=d
 for _ in range(3):
     ops.enc0_dw_sparse(cc, perm, cur, 0, B, G, h, dZ, h, gW, h, wsd)
 torch.cuda.synchronize()
-tim = torch.zeros(4096 * 8, dtype=torch.int64, device=dev)
+tim = torch.zeros(4096 * 8 + 8, dtype=torch.int64, device=dev)
 L.dcahip_enc0_dw_set_timing(tim.data_ptr())
 s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
 s.record(); ops.enc0_dw_sparse(cc, perm, cur, 0, B, G, h, dZ, h, gW, h, wsd); e.record(); torch.cuda.synchronize()
 L.dcahip_enc0_dw_set_timing(None)
-t = tim.cpu().numpy().reshape(-1, 8)
+dbg = tim.cpu().numpy()[4096 * 8:]
+if dbg.any():
+    print('  a visit of the formula path without a place: step %d, counts %016x %016x, lane/wave %d, or %d, any %d' % (int(dbg[0]), int(dbg[1]) & (2**64-1), int(dbg[2]) & (2**64-1), int(dbg[3]), int(dbg[4]), int(dbg[5])))
+t = tim.cpu().numpy()[:4096 * 8].reshape(-1, 8)
 nwg = int((t[:, 0] != 0).sum())
 t = t[:nwg].astype(float)
 print('launch (split + kernel + finish) %.4f ms; %d workgroups' % (s.elapsed_time(e), len(t)))
