@@ -135,6 +135,15 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& p0, uns
     p2 = pk_bf16(q0, q1);
 }
 // one value -> table entry {p0 | p1 << 16, p2}
+// log1p for counts BEYOND the per-cell table (x >= kLut / size factor), in the table kernels' formula paths: on the
+// transcendental unit (v_log_f32, 1 ulp) with Kahan's exact-ratio correction of the rounded 1 + x -- ~2e-7 relative.  The
+// library's log1pf (the table's own formula) costs such a path ~1100 more cycles per visit, and a whole workgroup waits at its
+// barrier for the wave that is in it (profiles/r05q_*).
+__device__ __forceinline__ float log1p_beyond_table(float x) {
+    const float u = 1.f + x, d1 = u - 1.f;
+    const float lg = __builtin_amdgcn_logf(u) * 0.69314718055994531f;
+    return d1 == 0.f ? x : lg * (x * __builtin_amdgcn_rcpf(d1));
+}
 __device__ __forceinline__ uint2 split_entry(float x) {
     unsigned a, b, c;
     split_pair(x, 0.f, a, b, c);
@@ -371,7 +380,7 @@ __global__ __launch_bounds__(64 * kDwWaves) void enc0_dw_kernel(DwArgs a) {
                         if (on && ci == 255u) val = escaped_count(a.c, srows[b][rl], gene);
                     }
                     float x = a.fac ? __fdiv_rn(val, rfac[b][rl]) : val;
-                    if (a.do_log) x = log1pf(x);
+                    if (a.do_log) x = log1p_beyond_table(x);
                     const uint2 e = split_entry(x);
 #pragma unroll
                     for (int k = 0; k < GK * 8; ++k)
@@ -623,18 +632,7 @@ __global__ __launch_bounds__(64 * kD2Waves) __attribute__((amdgpu_waves_per_eu(2
             float val = (float)c;
             if (__ballot(on && c == 255u)) { if (on && c == 255u) val = escaped_count(a.c, srow, g0 + 32 * m + l31); }
             float x = a.fac ? __fdiv_rn(val, fc) : val;
-#ifdef DCA_EXP_DW2_LIBM_LOG
-            if (a.do_log) x = log1pf(x);
-#else
-            // log1p on the transcendental unit (v_log_f32, 1 ulp) with Kahan's exact-ratio correction of the rounded 1 + x:
-            // ~2e-7 relative for x >= 64 / fac (the library's log1pf -- the table's formula -- costs this path ~1100 more
-            // cycles per visit, with the whole workgroup waiting at the barrier: profiles/r05q_*)
-            if (a.do_log) {
-                const float u = 1.f + x, d1 = u - 1.f;
-                const float lg = __builtin_amdgcn_logf(u) * 0.69314718055994531f;
-                x = d1 == 0.f ? x : lg * (x * __builtin_amdgcn_rcpf(d1));
-            }
-#endif
+            if (a.do_log) x = log1p_beyond_table(x);
             const uint2 e = split_entry(x);
             static_for<kD2MT * 8>([&](auto ic) __attribute__((always_inline)) {
                 constexpr int Q = decltype(ic)::value;
@@ -678,8 +676,12 @@ __global__ __launch_bounds__(64 * kD2Waves) __attribute__((amdgpu_waves_per_eu(2
         // One matrix instruction of the six-product scheme: product PR (0..5, small terms first) of gene tile M with dZ tile T.
         // The accumulator is tied to an (empty) instruction statement behind it: the compiler keeps the matrix instruction
         // between the LDS / vector work written before and after it.
+#ifdef DCA_EXP_DW2_NOMFMA
+#define DCA_MF(Ap, Bp, M, T, PR) { acc[M][T][PR] += __uint_as_float(Ap[M][PR % 3][0] ^ Bp[T][PR % 3][1]); asm volatile("" : "+v"(acc[M][T])); }
+#else
 #define DCA_MF(Ap, Bp, M, T, PR) { constexpr int PA_[6] = {2, 1, 0, 1, 0, 0}, PB_[6] = {0, 1, 2, 0, 1, 0}; \
             acc[M][T] = MFMA16(Ap[M][PA_[PR]], Bp[T][PB_[PR]], acc[M][T]); asm volatile("" : "+v"(acc[M][T])); }
+#endif
         // step k: cK = its counts (requested in the step before), Ap / Bp = table entries / dZ fragments of step k - 1; leaves
         // the counts of step k + 1 in cN, the operands of step k in An / Bk.  A wave's vector and LDS instructions ride behind
         // its OWN matrix instructions (about five per matrix instruction are free, tools/microbench/mfma_valu_interleave.hip);
@@ -740,7 +742,9 @@ __global__ __launch_bounds__(64 * kD2Waves) __attribute__((amdgpu_waves_per_eu(2
                 }
             });
             retire(min(k + kD2Lead, nsteps - 1) - (k + 2));   // step k + 2 has landed (mine); the LDS reads of stage sk are in registers
+#ifndef DCA_EXP_DW2_NOBARRIER
             __builtin_amdgcn_s_barrier();
+#endif
             asm volatile("" ::: "memory");
             sk = sn;
         };
@@ -1218,7 +1222,11 @@ __global__ __launch_bounds__(512) void enc0_fwd_lut_kernel(FlArgs a) {
                         if (on && code == 255u) val = escaped_count(a.c, sr, (ms >> 1) * (2 * kFlMS) + 64 * hi + 32 * h + 8 * ks + j);
                     }
                     float x = a.fac ? __fdiv_rn(val, facr) : val;
+#ifdef DCA_EXP_FWD_LIBM_LOG
                     if (a.do_log) x = log1pf(x);
+#else
+                    if (a.do_log) x = log1p_beyond_table(x);
+#endif
                     const uint2 e = split_entry(x);
 #pragma unroll
                     for (int k = 0; k < 8; ++k)

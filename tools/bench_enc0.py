@@ -4,6 +4,10 @@ import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+if os.environ.get('DCA_DW_LIB'):                    # an experiment build (tools/_dbg/libdcahip_<variant>.so) in place of the product
+    from dca_amd import build as _b
+    _b.LIB = os.path.join(ROOT, 'tools', '_dbg', os.environ['DCA_DW_LIB'])
+    _b.needs_build = lambda: False
 from dca_amd import synth, prep, compact
 from dca_amd.ops import HipOps
 
@@ -39,7 +43,7 @@ def timeit(fn, it=30):
     return s.elapsed_time(e) / it
 
 
-for B in (32, 128, 512, 1024, 2048, 4096, 8192):
+for B in ([int(b) for b in os.environ['BENCH_B'].split(',')] if os.environ.get('BENCH_B') else (32, 128, 512, 1024, 2048, 4096, 8192)):
     perm = torch.randperm(n, device=dev, dtype=torch.int32)[:B].contiguous()
     Z = torch.zeros(B, h, device=dev); Z2 = torch.zeros(B, h, device=dev)
     dZ = torch.randn(B, h, device=dev) * 1e-3
