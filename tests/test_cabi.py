@@ -193,3 +193,49 @@ def test_matrix_loops_of_the_product_kernels_are_spill_free():
         assert sum(b[2] for b in blocks) >= 24, (src, sub)
         bad = [(k[-48:], b, m, s) for k, b, m, s in blocks if s > allowed]
         assert not bad, (src, bad[:5])
+
+
+def test_ring_weight_gradient_loop_has_no_compiler_waits_on_the_ring():
+    """enc0_dw2_kernel fills its LDS ring with global_load_lds and retires the requests with COUNTED s_waitcnt vmcnt
+    statements of its own.  The compiler cannot tell which LDS bytes such a load writes: in front of any LDS read it generates
+    itself it puts s_waitcnt vmcnt(0), which stalls the ring for a memory round trip per step (measured).  So in every basic
+    block of the kernel that issues matrix instructions: all LDS reads and all vmcnt waits stand inside instruction statements
+    (between #ASMSTART / #ASMEND), and there is no scalar memory load (it would break the counted lgkmcnt waits)."""
+    import shutil
+    import subprocess
+    import tempfile
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, 'k.s')
+        subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-I' + os.path.join(ROOT, 'include'),
+                        '--cuda-device-only', '-S', os.path.join(ROOT, 'dca_amd', 'csrc', 'dcahip_sparse.hip'), '-o', out],
+                       check=True, capture_output=True)
+        asm = open(out).read()
+    m = re.search(r'^(_Z\w*enc0_dw2_kernel\w*):', asm, re.M)
+    assert m
+    body = asm[m.end():asm.index('s_endpgm', m.end())]
+    blocks, cur = [], []
+    for ln in body.split('\n'):
+        t = ln.strip()
+        if re.match(r'^\.LBB\d+_\d+:', t) or t.startswith(('s_cbranch', 's_branch')):
+            blocks.append(cur); cur = []
+            continue
+        cur.append(t)
+    blocks.append(cur)
+    seen = 0
+    for b in blocks:
+        if sum(1 for t in b if t.startswith('v_mfma')) < 12:
+            continue
+        seen += 1
+        inside = False
+        for t in b:
+            if t.startswith(';;#ASMSTART'):
+                inside = True
+            elif t.startswith(';;#ASMEND'):
+                inside = False
+            elif not inside:
+                assert not t.startswith(('ds_read', 'ds_load')), t
+                assert not t.startswith('s_waitcnt vmcnt'), t
+                assert not t.startswith(('s_load', 's_buffer_load')), t
+                assert not t.startswith('scratch_'), t
+    assert seen >= 4          # two phases of twelve matrix instructions per step, two steps per trip of the loop
