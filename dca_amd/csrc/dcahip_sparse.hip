@@ -151,6 +151,18 @@ __device__ __forceinline__ uint2 split_entry(float x) {
 }
 __device__ __forceinline__ int rowmap(int e, int hi) { return (e & 3) + 8 * (e >> 2) + 4 * hi; }   // row of accumulator element e
 
+// LDS reads as instructions.  The destination is written when the data arrives, not where the statement stands: EVERY
+// destination must appear in a tie ("+v") of an s_waitcnt statement before it dies -- a destination the compiler considers dead
+// is handed to another value and overwritten by the late data (seen: the last step's storage-row read landing in `any`).
+template <int OFF> __device__ __forceinline__ void lds_read_u8(unsigned& r, unsigned ad) { asm volatile("ds_read_u8 %0, %1 offset:%2" : "=v"(r) : "v"(ad), "n"(OFF)); }
+template <int OFF> __device__ __forceinline__ void lds_read_b64(u32x2& r, unsigned ad) { asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r) : "v"(ad), "n"(OFF)); }
+template <int OFF> __device__ __forceinline__ void lds_read_b128(u32x4& r, unsigned ad) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(ad), "n"(OFF)); }
+template <int... I, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
+
 constexpr int kLut = 64;            // table entries per cell (counts 0 .. 63: all but ~1e-4 of the non-zero counts of scRNA-seq data)
 
 __global__ __launch_bounds__(256) void enc0_lut_kernel(const float* fac, int do_log, int n, uint2* lutp) {
@@ -463,17 +475,6 @@ constexpr int kD2DzB = dz_step_elems(64) * 2;              // 6144: one K step o
 constexpr int kD2CodeChunk = 1024 + 32;                    // two count rows of 512 bytes land as one chunk; rows 8 apart sit 32 banks apart
 constexpr int kD2CodeB = 8 * kD2CodeChunk;                 // 8448
 constexpr int kD2StageB = kD2LutB + kD2DzB + kD2CodeB;     // 22784
-
-// LDS reads as instructions.  The destination is written when the data arrives, not where the statement stands: EVERY
-// destination must appear in a tie ("+v") of an s_waitcnt statement before it dies -- a destination the compiler considers dead
-// is handed to another value and overwritten by the late data (seen: the last step's storage-row read landing in `any`).
-template <int OFF> __device__ __forceinline__ void lds_read_u8(unsigned& r, unsigned ad) { asm volatile("ds_read_u8 %0, %1 offset:%2" : "=v"(r) : "v"(ad), "n"(OFF)); }
-template <int OFF> __device__ __forceinline__ void lds_read_b64(u32x2& r, unsigned ad) { asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r) : "v"(ad), "n"(OFF)); }
-template <int OFF> __device__ __forceinline__ void lds_read_b128(u32x4& r, unsigned ad) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(ad), "n"(OFF)); }
-template <int... I, class F>
-__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
 #ifdef DCA_DW_TIMING
 __device__ long long* g_dw_timing = nullptr;         // [workgroup][8]: clock at kernel entry, after the prologue, after the loop, at the end (wave 0) + realtime at entry / end
@@ -1185,80 +1186,133 @@ __global__ __launch_bounds__(512) void enc0_fwd_lut_kernel(FlArgs a) {
         lutl[row * kFlLutLd + seg * 2 + 1] = make_uint2(lv[k][2], lv[k][3]);
     }
     if (ms0 < ms1) { store_w(0); take_codes(ms0 >> 1, cn); }
-    // one macro step (half h of its super step; tile h of the LDS pair: ms0 is even)
+    // ---- software pipeline over the K steps (16 genes; four per macro step): while the 6 NTL matrix instructions of K step k
+    // run, the wave looks up the 8 values of K step k + 1, reads its W fragments and repacks the entries -- its OWN LDS / vector
+    // instructions between its own matrix instructions (the other wave of the SIMD does not hide them: round 5).
+    // The LDS reads are instruction statements in the order written; each matrix instruction's accumulator is tied to an empty
+    // statement so that the compiler keeps it between them.  One barrier per macro step, between its K steps 2 and 3: K step 3
+    // already prepares K step 0 of the next macro step from the other W tile.
+    const unsigned lp_ad = (unsigned)(size_t)(__attribute__((address_space(3))) uint2*)lutl + (unsigned)myrow * (kFlLutLd * 8);
+    const unsigned wl_ad = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned short*)wl[0] + (unsigned)(hi * 32 + l31) * 16u;
+    u32x4 A0[3], A1[3], Bf0[NTL][3], Bf1[NTL][3];
+    u32x2 ent[8];
+    // the formula for the values of one K step beyond the table (rare; `gene0` = gene of the step's first value)
+    auto beyond_table = [&](unsigned d0, unsigned d1, int gene0) __attribute__((always_inline)) {
+        unsigned bad = 0u;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bad |= ((((j >> 2) ? d1 : d0) >> (8 * (j & 3) + 5)) & 7u) != 0u ? 1u << j : 0u;
+#pragma unroll 1
+        while (__ballot(bad != 0u)) {
+            const bool on = bad != 0u;
+            const int j = on ? __builtin_ctz(bad) : 0;
+            bad &= bad - 1u;
+            const unsigned dw = (j >> 2) ? d1 : d0;
+            const unsigned code = (dw >> (8 * (j & 3))) & 255u;
+            float val = (float)code;
+            if (__ballot(on && code == 255u)) {     // an escape: the count itself from the row's overflow list
+                if (on && code == 255u) val = escaped_count(a.c, sr, gene0 + j);
+            }
+            float x = a.fac ? __fdiv_rn(val, facr) : val;
+            if (a.do_log) x = log1p_beyond_table(x);
+            const uint2 e = split_entry(x);
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (on && j == k) { ent[k][0] = e.x; ent[k][1] = e.y; }
+        }
+    };
+    // the work for K step `kn` (of the macro step whose counts are d[], W tile `bn`), cut into twelve pieces that ride behind
+    // the matrix instructions of the K step before it: piece v of prepare<KN>(...)
+    auto prepare = [&](auto kn_c, auto v_c, const unsigned (&d)[8], int bn, int gene0, u32x4 (&An)[3], u32x4 (&Bn)[NTL][3]) __attribute__((always_inline)) {
+        constexpr int KN = decltype(kn_c)::value, V = decltype(v_c)::value;
+        const unsigned wad = wl_ad + (unsigned)bn * (MSE * 2);
+        if constexpr (V < 4) {                       // lookups 2 V, 2 V + 1
+#pragma unroll
+            for (int j = 2 * V; j < 2 * V + 2; ++j) {
+                const unsigned idx = (d[2 * KN + (j >> 2)] >> (8 * (j & 3))) & (unsigned)(kFlLut - 1);
+                lds_read_b64<0>(ent[j], lp_ad + idx * 8u);
+            }
+        } else if constexpr (V < 7) {                // W fragments 2 (V - 4), 2 (V - 4) + 1 of 3 NTL
+            constexpr int f0 = 2 * (V - 4), f1 = f0 + 1;
+            if constexpr (f0 < 3 * NTL) lds_read_b128<(((f0 % 3) * NTL + f0 / 3) * 4 + KN) * 1024>(Bn[f0 / 3][f0 % 3], wad);
+            if constexpr (f1 < 3 * NTL) lds_read_b128<(((f1 % 3) * NTL + f1 / 3) * 4 + KN) * 1024>(Bn[f1 / 3][f1 % 3], wad);
+        } else if constexpr (V == 7) {               // the entries are in registers (the W fragments behind them may be in flight)
+            if constexpr (NTL == 2) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(ent[0]), "+v"(ent[1]), "+v"(ent[2]), "+v"(ent[3]), "+v"(ent[4]), "+v"(ent[5]), "+v"(ent[6]), "+v"(ent[7]));
+            else asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(ent[0]), "+v"(ent[1]), "+v"(ent[2]), "+v"(ent[3]), "+v"(ent[4]), "+v"(ent[5]), "+v"(ent[6]), "+v"(ent[7]));
+#ifndef DCA_EXP_FWD_NOFORMULA
+            if (__ballot(((d[2 * KN] | d[2 * KN + 1]) & 0xe0e0e0e0u) != 0u)) beyond_table(d[2 * KN], d[2 * KN + 1], gene0 + 8 * KN);
+#endif
+        } else {                                     // V = 8 .. 11: three of the twelve operand registers
+#pragma unroll
+            for (int r = 3 * (V - 8); r < 3 * (V - 8) + 3; ++r) {
+                const int q = r >> 2, jj = r & 3;
+                An[q][jj] = __builtin_amdgcn_perm(ent[2 * jj + 1][q == 2 ? 1 : 0], ent[2 * jj][q == 2 ? 1 : 0], q == 1 ? 0x07060302u : 0x05040100u);
+            }
+            if constexpr (V == 9) asm volatile("" : "+v"(An[0]));
+            if constexpr (V == 10) asm volatile("" : "+v"(An[1]));
+            if constexpr (V == 11) asm volatile("" : "+v"(An[2]));
+        }
+    };
+    // K step K of the current macro step: its 6 NTL matrix instructions (operands Ac, Bc), the next K step's preparation between
+    auto kstep = [&](auto kn_c, const unsigned (&dn)[8], int bn, int gene0n, u32x4 (&Ac)[3], u32x4 (&Bc)[NTL][3], u32x4 (&An)[3], u32x4 (&Bn)[NTL][3]) __attribute__((always_inline)) {
+        // (the W fragments of this K step: the only LDS reads still in flight)
+        if constexpr (NTL == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Bc[0][0]), "+v"(Bc[0][1]), "+v"(Bc[0][2]), "+v"(Bc[1][0]), "+v"(Bc[1][1]), "+v"(Bc[1][2]));
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Bc[0][0]), "+v"(Bc[0][1]), "+v"(Bc[0][2]));
+        constexpr int NS = 6 * NTL;
+        static_for<NS>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value, T = i % NTL, PR = i / NTL;
+            constexpr int PA_[6] = {2, 1, 0, 1, 0, 0}, PB_[6] = {0, 1, 2, 0, 1, 0};
+#ifdef DCA_EXP_FWD_NOMFMA
+            acc[T][PR] += __uint_as_float(Ac[PA_[PR]][0] ^ Bc[T][PB_[PR]][1]);
+#else
+            acc[T] = MFMA16(Ac[PA_[PR]], Bc[T][PB_[PR]], acc[T]);
+#endif
+            asm volatile("" : "+v"(acc[T]));
+            static_for<12 / NS>([&](auto jc) __attribute__((always_inline)) {
+                prepare(kn_c, std::integral_constant<int, i * (12 / NS) + decltype(jc)::value>{}, dn, bn, gene0n, An, Bn);
+            });
+        });
+    };
+    auto codes_of = [&](int h, unsigned (&d)[8]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { d[k] = cq[2 * h][k]; d[4 + k] = cq[2 * h + 1][k]; }
+    };
+    using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>;
+    using K2 = std::integral_constant<int, 2>; using K3 = std::integral_constant<int, 3>;
+    // one macro step (half h of its super step; W tile h of the LDS pair: ms0 is even).  On entry the operands of its K step 0
+    // are in A0 / Bf0 (fragments possibly in flight) and tile h is complete in LDS.
     auto step = [&](auto half, int ms) __attribute__((always_inline)) {
         constexpr int h = decltype(half)::value, b = h;
-        __syncthreads();                    // tile b (and, the first time, the tables) is in LDS; everyone is done with tile b ^ 1
         load_w(ms + 1);                     // (past the chunk's end: a tile nobody reads)
         if (h == 0) load_codes((ms >> 1) + 1, cn);
-        const unsigned short* wt = wl[b] + (hi * 32 + l31) * 8;
-        // the macro step's 32 values of this lane: all lookups first (one LDS round trip), then the products
-        const unsigned d[8] = {cq[2 * h][0], cq[2 * h][1], cq[2 * h][2], cq[2 * h][3],
-                               cq[2 * h + 1][0], cq[2 * h + 1][1], cq[2 * h + 1][2], cq[2 * h + 1][3]};
-        unsigned lo[32], hx[32];
-#pragma unroll
-        for (int i = 0; i < 32; ++i) {
-            const uint2 e = lp[(d[i >> 2] >> (8 * (i & 3))) & (unsigned)(kFlLut - 1)];
-            lo[i] = e.x; hx[i] = e.y;
-        }
-        // rare: counts beyond the table take the formula itself, one at a time -- checked per K step (8 values of the lane):
-        // about one macro step in two has such a count somewhere in the workgroup and everyone waits for that wave at
-        // the next barrier, so the repair touches 8 registers, not 32
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            if (__ballot(((d[2 * ks] | d[2 * ks + 1]) & 0xe0e0e0e0u) != 0u)) {
-                unsigned bad = 0u;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) bad |= (((d[2 * ks + (j >> 2)] >> (8 * (j & 3) + 5)) & 7u) != 0u ? 1u : 0u) << j;
-#pragma unroll 1
-                while (__ballot(bad != 0u)) {
-                    const bool on = bad != 0u;
-                    const int j = on ? __builtin_ctz(bad) : 0;
-                    bad &= bad - 1u;
-                    const unsigned dw = (j >> 2) ? d[2 * ks + 1] : d[2 * ks];
-                    const unsigned code = (dw >> (8 * (j & 3))) & 255u;
-                    float val = (float)code;
-                    if (__ballot(on && code == 255u)) {     // an escape: the count itself from the row's overflow list
-                        if (on && code == 255u) val = escaped_count(a.c, sr, (ms >> 1) * (2 * kFlMS) + 64 * hi + 32 * h + 8 * ks + j);
-                    }
-                    float x = a.fac ? __fdiv_rn(val, facr) : val;
-#ifdef DCA_EXP_FWD_LIBM_LOG
-                    if (a.do_log) x = log1pf(x);
-#else
-                    if (a.do_log) x = log1p_beyond_table(x);
-#endif
-                    const uint2 e = split_entry(x);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k)
-                        if (on && j == k) { lo[8 * ks + k] = e.x; hx[8 * ks + k] = e.y; }
-                }
-            }
-        }
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            u32x4 A[3];
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                A[0][jj] = __builtin_amdgcn_perm(lo[8 * ks + 2 * jj + 1], lo[8 * ks + 2 * jj], 0x05040100u);
-                A[1][jj] = __builtin_amdgcn_perm(lo[8 * ks + 2 * jj + 1], lo[8 * ks + 2 * jj], 0x07060302u);
-                A[2][jj] = __builtin_amdgcn_perm(hx[8 * ks + 2 * jj + 1], hx[8 * ks + 2 * jj], 0x05040100u);
-            }
-#pragma unroll
-            for (int t = 0; t < NTL; ++t) {
-                u32x4 Bf[3];
-#pragma unroll
-                for (int q = 0; q < 3; ++q)
-                    Bf[q] = *reinterpret_cast<const u32x4*>(wt + (((q * NTL + t) * 4 + ks) * 2) * 32 * 8);
-                MFMA_X3(A, Bf, acc[t])
-            }
-        }
+        unsigned d[8], dn[8];
+        codes_of(h, d);
+        const int gene0 = (ms >> 1) * (2 * kFlMS) + 64 * hi + 32 * h;
+        kstep(K1{}, d, b, gene0, A0, Bf0, A1, Bf1);
+        kstep(K2{}, d, b, gene0, A1, Bf1, A0, Bf0);
+        kstep(K3{}, d, b, gene0, A0, Bf0, A1, Bf1);
         store_w(b ^ 1);
+        if (h == 1) take_codes((ms >> 1) + 1, cn);          // the next super step's counts (requested a super step ago)
+        codes_of(h ^ 1, dn);
+#ifndef DCA_EXP_FWD_NOBARRIER
+        __syncthreads();                    // tile b ^ 1 is in LDS; everyone's reads of tile b are in registers
+#endif
+        kstep(K0{}, dn, b ^ 1, (((ms + 1) >> 1) * (2 * kFlMS)) + 64 * hi + 32 * (h ^ 1), A1, Bf1, A0, Bf0);
     };
+    if (ms0 < ms1) {                        // the operands of the first K step (no matrix instructions to put them behind)
+        __syncthreads();                    // tile 0 and the tables are in LDS
+        unsigned d[8];
+        codes_of(0, d);
+        const int gene0 = (ms0 >> 1) * (2 * kFlMS) + 64 * hi;
+        static_for<12>([&](auto vc) __attribute__((always_inline)) { prepare(K0{}, vc, d, 0, gene0, A0, Bf0); });
+    }
 #pragma unroll 1
     for (int ms = ms0; ms < ms1; ms += 2) {
         step(Half0{}, ms);
         step(Half1{}, ms + 1);
-        take_codes((ms >> 1) + 1, cn);
+    }
+    if (ms0 < ms1) {                        // (the last K step prepared operands nobody uses: their reads must not outlive the loop)
+        if constexpr (NTL == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Bf0[0][0]), "+v"(Bf0[0][1]), "+v"(Bf0[0][2]), "+v"(Bf0[1][0]), "+v"(Bf0[1][1]), "+v"(Bf0[1][2]));
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Bf0[0][0]), "+v"(Bf0[0][1]), "+v"(Bf0[0][2]));
     }
     if (ms0 >= ms1) __syncthreads();        // (an empty chunk never passed a barrier after csum was written)
     float* const dst = a.P + ((long)blockIdx.y * a.Bp + rg0 + wave * 32) * H1;
