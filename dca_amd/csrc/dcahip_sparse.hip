@@ -1094,110 +1094,123 @@ struct FlArgs {
     int n_ms, ms_per;               // macro steps in all / per gene chunk
 };
 
-template <int H1>
-__global__ __launch_bounds__(512) void enc0_fwd_lut_kernel(FlArgs a) {
-    constexpr int NTL = H1 / 32, MSE = fl_ms_elems(H1), UNITS = MSE / 8, UPT = (UNITS + 511) / 512;
+// RT = 32-row tiles per wave: 1 -> eight waves of 32 rows (two per SIMD), 2 -> four waves of 64 rows (one per SIMD, the W
+// fragments of a K step read from LDS once for both tiles).
+template <int H1, int RT>
+__global__ __launch_bounds__(kFlRows / (32 * RT) * 64) void enc0_fwd_lut_kernel(FlArgs a) {
+    constexpr int NT = kFlRows / (32 * RT) * 64;
+    constexpr int NTL = H1 / 32, MSE = fl_ms_elems(H1), UNITS = MSE / 8, UPT = (UNITS + NT - 1) / NT;
     __shared__ __attribute__((aligned(16))) uint2 lutl[kFlRows * kFlLutLd];
     __shared__ __attribute__((aligned(16))) unsigned short wl[2][MSE];
     __shared__ int srows[kFlRows];
     __shared__ float csum[H1];
-    __shared__ double cpart[512 / H1][H1];
+    __shared__ double cpart[NT / H1][H1];
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rg0 = blockIdx.x * kFlRows;
     const int ms0 = blockIdx.y * a.ms_per, ms1 = min(a.n_ms, ms0 + a.ms_per);
-    if (tid < kFlRows) {
+    for (int i = tid; i < kFlRows; i += NT) {
         const long long cur = (a.cursor ? *a.cursor : 0) + a.row_base;
-        const int r = min(rg0 + tid, a.B - 1);
-        srows[tid] = a.perm ? a.perm[cur + r] : (int)(cur + r);
+        const int r = min(rg0 + i, a.B - 1);
+        srows[i] = a.perm ? a.perm[cur + r] : (int)(cur + r);
     }
     {                                       // this chunk's share of -sum_g (mean / std) W0[g, :], macro steps spread over the threads
         const int col = tid % H1, part = tid / H1;
         double v = 0.0;
         if (a.C0P)
-            for (int ms = ms0 + part; ms < ms1; ms += 512 / H1) v += a.C0P[(long)ms * H1 + col];
+            for (int ms = ms0 + part; ms < ms1; ms += NT / H1) v += a.C0P[(long)ms * H1 + col];
         cpart[part][col] = v;
     }
     __syncthreads();
     if (tid < H1) {
         double v = 0.0;
 #pragma unroll
-        for (int k = 0; k < 512 / H1; ++k) v += cpart[k][tid];
+        for (int k = 0; k < NT / H1; ++k) v += cpart[k][tid];
         csum[tid] = (float)(-v);            // (read after the loop's barriers)
     }
     // the table rows of the workgroup's cells: requested here, stored behind the first counts / tile requests below (one
     // round trip to memory for the whole prologue instead of three)
-    constexpr int NU = kFlRows * (kFlLut / 2) / 512;
+    constexpr int NU = kFlRows * (kFlLut / 2) / NT;
     u32x4 lv[NU];
 #pragma unroll
     for (int k = 0; k < NU; ++k) {
-        const int u = tid + 512 * k;
+        const int u = tid + NT * k;
         lv[k] = *reinterpret_cast<const u32x4*>(a.lutp + (long)srows[u / (kFlLut / 2)] * kLut + (u % (kFlLut / 2)) * 2);
     }
-    const int myrow = wave * 32 + l31;
-    const long sr = srows[myrow];
-    const float facr = a.fac ? a.fac[sr] : 1.f;
-    const unsigned char* const yrow = a.c.yc + sr * a.c.ldc + 64 * hi;
-    const uint2* const lp = lutl + myrow * kFlLutLd;
-    f32x16 acc[NTL];
+    long sr[RT]; float facr[RT]; const unsigned char* yrow[RT]; unsigned lp_ad[RT];
 #pragma unroll
-    for (int t = 0; t < NTL; ++t)
+    for (int r = 0; r < RT; ++r) {
+        const int myrow = wave * (32 * RT) + 32 * r + l31;
+        sr[r] = srows[myrow];
+        facr[r] = a.fac ? a.fac[sr[r]] : 1.f;
+        yrow[r] = a.c.yc + sr[r] * a.c.ldc + 64 * hi;
+        lp_ad[r] = (unsigned)(size_t)(__attribute__((address_space(3))) uint2*)lutl + (unsigned)myrow * (kFlLutLd * 8);
+    }
+    f32x16 acc[RT][NTL];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-    u32x4 cq[4], cn[4], wr[UPT];
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int t = 0; t < NTL; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[r][t][e] = 0.f;
+    u32x4 cq[RT][4], cn[RT][4], wr[UPT];
     // every load of the loop is unconditional (addresses clamped, results selected): the loads of a step then form one
     // straight queue -- tile first, counts after -- and the wait before the tile's LDS store leaves the counts in flight
     const int ss_last = a.n_ms / 2 - 1;
     auto codes_ok = [&](int ss, int i) __attribute__((always_inline)) {
         return (long)min(ss, ss_last) * (2 * kFlMS) + 16 * i + 64 * hi + 16 <= a.c.ldc;
     };
-    auto load_codes = [&](int ss, u32x4 (&c)[4]) __attribute__((always_inline)) {        // raw: take_codes masks them
+    auto load_codes = [&](int ss) __attribute__((always_inline)) {        // raw: take_codes masks them
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            c[i] = *reinterpret_cast<const u32x4*>(yrow + (codes_ok(ss, i) ? (long)min(ss, ss_last) * (2 * kFlMS) + 16 * i : -64L * hi));
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                cn[r][i] = *reinterpret_cast<const u32x4*>(yrow[r] + (codes_ok(ss, i) ? (long)min(ss, ss_last) * (2 * kFlMS) + 16 * i : -64L * hi));
     };
-    auto take_codes = [&](int ss, const u32x4 (&c)[4]) __attribute__((always_inline)) {   // the first use of the loaded bytes
+    auto take_codes = [&](int ss) __attribute__((always_inline)) {        // the first use of the loaded bytes
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const bool ok = codes_ok(ss, i);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) cq[i][k] = ok ? c[i][k] : 0u;
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) cq[r][i][k] = ok ? cn[r][i][k] : 0u;
         }
     };
     auto load_w = [&](int ms) __attribute__((always_inline)) {
         const u32x4* src = reinterpret_cast<const u32x4*>(a.WP + (long)min(ms, a.n_ms - 1) * MSE);
 #pragma unroll
         for (int i = 0; i < UPT; ++i)
-            if ((i + 1) * 512 <= UNITS || tid + i * 512 < UNITS) wr[i] = src[tid + i * 512];
+            if ((i + 1) * NT <= UNITS || tid + i * NT < UNITS) wr[i] = src[tid + i * NT];
     };
     auto store_w = [&](int b) __attribute__((always_inline)) {
         u32x4* dst = reinterpret_cast<u32x4*>(wl[b]);
 #pragma unroll
         for (int i = 0; i < UPT; ++i)
-            if ((i + 1) * 512 <= UNITS || tid + i * 512 < UNITS) dst[tid + i * 512] = wr[i];
+            if ((i + 1) * NT <= UNITS || tid + i * NT < UNITS) dst[tid + i * NT] = wr[i];
     };
     using Half0 = std::integral_constant<int, 0>;
     using Half1 = std::integral_constant<int, 1>;
-    if (ms0 < ms1) { load_codes(ms0 >> 1, cn); load_w(ms0); }
+    if (ms0 < ms1) { load_codes(ms0 >> 1); load_w(ms0); }
 #pragma unroll
     for (int k = 0; k < NU; ++k) {
-        const int u = tid + 512 * k, row = u / (kFlLut / 2), seg = u % (kFlLut / 2);
+        const int u = tid + NT * k, row = u / (kFlLut / 2), seg = u % (kFlLut / 2);
         lutl[row * kFlLutLd + seg * 2] = make_uint2(lv[k][0], lv[k][1]);
         lutl[row * kFlLutLd + seg * 2 + 1] = make_uint2(lv[k][2], lv[k][3]);
     }
-    if (ms0 < ms1) { store_w(0); take_codes(ms0 >> 1, cn); }
-    // ---- software pipeline over the K steps (16 genes; four per macro step): while the 6 NTL matrix instructions of K step k
-    // run, the wave looks up the 8 values of K step k + 1, reads its W fragments and repacks the entries -- its OWN LDS / vector
-    // instructions between its own matrix instructions (the other wave of the SIMD does not hide them: round 5).
-    // The LDS reads are instruction statements in the order written; each matrix instruction's accumulator is tied to an empty
-    // statement so that the compiler keeps it between them.  One barrier per macro step, between its K steps 2 and 3: K step 3
-    // already prepares K step 0 of the next macro step from the other W tile.
-    const unsigned lp_ad = (unsigned)(size_t)(__attribute__((address_space(3))) uint2*)lutl + (unsigned)myrow * (kFlLutLd * 8);
+    if (ms0 < ms1) { store_w(0); take_codes(ms0 >> 1); }
+    // ---- software pipeline over the K steps (16 genes; four per macro step): while the 6 NTL RT matrix instructions of K step
+    // k run, the wave looks up the 8 RT values of K step k + 1, reads its W fragments and repacks the entries -- its OWN LDS /
+    // vector instructions between its own matrix instructions (the other wave of the SIMD does not hide them: round 5, DESIGN
+    // 4.3).  The LDS reads are instruction statements in the order written; each matrix instruction's accumulator is tied to
+    // an empty statement so that the compiler keeps it between them.  One barrier per macro step, between its K steps 2 and
+    // 3: K step 3 already prepares K step 0 of the next macro step from the other W tile.
     const unsigned wl_ad = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned short*)wl[0] + (unsigned)(hi * 32 + l31) * 16u;
-    u32x4 A0[3], A1[3], Bf0[NTL][3], Bf1[NTL][3];
-    u32x2 ent[8];
-    // the formula for the values of one K step beyond the table (rare; `gene0` = gene of the step's first value)
-    auto beyond_table = [&](unsigned d0, unsigned d1, int gene0) __attribute__((always_inline)) {
+    u32x4 A0[RT][3], A1[RT][3], Bf0[NTL][3], Bf1[NTL][3];
+    u32x2 ent[RT][8];
+    // the formula for the values of one K step of row tile r beyond the table (rare; `gene0` = gene of the step's first value)
+    auto beyond_table = [&](auto rc, unsigned d0, unsigned d1, int gene0) __attribute__((always_inline)) {
+        constexpr int r = decltype(rc)::value;
         unsigned bad = 0u;
 #pragma unroll
         for (int j = 0; j < 8; ++j) bad |= ((((j >> 2) ? d1 : d0) >> (8 * (j & 3) + 5)) & 7u) != 0u ? 1u << j : 0u;
@@ -1210,71 +1223,87 @@ __global__ __launch_bounds__(512) void enc0_fwd_lut_kernel(FlArgs a) {
             const unsigned code = (dw >> (8 * (j & 3))) & 255u;
             float val = (float)code;
             if (__ballot(on && code == 255u)) {     // an escape: the count itself from the row's overflow list
-                if (on && code == 255u) val = escaped_count(a.c, sr, gene0 + j);
+                if (on && code == 255u) val = escaped_count(a.c, sr[r], gene0 + j);
             }
-            float x = a.fac ? __fdiv_rn(val, facr) : val;
+            float x = a.fac ? __fdiv_rn(val, facr[r]) : val;
             if (a.do_log) x = log1p_beyond_table(x);
             const uint2 e = split_entry(x);
 #pragma unroll
             for (int k = 0; k < 8; ++k)
-                if (on && j == k) { ent[k][0] = e.x; ent[k][1] = e.y; }
+                if (on && j == k) { ent[r][k][0] = e.x; ent[r][k][1] = e.y; }
         }
     };
-    // the work for K step `kn` (of the macro step whose counts are d[], W tile `bn`), cut into twelve pieces that ride behind
+    // the work for K step `kn` (of the macro step whose counts are d[][], W tile `bn`), cut into twelve pieces that ride behind
     // the matrix instructions of the K step before it: piece v of prepare<KN>(...)
-    auto prepare = [&](auto kn_c, auto v_c, const unsigned (&d)[8], int bn, int gene0, u32x4 (&An)[3], u32x4 (&Bn)[NTL][3]) __attribute__((always_inline)) {
+    auto prepare = [&](auto kn_c, auto v_c, const unsigned (&d)[RT][8], int bn, int gene0, u32x4 (&An)[RT][3], u32x4 (&Bn)[NTL][3]) __attribute__((always_inline)) {
         constexpr int KN = decltype(kn_c)::value, V = decltype(v_c)::value;
         const unsigned wad = wl_ad + (unsigned)bn * (MSE * 2);
-        if constexpr (V < 4) {                       // lookups 2 V, 2 V + 1
+        if constexpr (V < 4) {                       // lookups 2 V, 2 V + 1 of every row tile
 #pragma unroll
-            for (int j = 2 * V; j < 2 * V + 2; ++j) {
-                const unsigned idx = (d[2 * KN + (j >> 2)] >> (8 * (j & 3))) & (unsigned)(kFlLut - 1);
-                lds_read_b64<0>(ent[j], lp_ad + idx * 8u);
-            }
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int j = 2 * V; j < 2 * V + 2; ++j) {
+                    const unsigned idx = (d[r][2 * KN + (j >> 2)] >> (8 * (j & 3))) & (unsigned)(kFlLut - 1);
+                    lds_read_b64<0>(ent[r][j], lp_ad[r] + idx * 8u);
+                }
         } else if constexpr (V < 7) {                // W fragments 2 (V - 4), 2 (V - 4) + 1 of 3 NTL
             constexpr int f0 = 2 * (V - 4), f1 = f0 + 1;
             if constexpr (f0 < 3 * NTL) lds_read_b128<(((f0 % 3) * NTL + f0 / 3) * 4 + KN) * 1024>(Bn[f0 / 3][f0 % 3], wad);
             if constexpr (f1 < 3 * NTL) lds_read_b128<(((f1 % 3) * NTL + f1 / 3) * 4 + KN) * 1024>(Bn[f1 / 3][f1 % 3], wad);
         } else if constexpr (V == 7) {               // the entries are in registers (the W fragments behind them may be in flight)
-            if constexpr (NTL == 2) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(ent[0]), "+v"(ent[1]), "+v"(ent[2]), "+v"(ent[3]), "+v"(ent[4]), "+v"(ent[5]), "+v"(ent[6]), "+v"(ent[7]));
-            else asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(ent[0]), "+v"(ent[1]), "+v"(ent[2]), "+v"(ent[3]), "+v"(ent[4]), "+v"(ent[5]), "+v"(ent[6]), "+v"(ent[7]));
+#define DCA_ENT8(r) "+v"(ent[r][0]), "+v"(ent[r][1]), "+v"(ent[r][2]), "+v"(ent[r][3]), "+v"(ent[r][4]), "+v"(ent[r][5]), "+v"(ent[r][6]), "+v"(ent[r][7])
+            if constexpr (NTL == 2) asm volatile("s_waitcnt lgkmcnt(6)" : DCA_ENT8(0));
+            else asm volatile("s_waitcnt lgkmcnt(3)" : DCA_ENT8(0));
+            if constexpr (RT == 2) asm volatile("" : DCA_ENT8(RT - 1));
+#undef DCA_ENT8
 #ifndef DCA_EXP_FWD_NOFORMULA
-            if (__ballot(((d[2 * KN] | d[2 * KN + 1]) & 0xe0e0e0e0u) != 0u)) beyond_table(d[2 * KN], d[2 * KN + 1], gene0 + 8 * KN);
+            static_for<RT>([&](auto rc) __attribute__((always_inline)) {
+                constexpr int r = decltype(rc)::value;
+                if (__ballot(((d[r][2 * KN] | d[r][2 * KN + 1]) & 0xe0e0e0e0u) != 0u)) beyond_table(rc, d[r][2 * KN], d[r][2 * KN + 1], gene0 + 8 * KN);
+            });
 #endif
-        } else {                                     // V = 8 .. 11: three of the twelve operand registers
+        } else {                                     // V = 8 .. 11: three of the twelve operand registers of every row tile
 #pragma unroll
-            for (int r = 3 * (V - 8); r < 3 * (V - 8) + 3; ++r) {
-                const int q = r >> 2, jj = r & 3;
-                An[q][jj] = __builtin_amdgcn_perm(ent[2 * jj + 1][q == 2 ? 1 : 0], ent[2 * jj][q == 2 ? 1 : 0], q == 1 ? 0x07060302u : 0x05040100u);
+            for (int r = 0; r < RT; ++r) {
+#pragma unroll
+                for (int x = 3 * (V - 8); x < 3 * (V - 8) + 3; ++x) {
+                    const int q = x >> 2, jj = x & 3;
+                    An[r][q][jj] = __builtin_amdgcn_perm(ent[r][2 * jj + 1][q == 2 ? 1 : 0], ent[r][2 * jj][q == 2 ? 1 : 0], q == 1 ? 0x07060302u : 0x05040100u);
+                }
+                if constexpr (V == 9) asm volatile("" : "+v"(An[r][0]));
+                if constexpr (V == 10) asm volatile("" : "+v"(An[r][1]));
+                if constexpr (V == 11) asm volatile("" : "+v"(An[r][2]));
             }
-            if constexpr (V == 9) asm volatile("" : "+v"(An[0]));
-            if constexpr (V == 10) asm volatile("" : "+v"(An[1]));
-            if constexpr (V == 11) asm volatile("" : "+v"(An[2]));
         }
     };
-    // K step K of the current macro step: its 6 NTL matrix instructions (operands Ac, Bc), the next K step's preparation between
-    auto kstep = [&](auto kn_c, const unsigned (&dn)[8], int bn, int gene0n, u32x4 (&Ac)[3], u32x4 (&Bc)[NTL][3], u32x4 (&An)[3], u32x4 (&Bn)[NTL][3]) __attribute__((always_inline)) {
+    // K step K of the current macro step: its 6 NTL RT matrix instructions (operands Ac, Bc), the next K step's preparation between
+    auto kstep = [&](auto kn_c, const unsigned (&dn)[RT][8], int bn, int gene0n, u32x4 (&Ac)[RT][3], u32x4 (&Bc)[NTL][3], u32x4 (&An)[RT][3], u32x4 (&Bn)[NTL][3]) __attribute__((always_inline)) {
         // (the W fragments of this K step: the only LDS reads still in flight)
         if constexpr (NTL == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Bc[0][0]), "+v"(Bc[0][1]), "+v"(Bc[0][2]), "+v"(Bc[1][0]), "+v"(Bc[1][1]), "+v"(Bc[1][2]));
         else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Bc[0][0]), "+v"(Bc[0][1]), "+v"(Bc[0][2]));
-        constexpr int NS = 6 * NTL;
+        constexpr int NS = 6 * NTL * RT;
         static_for<NS>([&](auto ic) __attribute__((always_inline)) {
-            constexpr int i = decltype(ic)::value, T = i % NTL, PR = i / NTL;
+            constexpr int i = decltype(ic)::value, T = i % NTL, R = (i / NTL) % RT, PR = i / (NTL * RT);
             constexpr int PA_[6] = {2, 1, 0, 1, 0, 0}, PB_[6] = {0, 1, 2, 0, 1, 0};
 #ifdef DCA_EXP_FWD_NOMFMA
-            acc[T][PR] += __uint_as_float(Ac[PA_[PR]][0] ^ Bc[T][PB_[PR]][1]);
+            acc[R][T][PR] += __uint_as_float(Ac[R][PA_[PR]][0] ^ Bc[T][PB_[PR]][1]);
 #else
-            acc[T] = MFMA16(Ac[PA_[PR]], Bc[T][PB_[PR]], acc[T]);
+            acc[R][T] = MFMA16(Ac[R][PA_[PR]], Bc[T][PB_[PR]], acc[R][T]);
 #endif
-            asm volatile("" : "+v"(acc[T]));
-            static_for<12 / NS>([&](auto jc) __attribute__((always_inline)) {
-                prepare(kn_c, std::integral_constant<int, i * (12 / NS) + decltype(jc)::value>{}, dn, bn, gene0n, An, Bn);
+            // (one wave per SIMD: the accumulators live in the AGPR half of its 512 registers -- a "+v" tie would copy them
+            // to vector registers and back around every matrix instruction)
+            if constexpr (RT == 2) asm volatile("" : "+a"(acc[R][T])); else asm volatile("" : "+v"(acc[R][T]));
+            constexpr int v0 = i * 12 / NS, v1 = (i + 1) * 12 / NS;          // pieces [v0, v1) behind this matrix instruction
+            static_for<v1 - v0>([&](auto jc) __attribute__((always_inline)) {
+                prepare(kn_c, std::integral_constant<int, v0 + decltype(jc)::value>{}, dn, bn, gene0n, An, Bn);
             });
         });
     };
-    auto codes_of = [&](int h, unsigned (&d)[8]) __attribute__((always_inline)) {
+    auto codes_of = [&](int h, unsigned (&d)[RT][8]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { d[k] = cq[2 * h][k]; d[4 + k] = cq[2 * h + 1][k]; }
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { d[r][k] = cq[r][2 * h][k]; d[r][4 + k] = cq[r][2 * h + 1][k]; }
     };
     using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>;
     using K2 = std::integral_constant<int, 2>; using K3 = std::integral_constant<int, 3>;
@@ -1283,15 +1312,15 @@ __global__ __launch_bounds__(512) void enc0_fwd_lut_kernel(FlArgs a) {
     auto step = [&](auto half, int ms) __attribute__((always_inline)) {
         constexpr int h = decltype(half)::value, b = h;
         load_w(ms + 1);                     // (past the chunk's end: a tile nobody reads)
-        if (h == 0) load_codes((ms >> 1) + 1, cn);
-        unsigned d[8], dn[8];
+        if (h == 0) load_codes((ms >> 1) + 1);
+        unsigned d[RT][8], dn[RT][8];
         codes_of(h, d);
         const int gene0 = (ms >> 1) * (2 * kFlMS) + 64 * hi + 32 * h;
         kstep(K1{}, d, b, gene0, A0, Bf0, A1, Bf1);
         kstep(K2{}, d, b, gene0, A1, Bf1, A0, Bf0);
         kstep(K3{}, d, b, gene0, A0, Bf0, A1, Bf1);
         store_w(b ^ 1);
-        if (h == 1) take_codes((ms >> 1) + 1, cn);          // the next super step's counts (requested a super step ago)
+        if (h == 1) take_codes((ms >> 1) + 1);              // the next super step's counts (requested a super step ago)
         codes_of(h ^ 1, dn);
 #ifndef DCA_EXP_FWD_NOBARRIER
         __syncthreads();                    // tile b ^ 1 is in LDS; everyone's reads of tile b are in registers
@@ -1300,7 +1329,7 @@ __global__ __launch_bounds__(512) void enc0_fwd_lut_kernel(FlArgs a) {
     };
     if (ms0 < ms1) {                        // the operands of the first K step (no matrix instructions to put them behind)
         __syncthreads();                    // tile 0 and the tables are in LDS
-        unsigned d[8];
+        unsigned d[RT][8];
         codes_of(0, d);
         const int gene0 = (ms0 >> 1) * (2 * kFlMS) + 64 * hi;
         static_for<12>([&](auto vc) __attribute__((always_inline)) { prepare(K0{}, vc, d, 0, gene0, A0, Bf0); });
@@ -1315,12 +1344,15 @@ __global__ __launch_bounds__(512) void enc0_fwd_lut_kernel(FlArgs a) {
         else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Bf0[0][0]), "+v"(Bf0[0][1]), "+v"(Bf0[0][2]));
     }
     if (ms0 >= ms1) __syncthreads();        // (an empty chunk never passed a barrier after csum was written)
-    float* const dst = a.P + ((long)blockIdx.y * a.Bp + rg0 + wave * 32) * H1;
 #pragma unroll
-    for (int t = 0; t < NTL; ++t) {
-        const float c0 = csum[32 * t + l31];
+    for (int r = 0; r < RT; ++r) {
+        float* const dst = a.P + ((long)blockIdx.y * a.Bp + rg0 + wave * (32 * RT) + 32 * r) * H1;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) dst[(long)rowmap(e, hi) * H1 + 32 * t + l31] = acc[t][e] + c0;
+        for (int t = 0; t < NTL; ++t) {
+            const float c0 = csum[32 * t + l31];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) dst[(long)rowmap(e, hi) * H1 + 32 * t + l31] = acc[r][t][e] + c0;
+        }
     }
 }
 
@@ -1622,6 +1654,14 @@ extern "C" int dcahip_enc0_fwd_sparse(const unsigned char* Yc, long ldc, const i
     return (int)hipGetLastError();
 }
 
+// 32-row tiles per wave of the matrix-pipe forward (1: eight waves, 2: four waves of 64 rows); dcahip_enc0_fwd_set_form
+int g_fl_rt = 1;
+extern "C" int dcahip_enc0_fwd_set_form(int form) {
+    const int old = g_fl_rt;
+    if (form == 1 || form == 2) g_fl_rt = form;
+    return old;
+}
+
 // workspace: WP | C0P | P
 extern "C" long dcahip_enc0_fwd_lut_workspace_bytes(int B, int G, int H1) {
     if (!fl_width_ok(H1) || B <= 0 || G <= 0) return 0;
@@ -1655,10 +1695,12 @@ extern "C" int dcahip_enc0_fwd_lut(const unsigned char* Yc, long ldc, const int*
     const dim3 grid((unsigned)fl_row_groups(B), (unsigned)nsk);
     if (H1 == 32) {
         hipLaunchKernelGGL(enc0_wsplit_kernel<32>, dim3((unsigned)n_ms, 1), dim3(256), 0, s, W, ldw, mean, stdv, G, WP, C0P);
-        hipLaunchKernelGGL(enc0_fwd_lut_kernel<32>, grid, dim3(512), 0, s, f);
+        if (g_fl_rt == 2) hipLaunchKernelGGL((enc0_fwd_lut_kernel<32, 2>), grid, dim3(256), 0, s, f);
+        else hipLaunchKernelGGL((enc0_fwd_lut_kernel<32, 1>), grid, dim3(512), 0, s, f);
     } else {
         hipLaunchKernelGGL(enc0_wsplit_kernel<64>, dim3((unsigned)n_ms, 2), dim3(256), 0, s, W, ldw, mean, stdv, G, WP, C0P);
-        hipLaunchKernelGGL(enc0_fwd_lut_kernel<64>, grid, dim3(512), 0, s, f);
+        if (g_fl_rt == 2) hipLaunchKernelGGL((enc0_fwd_lut_kernel<64, 2>), grid, dim3(256), 0, s, f);
+        else hipLaunchKernelGGL((enc0_fwd_lut_kernel<64, 1>), grid, dim3(512), 0, s, f);
     }
     int rc = (int)hipGetLastError();
     if (rc) return rc;

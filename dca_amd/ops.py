@@ -121,6 +121,10 @@ class HipOps:
                                                B, G, H1, p(dZ), ldz, p(gW), ldg, p(ws), ws.numel() * ws.element_size(),
                                                hip.stream()), 'enc0_dw_sparse')
 
+    def enc0_fwd_set_form(self, form):
+        """Shape of the matrix-pipe byte-store forward (1: eight waves of 32 rows, 2: four waves of 64 rows); returns the previous."""
+        return int(self.L.dcahip_enc0_fwd_set_form(int(form)))
+
     def enc0_dw_set_form(self, form):
         """Which kernel the 64-unit byte-store weight gradient takes (1, default: the ring kernel from 1024 rows up; 0: always the
         first kernel; 2: always the ring kernel); returns the previous."""

@@ -618,6 +618,12 @@ int dcahip_enc0_fwd_sparse(const unsigned char* Yc, long ldc, const int* ovf_ptr
  * dcahip_enc0_fwd_lut_workspace_bytes(B, G, H1), 16-byte aligned, any content; n_cells * ldc must stay below 2^32 (lutp).
  * Replaces Dense(hidden_size[0]) of dca/network.py:124-126 on the input of dca/io.py:88-111.
  */
+/* The matrix-pipe forward has two shapes of the same kernel (csrc/dcahip_sparse.hip enc0_fwd_lut_kernel<H1, RT>): form 1 --
+ * eight waves of 32 batch rows per workgroup, two waves per SIMD; form 2 -- four waves of 64 rows, one per SIMD, the W
+ * fragments of a K step read from LDS once for both 32-row tiles (the loop of form 1 is bound by its LDS reads).  Same
+ * products in the same order: bit-identical results.  Returns the previous form; other values only read it.  A switch for
+ * A/B runs and the parity tests of both; no reference call site. */
+int dcahip_enc0_fwd_set_form(int form);
 long dcahip_enc0_fwd_lut_workspace_bytes(int B, int G, int H1);
 int dcahip_enc0_fwd_lut(const unsigned char* Yc, long ldc, const int* ovf_ptr, const int* ovf_col,
                         const float* ovf_val, const float* fac, int do_log, const void* lutp, const float* mean,

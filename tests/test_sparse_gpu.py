@@ -150,13 +150,21 @@ def test_sparse_first_layer_vs_numpy(ops, B, G, H1, gather, use_fac, do_log, sca
     assert (nb > 0) == (H1 in (32, 64))
     if nb:
         wsl = torch.full((nb // 4 + 4,), float("nan"), device="cuda")
-        Zl = torch.full((B, H1), 7.0, device='cuda'); Zl2 = torch.full((B, H1), 3.0, device='cuda')
-        ops.enc0_fwd_lut(cc, dperm, dcur, base, B, G, H1, dW_, H1, db_, Zl, H1, wsl)
-        ops.enc0_fwd_lut(cc, dperm, dcur, base, B, G, H1, dW_, H1, db_, Zl2, H1, wsl)
-        torch.cuda.synchronize()
-        err = np.abs(Zl.cpu().numpy() - Z_ref)
-        assert (err <= 1e-6 * Z_abs + 1e-30).all(), float((err / Z_abs).max())
-        assert torch.equal(Zl, Zl2)
+        seen = []
+        for form in (1, 2):                 # eight waves of 32 rows / four waves of 64 rows: the same products in the same order
+            prev = ops.enc0_fwd_set_form(form)
+            try:
+                Zl = torch.full((B, H1), 7.0, device='cuda'); Zl2 = torch.full((B, H1), 3.0, device='cuda')
+                ops.enc0_fwd_lut(cc, dperm, dcur, base, B, G, H1, dW_, H1, db_, Zl, H1, wsl)
+                ops.enc0_fwd_lut(cc, dperm, dcur, base, B, G, H1, dW_, H1, db_, Zl2, H1, wsl)
+                torch.cuda.synchronize()
+                err = np.abs(Zl.cpu().numpy() - Z_ref)
+                assert (err <= 1e-6 * Z_abs + 1e-30).all(), (form, float((err / Z_abs).max()))
+                assert torch.equal(Zl, Zl2), form
+                seen.append(Zl)
+            finally:
+                ops.enc0_fwd_set_form(prev)
+        assert torch.equal(seen[0], seen[1])
     # ---- weight + bias gradient
     if not ops.enc0_sparse_supported(H1):
         return

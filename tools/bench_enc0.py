@@ -12,6 +12,8 @@ from dca_amd import synth, prep, compact
 from dca_amd.ops import HipOps
 
 ops = HipOps()
+if os.environ.get('FWD_FORM'):
+    ops.enc0_fwd_set_form(int(os.environ['FWD_FORM']))
 dev = torch.device('cuda')
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 h = int(sys.argv[2]) if len(sys.argv) > 2 else 64
