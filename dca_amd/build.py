@@ -31,12 +31,36 @@ def _hipcc():
     raise RuntimeError('hipcc not found: cannot build libdcahip.so')
 
 
+def _deps():
+    return [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.join(ROOT, 'include', 'dcahip.h')]
+
+
+def source_fingerprint():
+    """sha256 over the contents of everything libdcahip.so is compiled from."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in _deps():
+        h.update(os.path.basename(d).encode())
+        if os.path.exists(d):
+            with open(d, 'rb') as f:
+                h.update(f.read())
+    return h.hexdigest()
+
+
 def needs_build():
+    """True when the library is absent, older than a source, or was built from OTHER source contents (the fingerprint beside
+    it, LIB + '.src': modification times do not survive every copy of the tree, and a checkout can make a source older than a
+    library built from its edited state)."""
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.join(ROOT, 'include', 'dcahip.h')]
-    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+    if any(os.path.exists(d) and os.path.getmtime(d) > t for d in _deps()):
+        return True
+    try:
+        with open(LIB + '.src') as f:
+            return f.read().strip() != source_fingerprint()
+    except OSError:
+        return True
 
 
 def _obj_path(src, tag):
@@ -70,6 +94,9 @@ def build_hip(force=False, verbose=True, defines=(), out=None):
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)
+    if not defines and out == LIB:
+        with open(LIB + '.src', 'w') as f:
+            f.write(source_fingerprint() + '\n')
     return out
 
 

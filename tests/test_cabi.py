@@ -3,6 +3,8 @@ import ctypes
 import os
 import re
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -239,3 +241,25 @@ def test_ring_weight_gradient_loop_has_no_compiler_waits_on_the_ring():
                 assert not t.startswith(('s_load', 's_buffer_load')), t
                 assert not t.startswith('scratch_'), t
     assert seen >= 4          # two phases of twelve matrix instructions per step, two steps per trip of the loop
+
+
+def test_library_counts_as_stale_when_it_was_built_from_other_source_contents():
+    """Modification times do not say which sources a library was built from (a checkout makes a source OLDER than a library
+    built from its edited state; a copied tree has fresh times everywhere): build.needs_build() also compares the fingerprint
+    of the source contents stored beside the library."""
+    from dca_amd import build
+    side = build.LIB + '.src'
+    if not os.path.exists(build.LIB):
+        pytest.skip('library not built')
+    assert not build.needs_build()
+    keep = open(side).read()
+    try:
+        with open(side, 'w') as f:
+            f.write('0' * 64 + '\n')
+        assert build.needs_build()
+        os.remove(side)
+        assert build.needs_build()
+    finally:
+        with open(side, 'w') as f:
+            f.write(keep)
+    assert not build.needs_build()
