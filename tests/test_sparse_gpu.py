@@ -362,3 +362,51 @@ def test_small_batch_weight_gradient_from_the_byte_store(ops, B, monkeypatch):
         assert abs(res[on][0] - rl) < 1e-5 * abs(rl)
         assert_grads_close(res[on][1], rg)
     np.testing.assert_allclose(res['1'][1]['W0'], res['0'][1]['W0'], rtol=2e-4, atol=2e-6 * np.abs(res['0'][1]['W0']).max())
+
+
+def test_weight_gradient_kernels_on_random_shapes(ops):
+    """Both 64-unit weight-gradient kernels on shapes drawn around their edges: splits of one to a few K steps (fewer than
+    the ring kernel's five steps of lead), batches that are not a multiple of 16, gene counts across the 256 / 512 group
+    boundaries, rows with many counts beyond the table (the formula path in most steps), every run twice (bit for bit)."""
+    rng = np.random.RandomState(20260927)
+    shapes = [(1, 1), (15, 17), (16, 512), (17, 513), (33, 255), (100, 1024), (250, 600), (1030, 40), (1500, 530), (2500, 70)]
+    shapes += [(int(rng.randint(1, 1800)), int(rng.randint(1, 1400))) for _ in range(6)]
+    H1 = 64
+    for B, G in shapes:
+        n = B + 5
+        Y = counts_with_escapes(n, G, B * 7 + G, big=(B > 4 and G > 8))
+        hot = rng.randint(0, G, max(1, G // 40))                 # highly expressed genes: counts 64 .. 254 in half of the rows
+        for g in hot:
+            rows = rng.rand(n) < 0.5
+            Y[rows, g] = rng.randint(64, 255, int(rows.sum()))
+        fac = rng.lognormal(0, 0.4, n).astype(np.float32).astype(np.float64)
+        L = dense_input(Y, fac, True, None, None)
+        mean = L.mean(0).astype(np.float32).astype(np.float64)
+        std = np.maximum(L.std(0, ddof=1) if n > 1 else np.ones(G), 1e-3).astype(np.float32).astype(np.float64)
+        X = dense_input(Y, fac, True, mean, std)
+        perm = rng.permutation(n)[:B].astype(np.int32)
+        dZ = rng.normal(0, 1e-3, (B, H1)).astype(np.float32).astype(np.float64)
+        gW_ref = X[perm].T @ dZ
+        Lr = L[perm] / std[None, :]
+        gW_abs = np.abs(Lr).T @ np.abs(dZ) + np.abs(mean / std)[:, None] * np.abs(dZ).sum(0)[None, :] + \
+            np.abs(mean / std)[:, None] * np.abs(dZ.sum(0))[None, :]
+        _, cc = build_compact(ops, Y)
+        cc = cc.with_input(dev(fac), True, dev(mean), dev(std), ops=ops)
+        dperm = torch.as_tensor(perm).cuda()
+        dcur = torch.zeros(1, dtype=torch.int64, device='cuda')
+        ddZ = dev(dZ)
+        for form in (0, 2):
+            prev = ops.enc0_dw_set_form(form)
+            try:
+                ws = torch.full((ops.enc0_dw_sparse_workspace_bytes(B, G, H1) // 4 + 4,), float('nan'), device='cuda')
+                gW1 = torch.full((G + 1, H1), 7.0, device='cuda'); gW2 = torch.full((G + 1, H1), 3.0, device='cuda')
+                ops.enc0_dw_sparse(cc, dperm, dcur, 0, B, G, H1, ddZ, H1, gW1, H1, ws)
+                ops.enc0_dw_sparse(cc, dperm, dcur, 0, B, G, H1, ddZ, H1, gW2, H1, ws)
+                torch.cuda.synchronize()
+                got = gW1.cpu().numpy()
+                err = np.abs(got[:G] - gW_ref)
+                assert (err <= 1e-6 * gW_abs + 1e-30).all(), (B, G, form, float((err / np.maximum(gW_abs, 1e-30)).max()))
+                np.testing.assert_allclose(got[G], dZ.sum(0), rtol=0, atol=2e-6 * np.abs(dZ).sum(0).max() + 1e-30)
+                assert torch.equal(gW1, gW2), (B, G, form)
+            finally:
+                ops.enc0_dw_set_form(prev)
