@@ -17,7 +17,7 @@ class CompactCounts:
         self.Yc, self.ldc = Yc, int(ldc)
         self.ovf_ptr, self.ovf_col, self.ovf_val = ovf_ptr, ovf_col, ovf_val
         self.fac, self.do_log, self.mean, self.std = fac, bool(do_log), mean, std
-        self.lutp = None        # [n, 64] x 8 bytes: f(k / fac[r]) for the counts k = 0 .. 63 as bf16 pieces (dcahip_enc0_lut)
+        self.lutp = None        # [n, 128] x 8 bytes: f(k / fac[r]) for the counts k = 0 .. 127 as bf16 pieces (dcahip_enc0_lut)
 
     def with_input(self, fac, do_log, mean, std, ops=None):
         """The same store with the description of the network input (None when the store is too large for the sparse first
@@ -35,10 +35,10 @@ class CompactCounts:
     _warned_32bit = False
 
     def ensure_lut(self, ops):
-        """f(k / fac[r]) for the counts k = 0 .. 63 of every cell as bf16 pieces (dcahip_enc0_lut), once per store."""
+        """f(k / fac[r]) for the counts k = 0 .. 127 of every cell as bf16 pieces (dcahip_enc0_lut), once per store."""
         if self.lutp is None:
             n = self.Yc.shape[0]
-            self.lutp = torch.zeros(n, 64, 2, dtype=torch.int32, device=self.Yc.device)
+            self.lutp = torch.zeros(n, ops.enc0_lut_entries(), 2, dtype=torch.int32, device=self.Yc.device)
             ops.enc0_lut(self.fac, self.do_log, n, self.lutp)
         return self.lutp
 

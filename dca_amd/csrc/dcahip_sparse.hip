@@ -163,7 +163,7 @@ template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
 
-constexpr int kLut = 64;            // table entries per cell (counts 0 .. 63: all but ~1e-4 of the non-zero counts of scRNA-seq data)
+constexpr int kLut = 128;           // table entries per cell in memory (counts 0 .. 127); the kernels hold the first 32 / 64 / 128 in LDS
 
 __global__ __launch_bounds__(256) void enc0_lut_kernel(const float* fac, int do_log, int n, uint2* lutp) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -230,7 +230,7 @@ struct DwArgs {
     int RS;                         // batch rows per split (multiple of the row block)
 };
 
-constexpr int kDwLut = kLut;        // table entries per cell held in LDS: all of them (with 32, one block in two waits for a wave in the formula path)
+constexpr int kDwLut = 64;          // table entries per cell held in LDS (with 32, one block in two waits for a wave in the formula path)
 
 // Workgroups are dealt to the eight XCDs round-robin by their linear index, and each XCD has its own L2.  The weight-gradient
 // kernels want the workgroups of ONE row split (same table rows, same dZ pieces, all gene groups) behind the same L2: this
@@ -244,6 +244,22 @@ __device__ __forceinline__ void xcd_cell(int& bx, int& by) {
     const int cell = x * q + (x < r ? x : r) + (L >> 3);
     bx = cell % (int)gridDim.x; by = cell / (int)gridDim.x;
 #endif
+}
+
+// Column sums of one row split's dZ = sum of its K steps' sums, IN ORDER (the bias gradient's summation order), by the H1
+// threads of one workgroup per split.  All loads are issued before the first addition (64 at a time): as a loop of dependent
+// load -> add round trips this tail took 30 000 cycles and made those workgroups the last to finish.
+template <int H1>
+__device__ __forceinline__ void split_column_sums(const float* Spp, float* Sp, int split, int ks0, int ks1, int tid) {
+    float sum = 0.f;
+    for (int base = ks0; base < ks1; base += 64) {
+        float v[64];
+#pragma unroll
+        for (int i = 0; i < 64; ++i) v[i] = base + i < ks1 ? Spp[(long)(base + i) * H1 + tid] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 64; ++i) sum += v[i];
+    }
+    Sp[(long)split * H1 + tid] = sum;
 }
 
 template <int H1>
@@ -429,11 +445,7 @@ __global__ __launch_bounds__(64 * kDwWaves) void enc0_dw_kernel(DwArgs a) {
         block(Buf0{}, Buf1{}, rg0);
         if (rg0 + RB < re) block(Buf1{}, Buf0{}, rg0 + RB);
     }
-    if (bx == 0 && tid < H1) {                           // column sums of this split's rows: its K steps in order
-        float s = 0.f;
-        for (int ks = rb / kKS; ks * kKS < re; ++ks) s += a.Spp[(long)ks * H1 + tid];
-        a.Sp[(long)split * H1 + tid] = s;
-    }
+    if (bx == 0 && tid < H1) split_column_sums<H1>(a.Spp, a.Sp, split, rb / kKS, (re + kKS - 1) / kKS, tid);
     if (!wave_on) return;
 #pragma unroll
     for (int t = 0; t < NTL; ++t)
@@ -449,11 +461,11 @@ __global__ __launch_bounds__(64 * kDwWaves) void enc0_dw_kernel(DwArgs a) {
 // a SIMD in the same phase -- profiles/r05k_*, r05l_*):
 //   * a wave owns TWO 32-gene tiles (a workgroup 512 genes): the dZ fragments of a K step are read from LDS once for both,
 //     the table rows and dZ of a batch row are fetched by half as many workgroups;
-//   * a stage is ONE K step (16 batch rows: their counts, table rows and split dZ, 22.25 KB); six stages in a ring filled by
-//     global_load_lds_dwordx4 (no staging registers, no LDS store pass) FIVE steps ahead, retired with a counted
+//   * a stage is ONE K step (16 batch rows: their counts, 128-entry table rows and split dZ, 30.25 KB); five stages in a ring
+//     filled by global_load_lds_dwordx4 (no staging registers, no LDS store pass) FOUR steps ahead, retired with a counted
 //     s_waitcnt vmcnt; one barrier per step.  (Four stages -- two workgroups of four waves per CU -- were measured: the two
 //     steps of lead do not cover the memory round trip, 46 % of the wave cycles at the vmcnt wait.)
-//   * software pipeline over the steps: in step k a wave requests step k + 5, reads the counts of step k + 1, the table
+//   * software pipeline over the steps: in step k a wave requests step k + 4, reads the counts of step k + 1, the table
 //     entries of step k (its counts arrived during step k - 1) and the dZ fragments of step k, and issues the 24 matrix
 //     instructions of step k - 1: every LDS round trip stands behind matrix work;
 //   * waves 0..3 read first and multiply second, waves 4..7 (the other wave of each SIMD) multiply first: one wave's matrix
@@ -468,13 +480,14 @@ constexpr int kD2MT = 2;                                   // 32-gene tiles per 
 constexpr int kD2Genes = kD2Waves * kD2MT * 32;            // 512 genes per workgroup
 constexpr int kD2RB = kKS;                                 // rows per split are a multiple of this
 constexpr int kD2MaxRS = 1024;                             // batch rows per split at most (their storage rows sit in LDS)
-constexpr int kD2Stages = 6;
+constexpr int kD2Stages = 5;
 constexpr int kD2Lead = kD2Stages - 1;                     // a request goes into the stage the step before the current one used
-constexpr int kD2LutB = kKS * kLut * 8;                    // 8192: 16 table rows of 512 bytes
+constexpr int kD2LutB = kKS * kLut * 8;                    // 16384: 16 table rows of 1 KB (128 entries: with 64, the workgroups that hold
+                                                           // the most expressed genes visited the formula path 10-15 times and set the kernel's time)
 constexpr int kD2DzB = dz_step_elems(64) * 2;              // 6144: one K step of split dZ
 constexpr int kD2CodeChunk = 1024 + 32;                    // two count rows of 512 bytes land as one chunk; rows 8 apart sit 32 banks apart
 constexpr int kD2CodeB = 8 * kD2CodeChunk;                 // 8448
-constexpr int kD2StageB = kD2LutB + kD2DzB + kD2CodeB;     // 22784
+constexpr int kD2StageB = kD2LutB + kD2DzB + kD2CodeB;     // 30976
 
 #ifdef DCA_DW_TIMING
 __device__ long long* g_dw_timing = nullptr;         // [workgroup][8]: clock at kernel entry, after the prologue, after the loop, at the end (wave 0) + realtime at entry / end
@@ -486,7 +499,7 @@ __global__ __launch_bounds__(64 * kD2Waves) __attribute__((amdgpu_waves_per_eu(2
     constexpr int H1 = 64, NTL = 2;
     constexpr int KSE = dz_step_elems(H1);
     constexpr int NT = 64 * kD2Waves;
-    static_assert(kLut == 64 && kKS == 16 && kD2DzB == 6 * 1024 && kD2Waves == 8, "chunks of the loader");
+    static_assert(kLut == 128 && kKS == 16 && kD2DzB == 6 * 1024 && kD2Waves == 8, "chunks of the loader");
     __shared__ __attribute__((aligned(16))) unsigned char ring[kD2Stages * kD2StageB];
     __shared__ int srow_all[kD2MaxRS];
     __shared__ float fac_all[kD2MaxRS];                    // size factors of the split's rows (the formula path)
@@ -527,13 +540,13 @@ __global__ __launch_bounds__(64 * kD2Waves) __attribute__((amdgpu_waves_per_eu(2
     }
     __syncthreads();
 
-    // ---- the loader: a wave instruction moves 1 KB (lane-linear in LDS).  Per step 8 chunks of table rows and 8 of counts
+    // ---- the loader: a wave instruction moves 1 KB (lane-linear in LDS).  Per step 16 chunks of table rows and 8 of counts
     // (rows 2 wave and 2 wave + 1 of the step, one of each per wave) and 6 of split dZ (waves 0..5).
     const unsigned ring_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)ring;
     const unsigned srow_base = (unsigned)(size_t)(__attribute__((address_space(3))) int*)srow_all;
     const int ks_first = rb / kKS;
     const bool cseg_ok = gbase + l31 * 16 < a.c.ldc;
-    const bool three = wave < 6;                           // requests of this wave per step: 3 or 2
+    const bool three = wave < 6;                           // requests of this wave per step: 4 (with a dZ chunk) or 3
     const unsigned sr_ad = srow_base + (unsigned)(2 * wave + hi) * 4u;
     auto issue_srow = [&](int k, int& s0) __attribute__((always_inline)) {   // storage row of batch row 2 wave + hi of step k
         asm volatile("ds_read_b32 %0, %1" : "=v"(s0) : "v"(sr_ad + (unsigned)k * (kKS * 4u)));
@@ -542,8 +555,12 @@ __global__ __launch_bounds__(64 * kD2Waves) __attribute__((amdgpu_waves_per_eu(2
         unsigned char* st = ring + stage * kD2StageB;
         const unsigned char* lut = reinterpret_cast<const unsigned char*>(a.lutp);
         const unsigned char* dz = reinterpret_cast<const unsigned char*>(a.DZP + (long)(ks_first + k) * KSE);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(lut + (long)s0 * (kLut * 8) + l31 * 16),
-                                         (__attribute__((address_space(3))) void*)(st + wave * 1024), 16, 0, 0);
+        // table rows 2 wave and 2 wave + 1 of the step (1 KB each = one chunk): their storage rows sit in lanes 0 and 32
+        const long sA = __builtin_amdgcn_readlane(s0, 0), sB = __builtin_amdgcn_readlane(s0, 32);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(lut + sA * (kLut * 8) + lane * 16),
+                                         (__attribute__((address_space(3))) void*)(st + (2 * wave) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(lut + sB * (kLut * 8) + lane * 16),
+                                         (__attribute__((address_space(3))) void*)(st + (2 * wave + 1) * 1024), 16, 0, 0);
         if (cseg_ok)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.c.yc + (long)s0 * a.c.ldc + gbase + l31 * 16),
                                              (__attribute__((address_space(3))) void*)(st + kD2LutB + kD2DzB + wave * kD2CodeChunk), 16, 0, 0);
@@ -555,13 +572,13 @@ __global__ __launch_bounds__(64 * kD2Waves) __attribute__((amdgpu_waves_per_eu(2
     auto retire = [&](int newer) __attribute__((always_inline)) {
         if (newer <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if (three) {
+            if (newer == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (newer == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        } else {
             if (newer == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
             else if (newer == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-        } else {
-            if (newer == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else if (newer == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         }
     };
 
@@ -694,7 +711,7 @@ __global__ __launch_bounds__(64 * kD2Waves) __attribute__((amdgpu_waves_per_eu(2
             asm volatile("s_waitcnt lgkmcnt(0)" : DCA_TIE8(cK, 0), DCA_TIE8(cK, 1), "+v"(s0));
             asm volatile("" : "+v"(Bp[0][0]), "+v"(Bp[0][1]), "+v"(Bp[0][2]), "+v"(Bp[1][0]), "+v"(Bp[1][1]), "+v"(Bp[1][2]));
             unsigned any = 0u;
-            // ---- gene tile 0 of step k - 1, behind it: the request of step k + 5, the table entries and dZ fragments of step k
+            // ---- gene tile 0 of step k - 1, behind it: the request of the step kD2Lead ahead, the table entries and dZ fragments of step k
             const unsigned ead = lut_off + (unsigned)sk * kD2StageB, dad = dz_off + (unsigned)sk * kD2StageB;
             static_for<12>([&](auto ic) __attribute__((always_inline)) {
                 constexpr int i = decltype(ic)::value, T = i & 1, PR = i >> 1;
@@ -782,11 +799,7 @@ __global__ __launch_bounds__(64 * kD2Waves) __attribute__((amdgpu_waves_per_eu(2
     }
 #undef DCA_TIE8
 #undef DCA_TIE_ACC
-    if (bx == 0 && tid < H1) {                           // column sums of this split's rows: its K steps in order
-        float sum = 0.f;
-        for (int ks = rb / kKS; ks * kKS < re; ++ks) sum += a.Spp[(long)ks * H1 + tid];
-        a.Sp[(long)split * H1 + tid] = sum;
-    }
+    if (bx == 0 && tid < H1) split_column_sums<H1>(a.Spp, a.Sp, split, rb / kKS, (re + kKS - 1) / kKS, tid);
 #pragma unroll
     for (int m = 0; m < kD2MT; ++m)
 #pragma unroll
@@ -1558,6 +1571,8 @@ extern "C" long dcahip_enc0_dw_sparse_workspace_bytes(int B, int G, int H1) {
 #ifdef DCA_DW_TIMING
 extern "C" void dcahip_enc0_dw_set_timing(long long* buf) { hipMemcpyToSymbol(HIP_SYMBOL(g_dw_timing), &buf, sizeof(buf)); }
 #endif
+extern "C" int dcahip_enc0_lut_entries(void) { return kLut; }
+
 extern "C" int dcahip_enc0_dw_set_form(int form) {
     const int old = g_dw_form;
     if (form == 0 || form == 1 || form == 2) g_dw_form = form;

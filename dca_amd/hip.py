@@ -175,6 +175,7 @@ _SIGNATURES = {
     'dcahip_peer_exchange': (_c.c_int, [_f32p, _c.c_int, _vp, _vp, _c.c_int, _c.c_int, _c.c_int, _vp, _f32p, _c.c_int, _i32p,
                                         _c.c_long, _vp]),
     'dcahip_enc0_dw_set_form': (_c.c_int, [_c.c_int]),
+    'dcahip_enc0_lut_entries': (_c.c_int, []),
     'dcahip_enc0_fwd_set_form': (_c.c_int, [_c.c_int]),
     'dcahip_enc0_dw_small_max_rows': (_c.c_int, []),
     'dcahip_enc0_dw_small': (_c.c_int, [_vp, _c.c_long, _i32p, _i32p, _f32p, _f32p, _c.c_int, _f32p, _f32p, _i32p, _i64p,

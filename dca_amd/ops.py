@@ -100,6 +100,10 @@ class HipOps:
         hip.check(self.L.dcahip_counts_compact(hip.ptr(Y), ldy, n, G, hip.ptr(Yc), ldc, hip.ptr(status), hip.stream()),
                   'counts_compact')
 
+    def enc0_lut_entries(self):
+        """Entries per cell of the table enc0_lut writes."""
+        return int(self.L.dcahip_enc0_lut_entries())
+
     def enc0_lut(self, fac, do_log, n, lutp):
         hip.check(self.L.dcahip_enc0_lut(hip.ptr(fac), int(do_log), n, hip.ptr(lutp), hip.stream()), 'enc0_lut')
 

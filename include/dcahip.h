@@ -571,10 +571,13 @@ int dcahip_enc0_sparse_supported(int H1);
  *   workspace >= dcahip_enc0_dw_sparse_workspace_bytes(B, G, H1), 16-byte aligned.
  * Replaces the autodiff of dca/network.py:124-126 w.r.t. the first kernel on the input of dca/io.py:88-111.
  */
-/* lutp [n, 64] entries of 8 bytes: entry k of cell r = f(k / fac[r]) (f = log1p if do_log, fac NULL: 1) split into the
- * three bf16 pieces the matrix products use ({p0 | p1 << 16, p2}) -- made once per dataset, so that the weight gradient
- * LOOKS UP its operand instead of dividing, taking logarithms and splitting (counts beyond 63 take the formula). */
+/* lutp [n, dcahip_enc0_lut_entries() = 128] entries of 8 bytes: entry k of cell r = f(k / fac[r]) (f = log1p if do_log,
+ * fac NULL: 1) split into the three bf16 pieces the matrix products use ({p0 | p1 << 16, p2}) -- made once per dataset, so
+ * that the first-layer kernels LOOK UP their operand instead of dividing, taking logarithms and splitting.  The kernels
+ * hold the first 32 (forward), 64 (first weight-gradient kernel) or all 128 (ring weight-gradient kernel) entries of their
+ * cells in LDS; counts beyond take the formula (hardware log2 with an exact-ratio correction, ~2e-7 relative). */
 int dcahip_enc0_lut(const float* fac, int do_log, int n, void* lutp, void* stream);
+int dcahip_enc0_lut_entries(void);
 /* The same weight (+ bias) gradient for SMALL batches (B <= dcahip_enc0_dw_small_max_rows() = 64; the reference's default
  * batch is 32, dca/train.py:37), any first-layer width H1 <= 64 that is a multiple of 4: one pass over the batch's count bytes,
  * fp32 FMAs over the non-zero counts in row order (deterministic), no workspace, no table:
@@ -588,7 +591,7 @@ int dcahip_enc0_dw_small(const unsigned char* Yc, long ldc, const int* ovf_ptr, 
 long dcahip_enc0_dw_sparse_workspace_bytes(int B, int G, int H1);
 /* The 64-unit weight gradient has two kernels (csrc/dcahip_sparse.hip): enc0_dw_kernel (counts through an LDS tile, lookups
  * and products of a 64-row block between two barriers) and enc0_dw2_kernel (512 genes per workgroup, operands staged
- * global -> LDS into a six-stage ring five K steps ahead, a wave's LDS / vector work behind its own matrix instructions).
+ * global -> LDS into a five-stage ring four K steps ahead, a wave's LDS / vector work behind its own matrix instructions).
  * form 1 (default): the ring kernel from 1024 batch rows up, the first kernel below; 0: always the first; 2: always the ring
  * kernel.  Returns the previous form; other values only read it.  Same products, same row order inside a split; the number
  * of splits differs.  A switch for A/B runs and the parity tests of both; no reference call site. */
