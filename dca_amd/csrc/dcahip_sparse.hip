@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void counts_compact_kernel(const float* Y, lon
 //     sum_c x[c, g] dZ[c, :] = (sum_c L[c, g] dZ[c, :] - mean[g] colsum(dZ)) / std[g],   L = f(y / fac[c])
 // A wave owns a 32-gene tile and all H1 columns; K = the batch rows, 16 per step.  The A operand (32 genes x 16 rows
 // of L as three bf16 pieces) is LOOKED UP, not computed: 8 byte loads of counts per lane and step, each the index
-// into the cell's table of pre-split values lutp[cell][count] (counts 0 .. 63; larger ones take the formula -- a
+// into the cell's table of pre-split values lutp[cell][count] (the first 64 of its 128 entries; larger ones take the formula -- a
 // wave-uniform branch that is rare on count data; an escape byte looks its count up in the row's overflow list there).
 // The B operand (dZ as three bf16 pieces, laid out for the MFMA by enc0_split_dz once per call) is shared by the
 // workgroup's 8 waves through LDS, 64 rows at a time.
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(64 * kDwWaves) void enc0_dw_kernel(DwArgs a) {
 }
 
 // ---- second form of the weight gradient (64 first-layer units): operands staged global -> LDS directly into a deep ring,
-// a software pipeline over the K steps, the two waves of a SIMD out of phase.  What changed against enc0_dw_kernel above and why
+// a software pipeline over the K steps, each wave's LDS / vector work between its own matrix instructions.  What changed against enc0_dw_kernel above and why
 // (its counters: MfmaUtil 25 %, 46 % of a wave's cycles at s_waitcnt, 343 vector + 103 LDS instructions per 48 matrix
 // instructions; each block ran barrier -> counts -> table entries -> products with every LDS round trip exposed, both waves of
 // a SIMD in the same phase -- profiles/r05k_*, r05l_*):
@@ -468,8 +468,10 @@ __global__ __launch_bounds__(64 * kDwWaves) void enc0_dw_kernel(DwArgs a) {
 //   * software pipeline over the steps: in step k a wave requests step k + 4, reads the counts of step k + 1, the table
 //     entries of step k (its counts arrived during step k - 1) and the dZ fragments of step k, and issues the 24 matrix
 //     instructions of step k - 1: every LDS round trip stands behind matrix work;
-//   * waves 0..3 read first and multiply second, waves 4..7 (the other wave of each SIMD) multiply first: one wave's matrix
-//     instructions run while the other addresses, reads and repacks;
+//   * the step is written as 2 x 12 matrix instructions with the LDS reads, the request and the repacking v_perms between
+//     them, every accumulator tied to an empty instruction statement behind its MFMA so that the order survives the compiler:
+//     the two waves of a SIMD do not hide each other's vector / LDS work (tried: one half of the waves reading first, the
+//     other multiplying first; priorities; two workgroups per CU -- the times add), a wave's own matrix instructions do;
 //   * all LDS reads of the loop are written as instructions (lds_read_*): the compiler does not know which LDS bytes a
 //     global_load_lds writes and puts s_waitcnt vmcnt(0) in front of every LDS read it generates itself (measured with plain
 //     reads: the ring stands still for a memory round trip per step).
