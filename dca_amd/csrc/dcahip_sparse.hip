@@ -1379,9 +1379,13 @@ __global__ __launch_bounds__(256) void enc0_fwd_reduce_kernel(const float* P, lo
     if (idx >= (long)B * hq) return;
     const int r = (int)(idx / hq), j = (int)(idx - (long)r * hq) * 4;
     float4 v = beff ? *reinterpret_cast<const float4*>(beff + j) : make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int k = 0; k < nsk; ++k) {
-        const float4 t = *reinterpret_cast<const float4*>(P + ((long)k * Bp + r) * H1 + j);
-        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    for (int k0 = 0; k0 < nsk; k0 += 8) {                 // batches of 8 independent loads (one round trip each), added in chunk order
+        float4 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const float4*>(P + ((long)(k0 + u < nsk ? k0 + u : 0) * Bp + r) * H1 + j);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (k0 + u < nsk) { v.x += t[u].x; v.y += t[u].y; v.z += t[u].z; v.w += t[u].w; }
     }
     *reinterpret_cast<float4*>(Z + (long)r * ldz + j) = v;
 }
