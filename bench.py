@@ -107,6 +107,51 @@ def kernel_model(name, B, G, hidden, nheads=3):
     return 'mfma', fl.get(name)
 
 
+def step_roofline(cells_per_s, B, G, hidden, nheads, n_params, ae_type, heads_ms=None):
+    """SURVEY 8d's STEP-level bounds beside the measured figure (the per-kernel `roofline` prices the dominant launch only):
+    algorithmic GEMM flops per cell F = G (4 h1 + 6 hL nheads) + 6 sum h_i h_{i+1}; the matrix-pipe bound at the fp32-MFMA peak
+    (SURVEY's 'MFMA bound': the ridge of the fp32 design) and at dense bf16 / 6 (the bound of THIS arithmetic: six bf16 products
+    per fp32 product); the HBM bound of the unfused design SURVEY prices (72 G bytes per cell + 32 P / B parameter traffic).
+    `frac` = measured / the bf16 / 6 bound (<= 1 by construction); `frac_of_fp32_ridge` = measured / SURVEY's min(fp32-MFMA, HBM).
+    When profiles/sq_pipe_counts.json was measured on THIS source tree: the per-pipe floors of K-HEADS from its counted
+    instructions -- vector issue (SQ_INSTS_VALU / 1024 SIMDs x 4 cycles) and matrix pipe (SQ_INSTS_MFMA x 32 cycles / 1024) at
+    the profiled clock -- next to its measured launch time."""
+    h1, hL = hidden[0], hidden[-1]
+    F = G * (4.0 * h1 + 6.0 * hL * nheads) + 6.0 * sum(a * b for a, b in zip(hidden[:-1], hidden[1:]))
+    by = 72.0 * G + 32.0 * n_params / B
+    b_fp32 = MFMA_F32_PEAK_TFLOPS * 1e12 / F
+    b_x6 = MFMA_BF16_PEAK_TFLOPS / 6.0 * 1e12 / F
+    b_hbm = HBM_PEAK_GBS * 1e9 / by
+    out = {'achieved_cells_s': cells_per_s, 'flops_per_cell': F, 'unfused_hbm_bytes_per_cell': by,
+           'bound_fp32_mfma_cells_s': b_fp32, 'bound_bf16x6_cells_s': b_x6, 'bound_hbm_unfused_cells_s': b_hbm,
+           'bound_fp32_ridge': min(b_fp32, b_hbm), 'frac': cells_per_s / b_x6,
+           'frac_of_fp32_ridge': cells_per_s / min(b_fp32, b_hbm),
+           'definition': 'SURVEY.md 8d: F = G (4 h1 + 6 hL heads) + 6 sum h_i h_i+1 flops per cell; bounds = peak / F at 157.3 TF/s '
+                         '(fp32 MFMA) and 2 500 / 6 TF/s (six bf16 products per fp32 product); HBM: 72 G + 32 P / B bytes per cell '
+                         'at 8 TB/s'}
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'sq_pipe_counts.json')) as f:
+            pc = json.load(f)
+        k = pc['kernels'].get('heads_fused')
+        if k and pc.get('source_sha') == source_sha() and k.get('clock_GHz'):
+            clk = float(k['clock_GHz']) * 1e9
+            valu_ms = 1e3 * float(k['SQ_INSTS_VALU']) / 1024.0 * 4.0 / clk
+            mfma_ms = 1e3 * float(k['SQ_INSTS_MFMA']) * 32.0 / 1024.0 / clk
+            out['heads_fused_pipe_floors'] = {
+                'valu_issue_ms': valu_ms, 'matrix_pipe_ms': mfma_ms, 'measured_ms': heads_ms,
+                'profiled_ms': float(k['wall_ns']) * 1e-6, 'clock_GHz': float(k['clock_GHz']),
+                'SQ_INSTS_VALU': float(k['SQ_INSTS_VALU']), 'SQ_INSTS_MFMA': float(k['SQ_INSTS_MFMA']),
+                'MfmaUtil_pct': k.get('MfmaUtil_pct'), 'VALUBusy_pct': k.get('VALUBusy_pct'),
+                'source': 'profiles/sq_pipe_counts.json (tools/gpu_pmc_bench.sh on sources %s): counts are means over the full '
+                          'and partial batches of the bench sequence, so are the profiled ms' % pc['source_sha']}
+        elif k:
+            out['heads_fused_pipe_floors'] = 'not attached: profiles/sq_pipe_counts.json was measured on sources %s, this tree is %s' % (
+                pc.get('source_sha'), source_sha())
+    except (OSError, ValueError, KeyError):
+        pass
+    return out
+
+
 def cpu_baseline(Xh, Yh, sfh, params, hidden, B, budget_s, ae_type='zinb-conddisp'):
     """Times the oracle's torch-CPU port of the training step (oracle/torch_ref.py) on the host:
     at the reference's default batch size 32 (train.py:37 -- also the CPU's best throughput)
@@ -583,6 +628,12 @@ def main():
                                               '%s (tools/gpu_pmc_traffic.sh re-measures)' % (m.get('source_sha'), source_sha()))
             break
 
+    if roof is not None:
+        nheads = {'zinb-conddisp': 3, 'zinb': 2, 'nb-conddisp': 2, 'nb': 1}.get(ae_type, 3)
+        hm = [e['mean_ms'] for e in kernels if e['kernel'] == 'heads_fused']
+        roof['step'] = step_roofline(cells_timed / el / W, B, G, hidden, nheads, int(eng.lay.P), ae_type, hm[0] if hm else None)
+    if getattr(comm, 'peer', None) is not None:
+        comm.peer.check()                                  # K-PEER: an exchange a rank never joined fails the run here
     extra = {}
     _mark('timed region and kernel timing done')
     if not multi:

@@ -67,8 +67,30 @@ def _obj_path(src, tag):
     return os.path.join(CSRC, '_obj', os.path.basename(src) + ('.' + tag if tag else '') + '.o')
 
 
+def _obj_fingerprint(src, hdrs, defines):
+    """sha256 over what one object is compiled from: its source, every header, the -D list."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in [src] + list(hdrs):
+        h.update(os.path.basename(d).encode())
+        with open(d, 'rb') as f:
+            h.update(f.read())
+    h.update('\0'.join(defines).encode())
+    return h.hexdigest()
+
+
+def _obj_is_fresh(obj, fp):
+    try:
+        with open(obj + '.src') as f:
+            return os.path.exists(obj) and f.read().strip() == fp
+    except OSError:
+        return False
+
+
 def build_hip(force=False, verbose=True, defines=(), out=None):
-    """One object per source (compiled side by side, rebuilt only when the source or a header is newer), then the link.
+    """One object per source (compiled side by side), then the link.  An object is rebuilt when the CONTENTS it was compiled
+    from differ (the fingerprint beside it, obj + '.src'), not by modification time: a checkout can make an edited source
+    older than its stale object, and a stale object relinked under a fresh library fingerprint would stay stale for good.
     ``defines`` / ``out``: experiment builds next to the product library (tools/)."""
     out = out or LIB
     if not force and not defines and out == LIB and not needs_build():
@@ -77,19 +99,26 @@ def build_hip(force=False, verbose=True, defines=(), out=None):
     os.makedirs(os.path.join(CSRC, '_obj'), exist_ok=True)
     tag = '_'.join(d.replace('=', '-') for d in defines)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(ROOT, 'include', 'dcahip.h')]
-    hdr_t = max(os.path.getmtime(h) for h in hdrs if os.path.exists(h))
+    hdrs = [h for h in hdrs if os.path.exists(h)]
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    jobs = []
+    jobs, stamps = [], []
     for src in srcs:
         obj = _obj_path(src, tag)
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
+        fp = _obj_fingerprint(src, hdrs, defines)
+        if force or not _obj_is_fresh(obj, fp):
+            if os.path.exists(obj + '.src'):
+                os.remove(obj + '.src')              # no stamp survives a failed compile
             jobs.append([_hipcc(), '--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-c',
                          '-I' + os.path.join(ROOT, 'include')] + ['-D' + d for d in defines] + ['-o', obj, src])
+            stamps.append((obj, fp))
     if verbose:
         for j in jobs:
             print(' '.join(j), flush=True)
     with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
         list(ex.map(subprocess.check_call, jobs))
+    for obj, fp in stamps:
+        with open(obj + '.src', 'w') as f:
+            f.write(fp + '\n')
     cmd = [_hipcc(), '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', out] + [_obj_path(s, tag) for s in srcs]
     if verbose:
         print(' '.join(cmd), flush=True)

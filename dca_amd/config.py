@@ -20,7 +20,6 @@ Tested combinations (tests/, all against the same oracle numbers):
   fused_write = False                       test_api_gpu.py::test_fused_predict_writer_writes_the_files_of_predict_then_write
   dp_peer_exchange = True                   test_dp_gpu.py::test_peer_exchange_two_processes_on_one_gpu (raw exchanges, then a fit == the
                                             library-collective fit, bit for bit)
-  small_dw = True                           test_sparse_gpu.py::test_small_batch_weight_gradient_from_the_byte_store (engine step, both forms)
 Engine attributes a test sets directly instead (no knob): use_fused (K-HEADS vs separate kernels:
 test_fused_and_separate_heads_agree_stepwise, test_full_size_step_fused_equals_separate).
 """
@@ -53,21 +52,16 @@ class EngineConfig:
     device_prep: bool = True                # DCA_AMD_DEVICE_PREP
     # the command line's predict + write as one streaming pass (gene x cell blocks formatted while the next one computes)
     fused_write: bool = True                # DCA_AMD_FUSED_WRITE
-    # batches of at most 64 rows (the reference default 32): the first layer's weight gradient over the non-zero counts of the
-    # byte store in one launch instead of the rank-B update through the GEMM.  OFF: measured on the MI355X at G = 20 000, batch
-    # 32, the launch is bound by its memory round trips (11.2 us) and loses to the GEMM's 7.4 us (profiles/r05g_b32_*)
-    small_dw: bool = False                  # DCA_AMD_SMALL_DW
     # ---- measured constants (no environment variable; DESIGN.md holds the measurements)
     graph_steps: int = 8                    # consecutive training steps per hipGraph launch (fit loop and bench)
     sparse_dw_min: int = 512                # batch rows from which the first layer's weight gradient reads the byte store
     lut_fwd_min: int = 1024                 # ... and its forward product (looked-up operand on the matrix pipe; 32 / 64 units)
-    sparse_fwd_min: int = 1 << 30           # the forward over the non-zero counts only (never: its gathers of W0 rows lose to the dense GEMM)
     enc0_nt_min: int = 256                  # batch rows from which the first product runs in the NT form on a transposed W0
     predict_chunk: int = 1024               # rows per device -> host chunk of predict()
 
     _ENV = {'stack': 'DCA_AMD_STACK', 'bwd_chain': 'DCA_AMD_BWD_CHAIN', 'wide_planes': 'DCA_AMD_WIDE_PLANES',
             'dp_sharded_opt': 'DCA_AMD_DP_SHARDED_OPT', 'dp_graph': 'DCA_AMD_DP_GRAPH', 'device_prep': 'DCA_AMD_DEVICE_PREP',
-            'fused_write': 'DCA_AMD_FUSED_WRITE', 'small_dw': 'DCA_AMD_SMALL_DW', 'dp_peer_exchange': 'DCA_AMD_DP_PEER'}
+            'fused_write': 'DCA_AMD_FUSED_WRITE', 'dp_peer_exchange': 'DCA_AMD_DP_PEER'}
 
     @classmethod
     def from_env(cls):

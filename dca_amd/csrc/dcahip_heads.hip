@@ -943,13 +943,17 @@ __global__ __launch_bounds__(256) void heads_reduce_both_kernel(ReduceDhArgs qh,
     else reduce_dw_body(qw, blockIdx.x - n_dh, gridDim.x - n_dh);
 }
 
+// The pipelined one-wave-per-SIMD kernel (heads_p4.inc) is an EXPERIMENT build (-DDCA_EXP_HEADS_P4; the library then carries
+// dcahip_heads_set_p4_min_tiles, the row-tile count from which that kernel takes a launch): measured on the MI355X it loses
+// to the 8-wave kernel at every batch size (C3, 4 096 rows: 1.23 vs 0.81 ms; profiles/r05c_heads_p4_ab.txt, per-phase cycles
+// in profiles/r05c_heads_p4_timing.txt, why in DESIGN.md 4.1).  The product library has neither the kernel nor the switch.
+#ifdef DCA_EXP_HEADS_P4
 #include "heads_p4.inc"
-
-// Row tiles from which the pipelined one-wave-per-SIMD kernel (heads_p4.inc) takes the launch: NEVER in the product --
-// measured on the MI355X it loses to the 8-wave kernel at every batch size (C3, 4 096 rows: 1.23 vs 0.81 ms;
-// profiles/r05c_heads_p4_ab.txt, per-phase cycles in profiles/r05c_heads_p4_timing.txt, why in DESIGN.md 4.1).
-// dcahip_heads_set_p4_min_tiles moves the threshold: the parity tests run both kernels on one build.
 int g_p4_min_nt = 1 << 30;
+#else
+constexpr int g_p4_min_nt = 1 << 30;
+constexpr int kWR4 = 4;
+#endif
 
 struct HeadsPlan {
     bool small;                          // one row tile: the four-wave kernel, one workgroup per gene tile
@@ -1426,9 +1430,11 @@ __global__ __launch_bounds__(64) void x3_product_kernel(const float* A, const fl
 
 template <bool P, bool C, bool YC>
 void launch_fused_x3(const HeadsPlan& pl, const HeadsArgs2& a, hipStream_t s) {
+#ifdef DCA_EXP_HEADS_P4
     if constexpr (P) {
         if (pl.p4) { hipLaunchKernelGGL((heads_fused_p4_kernel<C, YC>), dim3(pl.grid), dim3(64 * kWR4), 0, s, a); return; }
     }
+#endif
     if (pl.small) hipLaunchKernelGGL((heads_fused_small_kernel<P, C, YC>), dim3(pl.grid), dim3(256), 0, s, a);
     else if (pl.WR == kWR2) hipLaunchKernelGGL((heads_fused_x3_kernel<P, C, kWR2, YC>), dim3(pl.grid), dim3(64 * kWR2), 0, s, a);
     else hipLaunchKernelGGL((heads_fused_x3_kernel<P, C, 1, YC>), dim3(pl.grid), dim3(64), 0, s, a);
@@ -1444,7 +1450,11 @@ extern "C" long dcahip_heads_fused_workspace_bytes(int B, int hL, int G, long pl
     long need = 0;
     for (int nt = 1; nt <= p.NT; ++nt) {
         const int b = nt * kTR < B ? nt * kTR : B;
+#ifdef DCA_EXP_HEADS_P4
         for (int p4_min : {1, 1 << 30}) {           // whichever kernel the threshold (dcahip_heads_set_p4_min_tiles) picks later
+#else
+        for (int p4_min : {1 << 30}) {
+#endif
             HeadsPlan q;
             if (!make_heads_plan(b, hL, G, plane, flags, &q, p4_min)) continue;
             const long n = q.dw_bytes + q.dh_bytes + q.hs_bytes;
@@ -1454,11 +1464,13 @@ extern "C" long dcahip_heads_fused_workspace_bytes(int B, int hL, int G, long pl
     return need;
 }
 
+#ifdef DCA_EXP_HEADS_P4
 extern "C" int dcahip_heads_set_p4_min_tiles(int nt) {
     const int old = g_p4_min_nt;
     if (nt > 0) g_p4_min_nt = nt;
     return old;
 }
+#endif
 
 extern "C" int dcahip_x3_product_32x32(const float* A, const float* B, float* C, int K, void* stream) {
     if (!A || !B || !C || K <= 0 || (K & 15)) return DCAHIP_EINVAL;

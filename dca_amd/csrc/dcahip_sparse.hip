@@ -870,6 +870,9 @@ __global__ __launch_bounds__(256) void enc0_dw_finish_kernel(DwFinishArgs a) {
     }
 }
 
+// (The round-2 forward over the NON-ZERO counts only -- gathers of W0 rows on the vector pipe -- lost to the dense product at
+// every batch size and is an experiment build: -DDCA_EXP_ENC0_SPARSE_FWD, tools/bench_enc0.py.)
+#ifdef DCA_EXP_ENC0_SPARSE_FWD
 // ------------------------------------------------------------------------------------------------- forward
 constexpr int kC0Blocks = 128;
 
@@ -1033,6 +1036,8 @@ __global__ __launch_bounds__(256) void enc0_fwd_kernel(FwArgs a) {
         *reinterpret_cast<float4*>(dst) = make_float4(acc.x + b.x, acc.y + b.y, acc.z + b.z, acc.w + b.w);
     }
 }
+
+#endif  // DCA_EXP_ENC0_SPARSE_FWD
 
 // ------------------------------------------------------------------------------------------------- forward on the matrix pipe
 // Z0 = L (W0 / std) + b_eff as a dense product whose A operand is LOOKED UP from the byte store (the mirror image of
@@ -1408,14 +1413,13 @@ inline bool dw_width_ok(int H1) { return H1 == 32 || H1 == 64 || H1 == 128; }
 
 // row splits: as many workgroups as are resident at once (or just below): one round
 // 64 units: the ring form (enc0_dw2_kernel) from kD2MinRows batch rows up (below, its longer prologue and the 512-gene
-// workgroups cost more than the pipeline saves: tools/ab_enc0_dw.py); dcahip_enc0_dw_set_form(0 / 2) forces the first / the
-// ring form at every size (A/B runs, tests)
+// workgroups cost more than the pipeline saves: tools/ab_enc0_dw.py); the `form` argument of dcahip_enc0_dw_sparse (1 / 2)
+// forces the first / the ring form at every size (A/B runs, tests), 0 = by the shape
 constexpr int kD2MinRows = 1024;
-int g_dw_form = 1;
-inline bool dw_second_form(int H1, int B) { return H1 == 64 && (g_dw_form == 2 || (g_dw_form == 1 && B >= kD2MinRows)); }
+inline bool dw_second_form(int H1, int B, int form) { return H1 == 64 && (form == 2 || (form == 0 && B >= kD2MinRows)); }
 
-inline int dw_splits(int B, int G, int H1) {
-    if (dw_second_form(H1, B)) return dw2_splits(B, G);
+inline int dw_splits(int B, int G, int H1, int form) {
+    if (dw_second_form(H1, B, form)) return dw2_splits(B, G);
     const int groups = (G + 32 * kDwWaves - 1) / (32 * kDwWaves);
     int ns = 256 / groups;                               // one 8-wave workgroup per CU (registers)
     const int maxs = (B + kDwRB - 1) / kDwRB;
@@ -1426,13 +1430,16 @@ inline int dw_splits(int B, int G, int H1) {
     if (ns < need) ns = need;
     return ns;
 }
-inline int dw_rows_per_split(int B, int ns, int H1) {
-    if (dw_second_form(H1, B)) return dw2_rows_per_split(B, ns);
+inline int dw_rows_per_split(int B, int ns, int H1, int form) {
+    if (dw_second_form(H1, B, form)) return dw2_rows_per_split(B, ns);
     return (((B + ns - 1) / ns) + kDwRB - 1) / kDwRB * kDwRB;
 }
 inline long r16(long x) { return (x + 15) / 16 * 16; }
 
 
+// (The byte-store weight gradient for batches of at most 64 rows measured 11.2 us against the GEMM's 7.4 us at batch 32
+// (profiles/r05g_*): an experiment build, -DDCA_EXP_DW_SMALL.)
+#ifdef DCA_EXP_DW_SMALL
 // ------------------------------------------------------------------------------------------------- small batches
 // The first layer's weight gradient at the reference's default batch (32 rows, dca/train.py:37; up to 64 here) straight
 // from the byte store: dW0[g, :] = (sum over the batch rows with a NON-ZERO count of f(y / fac) dZ[r, :] - mean[g] colsum(dZ)) / std[g]
@@ -1524,6 +1531,8 @@ __global__ __launch_bounds__(256) void enc0_dw_small_kernel(DwSmallArgs a) {
     *reinterpret_cast<float4*>(a.gW + (long)gene * a.ldg + 4 * t) = o;
 }
 
+#endif  // DCA_EXP_DW_SMALL
+
 }  // namespace
 
 extern "C" long dcahip_counts_compact_ld(int G) { return ((long)G + 15) / 16 * 16; }
@@ -1538,6 +1547,7 @@ extern "C" int dcahip_counts_compact(const float* Y, long ldy, int n, int G, uns
     return (int)hipGetLastError();
 }
 
+#ifdef DCA_EXP_DW_SMALL
 extern "C" int dcahip_enc0_dw_small_max_rows(void) { return kSmallRows; }
 
 extern "C" int dcahip_enc0_dw_small(const unsigned char* Yc, long ldc, const int* ovf_ptr, const int* ovf_col,
@@ -1553,6 +1563,8 @@ extern "C" int dcahip_enc0_dw_small(const unsigned char* Yc, long ldc, const int
     return (int)hipGetLastError();
 }
 
+#endif  // DCA_EXP_DW_SMALL
+
 extern "C" int dcahip_enc0_sparse_supported(int H1) { return dw_width_ok(H1) ? 1 : 0; }
 
 extern "C" int dcahip_enc0_lut(const float* fac, int do_log, int n, void* lutp, void* stream) {
@@ -1565,9 +1577,9 @@ extern "C" int dcahip_enc0_lut(const float* fac, int do_log, int n, void* lutp, 
 // workspace: P [NS][Gs][H1] | Sp [NS][H1] | Spp [steps][H1] | DZP [steps][...] bf16
 extern "C" long dcahip_enc0_dw_sparse_workspace_bytes(int B, int G, int H1) {
     if (!dw_width_ok(H1) || B <= 0 || G <= 0) return 0;
-    // (sufficient for either form of the 64-unit kernel: the form can be switched between the query and the launch)
-    int ns = dw_splits(B, G, H1);
-    if (H1 == 64) { const int n2 = dw2_splits(B, G); if (n2 > ns) ns = n2; const int old = g_dw_form; g_dw_form = 0; const int n1 = dw_splits(B, G, H1); g_dw_form = old; if (n1 > ns) ns = n1; }
+    // (sufficient for either form of the 64-unit kernel, whichever the launch's `form` argument names)
+    int ns = dw_splits(B, G, H1, 1);
+    if (H1 == 64) { const int n2 = dw2_splits(B, G); if (n2 > ns) ns = n2; }
     const long Gs = ((long)G + 511) / 512 * 512;
     const long steps = (B + kKS - 1) / kKS;
     return r16(((long)ns * Gs * H1 + (long)ns * H1) * 4) + r16(steps * H1 * 4) + r16(steps * (long)dz_step_elems(H1) * 2) + r16((long)B * 4);
@@ -1579,23 +1591,17 @@ extern "C" void dcahip_enc0_dw_set_timing(long long* buf) { hipMemcpyToSymbol(HI
 #endif
 extern "C" int dcahip_enc0_lut_entries(void) { return kLut; }
 
-extern "C" int dcahip_enc0_dw_set_form(int form) {
-    const int old = g_dw_form;
-    if (form == 0 || form == 1 || form == 2) g_dw_form = form;
-    return old;
-}
-
 extern "C" int dcahip_enc0_dw_sparse(const unsigned char* Yc, long ldc, const int* ovf_ptr, const int* ovf_col,
                                      const float* ovf_val, const float* fac, int do_log, const void* lutp, const float* mean,
                                      const float* stdv, const int* perm, const long long* cursor, long row_base,
                                      int B, int G, int H1, const float* dZ, long ldz, float* gW, long ldg,
-                                     void* workspace, long workspace_bytes, void* stream) {
+                                     void* workspace, long workspace_bytes, int form, void* stream) {
     if (!dw_width_ok(H1) || B <= 0 || G <= 0 || !Yc || !lutp || (ldc & 15) || ldc < G || !dZ || ldz < H1 || !gW ||
-        ldg < H1 || (reinterpret_cast<uintptr_t>(workspace) & 15) || !workspace)
+        ldg < H1 || (reinterpret_cast<uintptr_t>(workspace) & 15) || !workspace || form < 0 || form > 2)
         return DCAHIP_EINVAL;
     if (workspace_bytes < dcahip_enc0_dw_sparse_workspace_bytes(B, G, H1)) return DCAHIP_EINVAL;
-    const int ns = dw_splits(B, G, H1);
-    if (dw_second_form(H1, B) && dw_rows_per_split(B, ns, H1) > kD2MaxRS) return DCAHIP_EINVAL;
+    const int ns = dw_splits(B, G, H1, form);
+    if (dw_second_form(H1, B, form) && dw_rows_per_split(B, ns, H1, form) > kD2MaxRS) return DCAHIP_EINVAL;
     const long Gs = ((long)G + 511) / 512 * 512;
     const long steps = (B + kKS - 1) / kKS;
     char* wsb = static_cast<char*>(workspace);
@@ -1608,7 +1614,7 @@ extern "C" int dcahip_enc0_dw_sparse(const unsigned char* Yc, long ldc, const in
     unsigned short* DZP = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(Spp) + r16(steps * H1 * 4));
     int* srowb = reinterpret_cast<int*>(reinterpret_cast<char*>(DZP) + r16(steps * (long)dz_step_elems(H1) * 2));
     a.DZP = DZP; a.Spp = Spp; a.srowb = srowb;
-    a.RS = dw_rows_per_split(B, ns, H1);
+    a.RS = dw_rows_per_split(B, ns, H1, form);
     const dim3 grid((unsigned)((G + 32 * kDwWaves - 1) / (32 * kDwWaves)), (unsigned)ns);
     const dim3 block(64 * kDwWaves);
     hipStream_t s = (hipStream_t)stream;
@@ -1618,7 +1624,7 @@ extern "C" int dcahip_enc0_dw_sparse(const unsigned char* Yc, long ldc, const in
             hipLaunchKernelGGL(enc0_dw_kernel<32>, grid, block, 0, s, a); break;
         case 64:
             hipLaunchKernelGGL(enc0_split_dz_kernel<64>, dim3((unsigned)steps), dim3(256), 0, s, dZ, ldz, B, perm, cursor, row_base, DZP, Spp, srowb);
-            if (dw_second_form(H1, B))
+            if (dw_second_form(H1, B, form))
                 hipLaunchKernelGGL(enc0_dw2_kernel, dim3((unsigned)((G + kD2Genes - 1) / kD2Genes), (unsigned)ns), dim3(64 * kD2Waves), 0, s, a);
             else
                 hipLaunchKernelGGL(enc0_dw_kernel<64>, grid, block, 0, s, a);
@@ -1635,6 +1641,7 @@ extern "C" int dcahip_enc0_dw_sparse(const unsigned char* Yc, long ldc, const in
     return (int)hipGetLastError();
 }
 
+#ifdef DCA_EXP_ENC0_SPARSE_FWD
 extern "C" long dcahip_enc0_fwd_sparse_workspace_bytes(int H1) {
     return width_ok(H1) ? (long)kC0Blocks * H1 * 8 + 256 + (long)H1 * 4 : 0;
 }
@@ -1675,13 +1682,15 @@ extern "C" int dcahip_enc0_fwd_sparse(const unsigned char* Yc, long ldc, const i
     return (int)hipGetLastError();
 }
 
-// 32-row tiles per wave of the matrix-pipe forward (1: eight waves, 2: four waves of 64 rows); dcahip_enc0_fwd_set_form
-int g_fl_rt = 1;
-extern "C" int dcahip_enc0_fwd_set_form(int form) {
-    const int old = g_fl_rt;
-    if (form == 1 || form == 2) g_fl_rt = form;
-    return old;
-}
+#endif  // DCA_EXP_ENC0_SPARSE_FWD
+
+// 32-row tiles per wave of the matrix-pipe forward: 1 = eight waves (the product).  2 = four waves of 64 rows: built,
+// bit-identical, measured SLOWER (0.080 vs 0.067 ms) -- an experiment build (-DDCA_EXP_FWD_FORM2), not a switch.
+#ifdef DCA_EXP_FWD_FORM2
+constexpr int kFlRT = 2;
+#else
+constexpr int kFlRT = 1;
+#endif
 
 // workspace: WP | C0P | P
 extern "C" long dcahip_enc0_fwd_lut_workspace_bytes(int B, int G, int H1) {
@@ -1716,12 +1725,10 @@ extern "C" int dcahip_enc0_fwd_lut(const unsigned char* Yc, long ldc, const int*
     const dim3 grid((unsigned)fl_row_groups(B), (unsigned)nsk);
     if (H1 == 32) {
         hipLaunchKernelGGL(enc0_wsplit_kernel<32>, dim3((unsigned)n_ms, 1), dim3(256), 0, s, W, ldw, mean, stdv, G, WP, C0P);
-        if (g_fl_rt == 2) hipLaunchKernelGGL((enc0_fwd_lut_kernel<32, 2>), grid, dim3(256), 0, s, f);
-        else hipLaunchKernelGGL((enc0_fwd_lut_kernel<32, 1>), grid, dim3(512), 0, s, f);
+        hipLaunchKernelGGL((enc0_fwd_lut_kernel<32, kFlRT>), grid, dim3(512 / kFlRT), 0, s, f);
     } else {
         hipLaunchKernelGGL(enc0_wsplit_kernel<64>, dim3((unsigned)n_ms, 2), dim3(256), 0, s, W, ldw, mean, stdv, G, WP, C0P);
-        if (g_fl_rt == 2) hipLaunchKernelGGL((enc0_fwd_lut_kernel<64, 2>), grid, dim3(256), 0, s, f);
-        else hipLaunchKernelGGL((enc0_fwd_lut_kernel<64, 1>), grid, dim3(512), 0, s, f);
+        hipLaunchKernelGGL((enc0_fwd_lut_kernel<64, kFlRT>), grid, dim3(512 / kFlRT), 0, s, f);
     }
     int rc = (int)hipGetLastError();
     if (rc) return rc;

@@ -39,12 +39,19 @@ class TorchDistComm:
     def enable_peer_exchange(self, nmax):
         """Collective.  Small float32 device tensors (<= nmax elements) of all_gather_into(name='all_gather_small') and
         all_reduce_sum go through dcahip_peer_exchange from here on."""
-        from .peer import PeerExchange
+        from .peer import PeerExchange, PeerUnavailable
         if self.peer is not None and self.peer.nmax < nmax:
             self.peer.close()
             self.peer = None
         if self.peer is None:
-            self.peer = PeerExchange(self.rank, self.world, nmax, group=self.group)
+            try:
+                self.peer = PeerExchange(self.rank, self.world, nmax, group=self.group)
+            except PeerUnavailable as e:
+                # (raised on every rank alike: allocation, mapping or the init-time ping-pong failed somewhere) -- the small
+                # exchanges stay on the library's collectives, and the run says so
+                import warnings
+                warnings.warn('dca_amd: %s -- the SyncBN exchanges stay on RCCL collectives' % e, RuntimeWarning)
+                self.peer = None
         return self.peer
 
     def _peer_takes(self, t, n):

@@ -357,9 +357,9 @@ class Engine:
         self.row0 = 0               # this rank's first row inside the global batch
         self.Xb = None
         # compact counts (dca_amd/compact.py): K-HEADS reads its targets from the byte store (cc); with the input
-        # normalisation known (cc_in) the first Dense layer works on the non-zero counts only (K-SPARSE)
+        # normalisation known (cc_in) both first-layer products are built from it on the matrix pipe (K-SPARSE)
         self.cc = self.cc_in = None
-        self.ws_enc0 = self.ws_enc0f = self.ws_enc0l = None
+        self.ws_enc0 = self.ws_enc0l = None
         self.ws_stack = None
         # K-STACK at throughput batches: 'steps' = one launch per batch-wide dependency (9 launches instead of 22 for
         # the 64-32-64 stack), 'coop' = one cooperative launch per direction with grid barriers, 'off' = one launch per
@@ -368,9 +368,8 @@ class Engine:
         # batch rows from which the byte-store kernels replace the dense first-layer GEMMs -- measured on the MI355X at
         # the benchmark shape (profiles/r03*_enc0_*): the weight gradient on the matrix pipe from the byte store ties the
         # dense TN GEMM at 4096 rows on the 68 579-cell matrix (0.149-0.154 vs 0.157 ms) and wins on a cache-resident one
-        # (0.112 vs 0.150); the sparse forward (gathers of W0 rows from L2) loses to the dense NT GEMM at every batch
-        # (0.160 vs 0.107 ms at 4096 rows) and stays off
-        self.sparse_fwd_min = self.cfg.sparse_fwd_min
+        # (0.112 vs 0.150); the round-2 forward over the non-zero counts only (gathers of W0 rows from L2) lost to the dense
+        # NT GEMM at every batch (0.160 vs 0.107 ms at 4096 rows): an experiment build of the library, not an engine path
         self.sparse_dw_min = self.cfg.sparse_dw_min
 
     def _t(self, name):
@@ -596,7 +595,8 @@ class Engine:
         if self.Y is None or not hasattr(ops, 'counts_compact'):
             return
         if compact is False:
-            return                          # an earlier attach found these counts unfit for the byte store (train.py keeps the verdict)
+            self.cc_verdict = False         # an earlier attach found these counts unfit for the byte store: the callers keep
+            return                          # the verdict (no second full pass over Y on the next attach)
         if compact is None:
             from . import compact as _compact
             compact = _compact.build(ops, self.Y, self.Y.shape[0], lay.G_out)
@@ -613,9 +613,10 @@ class Engine:
             self.cc_verdict = False
             return
         self.cc = compact
+        # cc_in is not None <=> the byte-store kernels take this first-layer width (32 / 64 / 128 units): every other width
+        # keeps the dense products (_sparse_dw / _lut_fwd test nothing else about the width)
         if norm is not None and lay.hidden and lay.G_in == lay.G_out and n_esc <= 1e-5 * n_el and \
-                (ops.enc0_sparse_supported(lay.hidden[0]) or (hasattr(ops, 'enc0_dw_small') and lay.hidden[0] <= 64
-                                                               and lay.hidden[0] % 4 == 0)):
+                ops.enc0_sparse_supported(lay.hidden[0]):
             self.cc_in = compact.with_input(norm.get('fac'), norm.get('do_log', False), norm.get('mean'), norm.get('std'), ops=ops)
         self._sparse_workspaces()
 
@@ -624,11 +625,8 @@ class Engine:
             return
         lay, ops = self.lay, self.ops
         need = ops.enc0_dw_sparse_workspace_bytes(self.Bmax, lay.G_in, lay.hidden[0])
-        if self.ws_enc0 is None or self.ws_enc0.numel() * 4 < need:
+        if need and (self.ws_enc0 is None or self.ws_enc0.numel() * 4 < need):      # 0 bytes: width not taken (ws_enc0 stays None)
             self.ws_enc0 = torch.zeros(need // 4 + 4, dtype=torch.float32, device=self.dev)
-        if self.ws_enc0f is None:
-            self.ws_enc0f = torch.zeros(ops.enc0_fwd_sparse_workspace_bytes(lay.hidden[0]) // 4 + 4,
-                                        dtype=torch.float32, device=self.dev)
         if self.Bmax >= self.cfg.lut_fwd_min:
             # the matrix-pipe forward from the byte store: its partials grow with rows x gene chunks -- the largest over
             # the batch sizes this engine can be handed
@@ -636,10 +634,6 @@ class Engine:
                        for b in range(256, self.Bmax + 256, 256))
             if need and (self.ws_enc0l is None or self.ws_enc0l.numel() * 4 < need):
                 self.ws_enc0l = torch.zeros(need // 4 + 4, dtype=torch.float32, device=self.dev)
-
-    def _sparse_fwd(self, B, training):
-        return (self.cc_in is not None and self.ws_enc0f is not None and B >= self.sparse_fwd_min
-                and not (training and self.in_drop > 0.0))
 
     def _lut_fwd(self, B, training):
         # inference takes this form only once the per-cell tables exist (training made them): a predict-only run keeps the
@@ -649,13 +643,6 @@ class Engine:
 
     def _sparse_dw(self, B):
         return (self.cc_in is not None and self.ws_enc0 is not None and B >= self.sparse_dw_min and self.in_drop == 0.0)
-
-    def _small_dw(self, B):
-        """Small batches (the reference's default 32): the first layer's weight gradient over the non-zero counts of the
-        byte store in one launch, instead of the rank-B update through the GEMM + its split-K reduce."""
-        lay = self.lay
-        return (self.cc_in is not None and self.in_drop == 0.0 and self.cfg.small_dw and hasattr(self.ops, 'enc0_dw_small')
-                and 0 < B <= self.ops.enc0_dw_small_max_rows and lay.hidden[0] <= 64 and lay.hidden[0] % 4 == 0)
 
     def _set_tile_order(self):
         """K-HEADS: which 32-gene tiles share a workgroup.  A workgroup lasts as long as its slower tile and the
@@ -804,13 +791,6 @@ class Engine:
                         ops.enc0_fwd_lut(self.cc_in, self.perm if gather else None, self.cursor if gather else None,
                                          0 if gather else rows_from[1], B, K, h, Wi, h, bi, self.Z[0], self.ldh[0],
                                          self.ws_enc0l)
-                elif self._sparse_fwd(B, training):
-                    # K-SPARSE: the product over the non-zero counts of the batch rows (x = (log1p(y / fac) - mean) / std)
-                    gather = rows_from[0] == 'perm'
-                    with self._t('gemm_enc0_fwd'):
-                        ops.enc0_fwd_sparse(self.cc_in, self.perm if gather else None, self.cursor if gather else None,
-                                            0 if gather else rows_from[1], B, K, h, Wi, h, bi, self.Z[0], self.ldh[0],
-                                            self.ws_enc0f)
                 elif self._planes_enc0(B, training):
                     # wide first layer at throughput batches: the minibatch split into planes once (the weight gradient
                     # reads the same planes, contracting over their rows), the kernel split, the product from planes
@@ -940,7 +920,7 @@ class Engine:
 
     def _planes_enc0(self, B, training):
         return (self.pl is not None and 'X' in self.pl and self._wide_planes(B) and B <= self.pl['X'].shape[1]
-                and not (training and self.in_drop > 0.0) and not self._sparse_fwd(B, training)
+                and not (training and self.in_drop > 0.0)
                 and not self._lut_fwd(B, training))
 
     def _enc0_nt(self, B):
@@ -1134,6 +1114,24 @@ class Engine:
         self.row0 = int(sum(world_counts[:self.comm.rank]))
 
     # ------------------------------------------------------------------ one training step
+    def assert_finite(self, where=''):
+        """--debug (dca/__main__.py:111-113): the reference compiles tf.verify_tensor_all_finite on y_pred / t1 / t2 into the
+        loss (dca/loss.py:90-100) and fails the step that produces an inf / nan.  Here: the batch loss, every gradient and
+        every parameter of the step just taken (ONE host synchronisation per step: a debugging mode).  A non-finite
+        y_pred, t1 or t2 of any element makes the batch loss or a head gradient non-finite, so nothing the reference's check
+        catches passes this one."""
+        lay = self.lay
+        bad = []
+        if not bool(torch.isfinite(self.g[lay.P]).item()):
+            bad.append('loss')
+        if not bool(torch.isfinite(self.g[:lay.P]).all().item()) or not bool(torch.isfinite(self.w[:lay.P]).all().item()):
+            for name in lay.seg:
+                for flat, kind in ((self.g, 'gradient of '), (self.w, '')):
+                    if not bool(torch.isfinite(lay.view(flat, name)).all().item()):
+                        bad.append(kind + name)
+        if bad:
+            raise FloatingPointError('dca: %s has inf/nans%s' % (', '.join(bad), (' (' + where + ')') if where else ''))
+
     def train_step(self, B, B_global=None, world_counts=None, rows_per_slot=None):
         """Forward + backward + clipvalue/RMSprop on the B rows perm[cursor : cursor+B].
         Asynchronous: no host synchronisation (single GPU).  B may be 0 on a rank whose shard
@@ -1323,9 +1321,7 @@ class Engine:
             gW = lay.view(g, 'W%d' % i)
             if i == 0:
                 with self._t('gemm_enc0_dW'):
-                    if self._small_dw(B):
-                        ops.enc0_dw_small(self.cc_in, self.perm, self.cursor, 0, B, Kp, h, self.dZ[0], self.ldh[0], gW, h)
-                    elif self._sparse_dw(B):
+                    if self._sparse_dw(B):
                         if self.cc_in.lutp is None:              # the per-cell table of the common counts: first use only
                             self._not_capturing('first use of the byte-store weight gradient')
                             self.cc_in.ensure_lut(ops)

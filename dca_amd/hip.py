@@ -71,7 +71,6 @@ _SIGNATURES = {
                                       _f32p, _f32p, _c.c_long, _f64p, _c.POINTER(_c.c_int), _vp,
                                       _c.c_long, _vp]),
     'dcahip_heads_tile_order_len': (_c.c_int, [_c.c_int]),
-    'dcahip_heads_set_p4_min_tiles': (_c.c_int, [_c.c_int]),
     'dcahip_x3_product_32x32': (_c.c_int, [_f32p, _f32p, _f32p, _c.c_int, _vp]),
     'dcahip_heads_fused_ordered': (_c.c_int, [_f32p, _c.c_long, _f32p, _c.c_long, _f32p, _c.c_long, _f32p,
                                               _f32p, _c.c_long, _f32p, _i32p, _i64p, _c.c_int, _c.c_int,
@@ -169,21 +168,12 @@ _SIGNATURES = {
     'dcahip_enc0_lut': (_c.c_int, [_f32p, _c.c_int, _c.c_int, _vp, _vp]),
     'dcahip_enc0_dw_sparse': (_c.c_int, [_vp, _c.c_long, _i32p, _i32p, _f32p, _f32p, _c.c_int, _f32p, _f32p, _f32p, _i32p, _i64p,
                                          _c.c_long, _c.c_int, _c.c_int, _c.c_int, _f32p, _c.c_long, _f32p, _c.c_long,
-                                         _vp, _c.c_long, _vp]),
+                                         _vp, _c.c_long, _c.c_int, _vp]),
     'dcahip_peer_slot_bytes': (_c.c_long, [_c.c_int, _c.c_int]),
     'dcahip_peer_flag_bytes': (_c.c_long, [_c.c_int]),
     'dcahip_peer_exchange': (_c.c_int, [_f32p, _c.c_int, _vp, _vp, _c.c_int, _c.c_int, _c.c_int, _vp, _f32p, _c.c_int, _i32p,
                                         _c.c_long, _vp]),
-    'dcahip_enc0_dw_set_form': (_c.c_int, [_c.c_int]),
     'dcahip_enc0_lut_entries': (_c.c_int, []),
-    'dcahip_enc0_fwd_set_form': (_c.c_int, [_c.c_int]),
-    'dcahip_enc0_dw_small_max_rows': (_c.c_int, []),
-    'dcahip_enc0_dw_small': (_c.c_int, [_vp, _c.c_long, _i32p, _i32p, _f32p, _f32p, _c.c_int, _f32p, _f32p, _i32p, _i64p,
-                                        _c.c_long, _c.c_int, _c.c_int, _c.c_int, _f32p, _c.c_long, _f32p, _c.c_long, _vp]),
-    'dcahip_enc0_fwd_sparse_workspace_bytes': (_c.c_long, [_c.c_int]),
-    'dcahip_enc0_fwd_sparse': (_c.c_int, [_vp, _c.c_long, _i32p, _i32p, _f32p, _f32p, _c.c_int, _f32p, _f32p, _i32p, _i64p,
-                                          _c.c_long, _c.c_int, _c.c_int, _c.c_int, _f32p, _c.c_long, _f32p, _f32p, _c.c_long,
-                                          _vp, _c.c_long, _vp]),
     'dcahip_enc0_fwd_lut_workspace_bytes': (_c.c_long, [_c.c_int, _c.c_int, _c.c_int]),
     'dcahip_enc0_fwd_lut': (_c.c_int, [_vp, _c.c_long, _i32p, _i32p, _f32p, _f32p, _c.c_int, _vp, _f32p, _f32p, _i32p, _i64p,
                                        _c.c_long, _c.c_int, _c.c_int, _c.c_int, _f32p, _c.c_long, _f32p, _f32p, _c.c_long,
@@ -193,6 +183,20 @@ _SIGNATURES = {
                                               _c.c_int, _c.c_int, _c.c_int, _c.c_float, _c.c_float, _c.c_int, _f32p,
                                               _c.c_long, _f32p, _f32p, _c.c_long, _f64p, _c.POINTER(_c.c_int), _vp,
                                               _c.c_long, _i32p, _f32p, _vp]),
+}
+
+# Entry points that exist only in EXPERIMENT builds of the sources (-DDCA_EXP_HEADS_P4, -DDCA_EXP_DW_SMALL,
+# -DDCA_EXP_ENC0_SPARSE_FWD: kernels that were measured and lost, include/dcahip.h conventions): bound when the loaded
+# library has them (tools/ point build.LIB at such a build), absent from the product library (tests/test_cabi.py).
+_EXPERIMENT_SIGNATURES = {
+    'dcahip_heads_set_p4_min_tiles': (_c.c_int, [_c.c_int]),
+    'dcahip_enc0_dw_small_max_rows': (_c.c_int, []),
+    'dcahip_enc0_dw_small': (_c.c_int, [_vp, _c.c_long, _i32p, _i32p, _f32p, _f32p, _c.c_int, _f32p, _f32p, _i32p, _i64p,
+                                        _c.c_long, _c.c_int, _c.c_int, _c.c_int, _f32p, _c.c_long, _f32p, _c.c_long, _vp]),
+    'dcahip_enc0_fwd_sparse_workspace_bytes': (_c.c_long, [_c.c_int]),
+    'dcahip_enc0_fwd_sparse': (_c.c_int, [_vp, _c.c_long, _i32p, _i32p, _f32p, _f32p, _c.c_int, _f32p, _f32p, _i32p, _i64p,
+                                          _c.c_long, _c.c_int, _c.c_int, _c.c_int, _f32p, _c.c_long, _f32p, _f32p, _c.c_long,
+                                          _vp, _c.c_long, _vp]),
 }
 
 _lib = None
@@ -223,6 +227,10 @@ def lib():
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(L, name)          # AttributeError => header / library mismatch: loud
         fn.restype, fn.argtypes = res, args
+    for name, (res, args) in _EXPERIMENT_SIGNATURES.items():
+        if hasattr(L, name):
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
     assert L.dcahip_version() == 1
     _lib = L
     return L
@@ -230,6 +238,11 @@ def lib():
 
 def exported_symbols():
     return sorted(_SIGNATURES)
+
+
+def has(name):
+    """Whether the loaded library exports `name` (experiment entry points: only in -D builds)."""
+    return hasattr(lib(), name)
 
 
 def require_gpu():

@@ -66,8 +66,13 @@ class HipOps:
     def x3_product_32x32(self, A, B, C, K):
         hip.check(self.L.dcahip_x3_product_32x32(hip.ptr(A), hip.ptr(B), hip.ptr(C), K, hip.stream()), "x3_product_32x32")
 
+    def has(self, entry):
+        """Whether the loaded library exports `entry` (the experiment entry points exist only in -D builds)."""
+        return hasattr(self.L, entry)
+
     def heads_set_p4_min_tiles(self, nt):
-        """Row tiles from which K-HEADS takes its pipelined four-wave kernel (returns the previous value)."""
+        """EXPERIMENT build (-DDCA_EXP_HEADS_P4) only: row tiles from which K-HEADS takes its pipelined four-wave kernel
+        (returns the previous value)."""
         return int(self.L.dcahip_heads_set_p4_min_tiles(int(nt)))
 
     def heads_tile_order_len(self, G):
@@ -114,40 +119,34 @@ class HipOps:
         return int(self.L.dcahip_enc0_dw_sparse_workspace_bytes(B, G, H1))
 
     def enc0_fwd_sparse_workspace_bytes(self, H1):
+        """EXPERIMENT build (-DDCA_EXP_ENC0_SPARSE_FWD) only."""
         return int(self.L.dcahip_enc0_fwd_sparse_workspace_bytes(H1))
 
-    def enc0_dw_sparse(self, c, perm, cursor, row_base, B, G, H1, dZ, ldz, gW, ldg, ws):
-        """gW [G + 1, ldg] = [X^T dZ ; colsum dZ] with X described by the compact counts c (its normalisation fields)."""
+    def enc0_dw_sparse(self, c, perm, cursor, row_base, B, G, H1, dZ, ldz, gW, ldg, ws, form=0):
+        """gW [G + 1, ldg] = [X^T dZ ; colsum dZ] with X described by the compact counts c (its normalisation fields).
+        form: which of the two 64-unit kernels (0: by the shape, 1: the first, 2: the ring kernel; include/dcahip.h)."""
         p = hip.ptr
         c.ensure_lut(self)                   # the per-cell table of the common counts: made on the first call for this store
         hip.check(self.L.dcahip_enc0_dw_sparse(p(c.Yc), c.ldc, p(c.ovf_ptr), p(c.ovf_col), p(c.ovf_val), p(c.fac),
                                                int(c.do_log), p(c.lutp), p(c.mean), p(c.std), p(perm), p(cursor), int(row_base),
                                                B, G, H1, p(dZ), ldz, p(gW), ldg, p(ws), ws.numel() * ws.element_size(),
-                                               hip.stream()), 'enc0_dw_sparse')
-
-    def enc0_fwd_set_form(self, form):
-        """Shape of the matrix-pipe byte-store forward (1: eight waves of 32 rows, 2: four waves of 64 rows); returns the previous."""
-        return int(self.L.dcahip_enc0_fwd_set_form(int(form)))
-
-    def enc0_dw_set_form(self, form):
-        """Which kernel the 64-unit byte-store weight gradient takes (1, default: the ring kernel from 1024 rows up; 0: always the
-        first kernel; 2: always the ring kernel); returns the previous."""
-        return int(self.L.dcahip_enc0_dw_set_form(int(form)))
+                                               int(form), hip.stream()), 'enc0_dw_sparse')
 
     @property
     def enc0_dw_small_max_rows(self):
         return int(self.L.dcahip_enc0_dw_small_max_rows())
 
     def enc0_dw_small(self, c, perm, cursor, row_base, B, G, H1, dZ, ldz, gW, ldg):
-        """gW [G + 1, ldg] = X^T dZ (+ column sums of dZ in row G) for a batch of at most enc0_dw_small_max_rows rows, X
-        read from the byte store (non-zero counts only)."""
+        """EXPERIMENT build (-DDCA_EXP_DW_SMALL) only: gW [G + 1, ldg] = X^T dZ (+ column sums of dZ in row G) for a batch of
+        at most enc0_dw_small_max_rows rows, X read from the byte store (non-zero counts only)."""
         p = hip.ptr
         hip.check(self.L.dcahip_enc0_dw_small(p(c.Yc), c.ldc, p(c.ovf_ptr), p(c.ovf_col), p(c.ovf_val), p(c.fac),
                                               int(c.do_log), p(c.mean), p(c.std), p(perm), p(cursor), int(row_base),
                                               B, G, H1, p(dZ), ldz, p(gW), ldg, hip.stream()), 'enc0_dw_small')
 
     def enc0_fwd_sparse(self, c, perm, cursor, row_base, B, G, H1, W, ldw, bias, Z, ldz, ws):
-        """Z [B, ldz] = X W + bias; ws: zero-initialised once, private to this call site."""
+        """EXPERIMENT build (-DDCA_EXP_ENC0_SPARSE_FWD) only: Z [B, ldz] = X W + bias over the non-zero counts; ws:
+        zero-initialised once, private to this call site."""
         p = hip.ptr
         hip.check(self.L.dcahip_enc0_fwd_sparse(p(c.Yc), c.ldc, p(c.ovf_ptr), p(c.ovf_col), p(c.ovf_val), p(c.fac),
                                                 int(c.do_log), p(c.mean), p(c.std), p(perm), p(cursor), int(row_base),

@@ -67,7 +67,7 @@ class _EarlyStopping:         # keras defaults as used at train.py:73-75
 
 def fit_engine(eng, n_train_global, n_val_global, nt_local, nv_local, t0_global, *, epochs=300,
                batch_size=32, learning_rate=None, clip_grad=5.0, reduce_lr=10, early_stop=15,
-               verbose=False, shuffle_rng=None, use_graph=None, on_epoch=None, state=None):
+               verbose=False, shuffle_rng=None, use_graph=None, on_epoch=None, state=None, debug=False):
     """Runs the Keras-equivalent fit loop on an engine whose storage rows are
     [0, nt_local) = this rank's train shard and [nt_local, nt_local+nv_local) = its
     validation shard.  Returns History.
@@ -76,7 +76,11 @@ def fit_engine(eng, n_train_global, n_val_global, nt_local, nv_local, t0_global,
     counters, history) resumes the loop after that epoch: the engine must already hold the
     matching weights / optimizer slots (Engine.load_state).  NOTE: the shuffles consume the numpy
     RNG stream; a resumed run replays them for the skipped epochs so that the order of the
-    remaining epochs is the one an uninterrupted run would have seen."""
+    remaining epochs is the one an uninterrupted run would have seen.
+
+    ``debug`` (dca/__main__.py:111-113 -> dca/loss.py:90-100, the finite checks compiled into the reference's loss): every step
+    runs eagerly and is followed by Engine.assert_finite -- the batch loss, every gradient, every parameter -- which raises
+    FloatingPointError naming the tensors and the (epoch, step) of the first non-finite value."""
     comm = eng.comm
     W = comm.world
     rng = np.random if shuffle_rng is None else shuffle_rng
@@ -109,7 +113,7 @@ def fit_engine(eng, n_train_global, n_val_global, nt_local, nv_local, t0_global,
             es.best, es.wait = state['es_best'], state['es_wait']
         hist.history = {k: list(v) for k, v in state['history'].items()}
         hist.epoch = list(range(first_epoch))
-    runner = _StepRunner(eng, use_graph)
+    runner = _StepRunner(eng, False if debug else use_graph)
     for epoch in range(epochs):
         idx = np.arange(n_train_global)
         rng.shuffle(idx)                                       # numpy global RNG, like Keras
@@ -123,9 +127,11 @@ def fit_engine(eng, n_train_global, n_val_global, nt_local, nv_local, t0_global,
         t = 0
         while t < steps:                # runs of equal steps go to the runner together (it replays several per graph launch)
             n = 1
-            while t + n < steps and counts[t + n] == counts[t]:
+            while not debug and t + n < steps and counts[t + n] == counts[t]:
                 n += 1
             runner.run(counts[t][comm.rank], sum(counts[t]), counts[t], b_local, n)
+            if debug:
+                eng.assert_finite('epoch %d, step %d' % (epoch + 1, t + 1))
             t += n
         if nv_local > 0:
             eng.eval_loss_sum(nt_local, nt_local + nv_local, val_scale)
@@ -346,6 +352,7 @@ def train(adata, network, output_dir=None, optimizer='RMSprop', learning_rate=No
         vl = state['history'].get('val_loss') or []
         if vl:
             best['val'] = float(np.min(vl))
+    kwds.setdefault('debug', bool(getattr(network, 'debug', False)))       # --debug: finite checks per step (dca/loss.py:90-100)
     hist = fit_engine(eng, n_train, n_val, nt, nv, t0, epochs=epochs, batch_size=batch_size,
                       learning_rate=learning_rate, clip_grad=clip_grad, reduce_lr=reduce_lr,
                       early_stop=early_stop, verbose=verbose, on_epoch=on_epoch, state=state, **kwds)

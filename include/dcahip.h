@@ -11,8 +11,10 @@
  * Conventions
  *   - every pointer is a DEVICE pointer to row-major fp32 unless stated; the caller
  *     (host code / PyTorch as allocator) owns every buffer, the library allocates nothing
- *     and keeps no global state (no environment variables either: every choice of kernel is a pure function of the
- *     arguments; A/B variants exist only as -D builds of the sources);
+ *     and keeps no global state (no environment variables, no setters: every choice of kernel is a pure function of the
+ *     arguments of the call; kernels that were measured and lost -- the pipelined one-wave-per-SIMD K-HEADS, the
+ *     non-zero-only first-layer forward, the small-batch byte-store weight gradient, the four-wave matrix-pipe forward --
+ *     exist only as -D builds of the sources (DCA_EXP_*), never in the product library);
  *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), re-entrant
  *     across streams and capturable into a hipGraph (no host synchronisation inside);
  *   - return value: 0 on success, otherwise the hipError_t of the failed launch or
@@ -164,12 +166,6 @@ int dcahip_x3_product_32x32(const float* A, const float* B, float* C, int K, voi
  * 8 % of the kernel.  NULL = identity (what dcahip_heads_fused passes). */
 int dcahip_heads_tile_order_len(int G);
 
-/* K-HEADS has two persistent kernels for batches of 160 rows and more: eight waves per workgroup (two per SIMD, the phases of
- * a row tile one after the other) and four waves (one per SIMD) that overlap the three phases of consecutive row tiles
- * inside each wave (dca_amd/csrc/heads_p4.inc).  Launches with at least `nt` 32-row tiles take the second form; returns the
- * previous value; nt <= 0 only reads it.  Results are the same sums in the same orders either way (tests run both).
- * No reference call site: a launch-shape switch for measurements and tests. */
-int dcahip_heads_set_p4_min_tiles(int nt);
 int dcahip_heads_fused_ordered(const float* H, long ldh, const float* Wh, long ldw, const float* bh,
                                long plane, const float* theta_w,
                                const float* y, long ldy, const float* sf,
@@ -578,55 +574,27 @@ int dcahip_enc0_sparse_supported(int H1);
  * cells in LDS; counts beyond take the formula (hardware log2 with an exact-ratio correction, ~2e-7 relative). */
 int dcahip_enc0_lut(const float* fac, int do_log, int n, void* lutp, void* stream);
 int dcahip_enc0_lut_entries(void);
-/* The same weight (+ bias) gradient for SMALL batches (B <= dcahip_enc0_dw_small_max_rows() = 64; the reference's default
- * batch is 32, dca/train.py:37), any first-layer width H1 <= 64 that is a multiple of 4: one pass over the batch's count bytes,
- * fp32 FMAs over the non-zero counts in row order (deterministic), no workspace, no table:
- *   gW[g, :] = (sum_r f(y[r, g] / fac[r]) dZ[r, :] - mean[g] colsum(dZ)) / stdv[g],   gW[G, :] = colsum(dZ).
- * dZ, gW 16-byte aligned, ldz / ldg multiples of 4.  Replaces the same autodiff as dcahip_enc0_dw_sparse. */
-int dcahip_enc0_dw_small_max_rows(void);
-int dcahip_enc0_dw_small(const unsigned char* Yc, long ldc, const int* ovf_ptr, const int* ovf_col, const float* ovf_val,
-                         const float* fac, int do_log, const float* mean, const float* stdv, const int* perm,
-                         const long long* cursor, long row_base, int B, int G, int H1, const float* dZ, long ldz,
-                         float* gW, long ldg, void* stream);
 long dcahip_enc0_dw_sparse_workspace_bytes(int B, int G, int H1);
 /* The 64-unit weight gradient has two kernels (csrc/dcahip_sparse.hip): enc0_dw_kernel (counts through an LDS tile, lookups
  * and products of a 64-row block between two barriers) and enc0_dw2_kernel (512 genes per workgroup, operands staged
  * global -> LDS into a five-stage ring four K steps ahead, a wave's LDS / vector work behind its own matrix instructions).
- * form 1 (default): the ring kernel from 1024 batch rows up, the first kernel below; 0: always the first; 2: always the ring
- * kernel.  Returns the previous form; other values only read it.  Same products, same row order inside a split; the number
- * of splits differs.  A switch for A/B runs and the parity tests of both; no reference call site. */
-int dcahip_enc0_dw_set_form(int form);
+ * `form` (an argument of the call: the library keeps no switch): 0 = by the shape -- the ring kernel from 1024 batch rows
+ * up, the first kernel below --, 1 = always the first, 2 = always the ring kernel (A/B runs and the parity tests of both).
+ * Same products, same row order inside a split; the number of splits differs.  The workspace size covers either. */
 int dcahip_enc0_dw_sparse(const unsigned char* Yc, long ldc, const int* ovf_ptr, const int* ovf_col,
                           const float* ovf_val, const float* fac, int do_log, const void* lutp, const float* mean,
                           const float* stdv, const int* perm, const long long* cursor, long row_base,
                           int B, int G, int H1, const float* dZ, long ldz, float* gW, long ldg,
-                          void* workspace, long workspace_bytes, void* stream);
+                          void* workspace, long workspace_bytes, int form, void* stream);
 /*
- * Forward of the first Dense layer from the compact counts: Z [B, ldz] = X W + bias with X as above, W [G, ldw].
- * workspace >= dcahip_enc0_fwd_sparse_workspace_bytes(H1) bytes, 16-byte aligned, ZERO before the first call (it
- * holds the arrival counter of the bias-correction reduction; every call leaves it at zero).
- * Replaces Dense(hidden_size[0]) of dca/network.py:124-126 on the input of dca/io.py:88-111.
- */
-long dcahip_enc0_fwd_sparse_workspace_bytes(int H1);
-int dcahip_enc0_fwd_sparse(const unsigned char* Yc, long ldc, const int* ovf_ptr, const int* ovf_col,
-                           const float* ovf_val, const float* fac, int do_log, const float* mean,
-                           const float* stdv, const int* perm, const long long* cursor, long row_base,
-                           int B, int G, int H1, const float* W, long ldw, const float* bias,
-                           float* Z, long ldz, void* workspace, long workspace_bytes, void* stream);
-/*
- * The same product on the matrix pipe for large batches (H1 = 32 or 64; 0 workspace bytes = width not taken): the A
+ * Forward of the first Dense layer from the compact counts, Z [B, ldz] = X W + bias with X as above, W [G, ldw], on the
+ * matrix pipe (H1 = 32 or 64; 0 workspace bytes = width not taken): the A
  * operand is looked up from the byte store through lutp (dcahip_enc0_lut of the same cells: counts 0 .. 31 from the
  * table, larger ones and escapes by the formula), W / std is split into bf16 pieces once per call, six bf16 products per
  * fp32 product as dcahip_sgemm, gene chunks added in a fixed order: deterministic.  workspace >=
  * dcahip_enc0_fwd_lut_workspace_bytes(B, G, H1), 16-byte aligned, any content; n_cells * ldc must stay below 2^32 (lutp).
  * Replaces Dense(hidden_size[0]) of dca/network.py:124-126 on the input of dca/io.py:88-111.
  */
-/* The matrix-pipe forward has two shapes of the same kernel (csrc/dcahip_sparse.hip enc0_fwd_lut_kernel<H1, RT>): form 1 --
- * eight waves of 32 batch rows per workgroup, two waves per SIMD; form 2 -- four waves of 64 rows, one per SIMD, the W
- * fragments of a K step read from LDS once for both 32-row tiles (the loop of form 1 is bound by its LDS reads).  Same
- * products in the same order: bit-identical results.  Returns the previous form; other values only read it.  A switch for
- * A/B runs and the parity tests of both; no reference call site. */
-int dcahip_enc0_fwd_set_form(int form);
 long dcahip_enc0_fwd_lut_workspace_bytes(int B, int G, int H1);
 int dcahip_enc0_fwd_lut(const unsigned char* Yc, long ldc, const int* ovf_ptr, const int* ovf_col,
                         const float* ovf_val, const float* fac, int do_log, const void* lutp, const float* mean,
@@ -638,17 +606,20 @@ int dcahip_enc0_fwd_lut(const unsigned char* Yc, long ldc, const int* ovf_ptr, c
  * K-PEER (dca_amd/csrc/dcahip_peer.hip): the small exchanges of the data-parallel step without a library call.
  *   slots[q], flags[q]: device arrays of `world` pointers to every rank's exchange buffers (rank's own: its local
  *   allocation; the others: mapped with hipIpcOpenMemHandle), each dcahip_peer_slot_bytes(world, nmax) /
- *   dcahip_peer_flag_bytes(world) bytes, zero-initialised once.  epoch: one device counter per communicator, 0 at the start,
+ *   dcahip_peer_flag_bytes(world) bytes, zero-initialised once, in FINE-GRAINED device memory
+ *   (hipExtMallocWithFlags(hipDeviceMallocFinegrained)): a peer's stores over xGMI are not guaranteed visible to the owner's
+ *   spinning loads in a coarse-grained (plain hipMalloc) allocation.  epoch: one device counter per communicator, 0 at the start,
  *   advanced by every call (all ranks call in the same order).  reduce = 0: out [world * n] = concatenation of the ranks'
  *   vectors (all-gather); reduce = 1: out [n] = their sum in rank order (all-reduce; out may be local).  A peer that does
- *   not arrive within max_spin polls sets *status |= 1 and the call returns what it has (the caller checks status at its
- *   next synchronisation).  Asynchronous on `stream`; one workgroup.  Replaces torch.distributed.all_gather_into_tensor /
+ *   not arrive within timeout_us microseconds (100 MHz wall clock) sets *status |= 1 and `out` is filled with NaN: a missed
+ *   exchange poisons the step visibly instead of feeding it stale statistics (the caller checks status at its next
+ *   synchronisation).  Asynchronous on `stream`; one workgroup.  Replaces torch.distributed.all_gather_into_tensor /
  *   all_reduce on <= nmax floats (SyncBN statistics); no reference call site (the reference is single-process).
  */
 long dcahip_peer_slot_bytes(int world, int nmax);
 long dcahip_peer_flag_bytes(int world);
 int dcahip_peer_exchange(const float* local, int n, float* const* slots, unsigned* const* flags, int rank, int world, int nmax,
-                         unsigned long long* epoch, float* out, int reduce, int* status, long max_spin, void* stream);
+                         unsigned long long* epoch, float* out, int reduce, int* status, long timeout_us, void* stream);
 
 #ifdef __cplusplus
 }

@@ -30,6 +30,29 @@ def test_library_exports_every_declared_symbol():
     assert L.dcahip_version() == 1
 
 
+def test_product_library_has_no_setters_and_no_experiment_kernels():
+    """include/dcahip.h: "keeps no global state ... every choice of kernel is a pure function of the arguments".  The product
+    library exports no `*_set_*` switch, and the kernels that were measured and lost (pipelined one-wave-per-SIMD K-HEADS, the
+    non-zero-only first-layer forward, the small-batch byte-store weight gradient, the four-wave matrix-pipe forward) are in
+    experiment builds (-DDCA_EXP_*) only: neither their entry points nor their device code is in libdcahip.so."""
+    import shutil
+    import subprocess
+    from dca_amd import build
+    lib_path = build.build_hip(verbose=False)
+    nm = shutil.which('nm') or '/opt/rocm/lib/llvm/bin/llvm-nm'
+    syms = subprocess.run([nm, '-D', '--defined-only', lib_path], capture_output=True, text=True, check=True).stdout
+    exported = re.findall(r'\b(dcahip_\w+)', syms)
+    assert len(exported) >= 70
+    assert not [n for n in exported if '_set_' in n], [n for n in exported if '_set_' in n]
+    for gone in ('dcahip_enc0_dw_small', 'dcahip_enc0_fwd_sparse', 'dcahip_heads_set_p4_min_tiles'):
+        assert gone not in exported
+    assert set(exported) == set(_declared()), set(exported) ^ set(_declared())
+    blob = open(lib_path, 'rb').read()
+    for kernel in (b'heads_fused_p4_kernel', b'enc0_dw_small_kernel', b'enc0_fwd_kernel'):
+        assert kernel not in blob, kernel
+    assert b'enc0_fwd_lut_kernelILi64ELi2E' not in blob and b'enc0_fwd_lut_kernelILi64ELi1E' in blob
+
+
 def test_product_path_fails_loudly_without_gpu():
     import pytest
     import torch
@@ -96,7 +119,7 @@ def test_first_layer_plans_are_pure_functions_of_the_shape():
         want = r16(n_ms * tile) + r16(n_ms * H1 * 8) + r16(chunks * rgs * 256 * H1 * 4)
         assert L.dcahip_enc0_fwd_lut_workspace_bytes(B, G, H1) == want, (B, G, H1)
     # weight gradient: [splits][Gs][H1] partials + column sums ...: the number of splits follows from the size.  The 64-unit
-    # gradient has two kernels with different split counts (dcahip_enc0_dw_set_form); the workspace covers either
+    # gradient has two kernels with different split counts (the `form` argument of dcahip_enc0_dw_sparse); the workspace covers either
     def splits(B, G, H1):
         groups = (G + 255) // 256
         ns = max(1, min(16, 256 // groups, (B + 63) // 64))
@@ -136,7 +159,7 @@ def test_first_layer_kernels_stay_inside_their_budget():
         if 'enc0_dw_kernel' in n or 'enc0_dw2_kernel' in n or 'enc0_fwd_lut_kernel' in n:
             seen += 1
             assert s == 0 and l <= 163840, (n, s, l)
-    assert seen == 8          # weight gradient at 32 / 64 / 128 units + the ring form at 64, forward at 32 / 64 in both shapes
+    assert seen == 6          # weight gradient at 32 / 64 / 128 units + the ring form at 64, forward at 32 / 64
 
 
 def _blocks_with_matrix_instructions(asm, kernel_substr):

@@ -287,12 +287,21 @@ def _run_peer(rank, world, port, q):
                       LOCAL_RANK=str(rank), DCA_AMD_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
     try:
         from dca_amd.engine import Engine
+        from dca_amd import peer as _peer
         from dca_amd.peer import PeerExchange
         from dca_amd.train import fit_engine
         comm = ddist.init_from_env()
         dev = torch.device('cuda')
         # ---- raw exchanges: gathers and reductions of several lengths, 60 epochs, then the same inside a hipGraph
-        px = PeerExchange(rank, world, 128)
+        px = PeerExchange(rank, world, 128)        # (runs the init-time ping-pong self check: a failure raises PeerUnavailable)
+        # the exchange buffers are FINE-GRAINED device memory (csrc/dcahip_peer.hip: what makes a peer's stores over xGMI
+        # visible to the owner's spinning loads): as allocated, and as the ROCr runtime reports the allocation
+        fine = _peer.HSA_FLAG_FINE_GRAINED | _peer.HSA_FLAG_EXTENDED_SCOPE_FINE_GRAINED
+        assert len(px.mem_flags) == 2
+        assert all(f is not None and (f & fine) and not (f & _peer.HSA_FLAG_COARSE_GRAINED) for f in px.mem_flags), px.mem_flags
+        plain = torch.zeros(1024, device=dev)      # torch's allocator = plain hipMalloc: the query tells the two apart
+        pf = _peer.memory_flags(plain.data_ptr())
+        assert pf is not None and (pf & _peer.HSA_FLAG_COARSE_GRAINED), pf
         bad = 0
         for e in range(60):
             n = (1, 7, 64, 128)[e % 4]
@@ -322,6 +331,22 @@ def _run_peer(rank, world, port, q):
             bad += int((dst != want).sum().item()) + int((red != want.view(world, 16).sum(0)).sum().item())
         px.check()
         px.close()
+        # ---- a peer that never arrives: rank 0 exchanges alone with a 0.2 s timeout -> NaN results + status, check() raises
+        # (a fresh exchange object: its epochs are out of step afterwards)
+        px2 = PeerExchange(rank, world, 16)
+        if rank == 0:
+            px2.timeout_us = 200 * 1000
+            t = torch.ones(16, device=dev)
+            px2.reduce(t)
+            torch.cuda.synchronize()
+            bad += int((~torch.isnan(t)).sum().item())
+            try:
+                px2.check()
+                bad += 1000
+            except RuntimeError as e:
+                assert 'did not arrive' in str(e)
+        dist.barrier()
+        px2.close()
         # ---- the data-parallel fit with the SyncBN exchanges through K-PEER against the library's collectives
         n, G, hs, ae, B, epochs, seed = 300, 150, (64, 32, 64), 'zinb-conddisp', 64, 2, 17
         X, Y, sf, p = make_problem(n, G, hs, ae, True, seed=3)
@@ -357,7 +382,9 @@ def _run_peer(rank, world, port, q):
 
 def test_peer_exchange_two_processes_on_one_gpu():
     """K-PEER (dcahip_peer_exchange: peer stores into IPC-mapped slots + flags, no library call) with two processes sharing this
-    GPU: 60 gathers and 60 reductions of 1 .. 128 floats give exactly the expected vectors, eagerly and replayed from a hipGraph;
+    GPU: the exchange buffers are fine-grained memory (allocation flag + what the ROCr runtime reports; torch's plain hipMalloc
+    memory reports coarse-grained), the init-time self check passes, 60 gathers and 60 reductions of 1 .. 128 floats give exactly
+    the expected vectors, eagerly and replayed from a hipGraph; an exchange a peer never joins returns NaN and raises at check();
     then a two-epoch data-parallel fit whose SyncBN exchanges go through K-PEER (EngineConfig.dp_peer_exchange) equals the fit
     over the library's collectives BIT FOR BIT (two ranks: the sum a + b has one order) -- and did use the peer path."""
     W = 2

@@ -80,6 +80,28 @@ def test_fit_loop_matches_oracle(ae_type):
         np.testing.assert_allclose(newp[k], ref.p[k], rtol=5e-3, atol=2e-5, err_msg=k)
 
 
+def test_debug_flag_checks_every_step_for_non_finite_values():
+    """--debug (dca/__main__.py:111-113, dca/loss.py:90-100): the fit loop runs eagerly and checks loss, gradients and
+    parameters after every step.  A clean fit is unchanged by it; a parameter poisoned with NaN fails at the first step with
+    the tensors named."""
+    from dca_amd.train import fit_engine
+    n, G, hs = 75, 20, (6, 3, 6)
+    X, Y, sf, p = make_problem(n, G, hs, 'zinb-conddisp', True, seed=4)
+    n_train = int(n * 0.9)
+    hists = []
+    for debug in (False, True):
+        eng = make_engine(CpuRefOps(), 'zinb-conddisp', G, hs, True, 0.0, p, X, Y, sf)
+        hists.append(fit_engine(eng, n_train, n - n_train, n_train, n - n_train, 0, epochs=2, batch_size=16,
+                                shuffle_rng=np.random.RandomState(9), debug=debug).history)
+    assert hists[0]['loss'] == hists[1]['loss'] and hists[0]['val_loss'] == hists[1]['val_loss']
+    eng = make_engine(CpuRefOps(), 'zinb-conddisp', G, hs, True, 0.0, p, X, Y, sf)
+    eng.lay.view(eng.w, 'bh')[3] = float('nan')
+    with pytest.raises(FloatingPointError, match=r'has inf/nans \(epoch 1, step 1\)') as ei:
+        fit_engine(eng, n_train, n - n_train, n_train, n - n_train, 0, epochs=2, batch_size=16,
+                   shuffle_rng=np.random.RandomState(9), debug=True)
+    assert 'loss' in str(ei.value) and 'bh' in str(ei.value)
+
+
 def test_predict_matches_oracle():
     n, G, hs = 33, 26, (8, 4, 8)
     for ae_type in N.AE_TYPES:

@@ -179,7 +179,11 @@ def test_heads_fused_vs_oracle(ops, flags, B, G, hL):
 
 @pytest.fixture
 def p4_forced(ops):
-    """The pipelined four-wave kernel (dca_amd/csrc/heads_p4.inc) from 5 row tiles on instead of its product threshold."""
+    """The pipelined four-wave kernel (dca_amd/csrc/heads_p4.inc) from 5 row tiles on.  The kernel measured slower than the
+    8-wave one and exists only in EXPERIMENT builds of the library (-DDCA_EXP_HEADS_P4, e.g.
+    tools/ab_heads_p4.py): these tests run when such a build is the one loaded."""
+    if not ops.has('dcahip_heads_set_p4_min_tiles'):
+        pytest.skip('experiment kernel: build the library with -DDCA_EXP_HEADS_P4')
     old = ops.heads_set_p4_min_tiles(5)
     yield
     ops.heads_set_p4_min_tiles(old)
@@ -212,7 +216,10 @@ def test_heads_fused_pipelined_kernel_odd_counts_and_order(ops, p4_forced):
 
 def test_heads_fused_both_kernels_same_sums(ops):
     """The 8-wave and the pipelined kernel on one input (2 048 x 2 000): same operands, same six products, same order of the
-    K steps -- the weight gradients differ only by the association of their per-wave partial sums (4 waves instead of 8)."""
+    K steps -- the weight gradients differ only by the association of their per-wave partial sums (4 waves instead of 8).
+    (Experiment build only, see p4_forced.)"""
+    if not ops.has('dcahip_heads_set_p4_min_tiles'):
+        pytest.skip('experiment kernel: build the library with -DDCA_EXP_HEADS_P4')
     res = []
     for thr in (1 << 30, 5):
         old = ops.heads_set_p4_min_tiles(thr)

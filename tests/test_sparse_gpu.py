@@ -137,55 +137,47 @@ def test_sparse_first_layer_vs_numpy(ops, B, G, H1, gather, use_fac, do_log, sca
     dcur = torch.tensor([cur if gather else 0], dtype=torch.int64, device='cuda')
     base = 0 if gather else cur
     dW_, db_, ddZ = dev(W), dev(b), dev(dZ)
-    # ---- forward (run twice: the arrival counter of the bias correction must be back at zero)
-    Zd = torch.full((B, H1), 7.0, device='cuda')
-    wsf = torch.zeros(ops.enc0_fwd_sparse_workspace_bytes(H1) // 4 + 4, device='cuda')
-    for _ in range(2):
-        ops.enc0_fwd_sparse(cc, dperm, dcur, base, B, G, H1, dW_, H1, db_, Zd, H1, wsf)
-    torch.cuda.synchronize()
-    err = np.abs(Zd.cpu().numpy() - Z_ref)
-    assert (err <= 1e-6 * Z_abs + 1e-30).all(), float((err / Z_abs).max())
-    # ---- the same product on the matrix pipe (looked-up operand), where the width is taken; twice, bit for bit
+    # ---- forward over the non-zero counts only: an EXPERIMENT build of the library (-DDCA_EXP_ENC0_SPARSE_FWD; it lost to the
+    # dense product) -- checked when such a build is the one loaded (run twice: the arrival counter of the bias correction
+    # must be back at zero)
+    if ops.has('dcahip_enc0_fwd_sparse'):
+        Zd = torch.full((B, H1), 7.0, device='cuda')
+        wsf = torch.zeros(ops.enc0_fwd_sparse_workspace_bytes(H1) // 4 + 4, device='cuda')
+        for _ in range(2):
+            ops.enc0_fwd_sparse(cc, dperm, dcur, base, B, G, H1, dW_, H1, db_, Zd, H1, wsf)
+        torch.cuda.synchronize()
+        err = np.abs(Zd.cpu().numpy() - Z_ref)
+        assert (err <= 1e-6 * Z_abs + 1e-30).all(), float((err / Z_abs).max())
+    # ---- the product on the matrix pipe (looked-up operand), where the width is taken; twice, bit for bit
     nb = ops.enc0_fwd_lut_workspace_bytes(B, G, H1)
     assert (nb > 0) == (H1 in (32, 64))
     if nb:
         wsl = torch.full((nb // 4 + 4,), float("nan"), device="cuda")
-        seen = []
-        for form in (1, 2):                 # eight waves of 32 rows / four waves of 64 rows: the same products in the same order
-            prev = ops.enc0_fwd_set_form(form)
-            try:
-                Zl = torch.full((B, H1), 7.0, device='cuda'); Zl2 = torch.full((B, H1), 3.0, device='cuda')
-                ops.enc0_fwd_lut(cc, dperm, dcur, base, B, G, H1, dW_, H1, db_, Zl, H1, wsl)
-                ops.enc0_fwd_lut(cc, dperm, dcur, base, B, G, H1, dW_, H1, db_, Zl2, H1, wsl)
-                torch.cuda.synchronize()
-                err = np.abs(Zl.cpu().numpy() - Z_ref)
-                assert (err <= 1e-6 * Z_abs + 1e-30).all(), (form, float((err / Z_abs).max()))
-                assert torch.equal(Zl, Zl2), form
-                seen.append(Zl)
-            finally:
-                ops.enc0_fwd_set_form(prev)
-        assert torch.equal(seen[0], seen[1])
+        Zl = torch.full((B, H1), 7.0, device='cuda'); Zl2 = torch.full((B, H1), 3.0, device='cuda')
+        ops.enc0_fwd_lut(cc, dperm, dcur, base, B, G, H1, dW_, H1, db_, Zl, H1, wsl)
+        ops.enc0_fwd_lut(cc, dperm, dcur, base, B, G, H1, dW_, H1, db_, Zl2, H1, wsl)
+        torch.cuda.synchronize()
+        err = np.abs(Zl.cpu().numpy() - Z_ref)
+        assert (err <= 1e-6 * Z_abs + 1e-30).all(), float((err / Z_abs).max())
+        assert torch.equal(Zl, Zl2)
     # ---- weight + bias gradient
     if not ops.enc0_sparse_supported(H1):
         return
-    # (64 units: both kernels at every size -- the library itself takes the ring kernel from 1024 rows up)
-    for form in ((0, 2) if H1 == 64 else (1,)):
-        prev = ops.enc0_dw_set_form(form)
-        try:
-            gWd = torch.full((G + 1, H1), 7.0, device='cuda')
-            ws = torch.full((ops.enc0_dw_sparse_workspace_bytes(B, G, H1) // 4 + 4,), float('nan'), device='cuda')
-            ops.enc0_dw_sparse(cc, dperm, dcur, base, B, G, H1, ddZ, H1, gWd, H1, ws)
-            torch.cuda.synchronize()
-            got = gWd.cpu().numpy()
-            err = np.abs(got[:G] - gW_ref)
-            assert (err <= 1e-6 * gW_abs + 1e-30).all(), (form, float((err / np.maximum(gW_abs, 1e-30)).max()))
-            np.testing.assert_allclose(got[G], dZ.sum(0), rtol=0, atol=2e-6 * np.abs(dZ).sum(0).max())
-            # deterministic: a second launch reproduces every bit
-            gW2 = torch.zeros_like(gWd)
-            ops.enc0_dw_sparse(cc, dperm, dcur, base, B, G, H1, ddZ, H1, gW2, H1, ws)
-            assert torch.equal(gW2, gWd), form
-        finally:
-            ops.enc0_dw_set_form(prev)
+    # (64 units: both kernels at every size through the call's `form` argument -- by the shape the library takes the ring
+    # kernel from 1024 rows up)
+    for form in ((1, 2, 0) if H1 == 64 else (0,)):
+        gWd = torch.full((G + 1, H1), 7.0, device='cuda')
+        ws = torch.full((ops.enc0_dw_sparse_workspace_bytes(B, G, H1) // 4 + 4,), float('nan'), device='cuda')
+        ops.enc0_dw_sparse(cc, dperm, dcur, base, B, G, H1, ddZ, H1, gWd, H1, ws, form=form)
+        torch.cuda.synchronize()
+        got = gWd.cpu().numpy()
+        err = np.abs(got[:G] - gW_ref)
+        assert (err <= 1e-6 * gW_abs + 1e-30).all(), (form, float((err / np.maximum(gW_abs, 1e-30)).max()))
+        np.testing.assert_allclose(got[G], dZ.sum(0), rtol=0, atol=2e-6 * np.abs(dZ).sum(0).max())
+        # deterministic: a second launch reproduces every bit
+        gW2 = torch.zeros_like(gWd)
+        ops.enc0_dw_sparse(cc, dperm, dcur, base, B, G, H1, ddZ, H1, gW2, H1, ws, form=form)
+        assert torch.equal(gW2, gWd), form
 
 
 @pytest.mark.parametrize('flags', [1, 3, 0, 2])
@@ -228,8 +220,9 @@ def test_heads_read_the_byte_store_bit_for_bit(ops, flags, B, G):
 @pytest.mark.parametrize('ae_type', ['zinb-conddisp', 'zinb', 'nb-conddisp', 'nb'])
 @pytest.mark.parametrize('B', [32, 300])
 def test_step_with_compact_counts_matches_oracle(ops, ae_type, B):
-    """One full training step with the counts in the byte store and the first layer on the non-zero counts: loss and
-    every gradient against the fp64 oracle fed the dense input (the statement of test_single_step_matches_oracle)."""
+    """One full training step with the counts in the byte store and BOTH first-layer products built from it (at every batch
+    size: the thresholds are lowered): loss and every gradient against the fp64 oracle fed the dense input (the statement of
+    test_single_step_matches_oracle)."""
     from dca_amd.engine import Engine
     n, G, hs = 320, 700, (64, 32, 64)
     _, Y, _, p = make_problem(n, G, hs, ae_type, True, seed=B)
@@ -249,7 +242,8 @@ def test_step_with_compact_counts_matches_oracle(ops, ae_type, B):
     Gp = (G + 3) // 4 * 4
     Xd = torch.zeros(n, Gp, device='cuda'); Xd[:, :G] = dev(X)
     Yd = torch.zeros(n, Gp, device='cuda'); Yd[:, :G] = dev(Y)
-    eng.sparse_fwd_min = eng.sparse_dw_min = 1           # both byte-store kernels at every batch size
+    eng.sparse_dw_min = eng.cfg.lut_fwd_min = 1          # both byte-store kernels at every batch size
+    eng.reserve(B)
     norm = dict(fac=dev(sf), do_log=True, mean=dev(mean), std=dev(std))
     eng.attach_device_data(Xd, Yd, dev(sf), norm=norm)
     assert eng.cc is not None and eng.cc_in is not None
@@ -266,7 +260,7 @@ def test_step_with_compact_counts_matches_oracle(ops, ae_type, B):
         e4.attach_device_data(Xd, Ye, dev(sf), norm=norm)
         assert e4.cc is None and e4.cc_in is None
     loss, g, _ = run_single_step(eng, rows)
-    assert eng._sparse_fwd(B, True) and eng._sparse_dw(B)
+    assert eng._lut_fwd(B, True) and eng._sparse_dw(B)
     assert abs(loss - rl) < 1e-5 * abs(rl), (loss, rl)
     # (the biases in front of batch normalisation have an identically zero gradient: column sums of dZ that cancel --
     # the round-off left over depends on the order of the sum and is held to the absolute bound of the zero case)
@@ -289,9 +283,12 @@ def test_step_with_compact_counts_matches_oracle(ops, ae_type, B):
     (64, 77, 32, False, True, True, False, True), (1, 50, 64, True, True, True, True, False), (33, 90, 16, True, False, False, False, True),
     (40, 130, 48, False, True, False, True, False)])
 def test_small_batch_weight_gradient_kernel_vs_numpy(ops, B, G, H1, gather, use_fac, do_log, scale, esc):
-    """dcahip_enc0_dw_small: the first layer's weight + bias gradient of a batch of at most 64 rows (the reference's default
+    """(EXPERIMENT build -DDCA_EXP_DW_SMALL only: the kernel measured slower than the GEMM it would replace and is not in the
+    product library.)  dcahip_enc0_dw_small: the first layer's weight + bias gradient of a batch of at most 64 rows (the reference's default
     32, its 25-row last batch of C3, a single row) over the non-zero counts of the byte store, against fp64 numpy on the
     dense input: |err| <= 1e-6 of the summed magnitudes, the bias row to 2e-6; a second launch reproduces every bit."""
+    if not ops.has('dcahip_enc0_dw_small'):
+        pytest.skip('experiment entry point: build the library with -DDCA_EXP_DW_SMALL')
     rng = np.random.RandomState(B + G + H1)
     n = B + 9
     Y = counts_with_escapes(n, G, B + G, big=esc)
@@ -330,38 +327,36 @@ def test_small_batch_weight_gradient_kernel_vs_numpy(ops, B, G, H1, gather, use_
     assert torch.equal(gW2, gWd)
 
 
-@pytest.mark.parametrize('B', [32, 25])
-def test_small_batch_weight_gradient_from_the_byte_store(ops, B, monkeypatch):
-    """One training step at the reference's default batch with the first layer's weight gradient from the byte store
-    (EngineConfig.small_dw; off in the product: it measured slower) and through the GEMM: same loss, gradients within the single-step tolerance of each
-    other and of the fp64 oracle."""
+@pytest.mark.parametrize('hs,B', [((16, 8, 16), 512), ((48, 16, 48), 600), ((16, 8, 16), 32)])
+def test_first_layer_widths_the_byte_store_does_not_take_keep_the_dense_products(ops, hs, B):
+    """A first layer of 16 or 48 units (the byte-store kernels take 32 / 64 / 128) on K-PREP-resident counts with a known
+    normalisation, at a batch above the weight gradient's byte-store threshold: the engine keeps both dense products
+    (cc_in stays None: K-HEADS still reads its targets from the byte store) and the step matches the fp64 oracle."""
     from dca_amd import prep
     from dca_amd.engine import Engine
-    n, G, hs = 300, 1000, (64, 32, 64)
-    _, Yh, _, p = make_problem(n, G, hs, 'zinb-conddisp', True, seed=21)
-    Yh = np.minimum(Yh, 200.0)                   # (no escapes: the byte-store first layer takes stores with at most 1e-5 of them)
+    n, G = 640, 600
+    _, Yh, _, p = make_problem(n, G, hs, 'zinb-conddisp', True, seed=17)
+    Yh = np.minimum(Yh, 200.0)
     Gp = (G + 3) // 4 * 4
     Y = torch.zeros(n, Gp, device='cuda'); Y[:, :G] = dev(Yh)
     counts = prep.cell_counts(ops, Y, n, G)
     sf = counts / counts.median()
     X, norm = prep.transform(ops, Y, n, G, sf, True, True, return_norm=True)
-    rows = np.random.RandomState(3).permutation(n)[:B]
+    rows = np.random.RandomState(5).permutation(n)[:B]
     rt = torch.as_tensor(rows).cuda()
     ref = oracle_net('zinb-conddisp', p, hs, True)
     rl, rg = ref.loss_and_grads(X[rt][:, :G].cpu().numpy().astype(np.float64), Yh[rows].astype(np.float64),
                                 sf[rt].cpu().numpy().astype(np.float64))
-    res = {}
-    for on in ('1', '0'):
-        monkeypatch.setenv('DCA_AMD_SMALL_DW', on)
-        eng = Engine('zinb-conddisp', G, G, hs, True, 0.0, ops=ops)
-        eng.set_params(p)
-        eng.attach_device_data(X, Y, sf, norm=norm)
-        eng.reserve(B)
-        assert eng._small_dw(B) == (on == '1')
-        res[on] = run_single_step(eng, rows)
-        assert abs(res[on][0] - rl) < 1e-5 * abs(rl)
-        assert_grads_close(res[on][1], rg)
-    np.testing.assert_allclose(res['1'][1]['W0'], res['0'][1]['W0'], rtol=2e-4, atol=2e-6 * np.abs(res['0'][1]['W0']).max())
+    eng = Engine('zinb-conddisp', G, G, hs, True, 0.0, ops=ops)
+    eng.set_params(p)
+    eng.reserve(B)
+    eng.attach_device_data(X, Y, sf, norm=norm)
+    assert eng.cc is not None and eng.cc_in is None and eng.ws_enc0 is None
+    assert not eng._sparse_dw(B) and not eng._lut_fwd(B, True)
+    loss, g, _ = run_single_step(eng, rows)
+    assert abs(loss - rl) < 1e-5 * abs(rl), (loss, rl)
+    zero_b = tuple('b%d' % i for i in range(len(hs)))
+    assert_grads_close(g, rg, skip=zero_b)
 
 
 def test_weight_gradient_kernels_on_random_shapes(ops):
@@ -395,18 +390,14 @@ def test_weight_gradient_kernels_on_random_shapes(ops):
         dperm = torch.as_tensor(perm).cuda()
         dcur = torch.zeros(1, dtype=torch.int64, device='cuda')
         ddZ = dev(dZ)
-        for form in (0, 2):
-            prev = ops.enc0_dw_set_form(form)
-            try:
-                ws = torch.full((ops.enc0_dw_sparse_workspace_bytes(B, G, H1) // 4 + 4,), float('nan'), device='cuda')
-                gW1 = torch.full((G + 1, H1), 7.0, device='cuda'); gW2 = torch.full((G + 1, H1), 3.0, device='cuda')
-                ops.enc0_dw_sparse(cc, dperm, dcur, 0, B, G, H1, ddZ, H1, gW1, H1, ws)
-                ops.enc0_dw_sparse(cc, dperm, dcur, 0, B, G, H1, ddZ, H1, gW2, H1, ws)
-                torch.cuda.synchronize()
-                got = gW1.cpu().numpy()
-                err = np.abs(got[:G] - gW_ref)
-                assert (err <= 1e-6 * gW_abs + 1e-30).all(), (B, G, form, float((err / np.maximum(gW_abs, 1e-30)).max()))
-                np.testing.assert_allclose(got[G], dZ.sum(0), rtol=0, atol=2e-6 * np.abs(dZ).sum(0).max() + 1e-30)
-                assert torch.equal(gW1, gW2), (B, G, form)
-            finally:
-                ops.enc0_dw_set_form(prev)
+        for form in (1, 2):
+            ws = torch.full((ops.enc0_dw_sparse_workspace_bytes(B, G, H1) // 4 + 4,), float('nan'), device='cuda')
+            gW1 = torch.full((G + 1, H1), 7.0, device='cuda'); gW2 = torch.full((G + 1, H1), 3.0, device='cuda')
+            ops.enc0_dw_sparse(cc, dperm, dcur, 0, B, G, H1, ddZ, H1, gW1, H1, ws, form=form)
+            ops.enc0_dw_sparse(cc, dperm, dcur, 0, B, G, H1, ddZ, H1, gW2, H1, ws, form=form)
+            torch.cuda.synchronize()
+            got = gW1.cpu().numpy()
+            err = np.abs(got[:G] - gW_ref)
+            assert (err <= 1e-6 * gW_abs + 1e-30).all(), (B, G, form, float((err / np.maximum(gW_abs, 1e-30)).max()))
+            np.testing.assert_allclose(got[G], dZ.sum(0), rtol=0, atol=2e-6 * np.abs(dZ).sum(0).max() + 1e-30)
+            assert torch.equal(gW1, gW2), (B, G, form)

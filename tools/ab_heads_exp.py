@@ -13,7 +13,6 @@ import torch
 from dca_amd.ops import HipOps
 from dca_amd import synth, compact
 ops = HipOps(); dev = torch.device('cuda')
-ops.heads_set_p4_min_tiles(1 << 30)
 B, G, hL, flags = 4096, 20000, 64, 1
 Gp = G; NH = 3 * Gp; n = 68579
 Y = synth.generate_counts(n, G, device=dev); X, sf = synth.normalize_on_device(Y, G, None); del X

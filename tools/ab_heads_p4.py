@@ -5,6 +5,13 @@ import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from dca_amd import build as _b
+_P4 = os.path.join(ROOT, 'tools', '_dbg', 'libdcahip_DCA_EXP_HEADS_P4.so')      # the pipelined kernel lives in an experiment build only
+if not os.path.exists(_P4):
+    os.makedirs(os.path.dirname(_P4), exist_ok=True)
+    _b.build_hip(defines=('DCA_EXP_HEADS_P4',), out=_P4)
+_b.LIB = _P4
+_b.needs_build = lambda: False
 from dca_amd.ops import HipOps
 from dca_amd import synth, compact
 

@@ -49,8 +49,6 @@ def main():
     eng.init_params(0)
     eng.attach_device_data(X, Y, sf, norm=norm)
     eng.reserve(1024)
-    if os.environ.get('B32_SPARSE_FWD'):            # experiment: the forward over the non-zero counts (gathers of W0 rows) at this batch
-        eng.sparse_fwd_min = 1
     eng.clip = 5.0
     eng.set_lr(1e-3)
     k32 = 400

@@ -12,8 +12,8 @@ from dca_amd import synth, prep, compact
 from dca_amd.ops import HipOps
 
 ops = HipOps()
-if os.environ.get('FWD_FORM'):
-    ops.enc0_fwd_set_form(int(os.environ['FWD_FORM']))
+# (the four-wave shape of the matrix-pipe forward and the non-zero-only forward are experiment builds: DCA_DW_LIB = a library built
+# with -DDCA_EXP_FWD_FORM2 / -DDCA_EXP_ENC0_SPARSE_FWD, dca_amd.build.build_hip(defines=..., out=...))
 dev = torch.device('cuda')
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 h = int(sys.argv[2]) if len(sys.argv) > 2 else 64
@@ -29,7 +29,8 @@ W0 = torch.randn(G + 1, h, device=dev) * 0.01
 W0T = torch.zeros(h, Y.shape[1], device=dev)
 cur = torch.zeros(1, dtype=torch.int64, device=dev)
 ws = torch.zeros(256 * 1024 * 1024 // 4, device=dev)
-wsf = torch.zeros(ops.enc0_fwd_sparse_workspace_bytes(h) // 4 + 4, device=dev)
+HAS_SP = ops.has('dcahip_enc0_fwd_sparse')          # the non-zero-only forward: experiment builds only
+wsf = torch.zeros(ops.enc0_fwd_sparse_workspace_bytes(h) // 4 + 4, device=dev) if HAS_SP else None
 ldx = X.shape[1]
 
 
@@ -76,9 +77,9 @@ for B in ([int(b) for b in os.environ['BENCH_B'].split(',')] if os.environ.get('
         ops.enc0_dw_sparse(cc, perm, cur, 0, B, G, h, dZ, h, gW2, h, wsd)
 
     t = {'fwd dense NN': timeit(fwd_nn), 'fwd dense NT+transpose': timeit(fwd_nt) if B >= 256 else float('nan'),
-         'fwd sparse': timeit(fwd_sp), 'fwd lut': timeit(fwd_lut) if nbl else float('nan'), 'dW dense TN': timeit(dw_tn), 'dW sparse': timeit(dw_sp)}
-    fwd_nn(); fwd_sp(); dw_tn(); dw_sp(); torch.cuda.synchronize()
-    ez = (Z - Z2).abs().max().item() / Z.abs().max().item()
+         'fwd sparse': timeit(fwd_sp) if HAS_SP else float('nan'), 'fwd lut': timeit(fwd_lut) if nbl else float('nan'), 'dW dense TN': timeit(dw_tn), 'dW sparse': timeit(dw_sp)}
+    fwd_nn(); (fwd_sp() if HAS_SP else fwd_lut()); dw_tn(); dw_sp(); torch.cuda.synchronize()
+    ez = (Z - Z2).abs().max().item() / Z.abs().max().item() if HAS_SP else 0.0
     if nbl:
         fwd_lut(); torch.cuda.synchronize()
         ez = max(ez, (Z - Z3).abs().max().item() / Z.abs().max().item())

@@ -11,7 +11,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
   timeout 400 rocprofv3 --kernel-trace --pmc $set -d $OUT/p$i -o pmc --output-format csv -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline ${BENCH_ARGS} > $OUT/p$i.log 2>&1
   echo "pass $i rc=$?"
 done
-python tools/pmc_summary.py $OUT $OUT/sq_summary.csv
+python tools/pmc_summary.py $OUT $OUT/sq_summary.csv $OUT/sq_pipe_counts.json
 # keep the raw rows of our kernels only (the torch data-generation kernels are not of interest)
 for f in $(find $OUT -name '*counter_collection.csv'); do
   (head -1 $f; grep -E "heads_fused|heads_reduce|gemm_|splitk_reduce|zinb_nll|transpose|bn_|col_moments|rmsprop|enc0_|stack_" $f) > $f.filtered; mv $f.filtered $f

@@ -65,6 +65,24 @@ def main():
     w.writeheader()
     for r in rows:
         w.writerow({c: (('%.4g' % r[c]) if isinstance(r.get(c), float) else r.get(c, '')) for c in cols})
+    if len(sys.argv) > 3:
+        # per-pipe instruction counts of the dominant kernels, stamped with the kernel sources' fingerprint: bench.py turns
+        # them into the vector-issue / matrix-pipe floors of its `roofline.step` block (only when measured on ITS sources)
+        import json
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        pick = {}
+        for r in rows:
+            for key, pat in (('heads_fused', 'heads_fused_x3_kernel'), ('gemm_heads_fwd', 'gemm_p3w_kernel')):
+                if pat in r['kernel'] and r.get('SQ_INSTS_VALU') not in ('', None) and \
+                        (key not in pick or r['wall_ns'] > pick[key]['wall_ns']):
+                    pick[key] = {'kernel': r['kernel'], 'wall_ns': r['wall_ns'], 'clock_GHz': r.get('clock_GHz'),
+                                 'SQ_INSTS_VALU': r['SQ_INSTS_VALU'], 'SQ_INSTS_MFMA': r.get('SQ_INSTS_MFMA'),
+                                 'SQ_INSTS_LDS': r.get('SQ_INSTS_LDS'), 'MfmaUtil_pct': r.get('MfmaUtil_%'),
+                                 'VALUBusy_pct': r.get('VALUBusy_%'), 'launches_averaged': r['launches']}
+        json.dump({'source_sha': bench.source_sha(), 'bench_args': os.environ.get('BENCH_ARGS', ''),
+                   'note': 'mean per launch over the launches of tools/gpu_pmc_bench.sh (full and partial batches of the bench '
+                           'sequence); wall_ns is the profiled duration', 'kernels': pick}, open(sys.argv[3], 'w'), indent=1)
 
 
 if __name__ == '__main__':

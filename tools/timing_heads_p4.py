@@ -4,10 +4,11 @@ import os, sys, ctypes, subprocess
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-so = os.path.join(ROOT, 'tools', '_dbg', 'libdcahip_timing.so')
+so = os.path.join(ROOT, 'tools', '_dbg', 'libdcahip_timing_p4.so')     # the pipelined kernel lives in an experiment build only
 from dca_amd import build as b
 if not os.path.exists(so):
-    b.build_hip(force=False, verbose=False, defines=('DCA_HEADS_TIMING',), out=so)
+    os.makedirs(os.path.dirname(so), exist_ok=True)
+    b.build_hip(force=False, verbose=False, defines=('DCA_HEADS_TIMING', 'DCA_EXP_HEADS_P4'), out=so)
 b.LIB = so
 b.needs_build = lambda: False
 from dca_amd import hip, synth, compact
