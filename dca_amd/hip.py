@@ -182,14 +182,13 @@ _SIGNATURES = {
                                               _f32p, _c.c_long, _vp, _c.c_long, _i32p, _i32p, _f32p, _f32p, _i32p, _i64p,
                                               _c.c_int, _c.c_int, _c.c_int, _c.c_float, _c.c_float, _c.c_int, _f32p,
                                               _c.c_long, _f32p, _f32p, _c.c_long, _f64p, _c.POINTER(_c.c_int), _vp,
-                                              _c.c_long, _i32p, _f32p, _vp]),
+                                              _c.c_long, _i32p, _f32p, _c.c_int, _vp]),
 }
 
-# Entry points that exist only in EXPERIMENT builds of the sources (-DDCA_EXP_HEADS_P4, -DDCA_EXP_DW_SMALL,
-# -DDCA_EXP_ENC0_SPARSE_FWD: kernels that were measured and lost, include/dcahip.h conventions): bound when the loaded
-# library has them (tools/ point build.LIB at such a build), absent from the product library (tests/test_cabi.py).
+# Entry points that exist only in EXPERIMENT builds of the sources (-DDCA_EXP_DW_SMALL, -DDCA_EXP_ENC0_SPARSE_FWD: kernels
+# that were measured and lost, include/dcahip.h conventions): bound when the loaded library has them (tools/ point build.LIB
+# at such a build), absent from the product library (tests/test_cabi.py).
 _EXPERIMENT_SIGNATURES = {
-    'dcahip_heads_set_p4_min_tiles': (_c.c_int, [_c.c_int]),
     'dcahip_enc0_dw_small_max_rows': (_c.c_int, []),
     'dcahip_enc0_dw_small': (_c.c_int, [_vp, _c.c_long, _i32p, _i32p, _f32p, _f32p, _c.c_int, _f32p, _f32p, _i32p, _i64p,
                                         _c.c_long, _c.c_int, _c.c_int, _c.c_int, _f32p, _c.c_long, _f32p, _c.c_long, _vp]),

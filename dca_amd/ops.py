@@ -70,19 +70,15 @@ class HipOps:
         """Whether the loaded library exports `entry` (the experiment entry points exist only in -D builds)."""
         return hasattr(self.L, entry)
 
-    def heads_set_p4_min_tiles(self, nt):
-        """EXPERIMENT build (-DDCA_EXP_HEADS_P4) only: row tiles from which K-HEADS takes its pipelined four-wave kernel
-        (returns the previous value)."""
-        return int(self.L.dcahip_heads_set_p4_min_tiles(int(nt)))
-
     def heads_tile_order_len(self, G):
         return int(self.L.dcahip_heads_tile_order_len(G))
 
     def heads_fused(self, H, ldh, Wh, ldw, bh, plane, theta_w, Y, ldy, sf, perm, cursor, B, hL, G,
                     ridge, inv_n, flags, gW, ldg, g_theta, dH, lddh, partials, ws, tile_order=None, loss_out=None,
-                    compact=None):
+                    compact=None, d_exp=0):
         """loss_out (a device float): the call also finishes the batch loss there (no loss_finalize launch needed).
-        compact (dca_amd.compact.CompactCounts): the counts are read from the byte store instead of Y."""
+        compact (dca_amd.compact.CompactCounts): the counts are read from the byte store instead of Y.
+        d_exp (<= 0): scale exponent of the gradient planes for datasets with very large counts (include/dcahip.h)."""
         n = ctypes.c_int(0)
         p = hip.ptr
         c = compact
@@ -94,7 +90,7 @@ class HipOps:
                                                     p(sf), p(perm), p(cursor), B, hL, G, ridge, inv_n, flags,
                                                     p(gW), ldg, p(g_theta), p(dH), lddh, p(partials),
                                                     ctypes.byref(n), p(ws), ws.numel() * ws.element_size(),
-                                                    p(tile_order), p(loss_out), hip.stream()), 'heads_fused')
+                                                    p(tile_order), p(loss_out), int(d_exp), hip.stream()), 'heads_fused')
         return n.value
 
     # ------------------------------------------------------------------ compact counts, sparse first layer

@@ -153,10 +153,12 @@ int dcahip_heads_fused(const float* H, long ldh, const float* Wh, long ldw, cons
                        double* loss_partials, int* n_partials_out,
                        void* workspace, long workspace_bytes, void* stream);
 /* The arithmetic of K-HEADS' three matrix products, exposed for testing: C [32, 32] = A [32, K] B [K, 32]
- * (row-major fp32, K % 16 == 0) computed as the kernel does -- both operands split into three bf16 pieces
- * (round-to-nearest residuals), the six products a1b1, a1b2, a2b1, a1b3, a2b2, a3b1 accumulated in fp32 by
- * v_mfma_f32_32x32x16_bf16.  Contract (tests/test_heads_fused_gpu.py): |C - A B| <= 2.5e-7 sum|a b| per element,
- * i.e. the accuracy of an fp32 dot product (the fp32 MFMA measures 1.8e-7 .. 2.1e-7 on the same inputs). */
+ * (row-major fp32, K % 16 == 0) computed as the kernel does -- each operand scaled by the power of two that brings its
+ * largest magnitude into [2^13, 2^14) and split into TWO fp16 pieces (round-to-nearest residual: 2^-22 relative, 2^-25
+ * absolute where the second piece is an fp16 denormal, which the matrix pipe preserves), the THREE products a1b1, a1b2, a2b1
+ * accumulated in fp32 by v_mfma_f32_32x32x16_f16, the scales taken out at the end (exact).  Contract
+ * (tests/test_heads_fused_gpu.py): |C - A B| <= 5e-7 sum|a b| per element, i.e. the accuracy of an fp32 dot product
+ * (the fp32 MFMA measures 1.8e-7 .. 2.1e-7 on the same inputs; three bf16 pieces with six products, rounds 2-5: <= 2.5e-7). */
 int dcahip_x3_product_32x32(const float* A, const float* B, float* C, int K, void* stream);
 /* Same, with the order in which workgroups take the 32-gene tiles: tile_order = device array of
  * dcahip_heads_tile_order_len(G) ints, a permutation of 0 .. ceil(G/32)-1 (padded with values >= ceil(G/32));
@@ -543,7 +545,12 @@ long dcahip_counts_compact_ld(int G);
 int dcahip_counts_compact(const float* Y, long ldy, int n, int G, unsigned char* Yc, long ldc, int* status,
                           void* stream);
 /* K-HEADS (dcahip_heads_fused_loss) reading the counts from the compact store: yc != NULL selects it (y / ldy are then
- * unused and may be NULL / 0), yc == NULL is dcahip_heads_fused_loss.  4 x fewer count bytes per launch. */
+ * unused and may be NULL / 0), yc == NULL is dcahip_heads_fused_loss.  4 x fewer count bytes per launch.
+ * d_exp (<= 0; 0 for count matrices whose largest count stays below ~8 000, what the other entry points pass): the kernel
+ * carries the gradient planes as g 2^(1 + d_exp) in two fp16 pieces, g = the UNSCALED d nll / d pre-activation, |g| <=
+ * max(1e4, ~2 y_max).  Values beyond the fp16 range are still exact (their tile is rescaled as a whole: a slow path); a caller
+ * that knows its counts reach y_max passes d_exp = -ceil(log2(y_max / 8192)) and keeps every tile on the fast path.
+ * ridge must lie in [0, 1e3]. */
 int dcahip_heads_fused_compact(const float* H, long ldh, const float* Wh, long ldw, const float* bh,
                                long plane, const float* theta_w,
                                const float* y, long ldy,
@@ -554,7 +561,7 @@ int dcahip_heads_fused_compact(const float* H, long ldh, const float* Wh, long l
                                float* gW, long ldg, float* g_theta, float* dH, long lddh,
                                double* loss_partials, int* n_partials_out,
                                void* workspace, long workspace_bytes, const int* tile_order,
-                               float* loss_out, void* stream);
+                               float* loss_out, int d_exp, void* stream);
 /* First-layer widths the kernels below take (32, 64, 128). */
 int dcahip_enc0_sparse_supported(int H1);
 /*

@@ -177,66 +177,6 @@ def test_heads_fused_vs_oracle(ops, flags, B, G, hL):
     check(out)
 
 
-@pytest.fixture
-def p4_forced(ops):
-    """The pipelined four-wave kernel (dca_amd/csrc/heads_p4.inc) from 5 row tiles on.  The kernel measured slower than the
-    8-wave one and exists only in EXPERIMENT builds of the library (-DDCA_EXP_HEADS_P4, e.g.
-    tools/ab_heads_p4.py): these tests run when such a build is the one loaded."""
-    if not ops.has('dcahip_heads_set_p4_min_tiles'):
-        pytest.skip('experiment kernel: build the library with -DDCA_EXP_HEADS_P4')
-    old = ops.heads_set_p4_min_tiles(5)
-    yield
-    ops.heads_set_p4_min_tiles(old)
-
-
-@pytest.mark.parametrize('flags', [1, 3])
-@pytest.mark.parametrize('B,G,hL', [(160, 40, 64), (150, 203, 50), (260, 333, 64), (192, 777, 64), (512, 100, 16), (1000, 64, 64)])
-def test_heads_fused_pipelined_kernel_vs_oracle(ops, p4_forced, flags, B, G, hL):
-    """The ZINB likelihoods through the pipelined kernel at small shapes: 5 .. 32 row tiles (work items whose pipeline is
-    mostly fill and drain: 1, 2, 3 tiles per wave), ragged last row tile and gene tile, fewer than 64 hidden units --
-    the tolerances of every other case of this file."""
-    out = run_case(ops, flags, B, G, hL, seed=B + G, ridge=0.05)
-    check(out)
-
-
-def test_heads_fused_pipelined_kernel_odd_counts_and_order(ops, p4_forced):
-    """Non-integer counts, counts above 16 and beyond the queue's 16 bits through the pipelined kernel; and any order of the
-    gene tiles gives the weight gradients of the identity order bitwise."""
-    out = run_case(ops, 1, 200, 70, 64, seed=5, odd_counts=True)
-    check(out, edge=True)
-    G = 333
-    ntg, n_ord = (G + 31) // 32, ops.heads_tile_order_len(G)
-    a = run_case(ops, 3, 224, G, 64, seed=11)
-    b = run_case(ops, 3, 224, G, 64, seed=11, tile_order=np.r_[np.arange(ntg)[::-1], np.arange(ntg, n_ord)])
-    check(a); check(b)
-    for k in a:
-        if k.startswith(('gW_', 'gb_', 'g_theta')):
-            assert np.array_equal(np.asarray(a[k][0]), np.asarray(b[k][0])), k
-
-
-def test_heads_fused_both_kernels_same_sums(ops):
-    """The 8-wave and the pipelined kernel on one input (2 048 x 2 000): same operands, same six products, same order of the
-    K steps -- the weight gradients differ only by the association of their per-wave partial sums (4 waves instead of 8).
-    (Experiment build only, see p4_forced.)"""
-    if not ops.has('dcahip_heads_set_p4_min_tiles'):
-        pytest.skip('experiment kernel: build the library with -DDCA_EXP_HEADS_P4')
-    res = []
-    for thr in (1 << 30, 5):
-        old = ops.heads_set_p4_min_tiles(thr)
-        try:
-            res.append(run_case(ops, 1, 2048, 2000, 64, seed=3, ridge=0.01, threads=8))
-        finally:
-            ops.heads_set_p4_min_tiles(old)
-    check(res[0]); check(res[1])
-    a, b = res
-    assert abs(a['loss'][0] - b['loss'][0]) <= 1e-6 * abs(a['loss'][0])
-    for k in a:
-        if k in ('loss', '_mag') or k.startswith('pad_'):
-            continue
-        scale = np.abs(np.asarray(a[k][0])).max()
-        assert np.abs(np.asarray(a[k][0]) - np.asarray(b[k][0])).max() <= 4e-6 * scale, k
-
-
 @pytest.mark.parametrize('flags', [1, 3])
 def test_heads_fused_benchmark_shape_vs_oracle(ops, flags):
     """The launch bench.py's roofline line is quoted on (BASELINE configs[2] at the bench batch): B = 4 096 cells x
