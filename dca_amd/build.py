@@ -18,7 +18,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(CSRC, 'libdcahip.so')
 SOURCES = ['dcahip_zinb.hip', 'dcahip_gemm.hip', 'dcahip_layers.hip', 'dcahip_heads.hip', 'dcahip_prep.hip', 'dcahip_opt.hip',
            'dcahip_dropout.hip', 'dcahip_sparse.hip', 'dcahip_peer.hip']
-HEADERS = ['zinb_math.hpp']
+HEADERS = ['zinb_math.hpp', 'h2_math.hpp']
 ARCH = 'gfx950'
 HOST_LIB = os.path.join(CSRC, 'libdcahost.so')
 HOST_SOURCES = ['dcahost_tsv.cpp', 'dcahost_read.cpp']

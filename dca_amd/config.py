@@ -11,6 +11,7 @@ Tested combinations (tests/, all against the same oracle numbers):
   stack = 'coop' | 'off'                    test_engine_gpu.py::test_fused_hidden_stack_equals_the_per_operation_kernels
   bwd_chain = False                         test_engine_gpu.py::test_single_workgroup_backward_chain_equals_the_per_layer_kernels
   wide_planes = False                       test_engine_gpu.py::test_wide_network_step[planes=False]
+  wide_h2 = False                           test_engine_gpu.py::test_wide_network_step (both plane arithmetics against the oracle)
   dp_sharded_opt = True                     test_dp_gloo.py::test_sharded_optimizer_equals_the_all_reduce_path,
                                             test_dp_gloo.py::test_checkpoints_of_the_sharded_optimizer_...,
                                             test_dp_gpu.py::test_rccl_communicator_with_one_rank_...[sharded]
@@ -41,6 +42,9 @@ class EngineConfig:
     bwd_chain: bool = True                  # DCA_AMD_BWD_CHAIN
     # decoders wider than 64 units: every large product from pre-split bf16 planes (False: transposed fp32 operand copies)
     wide_planes: bool = True                # DCA_AMD_WIDE_PLANES
+    # ... and those planes as TWO fp16 pieces with three products per fp32 product (half the matrix instructions; False: three
+    # bf16 pieces, six products)
+    wide_h2: bool = True                    # DCA_AMD_WIDE_H2
     # data parallel: reduce-scatter -> per-rank clip + RMSprop on its shard -> all-gather (instead of two all-reduce buckets)
     dp_sharded_opt: bool = False            # DCA_AMD_DP_SHARDED_OPT
     # data parallel: capture the steps (RCCL exchanges included) into hipGraphs
@@ -59,7 +63,7 @@ class EngineConfig:
     enc0_nt_min: int = 256                  # batch rows from which the first product runs in the NT form on a transposed W0
     predict_chunk: int = 1024               # rows per device -> host chunk of predict()
 
-    _ENV = {'stack': 'DCA_AMD_STACK', 'bwd_chain': 'DCA_AMD_BWD_CHAIN', 'wide_planes': 'DCA_AMD_WIDE_PLANES',
+    _ENV = {'stack': 'DCA_AMD_STACK', 'bwd_chain': 'DCA_AMD_BWD_CHAIN', 'wide_planes': 'DCA_AMD_WIDE_PLANES', 'wide_h2': 'DCA_AMD_WIDE_H2',
             'dp_sharded_opt': 'DCA_AMD_DP_SHARDED_OPT', 'dp_graph': 'DCA_AMD_DP_GRAPH', 'device_prep': 'DCA_AMD_DEVICE_PREP',
             'fused_write': 'DCA_AMD_FUSED_WRITE', 'dp_peer_exchange': 'DCA_AMD_DP_PEER'}
 

@@ -25,6 +25,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include "dcahip.h"
+#include "h2_math.hpp"
 
 namespace {
 
@@ -987,6 +988,281 @@ __global__ __launch_bounds__(512) void gemm_p3w_kernel(Gemm3Args p) {
     }
 }
 
+// =====================================================================================================
+// The plane GEMM on TWO fp16 pieces per operand and three products per fp32 product (round 6; arithmetic: h2_math.hpp,
+// stated in full in dcahip_heads.hip): dcahip_split_planes_h2 scales a matrix by the power of two of its largest magnitude
+// (dcahip_absmax_exp: a device word, so nothing leaves the stream) and writes two planes; the 256 x 256 kernel below is
+// gemm_p3w_kernel with two planes per operand in its ring (stages of 32 KB instead of 48), HALF the matrix instructions and a
+// third fewer fragment reads per step; the block scales leave in the epilogue together with the caller's factor `alpha`.
+// =====================================================================================================
+#define MFMAH2(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h2_f16x8, a), __builtin_bit_cast(h2_f16x8, b), c, 0, 0, 0)
+
+struct GemmH2Args {
+    const unsigned short* A;
+    const unsigned short* B;
+    long lda, ldb, pa, pb;              // leading dimensions and plane strides, in elements
+    float* C;
+    const float* bias;
+    float* ws;
+    long ldc;
+    int M, N, K;
+    int split, kslab;
+    int colsum;
+    int mtiles, ntiles;
+    int tail_first, tail_split, tail_kslab;
+    float* tail_ws;
+    const int* exp_a; const int* exp_b;  // device words: the operands' block exponents (NULL: 0) ...
+    int exp_a_add, exp_b_add;            // ... plus these
+    float alpha;
+};
+
+template <bool KC>
+struct WideImageH {
+    static constexpr int CHUNK = KC ? 1024 : 1088;         // bytes between the LDS destinations of consecutive waves
+    static constexpr int PLANE = 8 * CHUNK;
+    static constexpr int BYTES = 2 * PLANE;
+    // Fragment reads are ISSUED here (inline asm: the compiler neither reorders them nor guards them with a vmcnt(0)
+    // against the LDS-DMA requests in flight) and RETIRED by the caller with a counted s_waitcnt lgkmcnt.
+    // lane_off: this lane's byte offset inside a plane for row / column tile 0 of the wave
+    static __device__ __forceinline__ unsigned lane_off(int idx0, int lane) {
+        const int l31 = lane & 31, hi = lane >> 5;
+        if (KC) return (unsigned)((idx0 + l31) * 32 + ((hi ^ ((l31 >> 3) & 1)) * 16));   // (halves of rows 8..15 mod 16 swapped)
+        const int t16 = lane & 15, r = t16 >> 2;           // k rows 8 hi + r and 8 hi + r + 4
+        return (unsigned)(r * CHUNK + hi * 512 + (idx0 + 16 * ((lane >> 4) & 1) + 4 * (t16 & 3)) * 2);
+    }
+    static constexpr int READS = KC ? 1 : 2;               // LDS instructions per fragment
+    // fragment of piece Q, tile TILE (32 rows / columns further per tile) at LDS address `addr` (stage + operand + lane_off)
+    template <int Q, int TILE>
+    static __device__ __forceinline__ void issue(u32x4& f, unsigned addr) {
+        if constexpr (KC) {
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f) : "v"(addr), "n"(Q * PLANE + TILE * 32 * 32));
+        } else {
+            u32x2 lo, hi;
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(addr), "n"(Q * PLANE + TILE * 64));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "n"(Q * PLANE + TILE * 64 + 4 * CHUNK));
+            f = u32x4{lo[0], lo[1], hi[0], hi[1]};
+        }
+    }
+    // this thread's source element offset inside a plane at k = 0 (add k for KC, k * ld for MN)
+    static __device__ __forceinline__ long src_off(int t, long ld, int idx0, int nidx) {
+        if (KC) {
+            // LDS slot t = (row t / 2, physical half t % 2); rows 8..15 (mod 16) keep their halves swapped, so that the
+            // 16 lanes of a ds_read_b128 phase (rows r .. r + 15, one k half) cover the 64 banks once
+            const int r = t >> 1, row = idx0 + r;
+            return (long)(row < nidx ? row : nidx - 1) * ld + (((t & 1) ^ ((r >> 3) & 1)) * 8);
+        } else {
+            const int l = t & 63, kk = (t >> 6) + 8 * (l >> 5);
+            int c = idx0 + (l & 31) * 8;
+            if (c >= nidx) c = 0;                            // (columns outside the matrix: any readable address)
+            return (long)kk * ld + c;
+        }
+    }
+};
+
+template <bool A_KC, bool B_KC, bool CS>
+__global__ __launch_bounds__(512) void gemm_h2w_kernel(GemmH2Args p) {
+    using IA = WideImageH<A_KC>;
+    using IB = WideImageH<B_KC>;
+    constexpr int STAGE = IA::BYTES + IB::BYTES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    int id = blockIdx.x;
+    int s, kbeg, kend;
+    const bool tail = p.tail_split > 1 && id >= p.tail_first;          // (tail_split > 1 only with split == 1)
+    if (tail) {
+        const int r = id - p.tail_first;
+        id = p.tail_first + r / p.tail_split;
+        s = r % p.tail_split;
+        kbeg = s * p.tail_kslab;
+        kend = min(p.K, kbeg + p.tail_kslab);
+    } else {
+        s = id % p.split; id /= p.split;
+        kbeg = s * p.kslab;
+        kend = min(p.K, kbeg + p.kslab);
+    }
+    const int tile = id;
+    const int nt = id % p.ntiles;
+    const int mt = id / p.ntiles;
+    const int m0 = mt * 256, n0 = nt * 256;
+    const int nsteps = (kend - kbeg) / kWBK;
+
+    // the source of this thread's unit in the step to request next (advanced by one step per request)
+    const unsigned short* ga = p.A + IA::src_off(t, p.lda, m0, p.M) + (A_KC ? (long)kbeg : (long)kbeg * p.lda);
+    const unsigned short* gb = p.B + IB::src_off(t, p.ldb, n0, p.N) + (B_KC ? (long)kbeg : (long)kbeg * p.ldb);
+    const long sa = A_KC ? (long)kWBK : (long)kWBK * p.lda, sb = B_KC ? (long)kWBK : (long)kWBK * p.ldb;
+    const int wa = wave * IA::CHUNK, wb = IA::BYTES + wave * IB::CHUNK;
+
+    auto request = [&](int stage) __attribute__((always_inline)) {
+        unsigned char* st = lds + stage * STAGE;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga + q * p.pa),
+                                             (__attribute__((address_space(3))) void*)(st + q * IA::PLANE + wa), 16, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + q * p.pb),
+                                             (__attribute__((address_space(3))) void*)(st + q * IB::PLANE + wb), 16, 0, 0);
+        ga += sa; gb += sb;
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int wm0 = (wave >> 2) * 128, wn0 = (wave & 3) * 64;
+    const unsigned aoff = IA::lane_off(wm0, lane), boff = IB::lane_off(wn0, lane);
+    const bool do_colsum = CS && !B_KC && p.colsum && mt == 0 && (wave >> 2) == 0;
+    float csum[2] = {0.f, 0.f};
+
+    if (nsteps > 0) request(0);
+    if (nsteps > 1) request(1);
+    int cur = 0, nxt = 2;                                  // stage of step k, stage step k + 2 goes to
+#pragma unroll 1
+    for (int k = 0; k < nsteps; ++k) {
+        if (k + 1 < nsteps) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const unsigned sa_ = (unsigned)(cur * STAGE) + aoff, sb_ = (unsigned)(cur * STAGE + IA::BYTES) + boff;
+        const int rq = nxt;
+        cur = cur == 2 ? 0 : cur + 1; nxt = nxt == 2 ? 0 : nxt + 1;
+        // fragments: B (2 column tiles x 3 pieces), then A row tile by row tile, each requested one tile ahead of its
+        // products; waits are counted in LDS instructions still allowed in flight (they return in order)
+        u32x4 b[2][2], a[2][2];
+        IB::template issue<0, 0>(b[0][0], sb_); IB::template issue<1, 0>(b[0][1], sb_);
+        IB::template issue<0, 1>(b[1][0], sb_); IB::template issue<1, 1>(b[1][1], sb_);
+        IA::template issue<0, 0>(a[0][0], sa_); IA::template issue<1, 0>(a[0][1], sa_);
+#define DCA_TIE4(x) "+v"(x[0][0]), "+v"(x[0][1]), "+v"(x[1][0]), "+v"(x[1][1])
+#define DCA_WAIT_LGKM(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" : DCA_TIE4(a), DCA_TIE4(b))
+#define DCA_PRODUCTS(I, AI) do { _Pragma("unroll") for (int pr = 0; pr < 3; ++pr) { \
+            constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0}; \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[I][j] = MFMAH2(a[AI][PA[pr]], b[j][PB[pr]], acc[I][j]); } } while (0)
+        IA::template issue<0, 1>(a[1][0], sa_); IA::template issue<1, 1>(a[1][1], sa_);
+        if constexpr (IA::READS == 1) DCA_WAIT_LGKM(2); else DCA_WAIT_LGKM(4);
+        if constexpr (CS && !B_KC) {
+            if (do_colsum) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) {
+                            const unsigned pw = b[j][q][w];
+                            csum[j] = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_f16x2, pw), h2_f16x2{(_Float16)1.f, (_Float16)1.f}, csum[j], false);
+                        }
+            }
+        }
+        DCA_PRODUCTS(0, 0);
+        // the next-but-one step's requests go out BEHIND the first products: their issue (an M0 write and an address per
+        // piece) fills the gaps of the matrix pipe instead of standing between the barrier and the first product
+        if (k + 2 < nsteps) request(rq);
+        IA::template issue<0, 2>(a[0][0], sa_); IA::template issue<1, 2>(a[0][1], sa_);
+        if constexpr (IA::READS == 1) DCA_WAIT_LGKM(2); else DCA_WAIT_LGKM(4);
+        DCA_PRODUCTS(1, 1);
+        IA::template issue<0, 3>(a[1][0], sa_); IA::template issue<1, 3>(a[1][1], sa_);
+        if constexpr (IA::READS == 1) DCA_WAIT_LGKM(2); else DCA_WAIT_LGKM(4);
+        DCA_PRODUCTS(2, 0);
+        DCA_WAIT_LGKM(0);
+        DCA_PRODUCTS(3, 1);
+#undef DCA_PRODUCTS
+#undef DCA_WAIT_LGKM
+#undef DCA_TIE4
+    }
+
+    // the operands' block scales out again (exact: powers of two) and the caller's factor in
+    const int ea = (p.exp_a ? *p.exp_a : 0) + p.exp_a_add, eb = (p.exp_b ? *p.exp_b : 0) + p.exp_b_add;
+    const float un = p.alpha * h2_pow2i(-(ea + eb)), un_b = p.alpha * h2_pow2i(-eb);
+    const int Mo = p.M + (p.colsum ? 1 : 0);
+    if (tail) {
+        // a K slice of a tail tile: the partial tile, tile-local, into the tail workspace
+        float* pt = p.tail_ws + ((long)(tile - p.tail_first) * p.tail_split + s) * (256L * 256);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    pt[(wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 256 + wn0 + j * 32 + (lane & 31)] = acc[i][j][r] * un;
+        return;                                            // (no column sums here: the host keeps m tile 0 out of the tail)
+    }
+    float* out = p.split > 1 ? p.ws + (long)s * Mo * p.N : p.C;
+    const long ldo = p.split > 1 ? (long)p.N : p.ldc;
+    const bool add_bias = p.split == 1 && p.bias != nullptr;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn0 + j * 32 + (lane & 31);
+        const float bv = (add_bias && n < p.N) ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < p.M && n < p.N) out[(long)m * ldo + n] = fmaf(acc[i][j][r], un, bv);
+            }
+        }
+        if (CS && do_colsum) {
+            // the lane holds the k rows 8 hi .. + 7 of column n: the other half's share through a lane exchange
+            const float tot = csum[j] + __shfl_xor(csum[j], 32, 64);
+            if ((lane >> 5) == 0 && n < p.N) out[(long)p.M * ldo + n] = tot * un_b;
+        }
+    }
+}
+
+
+// |x| maxima of a matrix as the bits of a non-negative float (order-preserving as unsigned): atomicMax is deterministic
+__global__ __launch_bounds__(256) void absmax_kernel(const float* src, long ld, long R, int C, unsigned* amax) {
+    const long units = (C + 3) / 4;
+    const long total = R * units;
+    float m = 0.f;
+    for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < total; u += (long)gridDim.x * 256) {
+        const long r = u / units;
+        const int c = (int)(u - r * units) * 4;
+        const float* sp = src + r * ld + c;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m = fmaxf(m, c + j < C ? fabsf(sp[j]) : 0.f);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(amax, __float_as_uint(m));
+}
+__global__ void absmax_exp_kernel(const unsigned* amax, int* exp_out) { *exp_out = h2_block_exp(__uint_as_float(*amax)); }
+
+// fp32 [R, C] (leading dimension ld) x 2^*exp -> two fp16 planes [2][R][ldp]; columns C .. ldp - 1 are written as zeros
+__global__ __launch_bounds__(256) void split_planes_h2_kernel(const float* src, long ld, const int* perm, const long long* cursor,
+                                                              long R, int C, unsigned short* dst, long ldp, long pstride, const int* exp) {
+    const long units = ldp / 8;
+    const long total = R * units;
+    const long long cur = cursor ? *cursor : 0;
+    const float sc = h2_pow2i(exp ? *exp : 0);
+    for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < total; u += (long)gridDim.x * 256) {
+        const long r = u / units;
+        const int c = (int)(u - r * units) * 8;
+        const long sr = perm ? (long)perm[cur + r] : (cursor ? (long)(cur + r) : r);
+        const float* sp = src + sr * ld + c;
+        float v[8];
+        if (c + 8 <= C && (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+            const float4 a = *reinterpret_cast<const float4*>(sp), b = *reinterpret_cast<const float4*>(sp + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = c + j < C ? sp[j] : 0.f;
+        }
+        u32x4 q0, q1;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            unsigned a0, a1;
+            h2_split_pair(v[2 * w] * sc, v[2 * w + 1] * sc, a0, a1);
+            q0[w] = a0; q1[w] = a1;
+        }
+        unsigned short* dp = dst + r * ldp + c;
+        *reinterpret_cast<u32x4*>(dp) = q0;
+        *reinterpret_cast<u32x4*>(dp + pstride) = q1;
+    }
+}
+
 // C tile = bias + sum over the K slices of a tail tile (ordered: deterministic); one workgroup per 16 rows of a tile
 __global__ __launch_bounds__(256) void gemm_p3w_tail_sum_kernel(const float* tail_ws, int tail_first, int tail_split, int ntiles,
                                                                int M, int N, const float* bias, float* C, long ldc) {
@@ -1303,6 +1579,93 @@ extern "C" int dcahip_gemm_p3(int ta, int tb, int M, int N, int K, const void* A
     else if (!ta && tb) hipLaunchKernelGGL((gemm_p3_kernel<true, true>), dim3(grid), dim3(256), 0, s, a);
     else if (ta && !tb) hipLaunchKernelGGL((gemm_p3_kernel<false, false>), dim3(grid), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((gemm_p3_kernel<false, true>), dim3(grid), dim3(256), 0, s, a);
+    int rc = (int)hipGetLastError();
+    if (rc != 0) return rc;
+    if (p.split > 1) {
+        const int Mo = M + (colsum_row ? 1 : 0);
+        const long total = (long)Mo * N;
+        long g = (total + 255) / 256;
+        if (g > 4096) g = 4096;
+        hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3((int)g), dim3(256), 0, s, a.ws, p.split, Mo, N, bias, M, C, ldc);
+        rc = (int)hipGetLastError();
+    } else if (tp.split > 1) {
+        const int ntail = p.mtiles * p.ntiles - tp.first;
+        hipLaunchKernelGGL(gemm_p3w_tail_sum_kernel, dim3(ntail * 16), dim3(256), 0, s, a.tail_ws, tp.first, tp.split, p.ntiles,
+                           M, N, bias, C, ldc);
+        rc = (int)hipGetLastError();
+    }
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// fp16 x 2 planes (see gemm_h2w_kernel)
+extern "C" int dcahip_absmax_exp(const float* src, long ld, long R, int C, int* exp_out, void* scratch_word, void* stream) {
+    if (!src || !exp_out || !scratch_word || R <= 0 || C <= 0 || ld < C) return DCAHIP_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    unsigned* amax = static_cast<unsigned*>(scratch_word);
+    int rc = (int)hipMemsetAsync(amax, 0, sizeof(unsigned), s);
+    if (rc != 0) return rc;
+    const long total = R * ((C + 3) / 4);
+    long g = (total + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(absmax_kernel, dim3((int)g), dim3(256), 0, s, src, ld, R, C, amax);
+    hipLaunchKernelGGL(absmax_exp_kernel, dim3(1), dim3(1), 0, s, amax, exp_out);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dcahip_split_planes_h2(const float* src, long ld, const int* perm, const long long* cursor, long R, int C,
+                                      void* planes, long ldp, long plane_stride, const int* exp, void* stream) {
+    if (!src || !planes || R <= 0 || C <= 0 || ld < C || ldp < C || ldp % 8 != 0 || plane_stride < R * ldp) return DCAHIP_EINVAL;
+    if (!al16(planes) || plane_stride % 8 != 0) return DCAHIP_EINVAL;
+    const long total = R * (ldp / 8);
+    long g = (total + 255) / 256;
+    if (g > 16384) g = 16384;
+    hipLaunchKernelGGL(split_planes_h2_kernel, dim3((int)g), dim3(256), 0, static_cast<hipStream_t>(stream), src, ld, perm, cursor,
+                       R, C, static_cast<unsigned short*>(planes), ldp, plane_stride, exp);
+    return (int)hipGetLastError();
+}
+
+// the shapes the 256 x 256 kernel takes (the same as the wide form of dcahip_gemm_p3)
+extern "C" int dcahip_gemm_h2_supported(int M, int N, int K) { return p3_wide(M, N, K, nullptr, nullptr) ? 1 : 0; }
+
+extern "C" long dcahip_gemm_h2_workspace_bytes(int M, int N, int K, int colsum_row, int split_k) {
+    if (!p3_wide(M, N, K, nullptr, nullptr)) return 0;
+    const Plan p = make_plan3(M, N, K, split_k, true);
+    if (p.split > 1) return (long)p.split * (M + (colsum_row ? 1 : 0)) * N * (long)sizeof(float);
+    return tail_plan(p, M, K, colsum_row).ws_bytes;
+}
+
+extern "C" int dcahip_gemm_h2(int ta, int tb, int M, int N, int K, const void* A, long lda, long plane_a, const int* exp_a, int exp_a_add,
+                              const void* B, long ldb, long plane_b, const int* exp_b, int exp_b_add, float alpha,
+                              float* C, long ldc, const float* bias, int colsum_row, int split_k,
+                              void* workspace, long workspace_bytes, void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C || ldc < N) return DCAHIP_EINVAL;
+    if (!p3_wide(M, N, K, nullptr, nullptr)) return DCAHIP_EINVAL;
+    if (colsum_row && tb) return DCAHIP_EINVAL;
+    if (!al16(A) || !al16(B) || lda % 8 != 0 || ldb % 8 != 0 || plane_a % 8 != 0 || plane_b % 8 != 0) return DCAHIP_EINVAL;
+    if ((!ta || tb) && K % 8 != 0) return DCAHIP_EINVAL;
+    if ((ta ? lda < (M + 7) / 8 * 8 : lda < K) || (tb ? ldb < K : ldb < (N + 7) / 8 * 8)) return DCAHIP_EINVAL;
+    const Plan p = make_plan3(M, N, K, split_k, true);
+    const TailPlan tp = tail_plan(p, M, K, colsum_row);
+    const long need = p.split > 1 ? (long)p.split * (M + (colsum_row ? 1 : 0)) * N * (long)sizeof(float) : tp.ws_bytes;
+    if (need > 0 && (!workspace || workspace_bytes < need)) return DCAHIP_EINVAL;
+    GemmH2Args a{static_cast<const unsigned short*>(A), static_cast<const unsigned short*>(B), lda, ldb, plane_a, plane_b,
+                 C, bias, static_cast<float*>(workspace), ldc, M, N, K, p.split, p.kslab, colsum_row,
+                 p.mtiles, p.ntiles, tp.first, tp.split, tp.kslab, static_cast<float*>(workspace), exp_a, exp_b, exp_a_add, exp_b_add, alpha};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int grid = p.mtiles * p.ntiles * p.split;
+    if (tp.split > 1) grid = tp.first + (p.mtiles * p.ntiles - tp.first) * tp.split;
+#define DCA_W(AKC, BKC, CSV) do { \
+        constexpr int bytes = 3 * (WideImageH<AKC>::BYTES + WideImageH<BKC>::BYTES); \
+        static bool set = false; \
+        if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h2w_kernel<AKC, BKC, CSV>), \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, bytes); set = true; } \
+        hipLaunchKernelGGL((gemm_h2w_kernel<AKC, BKC, CSV>), dim3(grid), dim3(512), bytes, s, a); } while (0)
+    if (!ta && !tb) { if (colsum_row) DCA_W(true, false, true); else DCA_W(true, false, false); }
+    else if (!ta && tb) DCA_W(true, true, false);
+    else if (ta && !tb) { if (colsum_row) DCA_W(false, false, true); else DCA_W(false, false, false); }
+    else DCA_W(false, true, false);
+#undef DCA_W
     int rc = (int)hipGetLastError();
     if (rc != 0) return rc;
     if (p.split > 1) {

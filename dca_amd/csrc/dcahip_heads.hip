@@ -233,16 +233,17 @@ __global__ __launch_bounds__(64 * kWR2) void heads_fused_h2_kernel(HeadsArgs2 p)
     constexpr int NH = 1 + (CONST_DISP ? 0 : 1) + (HAS_PI ? 1 : 0);
     constexpr int PI_H = NH - 1;
     constexpr int KT = 64;
-    constexpr int ST_PLANE = kTG * kLdS;
-    constexpr int NP = NH + (CONST_DISP ? 1 : 0);
-    constexpr int TH_P = NH;
-    constexpr int ST_WAVE = NP * ST_PLANE;
+    constexpr int ST_PLANE = kTG * kLdS;                   // fp32 [gene][row] plane of a per-gene dispersion's gradient sums
+    constexpr int QCAP = 192;                              // queue entries (16 bytes each): at most 63 left over + 2 x 64 pushed
+    constexpr int CELL_LD = 144;                           // bytes per gene of a head's cell tile: 8 cells of 16 bytes + one of padding
+    constexpr int HEAD_B = kTG * CELL_LD;                  // bytes of one head's cell tile
+    constexpr int PW_FLOATS = NH * HEAD_B / 4 + (CONST_DISP ? ST_PLANE : 0) + QCAP * 4;      // per wave
     constexpr int NTHREADS = 64 * WR;
     constexpr int W_PIECE = 64 * 64;                       // bytes of one (head, piece) weight image: 64 k x 32 genes fp16
     constexpr int W_FLOATS = NH * 2 * W_PIECE / 4;
     constexpr int NRED = NH * 2 * 16 + NH + 1;
     constexpr int BIAS_FLOATS = (NH + 1) * 32;             // biases (+ log-dispersion) of the 32 genes
-    constexpr int LDS_FLOATS = W_FLOATS + WR * (ST_WAVE + kQCap) + BIAS_FLOATS;
+    constexpr int LDS_FLOATS = W_FLOATS + WR * PW_FLOATS + BIAS_FLOATS;
     static_assert((WR / 2) * NRED * 64 <= LDS_FLOATS, "dW reduce scratch");
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     __shared__ double lred[WR];
@@ -279,8 +280,9 @@ __global__ __launch_bounds__(64 * kWR2) void heads_fused_h2_kernel(HeadsArgs2 p)
 #pragma unroll 1
     for (int j = 0; j < nrounds; ++j) {
     const int gb = j * p.npart + ((j & 1) ? p.npart - 1 - wq : wq);
-    int s = s_wg;
-    asm volatile("" : "+s"(s));              // opaque per round: what depends on it is recomputed, not kept live across rounds
+    int s_opaque = s_wg;
+    asm volatile("" : "+v"(s_opaque));       // opaque per round: what depends on it is recomputed, not kept live across rounds
+    const int s = __builtin_amdgcn_readfirstlane(s_opaque);
     const int gt = p.tile_order ? p.tile_order[gb] : gb;
     const int g0 = gt * kTG;
     const int gene = g0 + l31;
@@ -288,9 +290,14 @@ __global__ __launch_bounds__(64 * kWR2) void heads_fused_h2_kernel(HeadsArgs2 p)
     const bool gvalid = gene < p.G;
 
     unsigned char* const Wimg = reinterpret_cast<unsigned char*>(lds);
-    float* St = lds + W_FLOATS + wave * ST_WAVE;
-    unsigned* Q = reinterpret_cast<unsigned*>(lds + W_FLOATS + WR * ST_WAVE) + wave * kQCap;
-    float* const Bs = lds + W_FLOATS + WR * (ST_WAVE + kQCap);          // [head][32] biases, then [32] log-dispersion
+    // wave-private: the cell tile [head][32 genes][8 cells of 16 bytes] -- a cell is 4 consecutive row POSITIONS of a gene
+    // (positions: the order of the MFMA row map / of the transposed H image): first the four fp32 pre-activations F leaves
+    // there, then, IN PLACE, the gradient's two fp16 pieces [piece 0: 4 x fp16 | piece 1: 4 x fp16] --, the fp32 plane of a
+    // per-gene dispersion, the non-zero queue
+    unsigned char* const Pimg = reinterpret_cast<unsigned char*>(lds + W_FLOATS + wave * PW_FLOATS);
+    float* const Th = lds + W_FLOATS + wave * PW_FLOATS + NH * HEAD_B / 4;
+    u32x4* const Qe = reinterpret_cast<u32x4*>(lds + W_FLOATS + wave * PW_FLOATS + NH * HEAD_B / 4 + (CONST_DISP ? ST_PLANE : 0));
+    float* const Bs = lds + W_FLOATS + WR * PW_FLOATS;          // [head][32] biases, then [32] log-dispersion
 
     // ---- head weights of this gene tile -> LDS as fp16 pieces scaled by 2^eW (eW from the tile's largest weight), image
     // [head][piece][k][32 genes], the four 16-byte units of a row rotated by (k >> 2): conflict-free for the direct
@@ -380,7 +387,8 @@ __global__ __launch_bounds__(64 * kWR2) void heads_fused_h2_kernel(HeadsArgs2 p)
         int t = s * WR + r;
         const long dh_tstride = (long)p.npart * (kTR * KT);
         float* const dh_part = p.ws_dh + (long)(blockIdx.x / p.S) * (kTR * KT);            // this workgroup's partials
-        const int dh_lane = (4 * hi * KT + l31) * 4;
+        // the lane's 16-byte units of a dH partial: batch row of ROW POSITION l31 (bits 2 and 3 swapped), hidden units 4 hi ..
+        const int dh_lane = ((((l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1)) * KT) + 4 * hi) * 4;
         int srow_l = 0;
         float sf_l = 1.f;
         YV yA[kZU], yB[kZU];
@@ -439,6 +447,12 @@ __global__ __launch_bounds__(64 * kWR2) void heads_fused_h2_kernel(HeadsArgs2 p)
         auto w_dr = [&](int h, int q, int jb, int gs) {   // B operand of dH: hidden unit l31 + 32 jb, genes 16 gs + 8 hi ..
             return *reinterpret_cast<const u32x4*>(Wimg + (h * 2 + q) * W_PIECE + jb * 2048 + wdr[gs]);
         };
+        // Cell tile addresses.  Group g of the lane's 16 rows (accumulator elements 4 g .. 4 g + 3 = rows 8 g + 4 hi ..) holds
+        // the row positions 4 c .. 4 c + 3 with c = (g & 1) + 2 hi + 4 (g >> 1): cell c of the lane's gene.  dW reads the
+        // cells 2 hi + 4 ks and + 1 (its 8 positions of K step ks).  dtr: the lane's chunk of the transposing read of dH --
+        // gene 8 hi + t16 / 4 (+ 16 gs + 4 half) of a K step, cell 4 (lane / 16 & 1) + (t16 & 3) (+ 8 bytes: piece 1)
+        const int cell_lane = l31 * CELL_LD + 2 * hi * 16;          // + ((g & 1) + 4 (g >> 1)) * 16
+        const int dtr = (8 * hi + (t16 >> 2)) * CELL_LD + c8 * 16;
 
         int eHt = 0;
         if (t < p.NT) {
@@ -469,7 +483,184 @@ __global__ __launch_bounds__(64 * kWR2) void heads_fused_h2_kernel(HeadsArgs2 p)
             eHt = __builtin_amdgcn_readfirstlane(eHt);
             const int kDt = kD0 - (eHt - eHmin);
             const float fscale = pow2i(eHt + eW), funscale = pow2i(-(eHt + eW));
-            const float scs = pow2i(kDt);
+            // F and Z run until the tile's gradients fit the fp16 range at the scale 2^kDe: once, but for a tile that holds a
+            // count in the hundreds or a dispersion at its floor (wave-uniform, rare, exact: see Z)
+            int kDe = kDt;
+            float lacc;
+            const float thw = CONST_DISP ? Bs[NH * 32 + l31] : 0.f;
+            const int srow_n = load_srow(tn);
+            const int eHn = p.eH[tn];
+            float scs = 0.f;                          // 2^kDe
+            int qn = 0;                               // queue fill
+            float dmax = 0.f;                         // the lane's largest |D| of this tile (matrix-product planes only)
+#ifdef DCA_HEADS_TIMING
+            long long tsparse = 0;
+#endif
+            auto z_sparse = [&](int q0, int cnt) {
+                const bool act = lane < cnt;
+                const u32x4 ent = Qe[q0 + (act ? lane : 0)];
+                const unsigned e = ent[0];
+                const int gq = (e >> 5) & 31, row = e & 31;
+                const float sfr = __shfl(sf_l, row, 64);
+                const int sr = __shfl(srow_l, row, 64);
+                const float am = __uint_as_float(ent[1]);
+                const float ad = CONST_DISP ? Bs[NH * 32 + gq] : __uint_as_float(ent[2]);
+                const float ap = HAS_PI ? __uint_as_float(ent[3]) : 0.f;
+                float yq = (float)(e >> 16);
+                // counts that do not fit the queue's 16 bits (rare): a wave-uniform branch around the memory access, and the
+                // wait for it INSIDE the branch -- left to the compiler, the join in front of the first use of yq waits for
+                // vmcnt(0), i.e. for every prefetch in flight, in every batch
+                if (__ballot(act && (e >> 16) == 0xFFFFu)) {
+                    if (act && (e >> 16) == 0xFFFFu) yq = YC ? escaped_count(p, sr, g0 + gq) : p.y[(long)sr * p.ldy + g0 + gq];
+                    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
+                }
+                float o[3] = {0.f, 0.f, 0.f};
+                float nll;
+                if (HAS_PI) {
+                    nll = zinb_nz_elem<CONST_DISP, YC>(am, ad, ap, sfr, yq, p.ridge, o[0], o[1], o[2]);
+                } else {
+                    float dmu = 0.f, dth = 0.f, dpi = 0.f;
+                    const Heads hd = head_acts<HAS_PI, CONST_DISP>(am, ad, ap, sfr);
+                    nll = nll_elem<HAS_PI, true, true, YC>(hd, yq, p.ridge, dmu, dth, dpi);
+                    o[0] = dmu * hd.gm; o[1] = dth * hd.gd;
+                }
+                lacc += act ? nll : 0.f;
+                o[0] *= scs; o[1] *= scs; o[2] *= scs;
+                dmax = fmaxf(dmax, act ? fmaxf(fmaxf(fabsf(o[0]), CONST_DISP ? 0.f : fabsf(o[1])), fabsf(o[2])) : 0.f);
+                if (act) {
+                    const int pos = (row & 0x13) | ((row & 4) << 1) | ((row & 8) >> 1);
+                    unsigned char* pa = Pimg + gq * CELL_LD + (pos >> 2) * 16 + (pos & 3) * 2;
+                    auto put = [&](int h, float v) {
+                        const _Float16 h1 = (_Float16)v;
+                        const _Float16 h2 = (_Float16)(v - (float)h1);
+                        *reinterpret_cast<_Float16*>(pa + h * HEAD_B) = h1;
+                        *reinterpret_cast<_Float16*>(pa + h * HEAD_B + 8) = h2;
+                    };
+                    put(0, o[0]);
+                    if (CONST_DISP) Th[gq * kLdS + row] = o[1]; else put(1, o[1]);
+                    if (HAS_PI) put(PI_H, o[2]);
+                }
+            };
+            auto z_flush = [&](bool last) {
+                while (qn >= 64 || (last && qn > 0)) {
+                    const int c = qn < 64 ? qn : 64;
+                    wave_sync();
+#ifdef DCA_HEADS_TIMING
+                    const long long f0 = __builtin_readcyclecounter();
+#endif
+                    z_sparse(qn - c, c);
+#ifdef DCA_HEADS_TIMING
+                    tsparse += __builtin_readcyclecounter() - f0;        // (reported in slot 2; still part of slot 4's total)
+#endif
+                    qn -= c;
+                }
+            };
+            auto z_dense = [&](auto fullv, int grp, const YV (&yv)[kZU]) {
+                constexpr bool FULLV = decltype(fullv)::value;
+                // the group's pre-activations: one 16-byte cell per head
+                unsigned char* const cell = Pimg + cell_lane + ((grp & 1) + 4 * (grp >> 1)) * 16;
+                float i_am[kZU], i_ad[kZU], i_ap[kZU];
+                {
+                    const float4 vm = *reinterpret_cast<const float4*>(cell);
+                    i_am[0] = vm.x; i_am[1] = vm.y; i_am[2] = vm.z; i_am[3] = vm.w;
+                    if (CONST_DISP) {
+#pragma unroll
+                        for (int j = 0; j < kZU; ++j) i_ad[j] = thw;
+                    } else {
+                        const float4 vd = *reinterpret_cast<const float4*>(cell + HEAD_B);
+                        i_ad[0] = vd.x; i_ad[1] = vd.y; i_ad[2] = vd.z; i_ad[3] = vd.w;
+                    }
+                    if (HAS_PI) {
+                        const float4 vp = *reinterpret_cast<const float4*>(cell + PI_H * HEAD_B);
+                        i_ap[0] = vp.x; i_ap[1] = vp.y; i_ap[2] = vp.z; i_ap[3] = vp.w;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < kZU; ++j) i_ap[j] = 0.f;
+                    }
+                }
+                float o_m[kZU], o_d[kZU], o_p[kZU];
+                bool o_nz[kZU];
+#pragma unroll
+                for (int j = 0; j < kZU; ++j) {
+                    const int row = rowmap(grp * kZU + j, hi);
+                    const bool valid = FULLV || ((row0 + row < p.B) && gvalid);
+                    const YV yj = yv[j];
+                    bool nz;
+                    if constexpr (YC) nz = valid && yj != 0u;
+                    else nz = valid && (HAS_PI ? !(yj < kZeroThresh) : (yj != 0.f));
+                    const float sc = (valid && !nz) ? scs : 0.f;        // (a non-zero element's pieces come from the compacted pass)
+                    if (HAS_PI) {
+                        float gmv, gdv, gpv;
+                        const float nll = zinb_zero_elem<CONST_DISP>(i_am[j], i_ad[j], i_ap[j], __shfl(sf_l, row, 64), p.ridge, gmv, gdv, gpv);
+                        lacc += (valid && !nz) ? nll : 0.f;
+                        o_m[j] = gmv * sc;
+                        o_d[j] = gdv * sc;
+                        o_p[j] = gpv * sc;
+                        dmax = fmaxf(dmax, fmaxf(fabsf(o_m[j]), fabsf(o_p[j])));
+                    } else {
+                        float gmv, gdv;
+                        const float nll = nb_zero_elem<CONST_DISP>(i_am[j], i_ad[j], __shfl(sf_l, row, 64), gmv, gdv);
+                        lacc += (valid && !nz) ? nll : 0.f;
+                        o_m[j] = gmv * sc;
+                        o_d[j] = gdv * sc;
+                        o_p[j] = 0.f;
+                        dmax = fmaxf(dmax, fabsf(o_m[j]));
+                    }
+                    if (!CONST_DISP) dmax = fmaxf(dmax, fabsf(o_d[j]));
+                    o_nz[j] = nz;
+                }
+                // the group's gradients as fp16 pieces, in place of the pre-activations: [piece 0: 4 positions | piece 1]
+                {
+                    auto put4 = [&](int h, const float (&v)[kZU]) {
+                        unsigned a0, a1, b0, b1;
+                        split_pair(v[0], v[1], a0, a1);
+                        split_pair(v[2], v[3], b0, b1);
+                        *reinterpret_cast<u32x4*>(cell + h * HEAD_B) = u32x4{a0, b0, a1, b1};
+                    };
+                    put4(0, o_m);
+                    if (!CONST_DISP) put4(1, o_d);
+                    if (HAS_PI) put4(PI_H, o_p);
+                }
+#pragma unroll
+                for (int j = 0; j < kZU; ++j) {
+                    const int row = rowmap(grp * kZU + j, hi);
+                    const bool nz = o_nz[j];
+                    const unsigned long long m = __ballot(nz);
+                    const int slot = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                    if (nz) {
+                        const YV yj = yv[j];
+                        unsigned y16;
+                        if constexpr (YC) y16 = yj == 255u ? 0xFFFFu : yj;
+                        else y16 = (yj < 65535.f && yj == floorf(yj)) ? (unsigned)yj : 0xFFFFu;
+                        Qe[slot] = u32x4{(unsigned)(l31 * 32 + row) | (y16 << 16), __float_as_uint(i_am[j]), __float_as_uint(i_ad[j]),
+                                         __float_as_uint(i_ap[j])};
+                    } else if (CONST_DISP) {
+                        Th[l31 * kLdS + row] = o_d[j];
+                    }
+                    qn += __popcll(m);
+                    if (j == 1) z_flush(false);          // (the queue holds at most 63 + 2 x 64 entries)
+                }
+                z_flush(false);
+            };
+            auto load_y = [&](int srow_src, int grp, YV (&yv)[kZU]) {
+#pragma unroll
+                for (int j = 0; j < kZU; ++j) {
+                    const int sr = __shfl(srow_src, rowmap(grp * kZU + j, hi), 64);
+                    yv[j] = count_at(sr);
+                }
+            };
+            auto z_loop = [&](auto fullv) {             // (ONE call site of the dense pass: its code, and the non-zero pass
+#pragma unroll 1                                        //  inside it, exist once per row-range variant)
+                for (int grp = 0; grp < 16 / kZU; ++grp) {
+                    if (grp + 1 < 16 / kZU) load_y(srow_l, grp + 1, yB);
+                    else load_y(srow_n, 0, yB);          // the next tile's first group
+                    z_dense(fullv, grp, yA);
+#pragma unroll
+                    for (int j = 0; j < kZU; ++j) yA[j] = yB[j];
+                }
+                z_flush(true);
+            };
+            for (;;) {
             // ---- F: pre-activations, K = 64 as 4 steps of 16 (lane half hi covers k in [32 hi, 32 hi + 32))
             // (the accumulators start from the scaled bias of the lane's gene: one LDS read per head instead of 16 additions)
             f32x16 acc[NH];
@@ -496,187 +687,62 @@ __global__ __launch_bounds__(64 * kWR2) void heads_fused_h2_kernel(HeadsArgs2 p)
             }
             TSTAMP(1)
             TSTAMP(2)
-            // ---- stage [gene][row] (row stride 1, gene stride 33), unscaled
+            // ---- stage the unscaled pre-activations: one 16-byte cell per head and group of four rows
 #pragma unroll
             for (int h = 0; h < NH; ++h)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) St[h * ST_PLANE + l31 * kLdS + rowmap(e, hi)] = acc[h][e] * funscale;
-            const float thw = CONST_DISP ? Bs[NH * 32 + l31] : 0.f;
-            const int srow_n = load_srow(tn);
-            const int eHn = p.eH[tn];
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(Pimg + h * HEAD_B + cell_lane + ((g & 1) + 4 * (g >> 1)) * 16) =
+                        make_float4(acc[h][4 * g] * funscale, acc[h][4 * g + 1] * funscale, acc[h][4 * g + 2] * funscale, acc[h][4 * g + 3] * funscale);
             wave_sync();
             TSTAMP(3)
 
-            // ---- Z: element-wise likelihood and gradient (dense y = 0 pass + compacted non-zero pass); the gradients are
-            // staged as D = g 2^kDt
-            float lacc = 0.f;
-            int qn = 0;
-            float dmax = 0.f;                         // the lane's largest |D| of this tile (matrix-product planes only)
-            auto z_dense = [&](auto fullv, int grp, const YV (&yv)[kZU]) {
-                constexpr bool FULLV = decltype(fullv)::value;
-                float i_am[kZU], i_ad[kZU], i_ap[kZU];
-#pragma unroll
-                for (int j = 0; j < kZU; ++j) {
-                    const int row = rowmap(grp * kZU + j, hi);
-                    const int idx = l31 * kLdS + row;
-                    i_am[j] = St[idx];
-                    i_ad[j] = CONST_DISP ? thw : St[ST_PLANE + idx];
-                    i_ap[j] = HAS_PI ? St[PI_H * ST_PLANE + idx] : 0.f;
-                }
-                float o_m[kZU], o_d[kZU], o_p[kZU];
-                bool o_nz[kZU];
-#pragma unroll
-                for (int j = 0; j < kZU; ++j) {
-                    const int row = rowmap(grp * kZU + j, hi);
-                    const bool valid = FULLV || ((row0 + row < p.B) && gvalid);
-                    const YV yj = yv[j];
-                    bool nz;
-                    if constexpr (YC) nz = valid && yj != 0u;
-                    else nz = valid && (HAS_PI ? !(yj < kZeroThresh) : (yj != 0.f));
-                    if (HAS_PI) {
-                        float gmv, gdv, gpv;
-                        const float nll = zinb_zero_elem<CONST_DISP>(i_am[j], i_ad[j], i_ap[j], __shfl(sf_l, row, 64), p.ridge, gmv, gdv, gpv);
-                        const float sc = valid ? scs : 0.f;
-                        lacc += (valid && !nz) ? nll : 0.f;
-                        o_m[j] = gmv * sc;
-                        o_d[j] = gdv * sc;
-                        o_p[j] = gpv * sc;
-                        dmax = fmaxf(dmax, fmaxf(fabsf(o_m[j]), fabsf(o_p[j])));
-                    } else {
-                        float gmv, gdv;
-                        const float nll = nb_zero_elem<CONST_DISP>(i_am[j], i_ad[j], __shfl(sf_l, row, 64), gmv, gdv);
-                        const float sc = valid ? scs : 0.f;
-                        lacc += (valid && !nz) ? nll : 0.f;
-                        o_m[j] = gmv * sc;
-                        o_d[j] = gdv * sc;
-                        o_p[j] = 0.f;
-                        dmax = fmaxf(dmax, fabsf(o_m[j]));
-                    }
-                    if (!CONST_DISP) dmax = fmaxf(dmax, fabsf(o_d[j]));
-                    o_nz[j] = nz;
-                }
-#pragma unroll
-                for (int j = 0; j < kZU; ++j) {
-                    const int row = rowmap(grp * kZU + j, hi);
-                    const int idx = l31 * kLdS + row;
-                    const bool nz = o_nz[j];
-                    const unsigned long long m = __ballot(nz);
-                    const int slot = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                    if (nz) {
-                        const YV yj = yv[j];
-                        unsigned y16;
-                        if constexpr (YC) y16 = yj == 255u ? 0xFFFFu : yj;
-                        else y16 = (yj < 65535.f && yj == floorf(yj)) ? (unsigned)yj : 0xFFFFu;
-                        Q[slot] = (unsigned)idx | (y16 << 16);
-                    } else {
-                        St[idx] = o_m[j];
-                        if (CONST_DISP) St[TH_P * ST_PLANE + idx] = o_d[j]; else St[ST_PLANE + idx] = o_d[j];
-                        if (HAS_PI) St[PI_H * ST_PLANE + idx] = o_p[j];
-                    }
-                    qn += __popcll(m);
-                }
-            };
-            auto z_sparse = [&](int q0, int cnt) {
-                const bool act = lane < cnt;
-                const unsigned e = Q[q0 + (act ? lane : 0)];
-                const int idx = e & 2047;
-                const int gq = (idx * 1986) >> 16;          // idx / 33 for idx < 1056
-                const int row = idx - gq * kLdS;
-                const float sfr = __shfl(sf_l, row, 64);
-                const int sr = __shfl(srow_l, row, 64);
-                const float am = St[idx];
-                const float ad = CONST_DISP ? Bs[NH * 32 + gq] : St[ST_PLANE + idx];
-                const float ap = HAS_PI ? St[PI_H * ST_PLANE + idx] : 0.f;
-                float yq = (float)(e >> 16);
-                // counts that do not fit the queue's 16 bits (rare): a wave-uniform branch around the memory access, and the
-                // wait for it INSIDE the branch -- left to the compiler, the join in front of the first use of yq waits for
-                // vmcnt(0), i.e. for every prefetch in flight, in every batch
-                if (__ballot(act && (e >> 16) == 0xFFFFu)) {
-                    if (act && (e >> 16) == 0xFFFFu) yq = YC ? escaped_count(p, sr, g0 + gq) : p.y[(long)sr * p.ldy + g0 + gq];
-                    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
-                }
-                float o1, o2, o3 = 0.f, nll;
-                if (HAS_PI) {
-                    nll = zinb_nz_elem<CONST_DISP, YC>(am, ad, ap, sfr, yq, p.ridge, o1, o2, o3);
-                } else {
-                    float dmu = 0.f, dth = 0.f, dpi = 0.f;
-                    const Heads hd = head_acts<HAS_PI, CONST_DISP>(am, ad, ap, sfr);
-                    nll = nll_elem<HAS_PI, true, true, YC>(hd, yq, p.ridge, dmu, dth, dpi);
-                    o1 = dmu * hd.gm; o2 = dth * hd.gd;
-                }
-                lacc += act ? nll : 0.f;
-                o1 *= scs; o2 *= scs; o3 *= scs;
-                dmax = fmaxf(dmax, act ? fmaxf(fmaxf(fabsf(o1), CONST_DISP ? 0.f : fabsf(o2)), fabsf(o3)) : 0.f);
-                if (act) {
-                    St[idx] = o1;
-                    if (CONST_DISP) St[TH_P * ST_PLANE + idx] = o2; else St[ST_PLANE + idx] = o2;
-                    if (HAS_PI) St[PI_H * ST_PLANE + idx] = o3;
-                }
-            };
-            auto z_flush = [&](bool last) {
-                while (qn >= 64 || (last && qn > 0)) {
-                    const int c = qn < 64 ? qn : 64;
-                    wave_sync();
-                    z_sparse(qn - c, c);
-                    qn -= c;
-                }
-            };
-            auto load_y = [&](int srow_src, int grp, YV (&yv)[kZU]) {
-#pragma unroll
-                for (int j = 0; j < kZU; ++j) {
-                    const int sr = __shfl(srow_src, rowmap(grp * kZU + j, hi), 64);
-                    yv[j] = count_at(sr);
-                }
-            };
-            auto z_loop = [&](auto fullv) {
-#pragma unroll 1
-                for (int it = 0; it < 16 / (2 * kZU); ++it) {
-                    const bool last = it + 1 == 16 / (2 * kZU);
-                    load_y(srow_l, 2 * it + 1, yB);
-                    z_dense(fullv, 2 * it, yA);
-                    z_flush(false);
-                    if (!last) load_y(srow_l, 2 * it + 2, yA);
-                    else load_y(srow_n, 0, yA);
-                    z_dense(fullv, 2 * it + 1, yB);
-                    z_flush(last);
-                }
-            };
+            // ---- Z: element-wise likelihood and gradient (dense y = 0 pass over the staged cells; the non-zero elements compacted
+            // into 64-lane batches through a queue that carries their three pre-activations).  The gradients D = g 2^kDe are
+            // split ONCE, here, into their two fp16 pieces, which replace the pre-activations in their cell: dW reads its B
+            // operand with 8-byte reads, dH its A operand with transposing reads.  A tile whose largest |D| would leave the fp16
+            // range (a count in the hundreds, a dispersion at its floor) repeats F and this pass with the scale its maximum
+            // needs.
+            scs = pow2i(kDe);
+            lacc = 0.f;
+            qn = 0;
+            dmax = 0.f;
+#ifdef DCA_HEADS_TIMING
+            tsparse = 0;
+#endif
 #ifndef DCA_EXP_X3NOZ
             if (row0 + kTR <= p.B && g0 + kTG <= p.G) z_loop(std::true_type{}); else z_loop(std::false_type{});
 #endif
+#ifdef DCA_HEADS_TIMING
+            tacc[2] += tsparse;
+#endif
+            if (!__ballot(!(dmax <= kDLim))) break;   // (a NaN / inf gradient takes the slow branch once and stays what it is)
+            const float mx = wave_max(dmax);
+            const int need = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_frexp_expf(mx) - 1 - kTop);    // mx 2^-need < 2^(kTop + 1)
+            if (!(need > 0) || kDe < kDt - 200) break;
+            kDe -= need > 100 ? 100 : need;
+            load_y(srow_l, 0, yA);                   // the pass consumed the counts of its first group, F its first operands,
+            load_ha(t, 0, ha0);                      // and the cells hold pieces: once more from the products
+            wave_sync();
+            }   // F + Z (until the scale fits)
             dacc += (double)lacc;
             const float sf_n = p.sf[srow_n];
             wave_sync();
             TSTAMP(4)
-
-            // A tile whose non-zero pass produced a scaled gradient beyond the fp16 range (counts in the tens of thousands,
-            // a dispersion at its floor) is scaled down AS A WHOLE by what its largest value needs -- the staged D in place,
-            // the weight-gradient accumulators around its products (exact: powers of two).  Wave-uniform, rare.
-            int kDe = kDt;                            // the exponent the staged D carries from here on
-            int shift = 0;
-            if (__ballot(!(dmax <= kDLim))) {         // (a NaN / inf gradient takes the branch too and stays what it is)
-                const float m = wave_max(dmax);
-                const int need = __builtin_amdgcn_frexp_expf(m) - 1 - kTop;          // m 2^-need < 2^(kTop + 1)
-                shift = __builtin_amdgcn_readfirstlane(need > 0 ? (need > 100 ? 100 : need) : 0);
-                if (shift) {
-                    const float down = pow2i(-shift);
+            const int shift = kDt - kDe;
+            if (shift) {                             // the wave's accumulators to the scale of this tile's D
+                const float down = pow2i(-shift);
 #pragma unroll
-                    for (int h = 0; h < NP; ++h)
+                for (int h = 0; h < NH; ++h)
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) St[h * ST_PLANE + l31 * kLdS + rowmap(e, hi)] *= down;
+                    for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
-                    for (int h = 0; h < NH; ++h)
-#pragma unroll
-                        for (int ib = 0; ib < 2; ++ib)
-#pragma unroll
-                            for (int e = 0; e < 16; ++e) dW[h][ib][e] *= down;
-                    kDe = kDt - shift;
-                    wave_sync();
-                }
+                        for (int e = 0; e < 16; ++e) dW[h][ib][e] *= down;
             }
 
-            // ---- dH[row, i] = sum_genes D[row, gene] W[i, gene]: A = D read transposed from the staging tile
-            // (row l31, 8 genes per K-step half) and split on the fly, B = the weight image read directly
+            // ---- dH[row, i] = sum_genes D[row, gene] W[i, gene]: A = the D pieces read transposed (row position l31, 8 genes
+            // per K-step half), B = the weight image read directly.  MFMA row m = row POSITION m (the order of the transposed
+            // H image): batch row (m & 0x13) | bit 2 <-> bit 3.
             u32x4 htb[2][2][2];
             load_ht(t, 0, htb[0]);                   // first K step of the dW operands: in flight during the dH products
             __builtin_amdgcn_sched_barrier(0);
@@ -702,45 +768,51 @@ __global__ __launch_bounds__(64 * kWR2) void heads_fused_h2_kernel(HeadsArgs2 p)
 #pragma unroll
                     for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) {
-                            const unsigned u = __builtin_amdgcn_raw_buffer_load_b32(
-                                dh_rs, dh_lane + (((rowmap(e, 0) * KT + jb * 32) * 4) & 4095), ((rowmap(e, 0) * KT + jb * 32) * 4) & ~4095, 0);
-                            dHa[jb][e] = __uint_as_float(u) * fs;
+                        for (int eq = 0; eq < 4; ++eq) {
+                            const u32x4 u = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(dh_rs, dh_lane + 128 * jb + 32 * eq, 0, 0));
+#pragma unroll
+                            for (int w = 0; w < 4; ++w) { const unsigned uw = u[w]; dHa[jb][4 * eq + w] = __uint_as_float(uw) * fs; }
                         }
                 }
+                // the products TRANSPOSED -- hidden units x row positions: a lane then holds four consecutive hidden units of its
+                // row per accumulator quad, and the partial moves in 16-byte units (8 loads + 8 stores per tile instead of 32 + 32)
 #pragma unroll
                 for (int h = 0; h < NH; ++h)
 #pragma unroll
                     for (int gs = 0; gs < 2; ++gs) {
-                        float dv[8];
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) dv[j] = St[h * ST_PLANE + (16 * gs + 8 * hi + j) * kLdS + l31];
                         u32x4 af[2];
-                        split8(dv, af);
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const unsigned char* b0 = Pimg + h * HEAD_B + gs * 16 * CELL_LD + 8 * q + dtr;
+                            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(b0));
+                            const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(b0 + 4 * CELL_LD));
+                            const u32x2 a = __builtin_bit_cast(u32x2, lo), b = __builtin_bit_cast(u32x2, hi4);
+                            af[q] = u32x4{a[0], a[1], b[0], b[1]};
+                        }
 #pragma unroll
                         for (int jb = 0; jb < 2; ++jb) {
                             u32x4 bf[2] = {w_dr(h, 0, jb, gs), w_dr(h, 1, jb, gs)};
-                            MFMA_H3(af, bf, dHa[jb])
+                            MFMA_H3(bf, af, dHa[jb])
                         }
                     }
                 TSTAMP(7)
 #pragma unroll
                 for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const float v = dHa[jb][e] * fu;     // (a bit_cast of the vector element itself stores element 0)
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), dh_rs,
-                                                              dh_lane + (((rowmap(e, 0) * KT + jb * 32) * 4) & 4095),
-                                                              ((rowmap(e, 0) * KT + jb * 32) * 4) & ~4095, 0);   // 12-bit immediate + scalar offset
+                    for (int eq = 0; eq < 4; ++eq) {
+                        u32x4 v;
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) v[w] = __float_as_uint(dHa[jb][4 * eq + w] * fu);
+                        __builtin_amdgcn_raw_buffer_store_b128(v, dh_rs, dh_lane + 128 * jb + 32 * eq, 0, 0);
                     }
             }
             load_ht(t, 1, htb[1]);
             load_ha(tn, 0, ha0);                     // next tile's first forward step: in flight during the dW products
             __builtin_amdgcn_sched_barrier(0);
             TSTAMP(5)
-            // ---- dW[i, gene] += sum_rows H[row, i] D[row, gene]: B = the lane's own staged D column (rows in
+            // ---- dW[i, gene] += sum_rows H[row, i] D[row, gene]: B = the lane's own D column as stored (row positions in
             // the order of the MFMA row map = the order of the transposed H image), A = H^T pieces.  The accumulators carry
-            // 2^(eHmin + kD0) = 2^(eH[t] + kDt) in every tile.
+            // 2^(eHmin + kD0) = 2^(eH[t] + kDt) in every tile.  The column sums (bias gradients) from the pieces: v_dot2_f32_f16.
             float tsum[NH];
 #pragma unroll
             for (int h = 0; h < NH; ++h) tsum[h] = 0.f;
@@ -748,14 +820,18 @@ __global__ __launch_bounds__(64 * kWR2) void heads_fused_h2_kernel(HeadsArgs2 p)
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                 for (int h = 0; h < NH; ++h) {
-                    float dv[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        dv[j] = St[h * ST_PLANE + l31 * kLdS + rowmap(8 * ks + j, hi)];
-                        tsum[h] += dv[j];
-                    }
                     u32x4 bf[2];
-                    split8(dv, bf);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const unsigned char* c0 = Pimg + h * HEAD_B + cell_lane + 4 * ks * 16 + 8 * q;      // cells 2 hi + 4 ks and + 1
+                        const u32x2 lo = *reinterpret_cast<const u32x2*>(c0), hi2 = *reinterpret_cast<const u32x2*>(c0 + 16);
+                        bf[q] = u32x4{lo[0], lo[1], hi2[0], hi2[1]};
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) {
+                            const unsigned pw = bf[q][w];        // (a bit_cast of the vector element itself takes element 0)
+                            tsum[h] = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2v, pw), f16x2v{(_Float16)1.f, (_Float16)1.f}, tsum[h], false);
+                        }
+                    }
 #pragma unroll
                     for (int ib = 0; ib < 2; ++ib) {
                         u32x4 af[2] = {htb[ks][0][ib], htb[ks][1][ib]};
@@ -769,7 +845,7 @@ __global__ __launch_bounds__(64 * kWR2) void heads_fused_h2_kernel(HeadsArgs2 p)
                 if (CONST_DISP) {
                     float ts = 0.f;
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) ts += St[TH_P * ST_PLANE + l31 * kLdS + rowmap(e, hi)];
+                    for (int e = 0; e < 16; ++e) ts += Th[l31 * kLdS + rowmap(e, hi)];
                     thsum = fmaf(ts, gun, thsum);
                 }
             }

@@ -14,6 +14,7 @@
 #include <stdlib.h>
 #include "dcahip.h"
 #include "zinb_math.hpp"
+#include "h2_math.hpp"
 
 namespace {
 
@@ -32,6 +33,9 @@ struct NllArgs {
     // pl[h] + q * pstride + row * ldp + g
     unsigned short* pl[3];
     long ldp, pstride;
+    // fp16 x 2 planes (dcahip_zinb_nll_planes_h2): the head planes hold the UNSCALED gradient g 2^kD = pscale g in TWO pieces
+    // (h2_math.hpp); a per-gene dispersion's fp32 plane keeps inv_n
+    float pscale;
 };
 
 // the three bf16 pieces of fp32 values (x = p0 + p1 + p2 to 2^-24 |x|: the split of dcahip_sgemm / dcahip_split_planes)
@@ -55,6 +59,14 @@ __device__ __forceinline__ void store_planes4(unsigned short* base, long pstride
     *reinterpret_cast<u32x2*>(base) = u32x2{a0, b0};
     *reinterpret_cast<u32x2*>(base + pstride) = u32x2{a1, b1};
     *reinterpret_cast<u32x2*>(base + 2 * pstride) = u32x2{a2, b2};
+}
+// two fp16 pieces (the values arrive scaled: h2_math.hpp)
+__device__ __forceinline__ void store_planes4_h2(unsigned short* base, long pstride, const float (&v)[4]) {
+    unsigned a0, a1, b0, b1;
+    h2_split_pair(v[0], v[1], a0, a1);
+    h2_split_pair(v[2], v[3], b0, b1);
+    *reinterpret_cast<u32x2*>(base) = u32x2{a0, b0};
+    *reinterpret_cast<u32x2*>(base + pstride) = u32x2{a1, b1};
 }
 __device__ __forceinline__ void store_planes1(unsigned short* base, long pstride, float v) {
     unsigned a0, a1, a2;
@@ -284,8 +296,9 @@ constexpr int kRowsPerIter = DCA_ZINB_ROWS;
 #else
 constexpr int kRowsPerIter = 2;
 #endif
-template <bool HAS_PI, bool CONST_DISP, bool PL>
+template <bool HAS_PI, bool CONST_DISP, int PL>          // PL: 0 fp32 gradient planes, 1 three bf16 pieces, 2 two fp16 pieces of g 2^kD
 __global__ __launch_bounds__(256, kRowsPerIter <= 2 ? 4 : 3) void zinb_nll_rows_kernel(NllArgs a) {
+    const float psc = PL == 2 ? a.pscale : a.inv_n;        // scale of the head planes; a per-gene dispersion's plane: inv_n
     constexpr int V = 4, R = kRowsPerIter;
     __shared__ float4 queue[4][R * 256];                   // 8 KB per wave: every element of both rows may be non-zero
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -359,8 +372,8 @@ __global__ __launch_bounds__(256, kRowsPerIter <= 2 ? 4 : 3) void zinb_nll_rows_
                     if (HAS_PI) nll = zinb_zero_elem<CONST_DISP>(vm[r][j], vd[r][j], vp[r][j], sf[r], a.ridge, gmv, gdv, gpv);
                     else nll = nb_zero_elem<CONST_DISP>(vm[r][j], vd[r][j], sf[r], gmv, gdv);
                     lacc += (valid && !nz[r][j]) ? nll : 0.f;
-                    const float sc = valid ? a.inv_n : 0.f;
-                    om[r][j] = gmv * sc; od[r][j] = gdv * sc; op[r][j] = gpv * sc;
+                    const float sc = valid ? psc : 0.f, scd = valid ? (CONST_DISP ? a.inv_n : psc) : 0.f;
+                    om[r][j] = gmv * sc; od[r][j] = gdv * scd; op[r][j] = gpv * sc;
                     const unsigned long long m = __ballot(nz[r][j]);
                     mask[r][j] = m; base[r][j] = qn;
                     if (nz[r][j]) {
@@ -390,7 +403,7 @@ __global__ __launch_bounds__(256, kRowsPerIter <= 2 ? 4 : 3) void zinb_nll_rows_
                     o1 = dmu * hd.gm; o2 = dth * hd.gd;
                 }
                 lsp += act ? nll : 0.f;
-                if (act) Q[idx] = make_float4(o1 * a.inv_n, o2 * a.inv_n, o3 * a.inv_n, 0.f);
+                if (act) Q[idx] = make_float4(o1 * psc, o2 * (CONST_DISP ? a.inv_n : psc), o3 * psc, 0.f);
             }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -406,7 +419,12 @@ __global__ __launch_bounds__(256, kRowsPerIter <= 2 ? 4 : 3) void zinb_nll_rows_
                 if (qv && rv[r]) {
                     const int row = row0 + r * gridDim.y;
                     const long dof2 = (long)row * a.ldd + g;
-                    if (PL) {
+                    if (PL == 2) {
+                        const long dof = (long)row * a.ldp + g;
+                        store_planes4_h2(a.pl[0] + dof, a.pstride, om[r]);
+                        if (CONST_DISP) stv<V>(a.d_disp + dof2, od[r]); else store_planes4_h2(a.pl[1] + dof, a.pstride, od[r]);
+                        if (HAS_PI) store_planes4_h2(a.pl[2] + dof, a.pstride, op[r]);
+                    } else if (PL == 1) {
                         const long dof = (long)row * a.ldp + g;
                         store_planes4(a.pl[0] + dof, a.pstride, om[r]);
                         if (CONST_DISP) stv<V>(a.d_disp + dof2, od[r]); else store_planes4(a.pl[1] + dof, a.pstride, od[r]);
@@ -517,7 +535,7 @@ int launch_nll(const NllArgs& a, bool vec, dim3 grid, hipStream_t s) {
     constexpr bool patching = false;
 #endif
     const bool fits = !GRAD || (long)a.B * a.ldd < (1L << 32);
-    if (vec && fits && !plain && GRAD && !patching) hipLaunchKernelGGL((zinb_nll_rows_kernel<HAS_PI, CONST_DISP, false>), grid, dim3(256), 0, s, a);
+    if (vec && fits && !plain && GRAD && !patching) hipLaunchKernelGGL((zinb_nll_rows_kernel<HAS_PI, CONST_DISP, 0>), grid, dim3(256), 0, s, a);
     else if (vec && fits && !plain) hipLaunchKernelGGL((zinb_nll_compact_kernel<HAS_PI, CONST_DISP, GRAD>), grid, dim3(256), 0, s, a);
     else if (vec) hipLaunchKernelGGL((zinb_nll_kernel<HAS_PI, CONST_DISP, GRAD, 4>), grid, dim3(256), 0, s, a);
     else     hipLaunchKernelGGL((zinb_nll_kernel<HAS_PI, CONST_DISP, GRAD, 1>), grid, dim3(256), 0, s, a);
@@ -578,7 +596,7 @@ extern "C" int dcahip_zinb_nll(const float* a_mean, const float* a_disp, const f
 #undef DCA_DISPATCH
 }
 
-extern "C" int dcahip_zinb_nll_planes(const float* a_mean, const float* a_disp, const float* a_pi, long lda,
+static int zinb_nll_planes_impl(int h2, float pscale, const float* a_mean, const float* a_disp, const float* a_pi, long lda,
                                       const float* theta_w, const float* y, long ldy, const float* sf,
                                       const int* perm, const long long* cursor, int B, int G, float ridge,
                                       float inv_n, int flags, void* d_planes, long ldp, long plane_stride,
@@ -601,7 +619,7 @@ extern "C" int dcahip_zinb_nll_planes(const float* a_mean, const float* a_disp, 
     unsigned short* P = static_cast<unsigned short*>(d_planes);
     NllArgs a{a_mean, a_disp, a_pi, theta_w, y, sf, perm, cursor, lda, ldy, cdisp ? ldd_theta : 0,
               nullptr, cdisp ? d_theta : nullptr, nullptr, loss_partials, B, G, ridge, inv_n,
-              {P + col_mean, cdisp ? nullptr : P + col_disp, has_pi ? P + col_pi : nullptr}, ldp, plane_stride};
+              {P + col_mean, cdisp ? nullptr : P + col_disp, has_pi ? P + col_pi : nullptr}, ldp, plane_stride, pscale};
     const int nvec = (G + 3) / 4;
     const int nseg = (nvec + 255) / 256;
     const int gx = nseg < kMaxPartials ? nseg : kMaxPartials;
@@ -611,10 +629,17 @@ extern "C" int dcahip_zinb_nll_planes(const float* a_mean, const float* a_disp, 
     const dim3 grid(gx, gy);
     if (n_partials_out) *n_partials_out = gx * gy;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (h2) {
+        if (has_pi && cdisp) hipLaunchKernelGGL((zinb_nll_rows_kernel<true, true, 2>), grid, dim3(256), 0, s, a);
+        else if (has_pi) hipLaunchKernelGGL((zinb_nll_rows_kernel<true, false, 2>), grid, dim3(256), 0, s, a);
+        else if (cdisp) hipLaunchKernelGGL((zinb_nll_rows_kernel<false, true, 2>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((zinb_nll_rows_kernel<false, false, 2>), grid, dim3(256), 0, s, a);
+        return (int)hipGetLastError();
+    }
 #ifdef DCA_ZINB_PATCH
 #define DCA_ZK(P, C) zinb_nll_compact_kernel<P, C, true, true>
 #else
-#define DCA_ZK(P, C) zinb_nll_rows_kernel<P, C, true>
+#define DCA_ZK(P, C) zinb_nll_rows_kernel<P, C, 1>
 #endif
     if (has_pi && cdisp) hipLaunchKernelGGL((DCA_ZK(true, true)), grid, dim3(256), 0, s, a);
     else if (has_pi) hipLaunchKernelGGL((DCA_ZK(true, false)), grid, dim3(256), 0, s, a);
@@ -622,6 +647,29 @@ extern "C" int dcahip_zinb_nll_planes(const float* a_mean, const float* a_disp, 
     else hipLaunchKernelGGL((DCA_ZK(false, false)), grid, dim3(256), 0, s, a);
 #undef DCA_ZK
     return (int)hipGetLastError();
+}
+
+extern "C" int dcahip_zinb_nll_planes(const float* a_mean, const float* a_disp, const float* a_pi, long lda,
+                                      const float* theta_w, const float* y, long ldy, const float* sf,
+                                      const int* perm, const long long* cursor, int B, int G, float ridge,
+                                      float inv_n, int flags, void* d_planes, long ldp, long plane_stride,
+                                      long col_mean, long col_disp, long col_pi, float* d_theta, long ldd_theta,
+                                      double* loss_partials, int* n_partials_out, void* stream) {
+    return zinb_nll_planes_impl(0, 0.f, a_mean, a_disp, a_pi, lda, theta_w, y, ldy, sf, perm, cursor, B, G, ridge, inv_n, flags,
+                                d_planes, ldp, plane_stride, col_mean, col_disp, col_pi, d_theta, ldd_theta, loss_partials,
+                                n_partials_out, stream);
+}
+
+extern "C" int dcahip_zinb_nll_planes_h2(const float* a_mean, const float* a_disp, const float* a_pi, long lda,
+                                         const float* theta_w, const float* y, long ldy, const float* sf,
+                                         const int* perm, const long long* cursor, int B, int G, float ridge,
+                                         float inv_n, int flags, int d_exp, void* d_planes, long ldp, long plane_stride,
+                                         long col_mean, long col_disp, long col_pi, float* d_theta, long ldd_theta,
+                                         double* loss_partials, int* n_partials_out, void* stream) {
+    if (d_exp < -40 || d_exp > 40 || !(ridge >= 0.f)) return DCAHIP_EINVAL;
+    return zinb_nll_planes_impl(1, ldexpf(1.f, d_exp), a_mean, a_disp, a_pi, lda, theta_w, y, ldy, sf, perm, cursor, B, G, ridge, inv_n,
+                                flags, d_planes, ldp, plane_stride, col_mean, col_disp, col_pi, d_theta, ldd_theta, loss_partials,
+                                n_partials_out, stream);
 }
 
 extern "C" int dcahip_loss_finalize(const double* partials, int n_partials, double scale,

@@ -572,6 +572,7 @@ class Engine:
         sfv = np.ones(n, np.float32) if sf is None else np.asarray(sf, dtype=np.float32).reshape(-1)
         self.sf = torch.as_tensor(sfv).to(self.dev)
         self._set_tile_order()
+        self._data_scales()
         self.attach_compact()               # K-HEADS reads the byte store; the input normalisation of a host X is unknown
 
     def attach_device_data(self, X, Y, sf, norm=None, compact=None):
@@ -584,7 +585,51 @@ class Engine:
         self.n, self.ldx, self.ldy = X.shape[0], X.shape[1], lay.Gp
         self.X, self.Y, self.sf = X, Y, sf
         self._set_tile_order()
+        self._data_scales()
         self.attach_compact(compact, norm)
+
+    def _data_scales(self):
+        """What the fp16 x 2 plane products of the wide networks need to know about the resident data, once per dataset:
+        the block exponent of the input matrix X (a device word: dcahip_absmax_exp) and the exponent d_exp of the gradient
+        planes, from the bound |g| <= max(1e4, 2 y_max + 50) of the likelihood's formulas (include/dcahip.h,
+        dcahip_zinb_nll_planes_h2).  d_exp < 0 (counts beyond ~16 000): the wide path keeps the three-piece bf16 planes."""
+        self.x_exp = None
+        self.d_exp = None
+        ops = self.ops
+        if not (self.cfg.wide_h2 and hasattr(ops, 'gemm_h2') and self.lay.hidden and self.lay.hL > 64) or self.X is None:
+            return
+        if not self.X.is_cuda:
+            return
+        if self.Y is not None:
+            ymax = float(self.Y.max().item()) if self.Y.numel() else 0.0
+            bound = max(1e4, 2.0 * ymax + 50.0) + 0.5 * float(self.ridge)
+            self.d_exp = int(np.floor(np.log2(65000.0 / bound)))
+        if self.lay.hidden[0] >= 128:
+            self.x_exp = torch.zeros(2, dtype=torch.int32, device=self.dev)
+            ops.absmax_exp(self.X, self.ldx, self.X.shape[0], self.lay.G_in, self.x_exp)
+
+    def _h2(self, B):
+        """The wide networks' plane products on fp16 x 2 planes (half the matrix instructions of the bf16 x 3 planes) at this
+        batch: every product a shape the 256 x 256 kernel takes, the gradient planes inside the fp16 range by construction."""
+        lay, ops = self.lay, self.ops
+        if not (self.pl is not None and self.pl_exp is not None and self._wide_planes(B) and self._planes_nll(B)
+                and self.d_exp is not None and self.d_exp >= 0):
+            return False
+        if B not in self._h2_ok:
+            ok = (ops.gemm_h2_supported(B, lay.NH, _r16(lay.hL)) and ops.gemm_h2_supported(lay.hL, lay.NH, B)
+                  and ops.gemm_h2_supported(B, lay.hL, _r16(lay.NH)) and B % 16 == 0)
+            self._h2_ok[B] = bool(ok)
+        return self._h2_ok[B]
+
+    def _h2_enc0(self, B, training):
+        lay, ops = self.lay, self.ops
+        if not (self._h2(B) and 'X' in self.pl and self.x_exp is not None and self._planes_enc0(B, training)):
+            return False
+        key = ('enc0', B)
+        if key not in self._h2_ok:
+            self._h2_ok[key] = bool(ops.gemm_h2_supported(B, lay.hidden[0], _r16(lay.G_in))
+                                    and ops.gemm_h2_supported(lay.G_in, lay.hidden[0], B))
+        return self._h2_ok[key]
 
     def attach_compact(self, compact=None, norm=None):
         """Compact byte store of the resident counts (built here unless given) for K-HEADS and -- when the input
@@ -741,6 +786,8 @@ class Engine:
                     if self.XT is not None:
                         need = max(need, ops.sgemm_workspace_bytes(0, 1, lay.G_in, lay.hidden[0], b))
         self.pl = None
+        self.pl_exp = None
+        self._h2_ok = {}
         if self._wide_planes(B):
             def planes(rows, cols):
                 return torch.zeros(3, rows, _r16(cols), dtype=torch.bfloat16, device=self.dev)
@@ -754,6 +801,19 @@ class Engine:
                 if 'X' in self.pl:
                     need = max(need, ops.gemm_p3_workspace_bytes(b, lay.hidden[0], _r16(lay.G_in)),
                                ops.gemm_p3_workspace_bytes(lay.G_in, lay.hidden[0], b, True))
+            # the same buffers hold the TWO fp16 planes of the fp16 x 2 products (the first two planes: 16-bit elements either
+            # way); their block exponents are device words (nothing leaves the stream)
+            self.pl_exp = None
+            self._h2_ok = {}
+            if self.cfg.wide_h2 and hasattr(ops, 'gemm_h2'):
+                self.pl_exp = {k: torch.zeros(2, dtype=torch.int32, device=self.dev) for k in ('H', 'Wh', 'W0', 'dZ0')}
+                for b in cand:
+                    need = max(need, ops.gemm_h2_workspace_bytes(b, lay.NH, _r16(lay.hL)),
+                               ops.gemm_h2_workspace_bytes(lay.hL, lay.NH, b, True),
+                               ops.gemm_h2_workspace_bytes(b, lay.hL, _r16(lay.NH)))
+                    if 'X' in self.pl:
+                        need = max(need, ops.gemm_h2_workspace_bytes(b, lay.hidden[0], _r16(lay.G_in)),
+                                   ops.gemm_h2_workspace_bytes(lay.G_in, lay.hidden[0], b, True))
         self.ws = torch.zeros(max(need // 4, 4), **f32)
         self.ws_stack = None
         if hasattr(ops, 'hidden_stack_fwd') and lay.hidden and max(lay.hidden) <= 64 and len(lay.hidden) <= 8:
@@ -796,11 +856,20 @@ class Engine:
                     # reads the same planes, contracting over their rows), the kernel split, the product from planes
                     gather = rows_from[0] == 'perm'
                     with self._t('gemm_enc0_fwd'):
-                        ops.split_planes(self.X if gather else self.X[rows_from[1]:], self.ldx, B, K, self.pl['X'],
-                                         perm=self.perm if gather else None, cursor=self.cursor if gather else None)
-                        ops.split_planes(Wi, h, K, h, self.pl['W0'])
-                        ops.gemm_p3(0, 0, B, h, _r16(K), self.pl['X'], self.pl['W0'], self.Z[0], self.ldh[0], bias=bi,
-                                    ws=self.ws)
+                        if self._h2_enc0(B, training):
+                            # two fp16 planes per operand, three products: X scaled by its dataset-wide exponent, W0 by its own
+                            ops.split_planes_h2(self.X if gather else self.X[rows_from[1]:], self.ldx, B, K, self.pl['X'], self.x_exp,
+                                                perm=self.perm if gather else None, cursor=self.cursor if gather else None)
+                            ops.absmax_exp(Wi, h, K, h, self.pl_exp['W0'])
+                            ops.split_planes_h2(Wi, h, K, h, self.pl['W0'], self.pl_exp['W0'])
+                            ops.gemm_h2(0, 0, B, h, _r16(K), self.pl['X'], self.pl['W0'], self.Z[0], self.ldh[0],
+                                        exp_a=self.x_exp, exp_b=self.pl_exp['W0'], bias=bi, ws=self.ws)
+                        else:
+                            ops.split_planes(self.X if gather else self.X[rows_from[1]:], self.ldx, B, K, self.pl['X'],
+                                             perm=self.perm if gather else None, cursor=self.cursor if gather else None)
+                            ops.split_planes(Wi, h, K, h, self.pl['W0'])
+                            ops.gemm_p3(0, 0, B, h, _r16(K), self.pl['X'], self.pl['W0'], self.Z[0], self.ldh[0], bias=bi,
+                                        ws=self.ws)
                 elif training and self.in_drop > 0.0:
                     assert rows_from[0] == 'perm'
                     if self.Xb is None or self.Xb.shape[0] < self.Bmax:
@@ -1029,7 +1098,14 @@ class Engine:
         lay, ops = self.lay, self.ops
         Wh, bh = lay.view(self.w, 'Wh'), lay.view(self.w, 'bh')
         with self._t('gemm_heads_fwd'):
-            if self.pl is not None and self._wide_planes(B) and B <= self.pl['H'].shape[1]:
+            if self.pl is not None and self._wide_planes(B) and B <= self.pl['H'].shape[1] and self._h2(B):
+                ops.absmax_exp(self._hl[0], self._hl[1], B, lay.hL, self.pl_exp['H'])
+                ops.split_planes_h2(self._hl[0], self._hl[1], B, lay.hL, self.pl['H'], self.pl_exp['H'])
+                ops.absmax_exp(Wh, lay.NH, lay.hL, lay.NH, self.pl_exp['Wh'])
+                ops.split_planes_h2(Wh, lay.NH, lay.hL, lay.NH, self.pl['Wh'], self.pl_exp['Wh'])
+                ops.gemm_h2(0, 0, B, lay.NH, _r16(lay.hL), self.pl['H'], self.pl['Wh'], self.A, lay.ldA,
+                            exp_a=self.pl_exp['H'], exp_b=self.pl_exp['Wh'], bias=bh, ws=self.ws)
+            elif self.pl is not None and self._wide_planes(B) and B <= self.pl['H'].shape[1]:
                 ops.split_planes(self._hl[0], self._hl[1], B, lay.hL, self.pl['H'])
                 ops.split_planes(Wh, lay.NH, lay.hL, lay.NH, self.pl['Wh'])
                 ops.gemm_p3(0, 0, B, lay.NH, _r16(lay.hL), self.pl['H'], self.pl['Wh'], self.A, lay.ldA, bias=bh, ws=self.ws)
@@ -1067,8 +1143,16 @@ class Engine:
         lay, ops = self.lay, self.ops
         A, D = self.A, self.D
         tw = lay.view(self.w, 'theta_w') if lay.const_disp else None
+        if grad and self._h2(B):
+            # wide networks: the gradient planes leave K-ZINB as the two fp16 pieces of g 2^d_exp the backward products read
+            return ops.zinb_nll_planes_h2(self._plane(A, 'mean'), self._plane(A, 'disp'), self._plane(A, 'pi'), lay.ldA, tw,
+                                          Y, self.ldy, sf, perm, cursor, B, lay.G_out, self.ridge, inv_n, self.flags, self.d_exp,
+                                          self.pl['D'], lay.plane_offset('mean'),
+                                          0 if lay.const_disp else lay.plane_offset('disp'),
+                                          lay.plane_offset('pi') if 'pi' in lay.heads else 0,
+                                          self.Dth, self.ldD, self.partials)
         if grad and self._planes_nll(B):
-            # wide networks: the gradient planes leave K-ZINB as the bf16 pieces the two backward products read
+            # ... or as the three bf16 pieces
             return ops.zinb_nll_planes(self._plane(A, 'mean'), self._plane(A, 'disp'), self._plane(A, 'pi'), lay.ldA, tw,
                                        Y, self.ldy, sf, perm, cursor, B, lay.G_out, self.ridge, inv_n, self.flags,
                                        self.pl['D'], lay.plane_offset('mean'),
@@ -1327,6 +1411,11 @@ class Engine:
                             self.cc_in.ensure_lut(ops)
                         ops.enc0_dw_sparse(self.cc_in, self.perm, self.cursor, 0, B, Kp, h, self.dZ[0], self.ldh[0], gW, h,
                                            self.ws_enc0)
+                    elif self._h2_enc0(B, True):
+                        ops.absmax_exp(self.dZ[0], self.ldh[0], B, h, self.pl_exp['dZ0'])
+                        ops.split_planes_h2(self.dZ[0], self.ldh[0], B, h, self.pl['dZ0'], self.pl_exp['dZ0'])
+                        ops.gemm_h2(1, 0, Kp, h, B, self.pl['X'], self.pl['dZ0'], gW, h, exp_a=self.x_exp,
+                                    exp_b=self.pl_exp['dZ0'], colsum_row=True, ws=self.ws)
                     elif self._planes_enc0(B, True):
                         # the forward's planes of the minibatch, contracted over their rows; bias gradient = column sums
                         ops.split_planes(self.dZ[0], self.ldh[0], B, h, self.pl['dZ0'])
@@ -1360,6 +1449,17 @@ class Engine:
             n = self._nll(B, self.perm, self.cursor, self.Y, self.sf, inv_n, True)
         ops.loss_finalize(self.partials, n, inv_n, g[lay.P:])
         gWh, Wh = lay.view(g, 'Wh'), lay.view(w, 'Wh')
+        if self.pl is not None and self._wide_planes(B) and B <= self.pl['H'].shape[1] and self._h2(B):
+            # fp16 x 2 planes: the forward's H and Wh planes, the likelihood's D = g 2^d_exp; 1 / n leaves in the epilogues
+            with self._t('gemm_heads_dW'):
+                ops.gemm_h2(1, 0, lay.hL, lay.NH, B, self.pl['H'], self.pl['D'], gWh, lay.NH, exp_a=self.pl_exp['H'],
+                            exp_b_add=self.d_exp, alpha=inv_n, colsum_row=True, ws=self.ws)
+            if lay.const_disp:
+                ops.colsum_chain(self.Dth, self.ldD, B, lay.G_out, lay.view(w, 'theta_w'), lay.view(g, 'theta_w'))
+            with self._t('gemm_heads_dH'):
+                ops.gemm_h2(0, 1, B, lay.hL, _r16(lay.NH), self.pl['D'], self.pl['Wh'], self._dhl, self._hl[1],
+                            exp_a_add=self.d_exp, exp_b=self.pl_exp['Wh'], alpha=inv_n, ws=self.ws)
+            return
         if self.pl is not None and self._wide_planes(B) and B <= self.pl['H'].shape[1]:
             # the gradient planes split once for both products; pl['H'] and pl['Wh'] are the forward's
             with self._t('gemm_heads_dW'):

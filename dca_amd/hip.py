@@ -178,6 +178,17 @@ _SIGNATURES = {
     'dcahip_enc0_fwd_lut': (_c.c_int, [_vp, _c.c_long, _i32p, _i32p, _f32p, _f32p, _c.c_int, _vp, _f32p, _f32p, _i32p, _i64p,
                                        _c.c_long, _c.c_int, _c.c_int, _c.c_int, _f32p, _c.c_long, _f32p, _f32p, _c.c_long,
                                        _vp, _c.c_long, _vp]),
+    'dcahip_absmax_exp': (_c.c_int, [_f32p, _c.c_long, _c.c_long, _c.c_int, _i32p, _vp, _vp]),
+    'dcahip_split_planes_h2': (_c.c_int, [_f32p, _c.c_long, _i32p, _i64p, _c.c_long, _c.c_int, _vp, _c.c_long, _c.c_long, _i32p, _vp]),
+    'dcahip_gemm_h2_supported': (_c.c_int, [_c.c_int, _c.c_int, _c.c_int]),
+    'dcahip_gemm_h2_workspace_bytes': (_c.c_long, [_c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
+    'dcahip_gemm_h2': (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _vp, _c.c_long, _c.c_long, _i32p, _c.c_int,
+                                  _vp, _c.c_long, _c.c_long, _i32p, _c.c_int, _c.c_float, _f32p, _c.c_long, _f32p, _c.c_int, _c.c_int,
+                                  _vp, _c.c_long, _vp]),
+    'dcahip_zinb_nll_planes_h2': (_c.c_int, [_f32p, _f32p, _f32p, _c.c_long, _f32p, _f32p, _c.c_long, _f32p,
+                                             _i32p, _i64p, _c.c_int, _c.c_int, _c.c_float, _c.c_float, _c.c_int, _c.c_int,
+                                             _vp, _c.c_long, _c.c_long, _c.c_long, _c.c_long, _c.c_long, _f32p, _c.c_long, _f64p,
+                                             _c.POINTER(_c.c_int), _vp]),
     'dcahip_heads_fused_compact': (_c.c_int, [_f32p, _c.c_long, _f32p, _c.c_long, _f32p, _c.c_long, _f32p,
                                               _f32p, _c.c_long, _vp, _c.c_long, _i32p, _i32p, _f32p, _f32p, _i32p, _i64p,
                                               _c.c_int, _c.c_int, _c.c_int, _c.c_float, _c.c_float, _c.c_int, _f32p,

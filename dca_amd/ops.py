@@ -44,6 +44,17 @@ class HipOps:
                                                 p(partials), ctypes.byref(n), hip.stream()), 'zinb_nll_planes')
         return n.value
 
+    def zinb_nll_planes_h2(self, a_mean, a_disp, a_pi, lda, theta_w, Y, ldy, sf, perm, cursor, B, G, ridge, inv_n, flags, d_exp,
+                           planes, col_mean, col_disp, col_pi, d_theta, ldd_theta, partials):
+        """zinb_nll_planes with the head planes as TWO fp16 pieces of the unscaled gradient g 2^d_exp (the operand of gemm_h2)."""
+        n = ctypes.c_int(0)
+        p = hip.ptr
+        hip.check(self.L.dcahip_zinb_nll_planes_h2(p(a_mean), p(a_disp), p(a_pi), lda, p(theta_w), p(Y), ldy, p(sf), p(perm),
+                                                   p(cursor), B, G, ridge, inv_n, flags, int(d_exp), p(planes), planes.stride(1),
+                                                   planes.stride(0), col_mean, col_disp, col_pi, p(d_theta), ldd_theta,
+                                                   p(partials), ctypes.byref(n), hip.stream()), 'zinb_nll_planes_h2')
+        return n.value
+
     def loss_finalize(self, partials, n, scale, loss_out):
         hip.check(self.L.dcahip_loss_finalize(hip.ptr(partials), n, scale, hip.ptr(loss_out),
                                               hip.stream()), 'loss_finalize')
@@ -195,6 +206,31 @@ class HipOps:
         hip.check(self.L.dcahip_gemm_p3(int(ta), int(tb), M, N, K, p(A), A.stride(1), A.stride(0), p(B), B.stride(1),
                                         B.stride(0), p(C), ldc, p(bias), p(perm), p(cursor), int(colsum_row), split_k,
                                         p(ws), wsb, hip.stream()), 'gemm_p3')
+
+    # ---- fp16 x 2 planes (include/dcahip.h: dcahip_gemm_h2).  exp: an int32 device tensor [2] = (block exponent, scratch)
+    def absmax_exp(self, src, ld, R, C, exp):
+        """exp[0] <- the exponent that brings max |src [R, C]| into [2^13, 2^14) (stays on the device: capturable)."""
+        hip.check(self.L.dcahip_absmax_exp(hip.ptr(src), ld, R, C, hip.ptr(exp), hip.ptr(exp[1:]), hip.stream()), 'absmax_exp')
+
+    def split_planes_h2(self, src, ld, R, C, planes, exp=None, perm=None, cursor=None):
+        """planes [>= 2, >= R, ldp] <- the two fp16 pieces of src [R, C] 2^exp[0] (rows gathered through perm / cursor)."""
+        hip.check(self.L.dcahip_split_planes_h2(hip.ptr(src), ld, hip.ptr(perm), hip.ptr(cursor), R, C, hip.ptr(planes),
+                                                planes.shape[2], planes.stride(0), hip.ptr(exp), hip.stream()), 'split_planes_h2')
+
+    def gemm_h2_supported(self, M, N, K):
+        return bool(self.L.dcahip_gemm_h2_supported(M, N, K))
+
+    def gemm_h2_workspace_bytes(self, M, N, K, colsum_row=False, split_k=0):
+        return self.L.dcahip_gemm_h2_workspace_bytes(M, N, K, int(colsum_row), split_k)
+
+    def gemm_h2(self, ta, tb, M, N, K, A, B, C, ldc, exp_a=None, exp_b=None, exp_a_add=0, exp_b_add=0, alpha=1.0, bias=None,
+                colsum_row=False, split_k=0, ws=None):
+        """C = alpha 2^-(ea + eb) op(A) op(B) from fp16 x 2 planes A, B ([>= 2, rows, ld] tensors or views of them)."""
+        p = hip.ptr
+        wsb = ws.numel() * ws.element_size() if ws is not None else 0
+        hip.check(self.L.dcahip_gemm_h2(int(ta), int(tb), M, N, K, p(A), A.stride(1), A.stride(0), p(exp_a), int(exp_a_add),
+                                        p(B), B.stride(1), B.stride(0), p(exp_b), int(exp_b_add), float(alpha), p(C), ldc, p(bias),
+                                        int(colsum_row), split_k, p(ws), wsb, hip.stream()), 'gemm_h2')
 
     def transpose(self, src, ld_src, R, C, dst, ld_dst, perm=None, cursor=None):
         """dst [C, R] = src[rows]^T; rows = perm[cursor : cursor + R] when perm is given."""

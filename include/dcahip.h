@@ -95,6 +95,17 @@ int dcahip_zinb_nll_planes(const float* a_mean, const float* a_disp, const float
                            long col_mean, long col_disp, long col_pi, float* d_theta, long ldd_theta,
                            double* loss_partials, int* n_partials_out, void* stream);
 
+/* The same with the head planes as TWO fp16 pieces of the UNSCALED gradient g 2^d_exp (g = d nll / d pre-activation without the
+ * 1 / n factor; dcahip_gemm_h2 takes the factor and the exponent out): d_planes [2][>= B][ldp] fp16.  The caller picks d_exp
+ * from the bound |g| <= max(1e4, 2 y_max + 50) (+ ridge / 2) of the likelihood's formulas, so that nothing leaves the fp16
+ * range: d_exp = 2 for counts up to 8 000.  A per-gene dispersion's fp32 plane d_theta keeps inv_n. */
+int dcahip_zinb_nll_planes_h2(const float* a_mean, const float* a_disp, const float* a_pi, long lda,
+                              const float* theta_w, const float* y, long ldy, const float* sf,
+                              const int* perm, const long long* cursor, int B, int G, float ridge,
+                              float inv_n, int flags, int d_exp, void* d_planes, long ldp, long plane_stride,
+                              long col_mean, long col_disp, long col_pi, float* d_theta, long ldd_theta,
+                              double* loss_partials, int* n_partials_out, void* stream);
+
 /*
  * Deterministic second stage of the loss reduction: loss = scale * sum(partials) with
  * nan -> inf (dca/loss.py:148), written to *loss_out (fp32, device).
@@ -234,6 +245,31 @@ int dcahip_gemm_p3(int ta, int tb, int M, int N, int K, const void* A, long lda,
                    const int* perm, const long long* cursor, int colsum_row, int split_k,
                    void* workspace, long workspace_bytes, void* stream);
 long dcahip_gemm_p3_workspace_bytes(int M, int N, int K, int colsum_row, int split_k);
+/*
+ * The plane products on TWO fp16 pieces per operand and THREE products per fp32 product (round 6: the arithmetic of K-HEADS,
+ * dcahip_x3_product_32x32; half the matrix instructions of dcahip_gemm_p3).  An operand matrix is scaled by the power of two
+ * that brings its largest magnitude into [2^13, 2^14) before it is split: the exponent lives in a DEVICE word, so nothing
+ * leaves the stream (capturable).
+ *   dcahip_absmax_exp       *exp_out = that exponent for src [R, C] (scratch_word: 4 bytes of device memory the call may use)
+ *   dcahip_split_planes_h2  fp32 [R, C] (rows gathered through perm / cursor) x 2^*exp -> planes [2][R][ldp] fp16 (exp NULL: 0)
+ *   dcahip_gemm_h2          C = alpha 2^-(ea + eb) op(A) op(B) (+ bias), ea = (exp_a ? *exp_a : 0) + exp_a_add, eb likewise;
+ *                           colsum_row: row M of C = alpha 2^-eb x the column sums of B.  Shapes: those of the 256 x 256 kernel
+ *                           (dcahip_gemm_h2_supported; M, N >= 256, M N >= 2^18, K % 16 == 0, no row gather); layouts, ta / tb,
+ *                           split_k and the workspace as dcahip_gemm_p3.
+ * Contract (tests/test_gemm_h2_gpu.py): |C - alpha op(A) op(B)| <= 1e-6 alpha sum|a b| per element (a priori 3 x 2^-22 = 7.2e-7
+ * plus the fp32 accumulation over K; the worst of 3 M elements at K = 512 measured 5.7e-7), deterministic.
+ * A producer that writes planes directly (dcahip_zinb_nll_planes_h2: the gradient planes as g 2^d_exp) passes its static
+ * exponent through exp_*_add.  Replaces the same MatMul kernels as dcahip_sgemm (dca/network.py:124-126, 369-380 and autodiff).
+ */
+int dcahip_absmax_exp(const float* src, long ld, long R, int C, int* exp_out, void* scratch_word, void* stream);
+int dcahip_split_planes_h2(const float* src, long ld, const int* perm, const long long* cursor, long R, int C,
+                           void* planes, long ldp, long plane_stride, const int* exp, void* stream);
+int dcahip_gemm_h2_supported(int M, int N, int K);
+long dcahip_gemm_h2_workspace_bytes(int M, int N, int K, int colsum_row, int split_k);
+int dcahip_gemm_h2(int ta, int tb, int M, int N, int K, const void* A, long lda, long plane_a, const int* exp_a, int exp_a_add,
+                   const void* B, long ldb, long plane_b, const int* exp_b, int exp_b_add, float alpha,
+                   float* C, long ldc, const float* bias, int colsum_row, int split_k,
+                   void* workspace, long workspace_bytes, void* stream);
 /* dst [C, ld_dst] = src [R, ld_src]^T.  The first Dense layer's kernel W0 [genes, h1] is transposed once per step at
  * throughput batches so that its forward product X W0 runs in the NT form (both operands contiguous along the
  * contraction: the fast operand path of dcahip_sgemm). */
