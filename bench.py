@@ -107,12 +107,15 @@ def kernel_model(name, B, G, hidden, nheads=3):
     return 'mfma', fl.get(name)
 
 
-def step_roofline(cells_per_s, B, G, hidden, nheads, n_params, ae_type, heads_ms=None):
+def step_roofline(cells_per_s, B, G, hidden, nheads, n_params, ae_type, heads_ms=None, ppp_heads=3, ppp_enc0=6):
     """SURVEY 8d's STEP-level bounds beside the measured figure (the per-kernel `roofline` prices the dominant launch only):
     algorithmic GEMM flops per cell F = G (4 h1 + 6 hL nheads) + 6 sum h_i h_{i+1}; the matrix-pipe bound at the fp32-MFMA peak
-    (SURVEY's 'MFMA bound': the ridge of the fp32 design) and at dense bf16 / 6 (the bound of THIS arithmetic: six bf16 products
-    per fp32 product); the HBM bound of the unfused design SURVEY prices (72 G bytes per cell + 32 P / B parameter traffic).
-    `frac` = measured / the bf16 / 6 bound (<= 1 by construction); `frac_of_fp32_ridge` = measured / SURVEY's min(fp32-MFMA, HBM).
+    (SURVEY's 'MFMA bound': the ridge of the fp32 design) and at the dense 16-bit peak divided by the 16-bit products THIS
+    arithmetic spends per fp32 product (heads: three fp16 products since round 6; first layer: six bf16 products from the byte
+    store, three on the wide networks' planes; hidden stack: six); the HBM bound of the unfused design SURVEY prices (72 G bytes
+    per cell + 32 P / B parameter traffic).  `frac` = measured / that matrix-pipe bound (<= 1 by construction);
+    `frac_of_bf16x6_bound` = measured / the bound at six products everywhere (the denominator of rounds 2 - 5);
+    `frac_of_fp32_ridge` = measured / SURVEY's min(fp32-MFMA, HBM).
     When profiles/sq_pipe_counts.json was measured on THIS source tree: the per-pipe floors of K-HEADS from its counted
     instructions -- vector issue (SQ_INSTS_VALU / 1024 SIMDs x 4 cycles) and matrix pipe (SQ_INSTS_MFMA x 32 cycles / 1024) at
     the profiled clock -- next to its measured launch time."""
@@ -121,14 +124,19 @@ def step_roofline(cells_per_s, B, G, hidden, nheads, n_params, ae_type, heads_ms
     by = 72.0 * G + 32.0 * n_params / B
     b_fp32 = MFMA_F32_PEAK_TFLOPS * 1e12 / F
     b_x6 = MFMA_BF16_PEAK_TFLOPS / 6.0 * 1e12 / F
+    F16 = G * (4.0 * h1 * ppp_enc0 + 6.0 * hL * nheads * ppp_heads) + 36.0 * sum(a * b for a, b in zip(hidden[:-1], hidden[1:]))
+    b_arith = MFMA_BF16_PEAK_TFLOPS * 1e12 / F16
     b_hbm = HBM_PEAK_GBS * 1e9 / by
     out = {'achieved_cells_s': cells_per_s, 'flops_per_cell': F, 'unfused_hbm_bytes_per_cell': by,
-           'bound_fp32_mfma_cells_s': b_fp32, 'bound_bf16x6_cells_s': b_x6, 'bound_hbm_unfused_cells_s': b_hbm,
-           'bound_fp32_ridge': min(b_fp32, b_hbm), 'frac': cells_per_s / b_x6,
+           'bound_fp32_mfma_cells_s': b_fp32, 'bound_bf16x6_cells_s': b_x6, 'bound_16bit_products_cells_s': b_arith,
+           'products_per_fp32_product': {'heads': ppp_heads, 'first_layer': ppp_enc0, 'hidden_stack': 6},
+           'bound_hbm_unfused_cells_s': b_hbm,
+           'bound_fp32_ridge': min(b_fp32, b_hbm), 'frac': cells_per_s / b_arith, 'frac_of_bf16x6_bound': cells_per_s / b_x6,
            'frac_of_fp32_ridge': cells_per_s / min(b_fp32, b_hbm),
            'definition': 'SURVEY.md 8d: F = G (4 h1 + 6 hL heads) + 6 sum h_i h_i+1 flops per cell; bounds = peak / F at 157.3 TF/s '
-                         '(fp32 MFMA) and 2 500 / 6 TF/s (six bf16 products per fp32 product); HBM: 72 G + 32 P / B bytes per cell '
-                         'at 8 TB/s'}
+                         '(fp32 MFMA), at 2 500 TF/s over the 16-bit products this arithmetic issues per fp32 product (heads %d, first '
+                         'layer %d, hidden stack 6) and at 2 500 / 6 TF/s (rounds 2 - 5); HBM: 72 G + 32 P / B bytes per cell at 8 TB/s'
+                         % (ppp_heads, ppp_enc0)}
     try:
         with open(os.path.join(ROOT, 'profiles', 'sq_pipe_counts.json')) as f:
             pc = json.load(f)
@@ -579,18 +587,28 @@ def main():
             eng.train_step(B, B * W, counts, B)
         ksum = eng.prof.summary(); eng.prof = None
     kernels = []
+    # 16-bit matrix products spent per fp32 product: K-HEADS and the wide networks' plane GEMMs run on two fp16 pieces and three
+    # products (round 6); the first layer from the byte store (and the three-piece planes) on three bf16 pieces and six
+    wide_h2 = bool(getattr(eng, '_h2', None) and eng.pl is not None and eng._h2(B))
+    ppp = {'heads_fused': 3}
+    for nm in ('gemm_heads_fwd', 'gemm_heads_dW', 'gemm_heads_dH', 'gemm_enc0_fwd', 'gemm_enc0_dW'):
+        ppp[nm] = 3 if wide_h2 else 6
     for name, st in ksum.items():
         bound, work = kernel_model(name, B, G, hidden, nheads={'zinb-conddisp': 3, 'zinb': 2, 'nb-conddisp': 2, 'nb': 1}.get(ae_type, 3))
-        ent = {'kernel': name, 'mean_ms': st['mean_ms'], 'share_of_step': st['total_ms'] / st['count'] / (1e3 * el / steps_timed)}
+        ent = {'kernel': name, 'mean_ms': st['mean_ms'], 'median_ms': st.get('median_ms'), 'share_of_step': st['total_ms'] / st['count'] / (1e3 * el / steps_timed)}
         if work:
             if bound == 'hbm':
                 ent.update(bound='hbm', achieved=work / (st['mean_ms'] * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit='GB/s')
             else:
-                # The products are computed as six bf16 MFMAs per fp32 product: the bound of the matrix pipe for THIS result is
-                # the dense bf16 peak / 6 -- `peak`.  (The fp32-MFMA peak, 157.3 TF/s, prices the same algorithmic flops on
-                # an instruction these kernels do not use and can exceed: kept as a secondary field only.)
-                ent.update(bound='mfma', achieved=work / (st['mean_ms'] * 1e-3) / 1e12, peak=MFMA_BF16_PEAK_TFLOPS / 6.0,
+                # The products are computed as `n` 16-bit MFMAs per fp32 product (3: two fp16 pieces; 6: three bf16 pieces): the
+                # bound of the matrix pipe for THIS result is the dense 16-bit peak / n -- `peak`.  (The fp32-MFMA peak,
+                # 157.3 TF/s, prices the same algorithmic flops on an instruction these kernels do not use and can exceed:
+                # a secondary field; so is the fraction of peak / 6, the denominator of rounds 2 - 5.)
+                n16 = ppp.get(name, 6)
+                ent.update(bound='mfma', achieved=work / (st['mean_ms'] * 1e-3) / 1e12, peak=MFMA_BF16_PEAK_TFLOPS / n16,
                            unit='TFLOP/s')
+                ent['products_per_fp32_product'] = n16
+                ent['frac_of_bf16x6_peak'] = ent['achieved'] / (MFMA_BF16_PEAK_TFLOPS / 6.0)
                 ent['peak_fp32_mfma'] = MFMA_F32_PEAK_TFLOPS
                 ent['frac_of_fp32_mfma_peak'] = ent['achieved'] / MFMA_F32_PEAK_TFLOPS
             ent['frac'] = ent['achieved'] / ent['peak']
@@ -610,8 +628,13 @@ def main():
                     'traffic_source': None,
                     'timing': 'HIP events around each launch, ' + ('isolated eager steps after the graph-replayed timed region' if use_graph else 'inside the timed region')}
             if e['bound'] == 'mfma':
-                roof['peak_note'] = ('dense bf16 MFMA peak / 6: the matrix-pipe bound of an fp32-accurate product computed as six '
-                                     'bf16 products; the fp32-MFMA peak is a secondary field')
+                roof['peak_note'] = ('dense 16-bit MFMA peak (2 500 TF/s) / %d: the matrix-pipe bound of an fp32-accurate product '
+                                     'computed as %d 16-bit products (%s); frac_of_bf16x6_peak = the same launch against peak / 6, '
+                                     'the denominator of rounds 2 - 5; the fp32-MFMA peak is a secondary field'
+                                     % (e['products_per_fp32_product'], e['products_per_fp32_product'],
+                                        'two fp16 pieces per operand' if e['products_per_fp32_product'] == 3 else 'three bf16 pieces per operand'))
+                roof['products_per_fp32_product'] = e['products_per_fp32_product']
+                roof['frac_of_bf16x6_peak'] = e['frac_of_bf16x6_peak']
                 roof['peak_fp32_mfma'] = e['peak_fp32_mfma']
                 roof['frac_of_fp32_mfma_peak'] = e['frac_of_fp32_mfma_peak']
             m = pmc.get(e['kernel'])
@@ -631,7 +654,8 @@ def main():
     if roof is not None:
         nheads = {'zinb-conddisp': 3, 'zinb': 2, 'nb-conddisp': 2, 'nb': 1}.get(ae_type, 3)
         hm = [e['mean_ms'] for e in kernels if e['kernel'] == 'heads_fused']
-        roof['step'] = step_roofline(cells_timed / el / W, B, G, hidden, nheads, int(eng.lay.P), ae_type, hm[0] if hm else None)
+        roof['step'] = step_roofline(cells_timed / el / W, B, G, hidden, nheads, int(eng.lay.P), ae_type, hm[0] if hm else None,
+                                     ppp_heads=3 if (hm or wide_h2) else 6, ppp_enc0=3 if wide_h2 else 6)
     if getattr(comm, 'peer', None) is not None:
         comm.peer.check()                                  # K-PEER: an exchange a rank never joined fails the run here
     extra = {}
@@ -664,9 +688,11 @@ def main():
                        'exposed_comm_source': ('8 eager steps before the timed region: events round each exchange (and each wait for '
                                                'the asynchronous bucket) on the compute stream') if multi else None,
                        'optimizer': 'RMSprop+clipvalue', 'params': int(eng.lay.P),
-                       'arithmetic': 'fp32 results: matrix products as three-way bf16 splits, six products, fp32 accumulation '
-                                     '(fp32-dot-product accuracy, tests/test_heads_fused_gpu.py::test_x3_products_are_fp32_accurate); '
-                                     'likelihood in fp32',
+                       'arithmetic': 'fp32 results.  Heads (K-HEADS; the wide networks\' plane products): operands block-scaled by a '
+                                     'power of two and split into two fp16 pieces, three products, fp32 accumulation; first layer from '
+                                     'the byte store and the hidden stack: three bf16 pieces, six products (fp32-dot-product accuracy: '
+                                     'tests/test_heads_fused_gpu.py::test_x3_products_are_fp32_accurate, tests/test_gemm_h2_gpu.py, '
+                                     'tests/test_x3_arith_cpu.py); likelihood in fp32',
                        **extra},
             'loss_first': loss_first, 'loss_last': loss_last,
             'roofline': roof, 'kernels': kernels,

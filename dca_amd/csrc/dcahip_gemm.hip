@@ -1212,21 +1212,49 @@ __global__ __launch_bounds__(512) void gemm_h2w_kernel(GemmH2Args p) {
 }
 
 
-// |x| maxima of a matrix as the bits of a non-negative float (order-preserving as unsigned): atomicMax is deterministic
+// |x| maxima of a matrix as the bits of a non-negative float (order-preserving as unsigned): atomicMax is deterministic.
+// One atomic per WORKGROUP, and only when it can raise the word (the plain read is a filter: the word only grows, so a stale
+// read sends an atomic that changes nothing, never skips one that would) -- 16 k same-address atomics cost 130 us here.
 __global__ __launch_bounds__(256) void absmax_kernel(const float* src, long ld, long R, int C, unsigned* amax) {
     const long units = (C + 3) / 4;
     const long total = R * units;
-    float m = 0.f;
-    for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < total; u += (long)gridDim.x * 256) {
+    const bool vec = (ld % 4 == 0) && ((reinterpret_cast<unsigned long long>(src) & 15) == 0);
+    float m0 = 0.f, m1 = 0.f;
+    const long stride = (long)gridDim.x * 256;
+    long u = (long)blockIdx.x * 256 + threadIdx.x;
+    if (vec && ld == C) {                       // a dense matrix: one flat run of 16-byte units, four loads in flight
+        const float4* s4 = reinterpret_cast<const float4*>(src);
+        for (; u + 3 * stride < total; u += 4 * stride) {
+            const float4 a = s4[u], b = s4[u + stride], c = s4[u + 2 * stride], d = s4[u + 3 * stride];
+            m0 = fmaxf(m0, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
+            m1 = fmaxf(m1, fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w))));
+            m0 = fmaxf(m0, fmaxf(fmaxf(fabsf(c.x), fabsf(c.y)), fmaxf(fabsf(c.z), fabsf(c.w))));
+            m1 = fmaxf(m1, fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fmaxf(fabsf(d.z), fabsf(d.w))));
+        }
+    }
+    for (; u < total; u += stride) {
         const long r = u / units;
         const int c = (int)(u - r * units) * 4;
         const float* sp = src + r * ld + c;
+        if (vec && c + 4 <= C) {
+            const float4 v = *reinterpret_cast<const float4*>(sp);
+            m0 = fmaxf(m0, fmaxf(fabsf(v.x), fabsf(v.y)));
+            m1 = fmaxf(m1, fmaxf(fabsf(v.z), fabsf(v.w)));
+        } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) m = fmaxf(m, c + j < C ? fabsf(sp[j]) : 0.f);
+            for (int j = 0; j < 4; ++j) m0 = fmaxf(m0, c + j < C ? fabsf(sp[j]) : 0.f);
+        }
     }
+    float m = fmaxf(m0, m1);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(amax, __float_as_uint(m));
+    __shared__ float wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+        if (m > 0.f && __float_as_uint(m) > __atomic_load_n(amax, __ATOMIC_RELAXED)) atomicMax(amax, __float_as_uint(m));
+    }
 }
 __global__ void absmax_exp_kernel(const unsigned* amax, int* exp_out) { *exp_out = h2_block_exp(__uint_as_float(*amax)); }
 
@@ -1607,7 +1635,7 @@ extern "C" int dcahip_absmax_exp(const float* src, long ld, long R, int C, int* 
     if (rc != 0) return rc;
     const long total = R * ((C + 3) / 4);
     long g = (total + 255) / 256;
-    if (g > 4096) g = 4096;
+    if (g > 2048) g = 2048;
     hipLaunchKernelGGL(absmax_kernel, dim3((int)g), dim3(256), 0, s, src, ld, R, C, amax);
     hipLaunchKernelGGL(absmax_exp_kernel, dim3(1), dim3(1), 0, s, amax, exp_out);
     return (int)hipGetLastError();

@@ -237,7 +237,8 @@ __global__ __launch_bounds__(64 * kWR2) void heads_fused_h2_kernel(HeadsArgs2 p)
     constexpr int QCAP = 192;                              // queue entries (16 bytes each): at most 63 left over + 2 x 64 pushed
     constexpr int CELL_LD = 144;                           // bytes per gene of a head's cell tile: 8 cells of 16 bytes + one of padding
     constexpr int HEAD_B = kTG * CELL_LD;                  // bytes of one head's cell tile
-    constexpr int PW_FLOATS = NH * HEAD_B / 4 + (CONST_DISP ? ST_PLANE : 0) + QCAP * 4;      // per wave
+    constexpr int ROWT = 96;                               // the wave's row table: storage row of the tile's 32 rows (this tile | next) + size factors
+    constexpr int PW_FLOATS = NH * HEAD_B / 4 + (CONST_DISP ? ST_PLANE : 0) + QCAP * 4 + ROWT;      // per wave
     constexpr int NTHREADS = 64 * WR;
     constexpr int W_PIECE = 64 * 64;                       // bytes of one (head, piece) weight image: 64 k x 32 genes fp16
     constexpr int W_FLOATS = NH * 2 * W_PIECE / 4;
@@ -298,6 +299,10 @@ __global__ __launch_bounds__(64 * kWR2) void heads_fused_h2_kernel(HeadsArgs2 p)
     float* const Th = lds + W_FLOATS + wave * PW_FLOATS + NH * HEAD_B / 4;
     u32x4* const Qe = reinterpret_cast<u32x4*>(lds + W_FLOATS + wave * PW_FLOATS + NH * HEAD_B / 4 + (CONST_DISP ? ST_PLANE : 0));
     float* const Bs = lds + W_FLOATS + WR * PW_FLOATS;          // [head][32] biases, then [32] log-dispersion
+    // the wave's row table: the dense pass takes the storage rows / size factors of its four consecutive rows with ONE 16-byte
+    // read each (they live lane-distributed in registers: eight cross-lane reads per group before)
+    int* const Rt = reinterpret_cast<int*>(lds + W_FLOATS + wave * PW_FLOATS + PW_FLOATS - ROWT);      // [2][32]
+    float* const Sft = reinterpret_cast<float*>(Rt + 64);                                              // [32]
 
     // ---- head weights of this gene tile -> LDS as fp16 pieces scaled by 2^eW (eW from the tile's largest weight), image
     // [head][piece][k][32 genes], the four 16-byte units of a row rotated by (k >> 2): conflict-free for the direct
@@ -460,12 +465,14 @@ __global__ __launch_bounds__(64 * kWR2) void heads_fused_h2_kernel(HeadsArgs2 p)
             sf_l = p.sf[srow_l];
             eHt = p.eH[t];
             load_ha(t, 0, ha0);
-#pragma unroll
-            for (int j = 0; j < kZU; ++j) {
-                const int sr = __shfl(srow_l, rowmap(j, hi), 64);
-                yA[j] = count_at(sr);
+            if (lane < 32) { Rt[l31] = srow_l; Sft[l31] = sf_l; }
+            wave_sync();
+            {
+                const int4 r4 = *reinterpret_cast<const int4*>(Rt + 4 * hi);
+                yA[0] = count_at(r4.x); yA[1] = count_at(r4.y); yA[2] = count_at(r4.z); yA[3] = count_at(r4.w);
             }
         }
+        int rb = 0;                                  // which half of Rt holds the current tile's rows
 #ifdef DCA_HEADS_TIMING
         long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         long long tlast = __builtin_readcyclecounter();
@@ -473,7 +480,9 @@ __global__ __launch_bounds__(64 * kWR2) void heads_fused_h2_kernel(HeadsArgs2 p)
 #endif
         int tile_no = wave >> 2;
         for (; t < p.NT; t += tstep) {
-#if !defined(DCA_EXP_NOPRIO)
+#if defined(DCA_EXP_PHASEPRIO)
+            __builtin_amdgcn_s_setprio(2);           // experiment: the matrix phases above the element-wise pass
+#elif !defined(DCA_EXP_NOPRIO)
             if ((tile_no++) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
 #endif
             TSTAMP(0)
@@ -489,6 +498,7 @@ __global__ __launch_bounds__(64 * kWR2) void heads_fused_h2_kernel(HeadsArgs2 p)
             float lacc;
             const float thw = CONST_DISP ? Bs[NH * 32 + l31] : 0.f;
             const int srow_n = load_srow(tn);
+            if (lane < 32) Rt[(rb ^ 1) * 32 + l31] = srow_n;        // (read after the wave_sync that follows the staging stores)
             const int eHn = p.eH[tn];
             float scs = 0.f;                          // 2^kDe
             int qn = 0;                               // queue fill
@@ -580,6 +590,8 @@ __global__ __launch_bounds__(64 * kWR2) void heads_fused_h2_kernel(HeadsArgs2 p)
                 }
                 float o_m[kZU], o_d[kZU], o_p[kZU];
                 bool o_nz[kZU];
+                const float4 sf4 = *reinterpret_cast<const float4*>(Sft + 8 * grp + 4 * hi);       // rows 8 grp + 4 hi ..
+                const float sfj[kZU] = {sf4.x, sf4.y, sf4.z, sf4.w};
 #pragma unroll
                 for (int j = 0; j < kZU; ++j) {
                     const int row = rowmap(grp * kZU + j, hi);
@@ -591,7 +603,7 @@ __global__ __launch_bounds__(64 * kWR2) void heads_fused_h2_kernel(HeadsArgs2 p)
                     const float sc = (valid && !nz) ? scs : 0.f;        // (a non-zero element's pieces come from the compacted pass)
                     if (HAS_PI) {
                         float gmv, gdv, gpv;
-                        const float nll = zinb_zero_elem<CONST_DISP>(i_am[j], i_ad[j], i_ap[j], __shfl(sf_l, row, 64), p.ridge, gmv, gdv, gpv);
+                        const float nll = zinb_zero_elem<CONST_DISP>(i_am[j], i_ad[j], i_ap[j], sfj[j], p.ridge, gmv, gdv, gpv);
                         lacc += (valid && !nz) ? nll : 0.f;
                         o_m[j] = gmv * sc;
                         o_d[j] = gdv * sc;
@@ -599,7 +611,7 @@ __global__ __launch_bounds__(64 * kWR2) void heads_fused_h2_kernel(HeadsArgs2 p)
                         dmax = fmaxf(dmax, fmaxf(fabsf(o_m[j]), fabsf(o_p[j])));
                     } else {
                         float gmv, gdv;
-                        const float nll = nb_zero_elem<CONST_DISP>(i_am[j], i_ad[j], __shfl(sf_l, row, 64), gmv, gdv);
+                        const float nll = nb_zero_elem<CONST_DISP>(i_am[j], i_ad[j], sfj[j], gmv, gdv);
                         lacc += (valid && !nz) ? nll : 0.f;
                         o_m[j] = gmv * sc;
                         o_d[j] = gdv * sc;
@@ -642,18 +654,15 @@ __global__ __launch_bounds__(64 * kWR2) void heads_fused_h2_kernel(HeadsArgs2 p)
                 }
                 z_flush(false);
             };
-            auto load_y = [&](int srow_src, int grp, YV (&yv)[kZU]) {
-#pragma unroll
-                for (int j = 0; j < kZU; ++j) {
-                    const int sr = __shfl(srow_src, rowmap(grp * kZU + j, hi), 64);
-                    yv[j] = count_at(sr);
-                }
+            auto load_y = [&](int half, int grp, YV (&yv)[kZU]) {          // half: 0 this tile's rows, 1 the next tile's
+                const int4 r4 = *reinterpret_cast<const int4*>(Rt + (rb ^ half) * 32 + 8 * grp + 4 * hi);
+                yv[0] = count_at(r4.x); yv[1] = count_at(r4.y); yv[2] = count_at(r4.z); yv[3] = count_at(r4.w);
             };
             auto z_loop = [&](auto fullv) {             // (ONE call site of the dense pass: its code, and the non-zero pass
 #pragma unroll 1                                        //  inside it, exist once per row-range variant)
                 for (int grp = 0; grp < 16 / kZU; ++grp) {
-                    if (grp + 1 < 16 / kZU) load_y(srow_l, grp + 1, yB);
-                    else load_y(srow_n, 0, yB);          // the next tile's first group
+                    if (grp + 1 < 16 / kZU) load_y(0, grp + 1, yB);
+                    else load_y(1, 0, yB);               // the next tile's first group
                     z_dense(fullv, grp, yA);
 #pragma unroll
                     for (int j = 0; j < kZU; ++j) yA[j] = yB[j];
@@ -707,6 +716,9 @@ __global__ __launch_bounds__(64 * kWR2) void heads_fused_h2_kernel(HeadsArgs2 p)
             lacc = 0.f;
             qn = 0;
             dmax = 0.f;
+#if defined(DCA_EXP_PHASEPRIO)
+            __builtin_amdgcn_s_setprio(0);
+#endif
 #ifdef DCA_HEADS_TIMING
             tsparse = 0;
 #endif
@@ -721,12 +733,15 @@ __global__ __launch_bounds__(64 * kWR2) void heads_fused_h2_kernel(HeadsArgs2 p)
             const int need = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_frexp_expf(mx) - 1 - kTop);    // mx 2^-need < 2^(kTop + 1)
             if (!(need > 0) || kDe < kDt - 200) break;
             kDe -= need > 100 ? 100 : need;
-            load_y(srow_l, 0, yA);                   // the pass consumed the counts of its first group, F its first operands,
+            load_y(0, 0, yA);                        // the pass consumed the counts of its first group, F its first operands,
             load_ha(t, 0, ha0);                      // and the cells hold pieces: once more from the products
             wave_sync();
             }   // F + Z (until the scale fits)
             dacc += (double)lacc;
             const float sf_n = p.sf[srow_n];
+#if defined(DCA_EXP_PHASEPRIO)
+            __builtin_amdgcn_s_setprio(2);
+#endif
             wave_sync();
             TSTAMP(4)
             const int shift = kDt - kDe;
@@ -861,6 +876,8 @@ __global__ __launch_bounds__(64 * kWR2) void heads_fused_h2_kernel(HeadsArgs2 p)
             srow_l = srow_n;
             sf_l = sf_n;
             eHt = eHn;
+            if (lane < 32) Sft[l31] = sf_n;          // (the pass over this tile is over: its size factors are no longer read)
+            rb ^= 1;
             wave_sync();
             TSTAMP(6)
         }

@@ -103,7 +103,7 @@ class EventProfiler:
         out = {}
         for k, lst in self.ev.items():
             ms = [s.elapsed_time(e) for s, e in lst]
-            out[k] = {'count': len(ms), 'mean_ms': float(np.mean(ms)), 'total_ms': float(np.sum(ms))}
+            out[k] = {'count': len(ms), 'mean_ms': float(np.mean(ms)), 'median_ms': float(np.median(ms)), 'total_ms': float(np.sum(ms))}
         return out
 
 

@@ -120,7 +120,8 @@ def test_gemm_h2_static_exponent_and_unsupported_shapes(ops):
     pg = torch.zeros(2, K, N, dtype=torch.float16, device='cuda')
     ops.split_planes_h2(gs, N, K, N, pg, None)                          # ... unscaled by the split (exp NULL: 0)
     C = torch.zeros(M, N, device='cuda')
-    ops.gemm_h2(0, 0, M, N, K, pa, pg, C, N, exp_a=ea, exp_b_add=2, alpha=1.0 / 1024, ws=None)
+    ws = torch.zeros(max(ops.gemm_h2_workspace_bytes(M, N, K, False, 0) // 4, 4), device='cuda')
+    ops.gemm_h2(0, 0, M, N, K, pa, pg, C, N, exp_a=ea, exp_b_add=2, alpha=1.0 / 1024, ws=ws)
     ref = (a.astype(np.float64) @ g.astype(np.float64)) / 1024
     mag = (np.abs(a).astype(np.float64) @ np.abs(g).astype(np.float64)) / 1024
     assert (np.abs(C.cpu().numpy() - ref) <= TOL * mag).all()

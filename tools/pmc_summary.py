@@ -4,7 +4,8 @@ utilisation figures DESIGN.md quotes.
   python tools/pmc_summary.py <dir with p*/..counter_collection.csv> [out.csv]
 
 MfmaUtil  = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 256 CUs x 4 SIMDs)        (gfx94x formula; busy cycles
-            = 64 per v_mfma_f32_32x32x2_f32, cross-checked against SQ_INSTS_MFMA x 64)
+            = 64 per v_mfma_f32_32x32x2_f32 -- the `from_insts` column assumes that instruction; the 16-bit
+            v_mfma_f32_32x32x16_{bf16,f16} of rounds 2-6 occupy the pipe 32 cycles each: halve that column for them)
 VALUBusy  = SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x 1024)                       (quad-cycle units)
 """
 import csv
@@ -73,7 +74,7 @@ def main():
         import bench
         pick = {}
         for r in rows:
-            for key, pat in (('heads_fused', 'heads_fused_x3_kernel'), ('gemm_heads_fwd', 'gemm_p3w_kernel')):
+            for key, pat in (('heads_fused', 'heads_fused_h2_kernel'), ('gemm_heads_fwd', 'gemm_h2w_kernel')):
                 if pat in r['kernel'] and r.get('SQ_INSTS_VALU') not in ('', None) and \
                         (key not in pick or r['wall_ns'] > pick[key]['wall_ns']):
                     pick[key] = {'kernel': r['kernel'], 'wall_ns': r['wall_ns'], 'clock_GHz': r.get('clock_GHz'),
