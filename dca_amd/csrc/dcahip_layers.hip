@@ -613,37 +613,87 @@ struct SmallChainArgs {
 template <int RPT>
 __global__ __launch_bounds__(256) void hidden_small_chain_kernel(SmallChainArgs a) {
     __shared__ __attribute__((aligned(16))) float Hs[kFusedRows][kSmallK + 4];
-    __shared__ float Ws[2][kSmallK][64];        // kernel of the current stage / of the next one (requested a stage ahead)
+    __shared__ float Ws[2][kSmallK][64];        // kernels of two consecutive stages (stage st's in Ws[st & 1])
+    __shared__ float Ps[kChainMax][4][64];      // per-column inputs of every stage: bias, moving mean, moving variance, beta
     __shared__ float sm[256];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int c = tx;
-    if (a.l[0].W) small_operands_to_lds<RPT>(a.l[0].W, a.l[0].ldw, a.l[0].K, a.l[0].H, 0, a.Hin, a.ldin, a.B, Ws[0], Hs);
+    // ---- EVERYTHING the launch reads that does not depend on its own results is requested here, in one batch: the kernels of
+    // the first two stages that have one, every stage's per-column inputs (wave w takes stage w), the first stage's input.
+    // One memory round trip in front of the chain instead of one per stage (each was exposed: a stage's arithmetic is shorter
+    // than a trip to HBM) -- the launch is a chain of dependent latencies, nothing else.
+    const int s0 = a.l[0].W ? 0 : 1;             // first stage with a kernel (stage 0 may only normalise the first layer's product)
+    float wa[16], wb[16];
+    {
+        const SmallLayer& A0 = a.l[s0 < a.n ? s0 : 0];
+        const SmallLayer& A1 = a.l[s0 + 1 < a.n ? s0 + 1 : 0];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int idx = threadIdx.x + 256 * u, k = idx >> 6, cc = idx & 63;
+            wa[u] = (s0 < a.n) ? A0.W[(long)(k < A0.K ? k : A0.K - 1) * A0.ldw + (cc < A0.H ? cc : A0.H - 1)] : 0.f;
+            wb[u] = (s0 + 1 < a.n) ? A1.W[(long)(k < A1.K ? k : A1.K - 1) * A1.ldw + (cc < A1.H ? cc : A1.H - 1)] : 0.f;
+        }
+    }
+    float pin[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ty < a.n) {
+        const SmallLayer& P = a.l[ty];
+        const int cc = tx < P.H ? tx : P.H - 1;
+        if (P.W) pin[0] = P.bias[cc];
+        if (a.batchnorm) { pin[1] = P.mm[cc]; pin[2] = P.mv[cc]; if (P.beta) pin[3] = P.beta[cc]; }
+    }
+    float z0[RPT];                               // stage 0 without a kernel: its Z; with one: its input rows
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        if (a.l[0].W) {
+            const int idx = threadIdx.x + 256 * k, r = idx >> 6, kk = idx & 63;
+            z0[k] = a.Hin[(long)(r < a.B ? r : a.B - 1) * a.ldin + (kk < a.l[0].K ? kk : a.l[0].K - 1)];
+        } else {
+            const int i = ty + 4 * k;
+            z0[k] = a.l[0].Z[(long)(i < a.B ? i : a.B - 1) * a.l[0].ldz + (c < a.l[0].H ? c : a.l[0].H - 1)];
+        }
+    }
+    {
+        const int K0 = a.l[s0 < a.n ? s0 : 0].K, H0 = a.l[s0 < a.n ? s0 : 0].H;
+        const int K1 = a.l[s0 + 1 < a.n ? s0 + 1 : 0].K, H1 = a.l[s0 + 1 < a.n ? s0 + 1 : 0].H;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int idx = threadIdx.x + 256 * u, k = idx >> 6, cc = idx & 63;
+            if (s0 < a.n) Ws[s0 & 1][k][cc] = (k < K0 && cc < H0) ? wa[u] : 0.f;
+            if (s0 + 1 < a.n) Ws[(s0 + 1) & 1][k][cc] = (k < K1 && cc < H1) ? wb[u] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) Ps[ty][q][tx] = pin[q];
+    if (a.l[0].W) {
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int idx = threadIdx.x + 256 * k, r = idx >> 6, kk = idx & 63;
+            Hs[r][kk] = kk < a.l[0].K ? z0[k] : 0.f;
+        }
+    }
+    __syncthreads();
 #pragma unroll 1
     for (int st = 0; st < a.n; ++st) {
         const SmallLayer& L = a.l[st];
         const bool cv = c < L.H;
-        // everything this stage reads from memory is requested here: the NEXT stage's kernel (it does not depend on
-        // this stage) and the per-column inputs; the activations travel from stage to stage through LDS
-        const bool has_next = st + 1 < a.n;
-        const SmallLayer& Nx = a.l[has_next ? st + 1 : st];
+        // the kernel of the stage after the next (buffers: two): requested now, stored when this stage's products are done
+        const bool has_n2 = st >= s0 && st + 2 < a.n;
+        const SmallLayer& Nx = a.l[has_n2 ? st + 2 : st];
         float wn[16];
-        if (has_next) {
+        if (has_n2) {
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 const int idx = threadIdx.x + 256 * u, k = idx >> 6, cc = idx & 63;
                 wn[u] = Nx.W[(long)(k < Nx.K ? k : Nx.K - 1) * Nx.ldw + (cc < Nx.H ? cc : Nx.H - 1)];
             }
         }
-        const int cc_ = cv ? c : L.H - 1;
-        const float mm_in = a.batchnorm ? L.mm[cc_] : 0.f, mv_in = a.batchnorm ? L.mv[cc_] : 0.f;
-        const float beta_in = (a.batchnorm && L.beta) ? L.beta[cc_] : 0.f;
+        const float mm_in = Ps[st][1][tx], mv_in = Ps[st][2][tx], beta_in = Ps[st][3][tx];
         float z[RPT];
         if (L.W) {
             const int K4 = (L.K + 3) & ~3;
-            const float b = cv ? L.bias[cc_] : 0.f;
+            const float b = cv ? Ps[st][0][tx] : 0.f;
 #pragma unroll
             for (int k = 0; k < RPT; ++k) z[k] = b;
-            __syncthreads();            // Ws[st & 1] and Hs (the previous stage's output) are complete
             const float (*Wc)[64] = Ws[st & 1];
 #pragma unroll 1
             for (int kk = 0; kk < K4; kk += 4) {
@@ -660,16 +710,13 @@ __global__ __launch_bounds__(256) void hidden_small_chain_kernel(SmallChainArgs 
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < RPT; ++k) {
-                const int i = ty + 4 * k;
-                z[k] = L.Z[(long)(i < a.B ? i : a.B - 1) * L.ldz + cc_];
-            }
+            for (int k = 0; k < RPT; ++k) z[k] = z0[k];
         }
         float hout[RPT];
         if (!a.batchnorm) {
 #pragma unroll
             for (int k = 0; k < RPT; ++k) hout[k] = act_fwd(a.act, z[k]);
-            __syncthreads();            // every thread is done reading Hs
+            __syncthreads();            // every thread is done reading Hs and Ws[st & 1]
         } else {
             float s = 0.f;
 #pragma unroll
@@ -700,14 +747,15 @@ __global__ __launch_bounds__(256) void hidden_small_chain_kernel(SmallChainArgs 
             if (cv && i < a.B) L.Hout[(long)i * L.ldh + c] = hout[k];
             Hs[i][c] = cv ? hout[k] : 0.f;          // the next stage's input (columns beyond this layer's width: zero)
         }
-        if (has_next) {
-            float (*Wn)[64] = Ws[(st + 1) & 1];
+        if (has_n2) {
+            float (*Wn)[64] = Ws[st & 1];            // (this stage's kernel: every thread is past its products -- the barriers above)
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 const int idx = threadIdx.x + 256 * u, k = idx >> 6, cc = idx & 63;
                 Wn[k][cc] = (k < Nx.K && cc < Nx.H) ? wn[u] : 0.f;
             }
         }
+        __syncthreads();                // Hs (and a replaced kernel) complete before the next stage reads them
     }
 }
 

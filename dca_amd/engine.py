@@ -1308,20 +1308,28 @@ class Engine:
                 s = torch.zeros(2 * lay.hidden[i], dtype=torch.float32, device=self.dev)
                 self.comm.all_reduce_sum(s)
 
+    def heads_fused_launch(self, B, KL, inv_n):
+        """K-HEADS on the decoder output the last forward pass left (ops.heads_fused: the H split, the fused kernel, the reduce).
+        Idempotent -- it overwrites the heads' gradient block, the input gradient and the loss slot -- so bench.py can replay it
+        from a graph to time the operation as the product launches it."""
+        lay, w, g = self.lay, self.w, self.g
+        self.ops.heads_fused(self._hl[0], self._hl[1], lay.view(w, 'Wh'), lay.NH,
+                             lay.view(w, 'bh'), lay.Gp,
+                             lay.view(w, 'theta_w') if lay.const_disp else None, self.Y,
+                             self.ldy, self.sf, self.perm, self.cursor, B, KL, lay.G_out,
+                             self.ridge, inv_n, self.flags, lay.view(g, 'Wh'), lay.NH,
+                             lay.view(g, 'theta_w') if lay.const_disp else None,
+                             self._dhl, self._hl[1], self.partials, self.ws_heads,
+                             tile_order=self.tile_order, loss_out=g[lay.P:], **self._heads_compact())
+
     def _forward_backward(self, B, Bg, inv_n):
         lay, ops, comm = self.lay, self.ops, self.comm
         w, g = self.w, self.g
         KL = self._hidden_forward(B, ('perm',), True, self.counts_world)
+        self._last_heads_args = (B, KL, inv_n)
         if self.ws_heads is not None:
             with self._t('heads_fused'):
-                ops.heads_fused(self._hl[0], self._hl[1], lay.view(w, 'Wh'), lay.NH,
-                                    lay.view(w, 'bh'), lay.Gp,
-                                    lay.view(w, 'theta_w') if lay.const_disp else None, self.Y,
-                                    self.ldy, self.sf, self.perm, self.cursor, B, KL, lay.G_out,
-                                    self.ridge, inv_n, self.flags, lay.view(g, 'Wh'), lay.NH,
-                                    lay.view(g, 'theta_w') if lay.const_disp else None,
-                                    self._dhl, self._hl[1], self.partials, self.ws_heads,
-                                    tile_order=self.tile_order, loss_out=g[lay.P:], **self._heads_compact())
+                self.heads_fused_launch(B, KL, inv_n)
         else:
             self._heads_backward_unfused(B, KL, inv_n)
         self._launch_heads_bucket()
