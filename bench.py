@@ -755,6 +755,7 @@ def main():
                        'exposed_comm_source': ('8 eager steps before the timed region: events round each exchange (and each wait for '
                                                'the asynchronous bucket) on the compute stream') if multi else None,
                        'optimizer': 'RMSprop+clipvalue', 'params': int(eng.lay.P),
+                       'heads_d_exp': int(getattr(eng, 'heads_d_exp', 0)),
                        'arithmetic': 'fp32 results.  Heads (K-HEADS; the wide networks\' plane products): operands block-scaled by a '
                                      'power of two and split into two fp16 pieces, three products, fp32 accumulation; first layer from '
                                      'the byte store and the hidden stack: three bf16 pieces, six products (fp32-dot-product accuracy: '

@@ -52,6 +52,35 @@ def test_single_step_matches_oracle(ops, ae_type, batchnorm, n, G, hs, B):
             np.testing.assert_allclose(newp['mv%d' % i], ref.p['mv%d' % i], rtol=1e-4, atol=1e-6)
 
 
+def test_large_counts_start_k_heads_at_a_lower_gradient_exponent(ops):
+    """Counts in the hundreds throughout the matrix (full-length protocols): the engine hands K-HEADS a negative d_exp from a
+    sample of the counts (every 32 x 32 tile would otherwise repeat its forward product and likelihood pass); the step stays
+    inside the tolerances of test_single_step_matches_oracle.  UMI-like counts keep 0."""
+    n, G, hs, B = 300, 203, (64, 32, 64), 96
+    X, Y, sf, p = make_problem(n, G, hs, 'zinb-conddisp', True, seed=5)
+    rng = np.random.RandomState(3)
+    Yu = rng.poisson(0.3, Y.shape).astype(Y.dtype)                             # UMI-like: one count in 20 000 above 4
+    eng0 = make_engine(ops, 'zinb-conddisp', G, hs, True, 0.03, p, X, Yu, sf)
+    assert eng0.heads_d_exp == 0
+    Yb = (Y * 0 + rng.poisson(400.0, Y.shape)).astype(Y.dtype)                 # every count around 400
+    sfb = (Yb.sum(1) / np.median(Yb.sum(1))).astype(sf.dtype)
+    Xb = np.log1p(Yb / sfb[:, None]); Xb = ((Xb - Xb.mean(0)) / (Xb.std(0) + 1e-9)).astype(X.dtype)
+    rows = rng.permutation(n)[:B]
+    ref = oracle_net('zinb-conddisp', p, hs, True, 0.03)
+    rl, rg = ref.loss_and_grads(Xb[rows].astype(np.float64), Yb[rows].astype(np.float64), sfb[rows].astype(np.float64))
+    eng = make_engine(ops, 'zinb-conddisp', G, hs, True, 0.03, p, Xb, Yb, sfb)
+    assert -6 <= eng.heads_d_exp <= -2, eng.heads_d_exp
+    loss, g, _ = run_single_step(eng, rows)
+    assert abs(loss - rl) < 1e-5 * abs(rl), (loss, rl)
+    assert_grads_close(g, rg)
+    # the same step with the exponent forced back to 0 (every tile takes the repeat path): same results to the tolerances
+    eng2 = make_engine(ops, 'zinb-conddisp', G, hs, True, 0.03, p, Xb, Yb, sfb)
+    eng2.heads_d_exp = 0
+    loss0, g0, _ = run_single_step(eng2, rows)
+    assert abs(loss0 - rl) < 1e-5 * abs(rl)
+    assert_grads_close(g0, rg)
+
+
 def _golden_fit():
     import os
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'fit_c2_oracle.npz'))
