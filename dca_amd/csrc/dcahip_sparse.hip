@@ -761,7 +761,10 @@ __global__ __launch_bounds__(64 * kD2Waves) __attribute__((amdgpu_waves_per_eu(2
                     if constexpr ((i & 1) == 1) asm volatile("" : "+v"(An[M][Q]));
                 }
             });
-            retire(min(k + kD2Lead, nsteps - 1) - (k + 2));   // step k + 2 has landed (mine); the LDS reads of stage sk are in registers
+            retire(min(k + kD2Lead, nsteps - 1) - (k + 2));   // step k + 2 has landed (mine)
+            // the LDS reads of stage sk (six dZ fragments, the storage row) are in registers BEFORE another wave may refill that
+            // stage behind the barrier: LDS reads return in order, the sixteen count reads of stage sn issued last may stay in flight
+            asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");
 #ifndef DCA_EXP_DW2_NOBARRIER
             __builtin_amdgcn_s_barrier();
 #endif
