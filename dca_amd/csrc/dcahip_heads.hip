@@ -128,7 +128,11 @@ __device__ __forceinline__ void split8(const float (&x)[8], u32x4 (&f)[2]) {
     }
 }
 // the three products of one K = 16 step, small terms first
+#ifdef DCA_EXP_H2_TWO      // experiment (must FAIL the parity tests: tools/gpu_heads_narrow_check.sh): the A operand's second piece dropped
+#define MFMA_H3(A, Bf, ACC) { ACC = MFMAH(A[0], Bf[1], ACC); ACC = MFMAH(A[0], Bf[0], ACC); }
+#else
 #define MFMA_H3(A, Bf, ACC) { ACC = MFMAH(A[1], Bf[0], ACC); ACC = MFMAH(A[0], Bf[1], ACC); ACC = MFMAH(A[0], Bf[0], ACC); }
+#endif
 
 __device__ __forceinline__ float pow2i(int e) { return __uint_as_float((unsigned)(127 + e) << 23); }      // -126 <= e <= 127
 // the exponent that brings a block's largest magnitude m into [2^kTop, 2^(kTop + 1)); 0 for an all-zero block

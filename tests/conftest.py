@@ -11,8 +11,8 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
-    # DCA_AMD_TEST_LIB: run the suite against an experiment build of the HIP library (tools/gpu_heads_bwd3_check.sh shows
-    # that the parity tests reject a three-product build) -- test infrastructure, the product always loads its own library
+    # DCA_AMD_TEST_LIB: run the suite against an experiment build of the HIP library (tools/gpu_heads_narrow_check.sh shows
+    # that the parity tests reject a build with one matrix product fewer per fp32 product) -- test infrastructure, the product always loads its own library
     lib = os.environ.get('DCA_AMD_TEST_LIB')
     if lib:
         from dca_amd import build as _b

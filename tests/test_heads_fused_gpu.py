@@ -131,14 +131,16 @@ def run_case(ops, flags, B, G, hL, seed, ridge=0.0, use_perm=True, odd_counts=Fa
 def product_tol(key, rows):
     """Bound on |C - A B| / sum|a b| for the two backward matrix products of K-HEADS (dW = H^T D: keys gW_*, dH = D W^T), by
     the number of batch rows of the case.  What the bound carries: the products themselves (arithmetic contract
-    dcahip_x3_product_32x32: six bf16 products = an fp32 dot product, <= 5e-7) and the fp32 likelihood arithmetic behind D
-    (fast exp / log / rcp: up to ~3e-6 relative on single elements, 1e-7 typical -- it dominates where a sum has few terms).
-    Measured over every case of this file (profiles/r04g_heads_product_ratios.txt), six products | three products
-    (-DDCA_EXP_BWD3, tools/gpu_heads_bwd3_check.sh):
+    dcahip_x3_product_32x32: two fp16 pieces of block-scaled operands, three products = an fp32 dot product, <= 5e-7) and the
+    fp32 likelihood arithmetic behind D (fast exp / log / rcp: up to ~3e-6 relative on single elements, 1e-7 typical -- it
+    dominates where a sum has few terms).  The bounds are the ones the six-product bf16 kernel of rounds 2 - 5 was held to
+    (measured then, six | three bf16 products, profiles/r04g_heads_product_ratios.txt:
         dH, up to 260 rows   <= 4.0e-7 | >= 3.2e-6        gW, fewer than 96 rows  <= 4.0e-6 | >= 6.3e-6
-        dH, 4 096 rows       <= 7.2e-8 | >= 3.9e-7        gW, 96 rows and more    <= 9.9e-7 | >= 2.5e-6
-    Each bound sits between the two columns: every case of this file rejects a three-product build, which the 2e-4
-    relative tolerance of check() alone would not notice."""
+        dH, 4 096 rows       <= 7.2e-8 | >= 3.9e-7        gW, 96 rows and more    <= 9.9e-7 | >= 2.5e-6).
+    Round 6's kernel passes them with three fp16 products; a build with TWO (-DDCA_EXP_H2_TWO: one operand's second piece
+    dropped, 2^-11 instead of 2^-22) fails every case of this file and the golden-vector cases that go through the kernel --
+    39 of 39 (tools/gpu_heads_narrow_check.sh, profiles/r06n_heads_two_product_rejection.txt) -- which the 2e-4 relative
+    tolerance of check() alone would not notice."""
     if key == 'dH':
         return 2e-7 if rows >= 4096 else 1e-6
     return 1.5e-6 if rows >= 96 else 5e-6
