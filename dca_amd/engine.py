@@ -615,7 +615,9 @@ class Engine:
         gradient repeats its forward product and likelihood pass with the exponent it needs (exact, ~1.6 x the tile's time).
         Counts in the hundreds THROUGHOUT the matrix (full-length protocols) would make every tile repeat: start lower instead.
         From a sample of the counts: the count c that one element in 20 000 exceeds (1 tile in 20 holds such an element), with
-        |g| <~ 2 c.  UMI data (the benchmark matrices: c < 58) keeps 0."""
+        |g| <~ 2 c.  UMI data (the benchmark matrices: c < 58) keeps 0.  Rank-local on purpose (attach is not a collective:
+        predict may run on one rank): data-parallel ranks may start at different exponents, which moves their gradients within
+        the products' tolerance only."""
         Y = self.Y
         if Y is None or not getattr(Y, 'is_cuda', False) or Y.numel() == 0:
             return 0
