@@ -1016,10 +1016,10 @@ struct GemmH2Args {
     float alpha;
 };
 
-template <bool KC>
+template <bool KC, int NCH = 8>                             // NCH: 1 KB chunks per plane (8: 256 rows / columns; 4: 128, k-contiguous only)
 struct WideImageH {
     static constexpr int CHUNK = KC ? 1024 : 1088;         // bytes between the LDS destinations of consecutive waves
-    static constexpr int PLANE = 8 * CHUNK;
+    static constexpr int PLANE = NCH * CHUNK;
     static constexpr int BYTES = 2 * PLANE;
     // Fragment reads are ISSUED here (inline asm: the compiler neither reorders them nor guards them with a vmcnt(0)
     // against the LDS-DMA requests in flight) and RETIRED by the caller with a counted s_waitcnt lgkmcnt.
@@ -1211,6 +1211,115 @@ __global__ __launch_bounds__(512) void gemm_h2w_kernel(GemmH2Args p) {
     }
 }
 
+
+// The same products from 128 x 256 tiles by FOUR waves (A k-contiguous only: forward products and input gradients), two
+// workgroups per CU (76 KB of LDS each): a workgroup's epilogue -- 128 KB of fp32 through dword stores, during which its waves issue
+// no matrix instruction -- runs beside the other workgroup's K loop instead of idling the CU (one 8-wave workgroup per CU: 40 us of
+// a 98 us tile at K = 512).  The wave's work is that of gemm_h2w_kernel (128 x 64 per wave, the same fragment reads and product
+// order); the B image (256 columns) is requested by 256 threads in two halves.
+template <bool B_KC>
+__global__ __launch_bounds__(256, 2) void gemm_h2m_kernel(GemmH2Args p) {      // (two waves per SIMD: two workgroups per CU)
+    using IA = WideImageH<true, 4>;
+    using IB = WideImageH<B_KC, 8>;
+    constexpr int STAGE = IA::BYTES + IB::BYTES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    int id = blockIdx.x;
+    const int s = id % p.split; id /= p.split;
+    const int kbeg = s * p.kslab, kend = min(p.K, kbeg + p.kslab);
+    const int nt = id % p.ntiles, mt = id / p.ntiles;
+    const int m0 = mt * 128, n0 = nt * 256;
+    const int nsteps = (kend - kbeg) / kWBK;
+
+    const unsigned short* ga = p.A + IA::src_off(t, p.lda, m0, p.M) + (long)kbeg;
+    const unsigned short* gb0 = p.B + IB::src_off(t, p.ldb, n0, p.N) + (B_KC ? (long)kbeg : (long)kbeg * p.ldb);
+    const unsigned short* gb1 = p.B + IB::src_off(t + 256, p.ldb, n0, p.N) + (B_KC ? (long)kbeg : (long)kbeg * p.ldb);
+    const long sa = (long)kWBK, sb = B_KC ? (long)kWBK : (long)kWBK * p.ldb;
+    const int wa = wave * IA::CHUNK, wb0 = IA::BYTES + wave * IB::CHUNK, wb1 = IA::BYTES + (wave + 4) * IB::CHUNK;
+
+    auto request = [&](int stage) __attribute__((always_inline)) {
+        unsigned char* st = lds + stage * STAGE;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga + q * p.pa),
+                                             (__attribute__((address_space(3))) void*)(st + q * IA::PLANE + wa), 16, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb0 + q * p.pb),
+                                             (__attribute__((address_space(3))) void*)(st + q * IB::PLANE + wb0), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb1 + q * p.pb),
+                                             (__attribute__((address_space(3))) void*)(st + q * IB::PLANE + wb1), 16, 0, 0);
+        }
+        ga += sa; gb0 += sb; gb1 += sb;
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int wn0 = wave * 64;
+    const unsigned aoff = IA::lane_off(0, lane), boff = IB::lane_off(wn0, lane);
+
+    if (nsteps > 0) request(0);
+    if (nsteps > 1) request(1);
+    int cur = 0, nxt = 2;
+#pragma unroll 1
+    for (int k = 0; k < nsteps; ++k) {
+        if (k + 1 < nsteps) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const unsigned sa_ = (unsigned)(cur * STAGE) + aoff, sb_ = (unsigned)(cur * STAGE + IA::BYTES) + boff;
+        const int rq = nxt;
+        cur = cur == 2 ? 0 : cur + 1; nxt = nxt == 2 ? 0 : nxt + 1;
+        u32x4 b[2][2], a[2][2];
+        IB::template issue<0, 0>(b[0][0], sb_); IB::template issue<1, 0>(b[0][1], sb_);
+        IB::template issue<0, 1>(b[1][0], sb_); IB::template issue<1, 1>(b[1][1], sb_);
+        IA::template issue<0, 0>(a[0][0], sa_); IA::template issue<1, 0>(a[0][1], sa_);
+#define DCA_TIE4(x) "+v"(x[0][0]), "+v"(x[0][1]), "+v"(x[1][0]), "+v"(x[1][1])
+#define DCA_WAIT_LGKM(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" : DCA_TIE4(a), DCA_TIE4(b))
+#define DCA_PRODUCTS(I, AI) do { _Pragma("unroll") for (int pr = 0; pr < 3; ++pr) { \
+            constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0}; \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[I][j] = MFMAH2(a[AI][PA[pr]], b[j][PB[pr]], acc[I][j]); } } while (0)
+        IA::template issue<0, 1>(a[1][0], sa_); IA::template issue<1, 1>(a[1][1], sa_);
+        DCA_WAIT_LGKM(2);
+        DCA_PRODUCTS(0, 0);
+        if (k + 2 < nsteps) request(rq);
+        IA::template issue<0, 2>(a[0][0], sa_); IA::template issue<1, 2>(a[0][1], sa_);
+        DCA_WAIT_LGKM(2);
+        DCA_PRODUCTS(1, 1);
+        IA::template issue<0, 3>(a[1][0], sa_); IA::template issue<1, 3>(a[1][1], sa_);
+        DCA_WAIT_LGKM(2);
+        DCA_PRODUCTS(2, 0);
+        DCA_WAIT_LGKM(0);
+        DCA_PRODUCTS(3, 1);
+#undef DCA_PRODUCTS
+#undef DCA_WAIT_LGKM
+#undef DCA_TIE4
+    }
+
+    const int ea = (p.exp_a ? *p.exp_a : 0) + p.exp_a_add, eb = (p.exp_b ? *p.exp_b : 0) + p.exp_b_add;
+    const float un = p.alpha * h2_pow2i(-(ea + eb));
+    float* out = p.split > 1 ? p.ws + (long)s * p.M * p.N : p.C;
+    const long ldo = p.split > 1 ? (long)p.N : p.ldc;
+    const bool add_bias = p.split == 1 && p.bias != nullptr;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn0 + j * 32 + (lane & 31);
+        const float bv = (add_bias && n < p.N) ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < p.M && n < p.N) out[(long)m * ldo + n] = fmaf(acc[i][j][r], un, bv);
+            }
+        }
+    }
+}
 
 // |x| maxima of a matrix as the bits of a non-negative float (order-preserving as unsigned): atomicMax is deterministic.
 // One atomic per WORKGROUP, and only when it can raise the word (the plain read is a filter: the word only grows, so a stale
@@ -1681,6 +1790,36 @@ extern "C" int dcahip_gemm_h2(int ta, int tb, int M, int N, int K, const void* A
                  C, bias, static_cast<float*>(workspace), ldc, M, N, K, p.split, p.kslab, colsum_row,
                  p.mtiles, p.ntiles, tp.first, tp.split, tp.kslab, static_cast<float*>(workspace), exp_a, exp_b, exp_a_add, exp_b_add, alpha};
     hipStream_t s = static_cast<hipStream_t>(stream);
+#ifndef DCA_EXP_H2_NOHALFM
+    if (!ta && !tb && !colsum_row) {
+        // forward products (A k-contiguous, B n-contiguous): 128 x 256 tiles by four waves, two workgroups per CU
+        // (gemm_h2m_kernel).  Measured at configs[4] (tools/ab_heads_lib.py, one box): heads forward 0.87 - 0.90 -> 0.73 - 0.74 ms,
+        // first layer forward (split-K) 0.368 -> 0.362; the input gradient (B k-contiguous, split-K) 0.50 -> 0.64: stays on
+        // the 8-wave kernel
+        GemmH2Args h = a;
+        h.mtiles = (M + 127) / 128;
+        h.tail_first = 0; h.tail_split = 1;
+        const int gridm = h.mtiles * h.ntiles * h.split;
+#define DCA_M(BKC) do { \
+            constexpr int bytes = 3 * (WideImageH<true, 4>::BYTES + WideImageH<BKC, 8>::BYTES); \
+            static bool set = false; \
+            if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h2m_kernel<BKC>), \
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, bytes); set = true; } \
+            hipLaunchKernelGGL((gemm_h2m_kernel<BKC>), dim3(gridm), dim3(256), bytes, s, h); } while (0)
+        DCA_M(false);
+#undef DCA_M
+        int rcm = (int)hipGetLastError();
+        if (rcm != 0) return rcm;
+        if (h.split > 1) {
+            const long total = (long)M * N;
+            long g = (total + 255) / 256;
+            if (g > 4096) g = 4096;
+            hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3((int)g), dim3(256), 0, s, h.ws, h.split, M, N, bias, M, C, ldc);
+            rcm = (int)hipGetLastError();
+        }
+        return rcm;
+    }
+#endif
     int grid = p.mtiles * p.ntiles * p.split;
     if (tp.split > 1) grid = tp.first + (p.mtiles * p.ntiles - tp.first) * tp.split;
 #define DCA_W(AKC, BKC, CSV) do { \
