@@ -109,9 +109,12 @@ def _graph_timed(fn, n=10, reps=5):
     import torch
     fn(); torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.graph(g, stream=st, capture_error_mode='thread_local'):        # (RCCL's watchdog thread: see capture_step)
         for _ in range(n):
             fn()
+    torch.cuda.current_stream().wait_stream(st)
     g.replay(); torch.cuda.synchronize()
     out = []
     for _ in range(reps):
@@ -630,7 +633,7 @@ def main():
     # launches reads 0.76 - 0.79 ms that way against 0.70 ms for the same three kernels under rocprofv3.)
     graph_ms = {}
     last = getattr(eng, '_last_heads_args', None)
-    if last is not None and last[0] == B:
+    if last is not None and last[0] == B and not multi:       # (one process only: nothing new is captured beside live communicators)
         try:
             if eng.ws_heads is not None:
                 graph_ms['heads_fused'] = _graph_timed(lambda: eng.heads_fused_launch(*last))

@@ -623,7 +623,7 @@ class Engine:
             return 0
         rows = min(Y.shape[0], max(1, (1 << 24) // max(1, Y.shape[1])))
         samp = Y[:: max(1, Y.shape[0] // rows)][:rows, :self.lay.G_out]
-        cnt = torch.bincount(samp.clamp(0, 65535.0).to(torch.int64).reshape(-1), minlength=2)
+        cnt = torch.bincount(torch.nan_to_num(samp, nan=0.0).clamp(0, 65535.0).to(torch.int64).reshape(-1), minlength=2)
         tail = torch.flip(torch.cumsum(torch.flip(cnt, [0]), 0), [0]).to(torch.float64) / float(samp.numel())    # P(y >= c)
         over = torch.nonzero(tail > 5e-5)
         c = float(over.max().item()) if over.numel() else 0.0
