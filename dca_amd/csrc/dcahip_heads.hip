@@ -174,6 +174,7 @@ struct HeadsArgs2 {
     int S, NT;
     float ridge, inv_n;
     int d_exp;                        // kD0 = kDExp0 + d_exp (<= 0: datasets with counts beyond ~8 000)
+    int tile_base;                    // this launch takes the gene tiles tile_order[tile_base ..] (the tail launch: see make_heads_plan)
 };
 
 // the count behind an escape byte of the compact store (counts >= 255: rare)
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(64 * kWR2) void heads_fused_h2_kernel(HeadsArgs2 p)
     int s_opaque = s_wg;
     asm volatile("" : "+v"(s_opaque));       // opaque per round: what depends on it is recomputed, not kept live across rounds
     const int s = __builtin_amdgcn_readfirstlane(s_opaque);
-    const int gt = p.tile_order ? p.tile_order[gb] : gb;
+    const int gt = p.tile_order ? p.tile_order[gb + p.tile_base] : gb + p.tile_base;
     const int g0 = gt * kTG;
     const int gene = g0 + l31;
     const bool tile_ok = g0 < p.G;
@@ -999,21 +1000,39 @@ struct ReduceDwArgs {
     const float* ws; int S; long stride; int hL; long ldws, ncols; float* gW; long ldg;
     const float* theta_w; float* g_theta; int G;
     float scale;                       // the partials are sums of UNSCALED gradients (g units): 1 / n is applied here, once
+    // the gene tiles of the TAIL launch (make_heads_plan): their columns are summed from ws2 over S2 partials instead
+    const float* ws2; int S2; const int* tail_tiles; int ntail; long plane;
+    int tail_first;                    // tail_tiles == NULL (file order): the tail launch took the tiles tail_first .. tail_first + ntail - 1
 };
 
 // bid / nblk: this workgroup's index among the nblk that share the reduction (the stand-alone kernel: blockIdx / gridDim;
 // the combined launch below: the workgroups behind those of the dH reduction)
 __device__ __forceinline__ void reduce_dw_body(const ReduceDwArgs& q, int bid, int nblk) {
-    const float* ws = q.ws; const int S = q.S; const long stride = q.stride; const int hL = q.hL;
+    const int hL = q.hL;
     const long ldws = q.ldws, ncols = q.ncols; float* gW = q.gW; const long ldg = q.ldg;
     const float* theta_w = q.theta_w; float* g_theta = q.g_theta; const int G = q.G;
     const float sc = q.scale;
-    if ((ncols & 3) == 0 && (ldws & 3) == 0 && (ldg & 3) == 0 && (stride & 3) == 0 &&
-        ((reinterpret_cast<uintptr_t>(ws) | reinterpret_cast<uintptr_t>(gW)) & 15) == 0) {
-        // 16 bytes per lane (the plane width is a multiple of 4); partial s is added in order s = 0, 1, ..
+    // which gene tiles came from the tail launch (a bit per tile; kMaxGrid tiles at most)
+    __shared__ unsigned tailbm[kMaxGrid / 32];
+    if (q.ntail > 0) {
+        for (int i = threadIdx.x; i < kMaxGrid / 32; i += 256) tailbm[i] = 0u;
+        __syncthreads();
+        for (int i = threadIdx.x; i < q.ntail; i += 256) {
+            const int tl = q.tail_tiles ? q.tail_tiles[i] : q.tail_first + i;
+            if (tl >= 0 && tl < kMaxGrid) atomicOr(&tailbm[tl >> 5], 1u << (tl & 31));
+        }
+        __syncthreads();
+    }
+    auto is_tail = [&](long col_in_plane) { const int tl = (int)(col_in_plane / kTG); return q.ntail > 0 && ((tailbm[tl >> 5] >> (tl & 31)) & 1u); };
+    if ((ncols & 3) == 0 && (ldws & 3) == 0 && (ldg & 3) == 0 && (q.stride & 3) == 0 && (q.plane & 3) == 0 &&
+        ((reinterpret_cast<uintptr_t>(q.ws) | reinterpret_cast<uintptr_t>(gW) | reinterpret_cast<uintptr_t>(q.ws2)) & 15) == 0) {
+        // 16 bytes per lane (the plane width is a multiple of 4: a quad never straddles two gene tiles); partial s is added in
+        // order s = 0, 1, ..
         const long nq = ncols >> 2, totalq = (long)(hL + 1) * nq;
         for (long idx = (long)bid * 256 + threadIdx.x; idx < totalq; idx += (long)nblk * 256) {
             const long i = idx / nq, c = (idx - i * nq) << 2;
+            const bool tl = is_tail(c % q.plane);
+            const float* ws = tl ? q.ws2 : q.ws; const int S = tl ? q.S2 : q.S; const long stride = q.stride;
             float4 v = *reinterpret_cast<const float4*>(ws + i * ldws + c);
             for (int s = 1; s < S; ++s) {
                 const float4 x = *reinterpret_cast<const float4*>(ws + (long)s * stride + i * ldws + c);
@@ -1026,13 +1045,17 @@ __device__ __forceinline__ void reduce_dw_body(const ReduceDwArgs& q, int bid, i
         const long total = (long)(hL + 1) * ncols;
         for (long idx = (long)bid * 256 + threadIdx.x; idx < total; idx += (long)nblk * 256) {
             const long i = idx / ncols, c = idx - i * ncols;
+            const bool tl = is_tail(c % q.plane);
+            const float* ws = tl ? q.ws2 : q.ws; const int S = tl ? q.S2 : q.S;
             float v = 0.f;
-            for (int s = 0; s < S; ++s) v += ws[(long)s * stride + i * ldws + c];
+            for (int s = 0; s < S; ++s) v += ws[(long)s * q.stride + i * ldws + c];
             gW[i * ldg + c] = v * sc;
         }
     }
     if (g_theta) {
         for (long c = (long)bid * 256 + threadIdx.x; c < G; c += (long)nblk * 256) {
+            const bool tl = is_tail(c);
+            const float* ws = tl ? q.ws2 : q.ws; const int S = tl ? q.S2 : q.S; const long stride = q.stride;
             float v = 0.f;
             for (int s = 0; s < S; ++s) v += ws[(long)s * stride + (long)(hL + 1) * ldws + c];
             const float e = expf(theta_w[c]);
@@ -1048,6 +1071,7 @@ __global__ __launch_bounds__(256) void heads_reduce_dw_kernel(ReduceDwArgs q) { 
 struct ReduceDhArgs {
     const float* ws; int ntg, B, Bpad, KT, hL; float* dH; long lddh; float scale;
     const double* loss_partials; int n_partials; double loss_scale; float* loss_out;
+    const float* ws2; int ntg2;        // the tail launch's partials [row tile][ntg2][32][64] (ntg2 = 0: none), added behind the others
 };
 
 template <int GL>
@@ -1077,6 +1101,10 @@ __device__ __forceinline__ void reduce_dh_body(const ReduceDhArgs& q, int bid) {
 #pragma unroll
             for (int u = 0; u < 8; ++u)
                 if (gt0 + u * GL < ntg) { v.x += x[u].x; v.y += x[u].y; v.z += x[u].z; v.w += x[u].w; }
+        }
+        if (q.ntg2 > 0) {
+            const float4* src2 = reinterpret_cast<const float4*>(q.ws2) + t * q.ntg2 * tq + within;
+            for (int gt = gl; gt < q.ntg2; gt += GL) { const float4 x = src2[(long)gt * tq]; v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w; }
         }
     }
     red[threadIdx.x] = v;
@@ -1132,6 +1160,12 @@ struct HeadsPlan {
     int HLB, WR, S, NT, ntg, ngb, grid;
     int nitems, npart;                   // work items (S x gene tiles), dH partials per row tile
     long ldws, dw_stride, dw_bytes, dh_bytes, hs_bytes;
+    // TAIL launch (persistent kernel only; ntail = 0: none): the gene tiles a uniform plan would leave to a last, poorly filled
+    // round of workgroups -- tile_order[nmain ..] -- go to a second launch of the same kernel with S2 > S batch splits, so that
+    // the round they cost is a short one (25 000 genes at 4 096 rows: 782 tiles x 2 = 1 564 items = 6.1 rounds ran as 7;
+    // now 6 rounds + 14 tiles x 16 splits = 224 one-tile items).  Its partials live behind the main launch's.
+    int nmain, ntail, S2, grid2, npart2, nitems2;
+    long dh2_bytes, dw2_bytes;
 };
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -1179,10 +1213,39 @@ bool make_heads_plan(int B, int hL, int G, long plane, int flags, HeadsPlan* out
         if (p.grid > res) p.grid = res;
         p.npart = p.grid / p.S;
     }
+    p.nmain = p.ngb; p.ntail = 0; p.S2 = 0; p.grid2 = 0; p.npart2 = 0; p.nitems2 = 0;
+#ifndef DCA_EXP_NO_TAIL_LAUNCH
+    if (!p.small && p.S >= 2) {
+        const int full = p.ngb / p.npart, rem = p.ngb - full * p.npart;
+        const int tiles = (p.NT + p.S * p.WR - 1) / (p.S * p.WR);
+        if (full >= 1 && rem > 0) {
+            const double uniform = (double)(full + 1) * (tiles + item_cost);
+            double best2 = 1e300; int bestS = 0;
+            for (int S2 = 2 * p.S; S2 <= smax && (long)S2 * rem <= kMaxGrid; S2 *= 2) {
+                const long items2 = (long)S2 * rem;
+                const long rounds2 = (items2 + kCUs - 1) / kCUs;
+                const int tiles2 = (p.NT + S2 * p.WR - 1) / (S2 * p.WR);
+                const double c2 = (double)rounds2 * (tiles2 + item_cost);
+                if (c2 < best2 - 1e-9) { best2 = c2; bestS = S2; }
+            }
+            // (a second launch: its own prologue and ramp, priced at one tile)
+            if (bestS && (double)full * (tiles + item_cost) + best2 + 1.0 < uniform - 0.5) {
+                p.nmain = full * p.npart; p.ntail = rem; p.S2 = bestS;
+                p.nitems = p.S * p.nmain;                       // the main launch: whole rounds only
+                p.nitems2 = p.S2 * p.ntail;
+                const int res2 = kCUs / p.S2 * p.S2;
+                p.grid2 = p.nitems2 < res2 ? p.nitems2 : res2;
+                p.npart2 = p.grid2 / p.S2;
+            }
+        }
+    }
+#endif
     p.ldws = (long)NH * plane;
     p.dw_stride = (long)(hL + 2) * p.ldws;
     p.dw_bytes = (long)p.S * p.dw_stride * (long)sizeof(float);
     p.dh_bytes = (long)p.npart * p.NT * kTR * (p.HLB * 32) * (long)sizeof(float);
+    p.dw2_bytes = (long)p.S2 * p.dw_stride * (long)sizeof(float);
+    p.dh2_bytes = (long)p.npart2 * p.NT * kTR * (p.HLB * 32) * (long)sizeof(float);
     p.hs_bytes = 2L * p.NT * kHTile * 2 + (((long)p.NT * 4 + 15) & ~15L);      // split decoder output, both layouts + the tile exponents
     *out = p;
     return true;
@@ -1671,7 +1734,7 @@ extern "C" long dcahip_heads_fused_workspace_bytes(int B, int hL, int G, long pl
         const int b = nt * kTR < B ? nt * kTR : B;
         HeadsPlan q;
         if (!make_heads_plan(b, hL, G, plane, flags, &q)) continue;
-        const long n = q.dw_bytes + q.dh_bytes + q.hs_bytes;
+        const long n = q.dw_bytes + q.dh_bytes + q.hs_bytes + q.dw2_bytes + q.dh2_bytes;
         if (n > need) need = n;
     }
     return need;
@@ -1743,7 +1806,7 @@ extern "C" int dcahip_heads_fused_compact(const float* H, long ldh, const float*
     if (!make_heads_plan(B, hL, G, plane, flags, &pl)) return DCAHIP_EINVAL;
     if (!H || !Wh || !bh || (!y && !yc) || !sf || !gW || !dH || !loss_partials || !workspace) return DCAHIP_EINVAL;
     if (cdisp && (!theta_w || !g_theta)) return DCAHIP_EINVAL;
-    if (workspace_bytes < pl.dw_bytes + pl.dh_bytes + pl.hs_bytes) return DCAHIP_EINVAL;
+    if (workspace_bytes < pl.dw_bytes + pl.dh_bytes + pl.hs_bytes + pl.dw2_bytes + pl.dh2_bytes) return DCAHIP_EINVAL;
     if (!al16(H) || !al16(Wh) || !al16(workspace) || (ldh & 3) || (ldw & 3) || ldh < ((hL + 3) & ~3))
         return DCAHIP_EINVAL;
     // the y = 0 gradients stay below the fp16 range by the likelihood's own bounds (theta <= 1e4, |d / d pi| <= 1 + ridge / 2):
@@ -1754,10 +1817,13 @@ extern "C" int dcahip_heads_fused_compact(const float* H, long ldh, const float*
     if (yc ? (ldc < G || ldc > 0xffffffffL) : (ldy < G || ldy > 0xffffffffL)) return DCAHIP_EINVAL;
     float* ws_dh = static_cast<float*>(workspace);
     float* ws_dw = ws_dh + pl.dh_bytes / sizeof(float);
+    float* ws_dh2 = ws_dw + pl.dw_bytes / sizeof(float);             // (tail launch: behind the main launch's regions)
+    float* ws_dw2 = ws_dh2 + pl.dh2_bytes / sizeof(float);
     hipStream_t s = static_cast<hipStream_t>(stream);
     bool direct_dw = false;
     {
-        unsigned short* HA = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(workspace) + pl.dh_bytes + pl.dw_bytes);
+        unsigned short* HA = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(workspace) + pl.dh_bytes + pl.dw_bytes +
+                                                               pl.dh2_bytes + pl.dw2_bytes);
         unsigned short* HT = HA + (long)pl.NT * kHTile;
         int* eH = reinterpret_cast<int*>(HT + (long)pl.NT * kHTile);
         if (!pl.small) {                     // (the four-wave kernel splits its one row tile itself)
@@ -1768,33 +1834,49 @@ extern "C" int dcahip_heads_fused_compact(const float* H, long ldh, const float*
         direct_dw = pl.S == 1;
         HeadsArgs2 a{g_timing, HA, HT, eH, H, ldh, gW, ldg, g_theta, Wh, ldw, bh, theta_w, y, ldy, yc, ldc, ovf_ptr, ovf_col, ovf_val,
                      sf, perm, cursor, ws_dw, pl.dw_stride, ws_dh,
-                     pl.npart, pl.nitems, tile_order, loss_partials, plane, pl.ldws, B, hL, G, pl.S, pl.NT, ridge, inv_n, d_exp};
-        if (yc) {
-            if (has_pi && cdisp) launch_fused<true, true, true>(pl, a, s);
-            else if (has_pi) launch_fused<true, false, true>(pl, a, s);
-            else if (cdisp) launch_fused<false, true, true>(pl, a, s);
-            else launch_fused<false, false, true>(pl, a, s);
-        } else {
-            if (has_pi && cdisp) launch_fused<true, true, false>(pl, a, s);
-            else if (has_pi) launch_fused<true, false, false>(pl, a, s);
-            else if (cdisp) launch_fused<false, true, false>(pl, a, s);
-            else launch_fused<false, false, false>(pl, a, s);
+                     pl.npart, pl.nitems, tile_order, loss_partials, plane, pl.ldws, B, hL, G, pl.S, pl.NT, ridge, inv_n, d_exp, 0};
+        auto launch = [&](const HeadsPlan& q, const HeadsArgs2& b) {
+            if (yc) {
+                if (has_pi && cdisp) launch_fused<true, true, true>(q, b, s);
+                else if (has_pi) launch_fused<true, false, true>(q, b, s);
+                else if (cdisp) launch_fused<false, true, true>(q, b, s);
+                else launch_fused<false, false, true>(q, b, s);
+            } else {
+                if (has_pi && cdisp) launch_fused<true, true, false>(q, b, s);
+                else if (has_pi) launch_fused<true, false, false>(q, b, s);
+                else if (cdisp) launch_fused<false, true, false>(q, b, s);
+                else launch_fused<false, false, false>(q, b, s);
+            }
+        };
+        launch(pl, a);
+        if (pl.ntail > 0) {
+            // the tail launch: the same kernel over tile_order[nmain ..] with S2 batch splits, its own partial regions, its loss
+            // partials behind the main launch's
+            HeadsPlan q2 = pl;
+            q2.grid = pl.grid2; q2.S = pl.S2;
+            HeadsArgs2 b = a;
+            b.ws_dw = ws_dw2; b.ws_dh = ws_dh2; b.npart = pl.npart2; b.nitems = pl.nitems2; b.S = pl.S2;
+            b.partials = loss_partials + pl.grid; b.tile_base = pl.nmain;
+            launch(q2, b);
         }
     }
     int rc = (int)hipGetLastError();
     if (rc != 0) return rc;
-    if (n_partials_out) *n_partials_out = pl.grid;
+    const int n_part = pl.grid + pl.grid2;
+    if (n_partials_out) *n_partials_out = n_part;
     {
         const int KT = pl.HLB * 32;
         const long nq = (long)B * (KT / 4);
         // (every partial is a sum of UNSCALED gradients: the reductions apply 1 / n, once per output element)
-        const ReduceDhArgs qh{ws_dh, pl.npart, B, pl.NT * kTR, KT, hL, dH, lddh, inv_n, loss_partials, pl.grid, (double)inv_n, loss_out};
+        const ReduceDhArgs qh{ws_dh, pl.npart, B, pl.NT * kTR, KT, hL, dH, lddh, inv_n, loss_partials, n_part, (double)inv_n, loss_out,
+                              ws_dh2, pl.npart2};
         const long total = (long)(hL + 1) * pl.ldws;
         long gr = (total / 4 + 255) / 256;                  // the weight-gradient reduction moves 16 bytes per lane
         if (gr > 2048) gr = 2048;
         if (gr < 1) gr = 1;
         const ReduceDwArgs qw{ws_dw, pl.S, pl.dw_stride, hL, pl.ldws, pl.ldws, gW, ldg, cdisp ? theta_w : nullptr,
-                              cdisp ? g_theta : nullptr, G, inv_n};
+                              cdisp ? g_theta : nullptr, G, inv_n,
+                              ws_dw2, pl.S2, (pl.ntail > 0 && tile_order) ? tile_order + pl.nmain : nullptr, pl.ntail, plane, pl.nmain};
         const int gl = (nq <= 1024 && pl.npart >= 256) ? 64 : (nq >= 64L * 512 ? 4 : 16);
         const int n_dh = (int)((nq + 256 / gl - 1) / (256 / gl));
         if (!direct_dw) {

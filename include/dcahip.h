@@ -173,7 +173,11 @@ int dcahip_heads_fused(const float* H, long ldh, const float* Wh, long ldw, cons
 int dcahip_x3_product_32x32(const float* A, const float* B, float* C, int K, void* stream);
 /* Same, with the order in which workgroups take the 32-gene tiles: tile_order = device array of
  * dcahip_heads_tile_order_len(G) ints, a permutation of 0 .. ceil(G/32)-1 (padded with values >= ceil(G/32));
- * every 2 consecutive entries share a workgroup.  Results do not depend on it (each is per gene tile); a workgroup
+ * every 2 consecutive entries share a workgroup.  Results do not depend on it beyond fp32 re-association (the weight gradients
+ * are per gene tile: bitwise the same for every order, except that a launch whose plan ends in a poorly filled round of
+ * workgroups hands the LAST tiles of the order to a second launch with more batch splits -- e.g. 25 000 genes x 4 096 rows --
+ * and a tile's gradient is then the sum of 8 or 16 partial sums instead of 2); for a FIXED order every result is bit for
+ * bit reproducible.  A workgroup
  * lasts as long as its slower tile, so pairing tiles of similar non-zero load (sort by the non-zero count of the
  * tile's 32 count columns) removes the imbalance: measured 15 % between the two tiles of a workgroup in file order,
  * 8 % of the kernel.  NULL = identity (what dcahip_heads_fused passes). */

@@ -128,7 +128,7 @@ def run_case(ops, flags, B, G, hL, seed, ridge=0.0, use_perm=True, odd_counts=Fa
     return out
 
 
-def product_tol(key, rows):
+def product_tol(key, rows, genes=None):
     """Bound on |C - A B| / sum|a b| for the two backward matrix products of K-HEADS (dW = H^T D: keys gW_*, dH = D W^T), by
     the number of batch rows of the case.  What the bound carries: the products themselves (arithmetic contract
     dcahip_x3_product_32x32: two fp16 pieces of block-scaled operands, three products = an fp32 dot product, <= 5e-7) and the
@@ -142,7 +142,9 @@ def product_tol(key, rows):
     39 of 39 (tools/gpu_heads_narrow_check.sh, profiles/r06n_heads_two_product_rejection.txt) -- which the 2e-4 relative
     tolerance of check() alone would not notice."""
     if key == 'dH':
-        return 2e-7 if rows >= 4096 else 1e-6
+        # (dH sums over heads x genes: the 2e-7 of the benchmark shape is what 60 000 terms average the element errors to;
+        #  a launch over fewer genes keeps the bound of the small cases)
+        return 2e-7 if (rows >= 4096 and (genes is None or genes >= 20000)) else 1e-6
     return 1.5e-6 if rows >= 96 else 5e-6
 
 
@@ -157,9 +159,10 @@ def check(out, edge=False):
         g, r = v
         if k in mag and not edge:
             rows = out['dH'][0].shape[0]
+            genes = out['gW_mean'][0].shape[1]
             ratio = (np.abs(g - r) / np.maximum(mag[k], 1e-300)).max()
             worst = max(worst, ratio)
-            assert ratio <= product_tol(k, rows), (k, rows, float(ratio))
+            assert ratio <= product_tol(k, rows, genes), (k, rows, genes, float(ratio))
         scale = max(np.abs(r).max(), 1e-30)
         err = np.abs(g - r)
         if k.startswith('pad_'):
@@ -194,6 +197,17 @@ def test_heads_fused_benchmark_shape_vs_oracle(ops, flags):
     check(out)
 
 
+@pytest.mark.parametrize('flags,B,G', [(1, 2048, 16500), (3, 4096, 8500)])
+def test_heads_fused_tail_launch_vs_oracle(ops, flags, B, G):
+    """Shapes whose uniform plan would end in a poorly filled round of workgroups (make_heads_plan in dcahip_heads.hip):
+    2 048 rows x 16 500 genes = 516 gene tiles x 2 batch splits on 256 workgroups = 4 full rounds + 4 tiles, 4 096 x 8 500 = 266
+    tiles x 4 = 4 rounds + 10 tiles.  The left-over tiles go to a SECOND launch of the kernel with 8 / 16 batch splits, whose
+    partial sums the reduce kernels add per gene tile: every tolerance of the other cases, on both dispersion forms."""
+    import os
+    out = run_case(ops, flags, B, G, 64, seed=B + G, ridge=0.03, threads=max(1, min(64, os.cpu_count() or 1)))
+    check(out)
+
+
 @pytest.mark.parametrize('flags', [1, 0, 3, 2])
 def test_heads_fused_odd_counts(ops, flags):
     """Non-integer counts (libm lgamma route), counts above 16 (Stirling route), counts that do
@@ -218,12 +232,12 @@ def test_heads_fused_ragged_shapes(ops):
     check(out)
 
 
-@pytest.mark.parametrize('flags,B,G', [(1, 200, 777), (3, 96, 333), (0, 260, 1000)])
+@pytest.mark.parametrize('flags,B,G', [(1, 200, 777), (3, 96, 333), (0, 260, 1000), (1, 2048, 16500)])     # (the last: a tail launch)
 def test_heads_fused_tile_order_changes_nothing(ops, flags, B, G):
     """dcahip_heads_fused_ordered: any order of the 32-gene tiles gives the results of the identity order -- bitwise
-    for the weight / bias / dispersion gradients (each is per gene tile); the input gradient dH and the loss are sums
-    over gene tiles whose association follows the order (a workgroup accumulates the tiles it is handed), so they
-    agree to fp32 / fp64 re-association."""
+    for the weight / bias / dispersion gradients (each is per gene tile) unless the launch's plan has a tail launch (the
+    last case: see below); the input gradient dH and the loss are sums over gene tiles whose association follows the
+    order (a workgroup accumulates the tiles it is handed), so they agree to fp32 / fp64 re-association."""
     ntg = (G + 31) // 32
     n_ord = ops.heads_tile_order_len(G)
     assert n_ord == (ntg + 1) // 2 * 2
@@ -241,6 +255,11 @@ def test_heads_fused_tile_order_changes_nothing(ops, flags, B, G):
             elif k == 'dH':
                 scale = np.abs(a[k][0]).max()
                 assert np.abs(np.asarray(a[k][0]) - np.asarray(b[k][0])).max() <= 2e-6 * scale
+            elif G >= 16500:
+                # a plan with a TAIL launch: the tiles the order puts last are summed over more batch splits than the others
+                # (8 partial sums instead of 2), so a tile's gradient moves by fp32 re-association when the order moves it there
+                scale = np.abs(a[k][0]).max()
+                assert np.abs(np.asarray(a[k][0]) - np.asarray(b[k][0])).max() <= 2e-6 * scale, k
             else:
                 assert np.array_equal(np.asarray(a[k][0]), np.asarray(b[k][0])), k
 
